@@ -1,0 +1,31 @@
+"""Builds the in-tree native libraries with make (hipcc cross-compiles gfx950 without a GPU)."""
+import os
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+LIB = PKG / "lib"
+
+
+def _run(cmd, cwd):
+    env = dict(os.environ)
+    env.setdefault("PYTORCH_ROCM_ARCH", "gfx950")
+    r = subprocess.run(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{' '.join(cmd)} failed in {cwd}:\n{r.stdout}")
+    return r.stdout
+
+
+def build_all(jobs=4):
+    """Compiles libvoxelhip.so, libvoxelhost.so, the KAT binary and the CPU oracle."""
+    out = _run(["make", f"-j{jobs}", "-C", str(PKG), "all"], ROOT)
+    out += _run(["make", "-C", str(ROOT / "oracle"), "all"], ROOT)
+    return out
+
+
+def lib_path(name):
+    p = LIB / name
+    if not p.exists():
+        raise FileNotFoundError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C voxel-rs_amd)")
+    return p

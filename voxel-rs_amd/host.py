@@ -1,0 +1,168 @@
+"""ctypes binding of libvoxelhost.so: chunks and world SVOs (the reference's `world::chunk` / `world::hds`).
+
+Mirrors the Rust call sequence the reference's tests use (src/graphics/svo_shader_tests.rs:78-115):
+
+    chunk = Chunk(0, 0, 0, lod=5); chunk.set_block(31, 0, 0, 1); chunk.compact()
+    world = World(SVO_ESVO); world.set_chunk((0, 0, 0), chunk); world.serialize()
+    frame = world.frame()        # bytes of the mapped world buffer: [f32 2^-depth][preamble/root_ptr][arena]
+"""
+import ctypes as C
+
+import numpy as np
+
+from .build import lib_path
+
+SVO_ESVO = 1  # SvoType::Esvo, shader define "1" (src/graphics/svo.rs:35)
+SVO_CSVO = 2  # SvoType::Csvo, shader define "2" (src/graphics/svo.rs:36)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(str(lib_path("libvoxelhost.so")))
+        vp, u32, i32, u64, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_uint64, C.c_size_t
+        sig = {
+            "vxh_chunk_new": (vp, [i32, i32, i32, u32]),
+            "vxh_chunk_free": (None, [vp]),
+            "vxh_chunk_set_block": (None, [vp, u32, u32, u32, u32]),
+            "vxh_chunk_get_block": (u32, [vp, u32, u32, u32]),
+            "vxh_chunk_compact": (None, [vp]),
+            "vxh_chunk_set_lod": (None, [vp, u32]),
+            "vxh_chunk_fill_dense": (None, [vp, vp]),
+            "vxh_chunk_pos_hash": (u64, [i32, i32, i32]),
+            "vxh_world_new": (vp, [C.c_int]),
+            "vxh_world_free": (None, [vp]),
+            "vxh_world_set_chunk": (C.c_int, [vp, u32, u32, u32, vp, C.c_int]),
+            "vxh_world_serialize": (None, [vp]),
+            "vxh_world_depth": (u32, [vp]),
+            "vxh_world_size_in_bytes": (sz, [vp]),
+            "vxh_world_header_bytes": (sz, [vp]),
+            "vxh_world_write_to": (sz, [vp, vp]),
+            "vxh_world_write_changes_to": (C.c_int, [vp, vp, sz, C.c_int]),
+            "vxh_world_updated_ranges": (sz, [vp, vp, sz]),
+            "vxh_world_frame": (sz, [vp, vp, sz]),
+            "vxh_scene_build_heightfield": (u64, [vp, u32, u32, u32, vp, vp]),
+            "vxh_scene_height": (u32, [u32, u32, u32, u32]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class Chunk:
+    """32^3 voxel chunk (src/world/chunk.rs:94-131). Storage starts pre-expanded to depth 5."""
+
+    def __init__(self, x=0, y=0, z=0, lod=5):
+        self._h = lib().vxh_chunk_new(x, y, z, lod)
+        if not self._h:
+            raise MemoryError("vxh_chunk_new failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vxh_chunk_free(self._h)
+            self._h = None
+
+    def set_block(self, x, y, z, block):
+        lib().vxh_chunk_set_block(self._h, x, y, z, block)
+
+    def get_block(self, x, y, z):
+        return lib().vxh_chunk_get_block(self._h, x, y, z)
+
+    def compact(self):
+        lib().vxh_chunk_compact(self._h)
+
+    def set_lod(self, lod):
+        lib().vxh_chunk_set_lod(self._h, lod)
+
+    def fill_dense(self, ids):
+        """ids: uint32 array of shape (32, 32, 32) indexed [z][y][x]; 0 = empty (Chunk::fill_with)."""
+        a = np.ascontiguousarray(ids, dtype=np.uint32)
+        assert a.size == 32 * 32 * 32
+        lib().vxh_chunk_fill_dense(self._h, a.ctypes.data_as(C.c_void_p))
+
+    def apply_blocks(self, blocks):
+        """blocks: list of [x, y, z, id] or {"box": [[x0,x1],[y0,y1],[z0,z1]], "id": id} (golden fixture format)."""
+        for b in blocks:
+            if isinstance(b, dict):
+                (x0, x1), (y0, y1), (z0, z1) = b["box"]
+                for x in range(x0, x1):
+                    for z in range(z0, z1):
+                        for y in range(y0, y1):
+                            self.set_block(x, y, z, b["id"])
+            else:
+                self.set_block(*b)
+
+
+class World:
+    """World-level SVO (`Esvo<SerializedChunk>` / `Csvo`, src/world/hds/common.rs:3-15)."""
+
+    def __init__(self, svo_type):
+        self.svo_type = svo_type
+        self._h = lib().vxh_world_new(svo_type)
+        if not self._h:
+            raise ValueError(f"bad svo_type {svo_type}")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vxh_world_free(self._h)
+            self._h = None
+
+    def set_chunk(self, svo_pos, chunk, serialize=True):
+        lib().vxh_world_set_chunk(self._h, svo_pos[0], svo_pos[1], svo_pos[2], chunk._h, int(serialize))
+
+    def serialize(self):
+        lib().vxh_world_serialize(self._h)
+
+    @property
+    def depth(self):
+        return lib().vxh_world_depth(self._h)
+
+    @property
+    def size_in_bytes(self):
+        return lib().vxh_world_size_in_bytes(self._h)
+
+    @property
+    def header_bytes(self):
+        return lib().vxh_world_header_bytes(self._h)
+
+    def write_to(self):
+        buf = np.zeros(self.header_bytes + self.size_in_bytes, dtype=np.uint8)
+        n = lib().vxh_world_write_to(self._h, buf.ctypes.data_as(C.c_void_p))
+        return buf[:n]
+
+    def write_changes_to(self, dst_ptr, dst_len, reset=True):
+        """Writes header + dirty ranges at `dst_ptr` (an address), like WorldSvo::write_changes_to."""
+        rc = lib().vxh_world_write_changes_to(self._h, C.c_void_p(dst_ptr), dst_len, int(reset))
+        if rc != 0:
+            raise RuntimeError("dst is not large enough")  # the reference asserts (esvo.rs:328)
+
+    def updated_ranges(self):
+        n = lib().vxh_world_updated_ranges(self._h, None, 0)
+        out = np.zeros((max(n, 1), 2), dtype=np.uint64)
+        lib().vxh_world_updated_ranges(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return [(int(a), int(b)) for a, b in out[:n]]
+
+    def frame(self, pad_words=4):
+        """[f32 2^-depth][header][arena] as uint32 words (+ zero padding: CSVO's read_uint touches word+1)."""
+        need = lib().vxh_world_frame(self._h, None, 0)
+        words = (need + 3) // 4 + pad_words
+        buf = np.zeros(words, dtype=np.uint32)
+        lib().vxh_world_frame(self._h, buf.ctypes.data_as(C.c_void_p), words * 4)
+        return buf
+
+    def build_heightfield(self, depth, seed=0x5EED0001, threads=0):
+        """Seeded synthetic scene; returns dict(chunks, leaves, h_max)."""
+        import os
+
+        leaves, hmax = C.c_uint64(0), C.c_uint32(0)
+        threads = threads or min(32, os.cpu_count() or 1)
+        chunks = lib().vxh_scene_build_heightfield(self._h, depth, seed, threads, C.byref(leaves), C.byref(hmax))
+        return dict(chunks=int(chunks), leaves=int(leaves.value), h_max=int(hmax.value))
+
+
+def scene_height(depth, seed, x, z):
+    return lib().vxh_scene_height(depth, seed, x, z)
