@@ -107,3 +107,27 @@ def test_picker_end_to_end(golden, fmt):
         assert bool(got["inside_voxel"]) == exp["inside_voxel"]
         np.testing.assert_allclose(got["pos"], exp["pos"], rtol=0, atol=g["tol"])
         np.testing.assert_array_equal(got["normal"], np.asarray(exp["normal"], dtype=np.float32))
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_golden_results_bit_exact(golden, fmt):
+    """Stronger than the reference's own 1e-5: with the oracle's explicit FMA placement (svo_oracle.c header) the
+    printed golden floats of cast_inside_outside_all_axes and both traversal traces are reproduced bit for bit."""
+    g = golden["formats"][fmt]["cast_inside_outside_all_axes"]
+    scene, _ = oracle_scene(golden, fmt, g["svo_pos"], g["blocks"])
+    for case in g["cases"]:
+        res, _, _ = scene.intersect(case["pos"], orc.normalize(case["dir"]), g["max_dst"], g["cast_translucent"])
+        e = case["expected"]
+        assert np.float32(res.t) == np.float32(e["t"]), case["name"]
+        assert [np.float32(x) for x in res.pos] == [np.float32(x) for x in e["pos"]], case["name"]
+        assert [np.float32(x) for x in res.uv] == [np.float32(x) for x in e["uv"]], case["name"]
+    for name in ("shader_svo_traversal", "check_at_higher_coordinates"):
+        g = golden["formats"][fmt][name]
+        scene, _ = oracle_scene(golden, fmt, g["svo_pos"], g["blocks"])
+        ray = g["ray"]
+        res, frames, n = scene.intersect(ray["pos"], orc.normalize(ray["dir"]), ray["max_dst"], ray["cast_translucent"], max_frames=100)
+        e = g["result"]
+        assert np.float32(res.t) == np.float32(e["t"]), name
+        assert [np.float32(x) for x in res.pos] == [np.float32(x) for x in e["pos"]], name
+        assert [np.float32(x) for x in res.uv] == [np.float32(x) for x in e["uv"]], name
+        assert [np.float32(f["t_min"]) for f in frames] == [np.float32(f["t_min"]) for f in g["frames"]], name
