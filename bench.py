@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + shadow) at 1920x1080 on a synthetic depth-12 SVO (BASELINE.json).
+
+One "step" = one frame: vx_render of this rank's screen tiles (primary ray, shading, one shadow ray per lit pixel,
+sky) plus, for N > 1, the RCCL gather of the finished tiles to rank 0 and their assembly into the image.
+
+    python bench.py                      # 1 GPU, C3 workload (configs[2] of BASELINE.json)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line. `roofline.achieved` = algorithmic bytes per launch (step counters of the instrumented
+kernel variant x the byte model of DESIGN.md) / the render kernel's average duration, measured with HIP events on the
+stream it is launched on. `cpu_baseline` = the C oracle (restatement of the reference's GLSL; the reference has no CPU
+raycast) timed on this box's host cores over a bounded sample of the same frame.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s achievable)
+
+
+def algorithmic_bytes(fmt, c):
+    """SURVEY.md §8(d) byte model, per frame, from the step counters."""
+    nearest = c["leaf_tests"] - c["leaf_tests_trilinear"]
+    if fmt == "esvo":
+        # 4 B descriptor per iteration, 4 B child pointer per PUSH, per leaf test: pointer + value (8) + material row (32) + texel(s)
+        trav = 4 * c["iterations"] + 4 * c["pushes"] + c["leaf_tests"] * (8 + 32) + nearest * 4 + c["leaf_tests_trilinear"] * 32
+    else:
+        # node header bytes per iteration, pointer bytes per PUSH, per leaf test: u16 material offset + 8 mask bytes + u32 material
+        # + material row + texel(s); 5 B chunk frame header per boundary crossing
+        trav = (c["csvo_header_bytes"] + c["csvo_pointer_bytes"] + c["leaf_tests"] * (2 + 8 + 4 + 32) + nearest * 4 + c["leaf_tests_trilinear"] * 32
+                + 5 * c["boundaries"])
+    # per pixel: 16 B RGBA32F store; per lit pixel: 32 B material row + one normal-map sample (counted as one 4 B texel)
+    shade = 16 * c["pixels"] + c["lit_pixels"] * (32 + 4)
+    return trav + shade
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--format", choices=["esvo", "csvo"], default="csvo", help="node format; csvo is the reference's default build feature")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from _pkg import load_package
+
+    vra = load_package()
+    from voxel_rs_amd import hip, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    fmt = vra.SVO_ESVO if args.format == "esvo" else vra.SVO_CSVO
+    W, H = args.width, args.height
+
+    # ---- scene: replicated per GPU (every rank builds and uploads the same serialized SVO) ------------------------------
+    t0 = time.time()
+    world = vra.World(fmt)
+    st = world.build_heightfield(args.depth)
+    build_s = time.time() - t0
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20), device=local_rank)
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    t0 = time.time()
+    svo.update(world)
+    upload_s = time.time() - t0
+    # every primary hit casts its shadow ray ("primary + 1 shadow ray" of configs[2]); the game's default cut-off of
+    # 500 blocks would cast almost none from this altitude
+    uniforms = scenes.bench_camera(args.depth, st["h_max"], W, H, shadow_distance=3.0e38, render_shadows=True)
+
+    # ---- work per frame: deterministic for a fixed scene/camera -----------------------------------------------------------
+    counters = svo.render_counters(uniforms, W, H, rank, world_size)
+    my_rays = counters["rays"]
+    my_bytes = algorithmic_bytes(args.format, counters)
+
+    n_local = hip.local_tile_count(W, H, rank, world_size)
+    n_max = max(hip.local_tile_count(W, H, r, world_size) for r in range(world_size))
+    if world_size > 1:
+        tiles = torch.zeros((n_max, 32, 32, 4), dtype=torch.float32, device="cuda")
+        gathered = torch.zeros((world_size, n_max, 32, 32, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+        image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+        vx_stream = torch.cuda.ExternalStream(svo.stream)
+    else:
+        image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+
+    def step():
+        if world_size == 1:
+            svo.render_device(uniforms, W, H, image.data_ptr())
+            return
+        svo.render_device(uniforms, W, H, tiles.data_ptr(), tile_rank=rank, tile_count=world_size)
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(vx_stream)
+        # the one exchange step of the path: finished tiles -> rank 0, each peer over its own xGMI link
+        dist.gather(tiles, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+        if rank == 0:
+            vx_stream.wait_stream(cur)
+            svo.assemble_tiles(gathered.data_ptr(), n_max * 32 * 32 * 4, world_size, W, H, image.data_ptr())
+
+    def barrier():
+        svo.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    svo.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = svo.profile_read()
+    svo.profile_enable(False)
+
+    stats = torch.tensor([elapsed, float(my_rays), float(my_bytes), kernel_ms / max(launches, 1)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, total_rays = float(mx[0]), float(sm[1])
+    else:
+        total_rays = float(my_rays)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_rays / (ms_per_step * 1e-3) / 1e6  # Mrays/s, whole job
+    kernel_avg_ms = kernel_ms / max(launches, 1)
+    achieved = my_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "traffic": None, "kernel": "render_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4), "launches": launches,
+                "algorithmic_bytes_per_launch": int(my_bytes), "bytes_per_ray": round(my_bytes / max(my_rays, 1), 2)}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle as orc  # the checker, timed here as the CPU baseline ("port": the reference has no CPU raycast)
+
+        scene = orc.OracleScene(fmt, world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+        ou = orc.Uniforms.from_buffer_copy(bytes(uniforms))
+        cores = orc.lib().or_max_threads()
+        # probe a few rows spread over the image to size the sample for ~cpu_seconds of work
+        probe_rows = [int(H * f) for f in (0.1, 0.3, 0.5, 0.7, 0.9)]
+        pc = orc.Counters()
+        t0 = time.perf_counter()
+        for y in probe_rows:
+            scene.render(ou, W, H, rect=(0, y, W, y + 2), want_hits=False, counters=pc, threads=cores)
+        probe_s = time.perf_counter() - t0
+        rows_budget = int(len(probe_rows) * 2 * args.cpu_seconds / max(probe_s, 1e-6))
+        cc = orc.Counters()
+        if rows_budget >= H:
+            t0 = time.perf_counter()
+            scene.render(ou, W, H, want_hits=False, counters=cc, threads=cores)
+            cpu_s = time.perf_counter() - t0
+            sample = f"whole {W}x{H} frame"
+        else:
+            bands = 8
+            band_h = max(rows_budget // bands, 1)
+            t0 = time.perf_counter()
+            for b in range(bands):
+                y0 = int((b + 0.5) * H / bands) - band_h // 2
+                scene.render(ou, W, H, rect=(0, max(y0, 0), W, min(y0 + band_h, H)), want_hits=False, counters=cc, threads=cores)
+            cpu_s = time.perf_counter() - t0
+            sample = f"{bands} bands x {band_h} rows of the {W}x{H} frame"
+        cpu = {"value": round(cc.rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "sample": f"{sample}: {cc.rays} rays in {cpu_s:.2f} s (C restatement of the GLSL path, OpenMP; the reference has no CPU raycast)"}
+
+    out = {
+        "metric": "Mrays/sec (primary+shadow) at 1920x1080, depth-12 SVO; achieved HBM GB/s",
+        "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"C3: {W}x{H} primary + 1 shadow ray per lit pixel, textured + normal-mapped shading, depth-{args.depth} SVO "
+                               f"({args.format.upper()} nodes), 1 frame per step", "svo_format": args.format, "svo_bytes": world.size_in_bytes,
+                   "leaves": st["leaves"], "chunks": st["chunks"], "rays_per_frame": int(total_rays), "primary_rays": W * H,
+                   "parallelism": f"screen tiles (32x32, interleaved) over {world_size} GPU(s), SVO replicated, RCCL gather to rank 0",
+                   "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 3)},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

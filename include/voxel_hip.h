@@ -1,0 +1,226 @@
+/* voxel_hip.h -- C ABI of libvoxelhip.so: the MI355X (gfx950) drop-in for voxel-rs's `graphics::Svo`.
+ *
+ * Every entry point replaces one piece of the reference's OpenGL render/raycast surface
+ * (/root/reference/src/graphics/svo.rs); the citation next to each declaration names it. All positions are in
+ * SVO space [0, 2^depth) exactly as `graphics::Svo` expects (svo.rs:55); world<->SVO conversion stays with the
+ * caller (src/systems/worldsvo.rs:397-435). Single caller thread per context, like the reference (svo.rs:56-73
+ * holds RefCell'd GL state). No exceptions cross this boundary: functions return a vx_status, details via
+ * vx_last_error(). Plain pointers and sizes only.
+ *
+ * The reference-side binding (Rust `extern "C"` block + safe wrapper) is shown in INTEGRATION.md.
+ */
+#ifndef VOXEL_HIP_H
+#define VOXEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SvoType (svo.rs:18-39): the values are the reference's shader defines SVO_TYPE_ESVO / SVO_TYPE_CSVO
+ * (assets/shaders/svo.glsl:65-66). */
+#define VX_SVO_ESVO 1
+#define VX_SVO_CSVO 2
+
+typedef enum vx_status {
+    VX_OK = 0,
+    VX_ERR_INVALID_ARGUMENT = 1,
+    VX_ERR_NO_DEVICE = 2,      /* no usable HIP device: there is NO CPU fallback */
+    VX_ERR_OUT_OF_MEMORY = 3,
+    VX_ERR_CAPACITY = 4,       /* a range does not fit the world buffer (reference: assert!, esvo.rs:328 / csvo.rs:301) */
+    VX_ERR_HIP = 5,            /* a HIP runtime call failed */
+    VX_ERR_STATE = 6           /* e.g. render before any commit */
+} vx_status;
+
+typedef enum vx_memory { VX_MEM_HOST = 0, VX_MEM_DEVICE = 1 } vx_memory;
+
+typedef struct vx_context vx_context; /* replaces `struct Svo` (svo.rs:56-73): owns every device object */
+
+/* MaterialInstance, 32-byte rows indexed by BlockId (src/graphics/svo_registry.rs:29-40; svo.glsl:48-59).
+ * Texture fields are array layers, -1 = none. */
+typedef struct vx_material {
+    float specular_pow, specular_strength;
+    int32_t tex_top, tex_side, tex_bottom;
+    int32_t tex_top_normal, tex_side_normal, tex_bottom_normal;
+} vx_material;
+
+/* One dirty range of the serialized SVO arena, in the coordinates of the reference's
+ * `RangeBuffer::updated_ranges` (src/world/hds/internal.rs:151-154,166): byte offsets relative to the
+ * first byte AFTER the writer's header (ESVO: 20-byte preamble, esvo.rs:179-188; CSVO: 4-byte root pointer,
+ * csvo.rs:291-292). */
+typedef struct vx_range {
+    uint64_t start, length;
+} vx_range;
+
+/* The uniforms `Svo::render` sets on world.glsl (svo.rs:201-215; assets/shaders/world.glsl:12-25).
+ * `view` is u_view = look_to_rh(cam_pos, cam_fwd, cam_up)^-1, column-major (svo.rs:197).
+ * highlight_pos = NaN when nothing is selected (svo.rs:211). light_dir must be normalised by the caller
+ * (src/gamelogic/world.rs:106). */
+typedef struct vx_uniforms {
+    float view[16];
+    float fovy, aspect;
+    float ambient;
+    float light_dir[3];
+    float cam_pos[3];
+    int32_t render_shadows;
+    float shadow_distance;
+    float highlight_pos[3];
+} vx_uniforms;
+
+/* PickerTask / PickerResult with the std430 layout of assets/shaders/picker.glsl:9-27
+ * (src/graphics/svo_picker.rs:13-32): 48 bytes each, vec3s at 16 and 32. */
+typedef struct vx_picker_task {
+    float max_dst, _pad0[3];
+    float pos[3], _pad1;
+    float dir[3], _pad2;
+} vx_picker_task;
+
+typedef struct vx_picker_result {
+    float dst;             /* -1 = no hit */
+    uint32_t inside_voxel; /* GLSL bool */
+    float _pad0[2];
+    float pos[3], _pad1;
+    float normal[3], _pad2;
+} vx_picker_result;
+
+/* Optional per-pixel record of what trace_ray saw (world.glsl:27-90) -- the "hit position, depth" outputs
+ * used for parity checks; not part of the reference's surface. */
+typedef struct vx_hit {
+    float t;          /* primary hit distance in SVO units, -1 = miss */
+    uint32_t value;   /* BlockId of the hit voxel */
+    int32_t face_id;  /* 0..5 = -x,+x,-y,+y,-z,+z */
+    uint32_t flags;   /* bit0 hit, bit1 shadow ray cast, bit2 in shadow, bit3 highlight outline */
+    float pos[3];
+    float lod;
+    float uv[2];
+    float shadow_t;   /* hit distance of the shadow ray, -1 = unoccluded / not cast */
+    uint32_t steps;   /* traversal loop iterations, primary + shadow */
+} vx_hit;
+
+/* OctreeResult and StackFrame of the debug harness (assets/shaders/svo.glsl:31-40, svo.test.glsl:13-33). */
+typedef struct vx_result {
+    float t;
+    uint32_t value;
+    int32_t face_id;
+    float pos[3];
+    float uv[2];
+    float color[4];
+    float lod;
+    int32_t inside_voxel;
+} vx_result;
+
+typedef struct vx_frame {
+    float t_min;
+    uint32_t ptr, idx, parent_octant_idx; /* CSVO: 4th field = depth (svo.csvo.glsl:285) */
+    int32_t scale, is_child, is_leaf, crossed_boundary;
+    uint32_t next_ptr;
+} vx_frame;
+
+/* graphics::svo::Stats (svo.rs:75-83) */
+typedef struct vx_stats {
+    uint64_t used_bytes, capacity_bytes;
+    uint32_t depth;
+} vx_stats;
+
+/* Step counters of the instrumented kernel variant (algorithmic-bytes model). */
+typedef struct vx_counters {
+    uint64_t rays, iterations, pushes, leaf_tests, leaf_tests_trilinear, boundaries;
+    uint64_t csvo_header_bytes, csvo_pointer_bytes;
+    uint64_t pixels, lit_pixels, shadow_rays;
+} vx_counters;
+
+/* Where vx_render writes. Tiles are 32x32 pixels, numbered row-major from the bottom-left; a context renders
+ * the tiles t with t % tile_count == tile_rank (multi-GPU screen sharding; 0/1 = whole image).
+ *   tile_count <= 1: rgba32f is width*height RGBA32F pixels, row 0 = bottom -- the image2D of world.glsl:10.
+ *   tile_count  > 1: rgba32f is a compact tile list: local tile k (global tile k*tile_count + tile_rank)
+ *                    occupies floats [k*4096, (k+1)*4096), pixel (x,y) of the tile at (y*32+x)*4.
+ * hits (optional) uses the same indexing with vx_hit elements. */
+typedef struct vx_target {
+    void* rgba32f;
+    vx_hit* hits;
+    int32_t memory; /* vx_memory of both pointers */
+    uint32_t tile_rank, tile_count;
+} vx_target;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+
+/* Svo::new (svo.rs:109-149): capacity_bytes = size_mb * 1000 * 1000 of world buffer (svo.rs:133). Allocates
+ * the pinned staging mirror, the device world buffer, streams and events on HIP device `device`. */
+int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out);
+/* Drop for Svo (src/graphics/buffer.rs:41-47,95-101) */
+void vx_destroy(vx_context* ctx);
+
+/* ---- resources ------------------------------------------------------------------------------------------ */
+
+/* VoxelRegistry::build_material_buffer (svo_registry.rs:135-165): rows indexed by BlockId. */
+int vx_set_materials(vx_context* ctx, const vx_material* rows, uint32_t count);
+/* TextureArrayBuilder::build + TextureArray::new (src/graphics/texture_array.rs:83-153,191-236): `rgba8` is
+ * layers*height*width*4 bytes, base level only, ALREADY flipped vertically (row 0 = bottom, :92,126);
+ * mip_levels is clamped to min(mip_levels, ilog2(min(w,h))) like :108 and the chain is generated here
+ * (2x2 box filter, the glGenerateMipmap of :259). Sampler state is fixed to the reference's (:200-203). */
+int vx_set_textures(vx_context* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t layers, uint32_t mip_levels);
+
+/* ---- SVO upload ------------------------------------------------------------------------------------------ */
+
+/* MappedBuffer::cast / offset (svo.rs:175,181): host-pinned mirror of the world buffer, capacity_bytes long,
+ * valid until vx_destroy. The caller's `WorldSvo::write_changes_to(ptr + 4, capacity - 1, reset)` writes here
+ * exactly as it writes into the mapped SSBO. */
+uint8_t* vx_staging_ptr(vx_context* ctx);
+size_t vx_capacity(const vx_context* ctx);
+/* Svo::update (svo.rs:171-189): stores f32 2^-depth at byte 0 (:173-175), waits for in-flight renders like
+ * render_fence.wait() (:178), then copies the writer's header and the given dirty arena ranges to the device
+ * (asynchronously; later renders/raycasts are ordered after it). used_bytes = WorldSvo::size_in_bytes() for
+ * vx_get_stats (:183-187). */
+int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes);
+/* Same, treating [0, used_bytes) of the arena as dirty (what the first write_changes_to after write_to does). */
+int vx_commit_all(vx_context* ctx, uint32_t depth, uint64_t used_bytes);
+/* Svo::get_stats (svo.rs:191-193) */
+int vx_get_stats(const vx_context* ctx, vx_stats* out);
+
+/* ---- the hot path ---------------------------------------------------------------------------------------- */
+
+/* Svo::render (svo.rs:196-229) = world.glsl main for every pixel: primary ray, shading, <=1 shadow ray, sky.
+ * Device targets are written asynchronously on the context's stream (vx_sync = the render fence); host
+ * targets return when the image is in place. */
+int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, const vx_target* target);
+/* Svo::raycast (svo.rs:233-255) = picker.glsl over `count` tasks (no 100-task cap); synchronous like the
+ * reference's fence wait (:248-249). Host pointers. */
+int vx_raycast(vx_context* ctx, const vx_picker_task* tasks, uint32_t count, vx_picker_result* results);
+/* svo.test.glsl (assets/shaders/svo.test.glsl:63-76): one ray with a StackFrame per loop iteration.
+ * n_frames receives the number of iterations (may exceed max_frames). Host pointers. */
+int vx_debug_trace(vx_context* ctx, const float pos[3], const float dir[3], float max_dst, int cast_translucent, vx_result* result,
+                   vx_frame* frames, uint32_t max_frames, uint32_t* n_frames);
+/* Fence::wait for everything enqueued on this context (src/graphics/fence.rs:8-42). */
+int vx_sync(vx_context* ctx);
+
+/* ---- multi-GPU image assembly ----------------------------------------------------------------------------- */
+
+/* Scatters `tile_count` gathered compact tile lists (rank r's list at tiles + r*stride_floats) into a
+ * width*height RGBA32F image; all pointers are device memory on this context's device. */
+int vx_assemble_tiles(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
+                      float* out_rgba32f);
+/* Number of tiles (32x32) rank `tile_rank` of `tile_count` owns for a width x height image. */
+uint32_t vx_local_tile_count(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count);
+
+/* ---- measurement ------------------------------------------------------------------------------------------ */
+
+/* Instrumented variant of vx_render (same rays, per-phase step counters, no image kept). */
+int vx_render_counters(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count,
+                       vx_counters* out);
+/* While enabled, every render-kernel launch is bracketed by HIP events on the stream it is launched on. */
+int vx_profile_enable(vx_context* ctx, int enabled);
+/* Sum of the bracketed kernel durations (ms) and their count since the last call; synchronises. */
+int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches);
+/* hipStream_t the context launches on (as void*), for callers that order their own work after it. */
+void* vx_stream(vx_context* ctx);
+int vx_device(const vx_context* ctx);
+
+const char* vx_last_error(void);
+const char* vx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

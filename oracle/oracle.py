@@ -55,7 +55,7 @@ class Uniforms(C.Structure):
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("value", "<u4"), ("face_id", "<i4"), ("flags", "<u4"), ("pos", "<f4", 3), ("lod", "<f4"), ("uv", "<f4", 2),
-                      ("shadow_t", "<f4"), ("pad", "<u4")])
+                      ("shadow_t", "<f4"), ("steps", "<u4")])
 PICKER_TASK_DTYPE = np.dtype([("max_dst", "<f4"), ("_p0", "<f4", 3), ("pos", "<f4", 3), ("_p1", "<f4"), ("dir", "<f4", 3), ("_p2", "<f4")])
 PICKER_RESULT_DTYPE = np.dtype([("dst", "<f4"), ("inside_voxel", "<u4"), ("_p0", "<f4", 2), ("pos", "<f4", 3), ("_p1", "<f4"), ("normal", "<f4", 3),
                                 ("_p2", "<f4")])

@@ -549,10 +549,19 @@ static void sky_color(const float rd[3], float out[3]) { /* world.glsl:92-108 */
     for (int k = 0; k < 3; ++k) out[k] = HORIZON[k] * (1.0f - grad) + SKY[k] * grad;
 }
 
+static void add_counters(or_counters* dst, const or_counters* src) {
+    dst->rays += src->rays; dst->iterations += src->iterations; dst->pushes += src->pushes;
+    dst->leaf_tests += src->leaf_tests; dst->leaf_tests_trilinear += src->leaf_tests_trilinear;
+    dst->boundaries += src->boundaries; dst->csvo_header_bytes += src->csvo_header_bytes;
+    dst->csvo_pointer_bytes += src->csvo_pointer_bytes;
+}
+
 static void trace_ray(const or_scene* scene, const or_uniforms* u, const float ro[3], const float rd[3], float color[4], int* hit,
                       or_hit* rec, or_counters* ctr) { /* world.glsl:27-90 */
     or_result res;
-    or_intersect(scene, ro, rd, -1.0f, 1, &res, NULL, 0, NULL, ctr);
+    or_counters pc; /* this pixel's own step counters: iterations are reported per pixel for parity checks */
+    memset(&pc, 0, sizeof pc);
+    or_intersect(scene, ro, rd, -1.0f, 1, &res, NULL, 0, NULL, &pc);
     *hit = res.t != -1.0f;
     if (rec) {
         memset(rec, 0, sizeof *rec);
@@ -563,7 +572,11 @@ static void trace_ray(const or_scene* scene, const or_uniforms* u, const float r
         if (*hit) rec->flags |= 1u;
     }
     color[0] = color[1] = color[2] = color[3] = 0.0f;
-    if (res.t < 0.0f) return;
+    if (res.t < 0.0f) {
+        if (rec) rec->steps = (uint32_t)pc.iterations;
+        if (ctr) add_counters(ctr, &pc);
+        return;
+    }
 
     if (floorf(res.pos[0]) == floorf(u->highlight_pos[0]) && floorf(res.pos[1]) == floorf(u->highlight_pos[1]) &&
         floorf(res.pos[2]) == floorf(u->highlight_pos[2])) {
@@ -571,7 +584,8 @@ static void trace_ray(const or_scene* scene, const or_uniforms* u, const float r
         float lx = fabsf(res.uv[0] - 0.5f) * 2.0f, ly = fabsf(res.uv[1] - 0.5f) * 2.0f;
         if (gmax(lx, ly) > 1.0f - thickness) {
             color[0] = color[1] = color[2] = color[3] = 1.0f;
-            if (rec) rec->flags |= 8u;
+            if (rec) { rec->flags |= 8u; rec->steps = (uint32_t)pc.iterations; }
+            if (ctr) add_counters(ctr, &pc);
             return;
         }
     }
@@ -610,7 +624,7 @@ static void trace_ray(const or_scene* scene, const or_uniforms* u, const float r
     if (u->render_shadows && res.t < u->shadow_distance) {
         float so[3] = {res.pos[0] + normal[0] * 0.001f, res.pos[1] + normal[1] * 0.001f, res.pos[2] + normal[2] * 0.001f};
         or_result sres;
-        or_intersect(scene, so, neg_l, -1.0f, 1, &sres, NULL, 0, NULL, ctr);
+        or_intersect(scene, so, neg_l, -1.0f, 1, &sres, NULL, 0, NULL, &pc);
         shadow = sres.t < 0.0f ? 1.0f : 0.0f;
         if (rec) {
             rec->flags |= 2u;
@@ -624,13 +638,8 @@ static void trace_ray(const or_scene* scene, const or_uniforms* u, const float r
     color[1] = res.color[1] * light;
     color[2] = res.color[2] * light;
     color[3] = res.color[3];
-}
-
-static void add_counters(or_counters* dst, const or_counters* src) {
-    dst->rays += src->rays; dst->iterations += src->iterations; dst->pushes += src->pushes;
-    dst->leaf_tests += src->leaf_tests; dst->leaf_tests_trilinear += src->leaf_tests_trilinear;
-    dst->boundaries += src->boundaries; dst->csvo_header_bytes += src->csvo_header_bytes;
-    dst->csvo_pointer_bytes += src->csvo_pointer_bytes;
+    if (rec) rec->steps = (uint32_t)pc.iterations;
+    if (ctr) add_counters(ctr, &pc);
 }
 
 void or_render(const or_scene* scene, const or_uniforms* u, uint32_t w, uint32_t h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,

@@ -90,7 +90,7 @@ typedef struct {
     float lod;
     float uv[2];
     float shadow_t;   /* t of the shadow ray's hit, -1 = unoccluded or not cast */
-    uint32_t pad;
+    uint32_t steps;   /* traversal loop iterations, primary + shadow */
 } or_hit;
 
 /* picker.glsl:19-35, std430 (48-byte) layouts of src/graphics/svo_picker.rs:13-32 */

@@ -1,0 +1,324 @@
+"""GPU parity: the HIP path (through the C ABI of libvoxelhip.so) against the CPU oracle and the reference's goldens.
+
+Bar: hit identity, step counts and every traversal float (t, pos, uv, per-iteration t_min) are
+BIT-EXACT against the oracle; shaded colour within COLOR_TOL (libm vs ocml in pow/acos). The reference's own golden
+vectors are replayed through the GPU with the tolerances the reference's tests state (1e-5).
+"""
+import numpy as np
+import pytest
+
+from helpers import SVO_TYPES, build_world, golden_materials, golden_textures, oracle_scene, orc, vra
+
+pytestmark = pytest.mark.gpu
+
+FMTS = ["esvo", "csvo"]
+EPS = 1e-5
+COLOR_TOL = 2e-6  # absolute, on colours in [0,1]: powf/acosf differ by a few ulp between glibc and ocml
+
+
+def f32(x):
+    return np.asarray(x, dtype=np.float32).astype(np.float64)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from voxel_rs_amd import hip as h
+
+    return h
+
+
+def gpu_svo(hip, golden, fmt, world, capacity=8 << 20):
+    svo = hip.Svo(SVO_TYPES[fmt], capacity)
+    svo.set_materials(golden_materials(golden))
+    tex, mips = golden_textures(golden)
+    svo.set_textures(tex, mips)
+    svo.update(world)
+    return svo
+
+
+def same_bits(a, b):
+    return np.array_equal(np.asarray(a, dtype=np.float32).view(np.uint32), np.asarray(b, dtype=np.float32).view(np.uint32))
+
+
+def assert_result_equal(gpu, cpu, what):
+    assert same_bits(gpu.t, cpu.t), (what, "t", gpu.t, cpu.t)
+    assert gpu.value == cpu.value and gpu.face_id == cpu.face_id and bool(gpu.inside_voxel) == bool(cpu.inside_voxel), what
+    assert same_bits(list(gpu.pos), list(cpu.pos)), (what, "pos", list(gpu.pos), list(cpu.pos))
+    assert same_bits(list(gpu.uv), list(cpu.uv)), (what, "uv")
+    assert same_bits(list(gpu.color), list(cpu.color)), (what, "color")
+
+
+# ---- the reference's single-ray tests (svo_shader_tests.rs) replayed on the GPU -----------------------------------
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("case", ["shader_svo_traversal", "check_at_higher_coordinates"])
+def test_traversal_frames(hip, golden, fmt, case):
+    g = golden["formats"][fmt][case]
+    scene, world = oracle_scene(golden, fmt, g["svo_pos"], g["blocks"])
+    svo = gpu_svo(hip, golden, fmt, world)
+    ray = g["ray"]
+    d = orc.normalize(ray["dir"])
+    res, frames, n = svo.debug_trace(ray["pos"], d, ray["max_dst"], ray["cast_translucent"], max_frames=100)
+    cres, cframes, cn = scene.intersect(ray["pos"], d, ray["max_dst"], ray["cast_translucent"], max_frames=100)
+    # against the reference's golden frames
+    assert n == len(g["frames"])
+    for i, (got, exp) in enumerate(zip(frames, g["frames"])):
+        assert abs(float(got["t_min"]) - float(f32(exp["t_min"]))) < EPS, (i, got, exp)
+        for k in ("ptr", "idx", "parent_octant_idx", "scale", "is_child", "is_leaf", "crossed_boundary"):
+            assert int(got[k]) == exp[k], (i, k, got, exp)
+        if fmt == "csvo":
+            assert int(got["next_ptr"]) == exp["next_ptr"], (i, got, exp)
+    # and bit for bit against the oracle
+    assert n == cn
+    assert frames.tobytes() == cframes.tobytes()
+    assert_result_equal(res, cres, case)
+    e = g["result"]
+    assert abs(res.t - float(f32(e["t"]))) <= max(e["t_tol"], 0) + 1e-12
+    np.testing.assert_allclose(list(res.pos), f32(e["pos"]), rtol=0, atol=max(e["pos_tol"], 1e-12))
+    np.testing.assert_allclose(list(res.uv), f32(e["uv"]), rtol=0, atol=max(e["uv_tol"], 1e-12))
+    np.testing.assert_allclose(list(res.color), f32(e["color"]), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_golden_result_tables(hip, golden, fmt):
+    """cast_inside_outside_all_axes, uv_coords_on_all_sides, casting_against_translucent_leafs, detect_inside_leaf_voxel."""
+    G = golden["formats"][fmt]
+    for name in ("cast_inside_outside_all_axes", "uv_coords_on_all_sides", "casting_against_translucent_leafs", "detect_inside_leaf_voxel"):
+        g = G[name]
+        scene, world = oracle_scene(golden, fmt, g["svo_pos"], g["blocks"])
+        svo = gpu_svo(hip, golden, fmt, world)
+        for case in g["cases"]:
+            d = orc.normalize(case["dir"])
+            ct = case.get("cast_translucent", g.get("cast_translucent", False))
+            res, _, _ = svo.debug_trace(case["pos"], d, g["max_dst"], ct, max_frames=0)
+            cres, _, _ = scene.intersect(case["pos"], d, g["max_dst"], ct)
+            assert_result_equal(res, cres, (name, case.get("name")))
+            if "expected" in case:
+                e = case["expected"]
+                tol = lambda k: max(e[k], EPS if name == "cast_inside_outside_all_axes" else 0.0) + 1e-12  # noqa: E731
+                assert abs(res.t - float(f32(e["t"]))) <= tol("t_tol"), (name, case.get("name"))
+                assert res.value == e["value"] and res.face_id == e["face_id"] and bool(res.inside_voxel) == e["inside_voxel"]
+                np.testing.assert_allclose(list(res.pos), f32(e["pos"]), rtol=0, atol=tol("pos_tol"))
+                np.testing.assert_allclose(list(res.uv), f32(e["uv"]), rtol=0, atol=tol("uv_tol"))
+                np.testing.assert_allclose(list(res.color), f32(e["color"]), rtol=0, atol=tol("color_tol"))
+            else:
+                np.testing.assert_allclose(list(res.uv), f32(case["expected_uv"]), rtol=0, atol=EPS)
+                np.testing.assert_allclose(list(res.color), f32(case["expected_color"]), rtol=0, atol=EPS)
+            if name == "cast_inside_outside_all_axes":
+                # printed golden floats are reproduced bit for bit
+                assert same_bits(res.t, e["t"]) and same_bits(list(res.pos), e["pos"]) and same_bits(list(res.uv), e["uv"]), case["name"]
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_picker_end_to_end(hip, golden, fmt):
+    """src/graphics/svo.rs:402-449 through vx_raycast."""
+    g = golden["picker_raycast"]
+    scene, world = oracle_scene(golden, fmt, [0, 0, 0], g["blocks"], compact=g["compact_chunk"])
+    svo = gpu_svo(hip, golden, fmt, world)
+    tasks = np.zeros(len(g["rays"]), dtype=hip.PICKER_TASK_DTYPE)
+    for i, r in enumerate(g["rays"]):
+        tasks[i]["max_dst"], tasks[i]["pos"], tasks[i]["dir"] = r["max_dst"], r["pos"], r["dir"]
+    out = svo.raycast(tasks)
+    for got, exp in zip(out, g["expected"]):
+        assert abs(float(got["dst"]) - exp["dst"]) < g["tol"]
+        assert bool(got["inside_voxel"]) == exp["inside_voxel"]
+        np.testing.assert_allclose(got["pos"], exp["pos"], rtol=0, atol=g["tol"])
+        np.testing.assert_array_equal(got["normal"], np.asarray(exp["normal"], dtype=np.float32))
+    assert out.tobytes() == scene.picker(tasks.view(orc.PICKER_TASK_DTYPE)).tobytes()
+
+
+# ---- seeded random worlds: picker rays, GPU vs oracle, bit-exact ---------------------------------------------------
+
+
+def random_chunk_blocks(rng, n, ids):
+    pts = rng.integers(0, 32, size=(n, 3))
+    return [[int(x), int(y), int(z), int(rng.choice(ids))] for x, y, z in pts]
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("seed,svo_pos,n_blocks", [(1, (0, 0, 0), 40), (2, (1, 0, 1), 600), (3, (3, 2, 1), 6000), (4, (0, 0, 0), 0)])
+def test_random_world_picker_rays(hip, golden, fmt, seed, svo_pos, n_blocks):
+    rng = np.random.default_rng(seed)
+    blocks = random_chunk_blocks(rng, n_blocks, [1, 2, 3, 4])
+    if n_blocks == 0:
+        blocks = [[5, 5, 5, 1]]  # an (almost) empty world: nearly every ray misses
+    scene, world = oracle_scene(golden, fmt, svo_pos, blocks)
+    svo = gpu_svo(hip, golden, fmt, world)
+    n = 4096
+    size = float(1 << world.depth)
+    tasks = np.zeros(n, dtype=hip.PICKER_TASK_DTYPE)
+    origin = rng.uniform(-8.0, size + 8.0, size=(n, 3)).astype(np.float32)
+    target = (np.asarray(svo_pos, dtype=np.float32) * 32 + rng.uniform(0, 32, size=(n, 3))).astype(np.float32)
+    d = target - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::17] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, size=len(d[::17]))] * rng.choice([-1.0, 1.0], size=(len(d[::17]), 1))  # axis-aligned rays (zero components)
+    tasks["pos"], tasks["dir"] = origin, d.astype(np.float32)
+    tasks["max_dst"] = np.where(rng.random(n) < 0.3, rng.uniform(1, 40, size=n), -1.0).astype(np.float32)
+    got = svo.raycast(tasks)
+    exp = scene.picker(tasks.view(orc.PICKER_TASK_DTYPE), threads=4)
+    assert got.tobytes() == exp.tobytes()
+    assert (exp["dst"] > 0).sum() > (0 if n_blocks == 0 else n // 20)
+
+
+# ---- full frames: shading, shadows, translucency, trilinear sampling -------------------------------------------------
+
+
+def compare_frames(img, hits, cimg, chits):
+    for k in ("t", "pos", "uv", "lod", "shadow_t"):
+        assert same_bits(hits[k], chits[k]), k
+    for k in ("value", "face_id", "flags", "steps"):
+        assert np.array_equal(hits[k], chits[k]), k
+    nan_g, nan_c = np.isnan(img), np.isnan(cimg)
+    assert np.array_equal(nan_g, nan_c)  # sky colour is NaN where acos' argument exceeds 1 (world.glsl:98), on both sides
+    diff = np.abs(np.where(nan_g, 0, img) - np.where(nan_c, 0, cimg))
+    assert diff.max() <= COLOR_TOL, diff.max()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("depth,size", [(7, (160, 96)), (9, (320, 180))])
+def test_heightfield_frame(hip, fmt, depth, size):
+    from voxel_rs_amd import scenes
+
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(depth, threads=4)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+    assert svo.get_stats()["depth"] == depth
+    w, h = size
+    for shadows, sd in ((True, 500.0), (False, 500.0), (True, 40.0)):
+        u = scenes.bench_camera(depth, st["h_max"], w, h, shadow_distance=sd, render_shadows=shadows)
+        img, hits = svo.render(u, w, h, want_hits=True)
+        cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
+        compare_frames(img, hits, cimg, chits)
+        assert (hits["flags"] & 1).mean() > 0.2
+        img2, _ = svo.render(u, w, h, want_hits=False)  # the kernel variant without hit records
+        assert img2.tobytes() == img.tobytes()
+        # instrumented variant counts exactly what the oracle counts
+        oc = orc.Counters()
+        scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h, want_hits=False, counters=oc)
+        gc = svo.render_counters(u, w, h)
+        for k, v in oc.as_dict().items():
+            assert gc[k] == v, (k, gc[k], v)
+        assert gc["pixels"] == w * h
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_translucent_blocks_frame(hip, fmt):
+    """Glass panes and leaves in front of terrain: the adjacency/translucency rule (svo.esvo.glsl:241-265) in a frame,
+    a highlighted voxel (world.glsl:37-45) and a camera inside the domain looking at nearby geometry (NEAREST sampling)."""
+    from voxel_rs_amd import scenes
+
+    chunk = vra.Chunk(0, 0, 0, 5)
+    for x in range(32):
+        for z in range(32):
+            chunk.set_block(x, 0, z, 3 if (x + z) % 3 else 7)
+    for x in range(4, 28):
+        for y in range(1, 9):
+            chunk.set_block(x, y, 10, 5)   # glass wall
+            chunk.set_block(x, y, 11, 5)   # second identical layer: skipped as "not first of its kind"
+            chunk.set_block(x, y, 14, 10)  # leaves
+    for y in range(1, 12):
+        chunk.set_block(16, y, 20, 9)
+    chunk.compact()
+    world = vra.World(SVO_TYPES[fmt])
+    world.set_chunk((0, 0, 0), chunk)
+    world.serialize()
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    svo = hip.Svo(SVO_TYPES[fmt], 4 << 20)
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+    w, h = 256, 160
+    u = scenes.render_params_to_uniforms((16.0, 6.0, -6.0), (0.0, -0.1, 1.0), (0.0, 1.0, 0.0), np.radians(72.0), w / h, selected_voxel=(10.0, 3.0, 10.0))
+    img, hits = svo.render(u, w, h, want_hits=True)
+    cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
+    compare_frames(img, hits, cimg, chits)
+    assert (hits["flags"] & 8).any(), "highlight outline not exercised"
+    assert (hits["value"] == 9).any() and (hits["value"] == 5).any()
+
+
+# ---- incremental update, tile sharding, error behaviour ------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_incremental_update_ranges(hip, golden, fmt):
+    """Svo::update with dirty ranges only (svo.rs:171-189): add a second chunk, re-commit, compare with a fresh oracle."""
+    c0 = vra.Chunk(0, 0, 0, 5)
+    c0.apply_blocks([dict(box=[[0, 32], [0, 2], [0, 32]], id=1)])
+    c0.compact()
+    world = vra.World(SVO_TYPES[fmt])
+    world.set_chunk((0, 0, 0), c0)
+    world.serialize()
+    svo = gpu_svo(hip, golden, fmt, world)
+    c1 = vra.Chunk(1, 0, 0, 5)
+    c1.apply_blocks([dict(box=[[0, 32], [0, 6], [0, 32]], id=2)])
+    c1.compact()
+    world.set_chunk((1, 0, 0), c1)
+    world.serialize()
+    ranges = world.updated_ranges()
+    assert ranges and sum(n for _, n in ranges) < world.size_in_bytes + 1
+    svo.update(world)
+    tex, mips = golden_textures(golden)
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), golden_materials(golden), tex, mips)
+    rng = np.random.default_rng(7)
+    n = 2048
+    tasks = np.zeros(n, dtype=hip.PICKER_TASK_DTYPE)
+    tasks["pos"] = rng.uniform(0, 64, size=(n, 3)).astype(np.float32) * np.float32([1, 0.3, 0.5]) + np.float32([0, 8, 0])
+    tasks["dir"] = np.float32([0, -1, 0])
+    tasks["max_dst"] = -1.0
+    got = svo.raycast(tasks)
+    assert got.tobytes() == scene.picker(tasks.view(orc.PICKER_TASK_DTYPE)).tobytes()
+    top = got["pos"][:, 1][got["dst"] > 0]
+    assert set(np.round(top).astype(int)) == {2, 6}
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_tile_sharded_render_matches_full(hip, fmt):
+    import ctypes as C
+
+    import torch
+    from voxel_rs_amd import scenes
+
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(8, threads=4)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+    w, h = 200, 120  # not a multiple of the 32-pixel tile
+    u = scenes.bench_camera(8, st["h_max"], w, h)
+    full, _ = svo.render(u, w, h)
+    count = 3
+    per = max(hip.local_tile_count(w, h, r, count) for r in range(count))
+    gathered = torch.zeros((count, per, 32, 32, 4), dtype=torch.float32, device="cuda")
+    for r in range(count):
+        svo.render_device(u, w, h, gathered[r].data_ptr(), tile_rank=r, tile_count=count)
+    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    svo.assemble_tiles(gathered.data_ptr(), per * 32 * 32 * 4, count, w, h, out.data_ptr())
+    svo.sync()
+    got = out.cpu().numpy()
+    assert got.tobytes() == full.tobytes()
+    # the host-memory flavour of a sharded render returns the same compact tile list
+    tiles, _ = svo.render(u, w, h, tile_rank=1, tile_count=count)
+    assert tiles.tobytes() == gathered[1, : tiles.shape[0]].cpu().numpy().tobytes()
+    del C
+
+
+def test_error_behaviour(hip):
+    """No panics across the ABI: capacity overflow and misuse come back as error codes (svo.rs panics, esvo.rs:328 asserts)."""
+    svo = hip.Svo(1, 1 << 16)
+    with pytest.raises(hip.VoxelHipError, match="no SVO committed"):
+        svo.render(hip.make_uniforms(np.eye(4, dtype=np.float32).ravel(), 1.0, 1.0, 0.3, (0, -1, 0), (0, 0, 0), 0, 1.0), 8, 8)
+    r = (hip.Range * 1)()
+    r[0].start, r[0].length = 1 << 15, 1 << 16
+    rc = hip.lib().vx_commit(svo._h, 6, r, 1, 0)
+    assert rc == 4 and b"not large enough" in hip.lib().vx_last_error()
+    with pytest.raises(hip.VoxelHipError):
+        hip.Svo(3, 1 << 16)

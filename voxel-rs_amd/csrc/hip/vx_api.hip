@@ -1,0 +1,662 @@
+// libvoxelhip.so: kernels and the host runtime behind include/voxel_hip.h.
+//
+// Replaces the OpenGL side of the reference's graphics::Svo (src/graphics/svo.rs:56-256): persistently mapped
+// SSBO -> pinned staging + hipMalloc'd world buffer with range uploads; glDispatchCompute(world.glsl) ->
+// render kernel; glDispatchCompute(picker.glsl) -> picker kernel; glFenceSync/glClientWaitSync -> HIP events.
+// There is no CPU path: without a HIP device every entry point fails with VX_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "voxel_hip.h"
+#include "vx_device.hpp"
+
+using namespace vxd;
+
+// =================================================================================================================
+// kernels
+// =================================================================================================================
+
+namespace {
+
+constexpr uint32_t kTile = 32;         // multi-GPU sharding unit (pixels per edge)
+constexpr uint32_t kBlockEdge = 16;    // one 256-thread workgroup shades 16x16 pixels: 4 waves x (8x8)
+constexpr uint32_t kBlockThreads = 256;
+
+__device__ __forceinline__ Stack make_stack(unsigned char* smem, uint32_t levels, uint32_t threads, uint32_t tid) {
+    Stack st;
+    st.ptr = reinterpret_cast<uint32_t*>(smem);
+    st.t_max = reinterpret_cast<float*>(smem + size_t(levels) * threads * 4);
+    st.aux = smem + size_t(levels) * threads * 8;
+    st.stride = threads;
+    st.tid = tid;
+    st.levels = levels;
+    return st;
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2). Remap so that each XCD shades a
+// contiguous run of screen blocks and its L2 keeps that region's octree nodes (speed only, never correctness).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    constexpr uint32_t X = 8;
+    const uint32_t per = n / X, rem = n % X;
+    const uint32_t xcd = b % X, slot = b / X;
+    // XCDs [0, rem) own per+1 blocks, the rest own per
+    const uint32_t start = xcd * per + (xcd < rem ? xcd : rem);
+    return start + slot;
+}
+
+// morton decode of the low 6 bits into (x, y) in [0,8)
+__device__ __forceinline__ void lane_to_xy(uint32_t lane, uint32_t& x, uint32_t& y) {
+    x = (lane & 1u) | ((lane >> 1) & 2u) | ((lane >> 2) & 4u);
+    y = ((lane >> 1) & 1u) | ((lane >> 2) & 2u) | ((lane >> 3) & 4u);
+}
+
+template <int SVO, bool HITS, bool STATS>
+__global__ __launch_bounds__(kBlockThreads) void render_kernel(DevScene sc, RenderParams p, float4* __restrict__ out, vx_hit* __restrict__ hits,
+                                                               unsigned long long* __restrict__ counters, uint32_t levels) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const Stack st = make_stack(smem, levels, kBlockThreads, tid);
+
+    // block -> (local tile, 16x16 sub-block) -> pixel
+    const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t local_tile = b >> 2, sub = b & 3u;
+    const uint32_t tile = local_tile * p.tile_count + p.tile_rank;
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    uint32_t lx, ly;
+    lane_to_xy(lane, lx, ly);
+    const uint32_t in_x = (sub & 1u) * kBlockEdge + (wave & 1u) * 8 + lx;  // position inside the 32x32 tile
+    const uint32_t in_y = (sub >> 1) * kBlockEdge + (wave >> 1) * 8 + ly;
+    const uint32_t x = tx * kTile + in_x, y = ty * kTile + in_y;
+    const bool active = tile < p.tiles_x * p.tiles_y && x < p.width && y < p.height;
+
+    Counters ctr = {};
+    uint32_t lit = 0, shadow_rays = 0;
+    if (active) {
+        float color[4];
+        vx_hit rec;
+        shade_pixel<SVO, STATS>(sc, p, x, y, st, color, HITS ? &rec : nullptr, STATS ? &ctr : nullptr, &lit, &shadow_rays);
+        const size_t index = p.tile_count > 1 ? size_t(local_tile) * (kTile * kTile) + in_y * kTile + in_x : size_t(y) * p.width + x;
+        if (out) out[index] = make_float4(color[0], color[1], color[2], color[3]);
+        if (HITS) hits[index] = rec;
+    }
+
+    if (STATS) {
+        uint32_t v[11] = {ctr.rays, ctr.iterations, ctr.pushes, ctr.leaf_tests, ctr.leaf_tests_trilinear, ctr.boundaries, ctr.csvo_header_bytes,
+                          ctr.csvo_pointer_bytes, active ? 1u : 0u, lit, shadow_rays};
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            unsigned long long s = v[k];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0 && s) atomicAdd(&counters[k], s);
+        }
+    }
+}
+
+template <int SVO>
+__global__ __launch_bounds__(64) void picker_kernel(DevScene sc, const vx_picker_task* __restrict__ tasks, uint32_t n,
+                                                    vx_picker_result* __restrict__ results, uint32_t levels) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Stack st = make_stack(smem, levels, 64, threadIdx.x);
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    // picker.glsl:30-51
+    const vx_picker_task task = tasks[i];
+    Result res;
+    uint32_t steps = 0, nf = 0;
+    intersect<SVO, false, false>(sc, task.pos, task.dir, task.max_dst, false, st, res, steps, nullptr, 0, nf, nullptr);
+    vx_picker_result r;
+    memset(&r, 0, sizeof r);
+    if (res.t > 0.0f) {
+        r.dst = res.t;
+        r.inside_voxel = res.inside_voxel ? 1u : 0u;
+        r.pos[0] = res.pos[0]; r.pos[1] = res.pos[1]; r.pos[2] = res.pos[2];
+        r.normal[0] = kFaceNormals[res.face_id][0]; r.normal[1] = kFaceNormals[res.face_id][1]; r.normal[2] = kFaceNormals[res.face_id][2];
+    } else {
+        r.dst = -1.0f;
+    }
+    results[i] = r;
+}
+
+struct TraceArgs {
+    float pos[3], dir[3];
+    float max_dst;
+    int cast_translucent;
+};
+
+template <int SVO>
+__global__ __launch_bounds__(64) void trace_kernel(DevScene sc, TraceArgs a, vx_result* __restrict__ result, vx_frame* __restrict__ frames,
+                                                   uint32_t max_frames, uint32_t* __restrict__ n_frames, uint32_t levels) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Stack st = make_stack(smem, levels, 64, threadIdx.x);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Result res;
+    uint32_t steps = 0, nf = 0;
+    intersect<SVO, true, false>(sc, a.pos, a.dir, a.max_dst, a.cast_translucent != 0, st, res, steps, frames, max_frames, nf, nullptr);
+    vx_result r;
+    r.t = res.t; r.value = res.value; r.face_id = res.face_id;
+    r.pos[0] = res.pos[0]; r.pos[1] = res.pos[1]; r.pos[2] = res.pos[2];
+    r.uv[0] = res.uv[0]; r.uv[1] = res.uv[1];
+    r.color[0] = res.color[0]; r.color[1] = res.color[1]; r.color[2] = res.color[2]; r.color[3] = res.color[3];
+    r.lod = res.lod;
+    r.inside_voxel = res.inside_voxel ? 1 : 0;
+    *result = r;
+    *n_frames = nf;
+}
+
+// scatter gathered compact tile lists back into a row-major image (one thread per pixel, float4 stores)
+__global__ __launch_bounds__(256) void assemble_kernel(const float4* __restrict__ tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width,
+                                                       uint32_t height, uint32_t tiles_x, float4* __restrict__ out) {
+    const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15u), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= width || y >= height) return;
+    const uint32_t tile = (y / kTile) * tiles_x + (x / kTile);
+    const uint32_t rank = tile % tile_count, local = tile / tile_count;
+    out[size_t(y) * width + x] = tiles[rank * stride_px + size_t(local) * (kTile * kTile) + (y % kTile) * kTile + (x % kTile)];
+}
+
+}  // namespace
+
+// =================================================================================================================
+// host runtime
+// =================================================================================================================
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(call)                                                                                              \
+    do {                                                                                                           \
+        hipError_t e_ = (call);                                                                                    \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? VX_ERR_OUT_OF_MEMORY : VX_ERR_HIP,           \
+                                          std::string(#call) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+struct ProfiledLaunch {
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct vx_context {
+    int svo_type = 0;
+    int device = 0;
+    size_t capacity = 0;
+    uint8_t* staging = nullptr;   // pinned host mirror of the world buffer
+    uint8_t* d_world = nullptr;
+    hipStream_t stream = nullptr;         // render / raycast launches
+    hipStream_t upload_stream = nullptr;  // range uploads
+    hipEvent_t upload_done = nullptr, render_done = nullptr;
+    bool committed = false, render_recorded = false;
+    vx_stats stats = {};
+
+    vx_material* d_materials = nullptr;
+    uint32_t n_materials = 0;
+    uint8_t* d_tex = nullptr;
+    DevTextures tex = {};
+
+    // scratch
+    float* d_image = nullptr;  size_t d_image_bytes = 0;
+    vx_hit* d_hits = nullptr;  size_t d_hits_bytes = 0;
+    vx_picker_task* d_tasks = nullptr;  vx_picker_result* d_results = nullptr;  uint32_t picker_cap = 0;
+    vx_result* d_trace_result = nullptr;  vx_frame* d_trace_frames = nullptr;  uint32_t* d_trace_count = nullptr;  uint32_t trace_cap = 0;
+    unsigned long long* d_counters = nullptr;
+
+    bool profile = false;
+    std::vector<ProfiledLaunch> launches;
+    std::vector<ProfiledLaunch> event_pool;
+};
+
+namespace {
+
+uint32_t header_bytes(const vx_context* c) { return c->svo_type == VX_SVO_ESVO ? 20u : 4u; }
+
+// slots a ray's stack can need: one per level above the leaves, +1 spare; clamped into the algorithm's range
+uint32_t stack_levels(const vx_context* c) {
+    uint32_t l = c->stats.depth + 1;
+    if (l < 2) l = 2;
+    if (l > uint32_t(kMaxScale)) l = kMaxScale;
+    return l;
+}
+
+DevScene scene_of(const vx_context* c) {
+    DevScene s;
+    s.world = c->d_world;
+    s.world_bytes = c->capacity;
+    s.materials = c->d_materials;
+    s.n_materials = c->n_materials;
+    s.tex = c->tex;
+    return s;
+}
+
+int ensure(void** p, size_t* have, size_t need) {
+    if (*have >= need && *p) return VX_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(p, need));
+    *have = need;
+    return VX_OK;
+}
+
+int check_ready(vx_context* ctx) {
+    if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->committed) return fail(VX_ERR_STATE, "no SVO committed yet (call vx_commit / vx_commit_all first)");
+    return VX_OK;
+}
+
+template <bool HITS, bool STATS>
+int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hits, unsigned long long* counters) {
+    const uint32_t levels = stack_levels(ctx);
+    const size_t lds = size_t(levels) * kBlockThreads * 9;
+    const dim3 grid(p.n_local_tiles * 4), block(kBlockThreads);
+    if (grid.x == 0) return VX_OK;
+    const DevScene sc = scene_of(ctx);
+
+    ProfiledLaunch ev{};
+    if (ctx->profile) {
+        if (!ctx->event_pool.empty()) {
+            ev = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(&ev.start));
+            HIP_TRY(hipEventCreate(&ev.stop));
+        }
+        HIP_TRY(hipEventRecord(ev.start, ctx->stream));
+    }
+    if (ctx->svo_type == VX_SVO_ESVO)
+        hipLaunchKernelGGL((render_kernel<VX_SVO_ESVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters, levels);
+    else
+        hipLaunchKernelGGL((render_kernel<VX_SVO_CSVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters, levels);
+    HIP_TRY(hipGetLastError());
+    if (ctx->profile) {
+        HIP_TRY(hipEventRecord(ev.stop, ctx->stream));
+        ctx->launches.push_back(ev);
+    }
+    HIP_TRY(hipEventRecord(ctx->render_done, ctx->stream));
+    ctx->render_recorded = true;
+    return VX_OK;
+}
+
+int fill_params(const vx_uniforms* u, uint32_t w, uint32_t h, uint32_t tile_rank, uint32_t tile_count, RenderParams& p) {
+    if (!u || w == 0 || h == 0) return fail(VX_ERR_INVALID_ARGUMENT, "bad uniforms or size");
+    if (tile_count == 0) tile_count = 1;
+    if (tile_rank >= tile_count) return fail(VX_ERR_INVALID_ARGUMENT, "tile_rank >= tile_count");
+    p.u = *u;
+    p.tan_half_fovy = tanf(u->fovy * 0.5f);
+    p.width = w;
+    p.height = h;
+    p.tiles_x = (w + kTile - 1) / kTile;
+    p.tiles_y = (h + kTile - 1) / kTile;
+    p.tile_rank = tile_rank;
+    p.tile_count = tile_count;
+    p.n_local_tiles = vx_local_tile_count(w, h, tile_rank, tile_count);
+    return VX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vx_last_error(void) { return g_last_error.c_str(); }
+const char* vx_version(void) { return "voxel-hip 0.1 (gfx950)"; }
+
+uint32_t vx_local_tile_count(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count) {
+    if (tile_count == 0) tile_count = 1;
+    const uint32_t total = ((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile);
+    if (tile_rank >= tile_count) return 0;
+    return (total - tile_rank + tile_count - 1) / tile_count;
+}
+
+int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out) {
+    if (!out) return fail(VX_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO) return fail(VX_ERR_INVALID_ARGUMENT, "svo_type must be VX_SVO_ESVO or VX_SVO_CSVO");
+    if (capacity_bytes < 64) return fail(VX_ERR_INVALID_ARGUMENT, "capacity_bytes too small");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(VX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(VX_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    vx_context* c = new (std::nothrow) vx_context();
+    if (!c) return fail(VX_ERR_OUT_OF_MEMORY, "context allocation failed");
+    c->svo_type = svo_type;
+    c->device = device;
+    c->capacity = (capacity_bytes + 15) & ~size_t(15);
+    c->stats.capacity_bytes = capacity_bytes;
+    auto cleanup = [&](int code) {
+        vx_destroy(c);
+        return code;
+    };
+#define CREATE_TRY(call)                                                                                                   \
+    do {                                                                                                                   \
+        hipError_t e_ = (call);                                                                                            \
+        if (e_ != hipSuccess) {                                                                                            \
+            g_last_error = std::string(#call) + ": " + hipGetErrorString(e_);                                              \
+            return cleanup(e_ == hipErrorOutOfMemory ? VX_ERR_OUT_OF_MEMORY : VX_ERR_HIP);                                 \
+        }                                                                                                                  \
+    } while (0)
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->staging), c->capacity, hipHostMallocDefault));
+    std::memset(c->staging, 0, c->capacity);
+    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_world), c->capacity));
+    CREATE_TRY(hipMemset(c->d_world, 0, c->capacity));
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&c->render_done, hipEventDisableTiming));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
+    // one all-zero material and a 1x1 transparent-black texture so that rendering works before any registry is set
+    const vx_material zero_mat = {0, 0, -1, -1, -1, -1, -1, -1};
+    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_materials), sizeof zero_mat));
+    CREATE_TRY(hipMemcpy(c->d_materials, &zero_mat, sizeof zero_mat, hipMemcpyHostToDevice));
+    c->n_materials = 1;
+#undef CREATE_TRY
+    *out = c;
+    return VX_OK;
+}
+
+void vx_destroy(vx_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->upload_stream) (void)hipStreamSynchronize(c->upload_stream);
+    for (auto& l : c->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
+    for (auto& l : c->event_pool) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
+    if (c->staging) (void)hipHostFree(c->staging);
+    void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_image, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
+                   c->d_trace_count, c->d_counters};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    if (c->upload_done) (void)hipEventDestroy(c->upload_done);
+    if (c->render_done) (void)hipEventDestroy(c->render_done);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
+    delete c;
+}
+
+int vx_set_materials(vx_context* ctx, const vx_material* rows, uint32_t count) {
+    if (!ctx || !rows || count == 0) return fail(VX_ERR_INVALID_ARGUMENT, "materials: null or empty");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_materials) (void)hipFree(ctx->d_materials);
+    ctx->d_materials = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_materials), size_t(count) * sizeof(vx_material)));
+    HIP_TRY(hipMemcpy(ctx->d_materials, rows, size_t(count) * sizeof(vx_material), hipMemcpyHostToDevice));
+    ctx->n_materials = count;
+    return VX_OK;
+}
+
+int vx_set_textures(vx_context* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t layers, uint32_t mip_levels) {
+    if (!ctx || !rgba8 || !width || !height || !layers) return fail(VX_ERR_INVALID_ARGUMENT, "textures: null or empty");
+    HIP_TRY(hipSetDevice(ctx->device));
+    // mip_levels = min(requested, ilog2(min(w, h))), never below 1 (texture_array.rs:108, :193)
+    uint32_t m = width < height ? width : height, lg = 0;
+    while (m >>= 1) ++lg;
+    uint32_t levels = mip_levels < lg ? mip_levels : lg;
+    if (levels < 1) levels = 1;
+    if (levels > 16) levels = 16;
+
+    DevTextures t = {};
+    t.width = width; t.height = height; t.layers = layers; t.levels = levels;
+    size_t total = 0;
+    for (uint32_t l = 0; l < levels; ++l) {
+        const uint32_t w = (width >> l) ? (width >> l) : 1, h = (height >> l) ? (height >> l) : 1;
+        t.level_offset[l] = uint32_t(total);
+        total += size_t(layers) * w * h * 4;
+    }
+    std::vector<uint8_t> chain(total);
+    std::memcpy(chain.data(), rgba8, size_t(layers) * width * height * 4);
+    // glGenerateMipmap (texture_array.rs:259): 2x2 box filter, each level from the previous one
+    for (uint32_t l = 1; l < levels; ++l) {
+        const uint32_t sw = (width >> (l - 1)) ? (width >> (l - 1)) : 1, sh = (height >> (l - 1)) ? (height >> (l - 1)) : 1;
+        const uint32_t dw = (width >> l) ? (width >> l) : 1, dh = (height >> l) ? (height >> l) : 1;
+        const uint8_t* src = chain.data() + t.level_offset[l - 1];
+        uint8_t* dst = chain.data() + t.level_offset[l];
+        for (uint32_t layer = 0; layer < layers; ++layer)
+            for (uint32_t y = 0; y < dh; ++y)
+                for (uint32_t x = 0; x < dw; ++x) {
+                    const uint32_t xa = 2 * x, xb = xa + 1 < sw ? xa + 1 : sw - 1, ya = 2 * y, yb = ya + 1 < sh ? ya + 1 : sh - 1;
+                    const uint8_t* s = src + size_t(layer) * sw * sh * 4;
+                    for (uint32_t ch = 0; ch < 4; ++ch) {
+                        const uint32_t sum = s[(size_t(ya) * sw + xa) * 4 + ch] + s[(size_t(ya) * sw + xb) * 4 + ch] + s[(size_t(yb) * sw + xa) * 4 + ch] +
+                                             s[(size_t(yb) * sw + xb) * 4 + ch];
+                        dst[((size_t(layer) * dh + y) * dw + x) * 4 + ch] = uint8_t((sum + 2) / 4);
+                    }
+                }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_tex) (void)hipFree(ctx->d_tex);
+    ctx->d_tex = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_tex), total));
+    HIP_TRY(hipMemcpy(ctx->d_tex, chain.data(), total, hipMemcpyHostToDevice));
+    t.base = ctx->d_tex;
+    ctx->tex = t;
+    return VX_OK;
+}
+
+uint8_t* vx_staging_ptr(vx_context* ctx) { return ctx ? ctx->staging : nullptr; }
+size_t vx_capacity(const vx_context* ctx) { return ctx ? size_t(ctx->stats.capacity_bytes) : 0; }
+
+int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes) {
+    if (!ctx || (count && !ranges)) return fail(VX_ERR_INVALID_ARGUMENT, "commit: null argument");
+    if (depth > uint32_t(kMaxScale)) return fail(VX_ERR_INVALID_ARGUMENT, "depth exceeds the traversal's 23-level limit (svo.esvo.glsl:21)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t head = 4 + header_bytes(ctx);
+    for (uint32_t i = 0; i < count; ++i)
+        if (ranges[i].start + ranges[i].length > ctx->stats.capacity_bytes - head || ranges[i].start + ranges[i].length < ranges[i].start)
+            return fail(VX_ERR_CAPACITY, "dst is not large enough: a dirty range exceeds the world buffer");
+
+    // octree_scale = 2^-depth as f32 at byte 0 (svo.rs:173-175)
+    const float scale = std::exp2(-float(depth));
+    std::memcpy(ctx->staging, &scale, 4);
+
+    // render_fence.wait() (svo.rs:178): do not overwrite nodes a frame in flight is still traversing
+    if (ctx->render_recorded) HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, ctx->render_done, 0));
+    HIP_TRY(hipMemcpyAsync(ctx->d_world, ctx->staging, head, hipMemcpyHostToDevice, ctx->upload_stream));
+    for (uint32_t i = 0; i < count; ++i) {
+        if (!ranges[i].length) continue;
+        const uint64_t off = head + ranges[i].start;
+        HIP_TRY(hipMemcpyAsync(ctx->d_world + off, ctx->staging + off, ranges[i].length, hipMemcpyHostToDevice, ctx->upload_stream));
+    }
+    HIP_TRY(hipEventRecord(ctx->upload_done, ctx->upload_stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_done, 0));
+    // the caller may rewrite the staging mirror as soon as we return: wait for the copies to have read it
+    HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+
+    ctx->stats.depth = depth;
+    ctx->stats.used_bytes = used_bytes;
+    ctx->committed = true;
+    return VX_OK;
+}
+
+int vx_commit_all(vx_context* ctx, uint32_t depth, uint64_t used_bytes) {
+    const vx_range all = {0, used_bytes};
+    return vx_commit(ctx, depth, &all, 1, used_bytes);
+}
+
+int vx_get_stats(const vx_context* ctx, vx_stats* out) {
+    if (!ctx || !out) return fail(VX_ERR_INVALID_ARGUMENT, "stats: null argument");
+    *out = ctx->stats;
+    return VX_OK;
+}
+
+int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, const vx_target* target) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!target || !target->rgba32f) return fail(VX_ERR_INVALID_ARGUMENT, "render: null target");
+    RenderParams p;
+    if (int rc = fill_params(uniforms, width, height, target->tile_rank, target->tile_count, p)) return rc;
+    const size_t pixels = p.tile_count > 1 ? size_t(p.n_local_tiles) * kTile * kTile : size_t(width) * height;
+
+    float* out = static_cast<float*>(target->rgba32f);
+    vx_hit* hits = target->hits;
+    if (target->memory == VX_MEM_HOST) {
+        if (int rc = ensure(reinterpret_cast<void**>(&ctx->d_image), &ctx->d_image_bytes, pixels * 16)) return rc;
+        out = ctx->d_image;
+        if (hits) {
+            if (int rc = ensure(reinterpret_cast<void**>(&ctx->d_hits), &ctx->d_hits_bytes, pixels * sizeof(vx_hit))) return rc;
+            hits = ctx->d_hits;
+        }
+    }
+    const int rc = hits ? launch_render<true, false>(ctx, p, out, hits, nullptr) : launch_render<false, false>(ctx, p, out, nullptr, nullptr);
+    if (rc) return rc;
+    if (target->memory == VX_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(target->rgba32f, ctx->d_image, pixels * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (target->hits) HIP_TRY(hipMemcpyAsync(target->hits, ctx->d_hits, pixels * sizeof(vx_hit), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return VX_OK;
+}
+
+int vx_render_counters(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count,
+                       vx_counters* out) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!out) return fail(VX_ERR_INVALID_ARGUMENT, "counters: null output");
+    RenderParams p;
+    if (int rc = fill_params(uniforms, width, height, tile_rank, tile_count, p)) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    const bool was = ctx->profile;
+    ctx->profile = false;
+    const int rc = launch_render<false, true>(ctx, p, nullptr, nullptr, ctx->d_counters);
+    ctx->profile = was;
+    if (rc) return rc;
+    unsigned long long h[16];
+    HIP_TRY(hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    out->rays = h[0]; out->iterations = h[1]; out->pushes = h[2]; out->leaf_tests = h[3]; out->leaf_tests_trilinear = h[4];
+    out->boundaries = h[5]; out->csvo_header_bytes = h[6]; out->csvo_pointer_bytes = h[7];
+    out->pixels = h[8]; out->lit_pixels = h[9]; out->shadow_rays = h[10];
+    return VX_OK;
+}
+
+int vx_raycast(vx_context* ctx, const vx_picker_task* tasks, uint32_t count, vx_picker_result* results) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (count == 0) return VX_OK;
+    if (!tasks || !results) return fail(VX_ERR_INVALID_ARGUMENT, "raycast: null argument");
+    if (ctx->picker_cap < count) {
+        if (ctx->d_tasks) (void)hipFree(ctx->d_tasks);
+        if (ctx->d_results) (void)hipFree(ctx->d_results);
+        ctx->d_tasks = nullptr; ctx->d_results = nullptr; ctx->picker_cap = 0;
+        const uint32_t cap = count < 128 ? 128 : count;  // the reference sizes these for 100 tasks (svo.rs:138-139)
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_tasks), size_t(cap) * sizeof(vx_picker_task)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_results), size_t(cap) * sizeof(vx_picker_result)));
+        ctx->picker_cap = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->d_tasks, tasks, size_t(count) * sizeof(vx_picker_task), hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t levels = stack_levels(ctx);
+    const size_t lds = size_t(levels) * 64 * 9;
+    const DevScene sc = scene_of(ctx);
+    const dim3 grid((count + 63) / 64), block(64);
+    if (ctx->svo_type == VX_SVO_ESVO)
+        hipLaunchKernelGGL((picker_kernel<VX_SVO_ESVO>), grid, block, lds, ctx->stream, sc, ctx->d_tasks, count, ctx->d_results, levels);
+    else
+        hipLaunchKernelGGL((picker_kernel<VX_SVO_CSVO>), grid, block, lds, ctx->stream, sc, ctx->d_tasks, count, ctx->d_results, levels);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->render_done, ctx->stream));
+    ctx->render_recorded = true;
+    HIP_TRY(hipMemcpyAsync(results, ctx->d_results, size_t(count) * sizeof(vx_picker_result), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the reference blocks on its fence too (svo.rs:248-249)
+    return VX_OK;
+}
+
+int vx_debug_trace(vx_context* ctx, const float pos[3], const float dir[3], float max_dst, int cast_translucent, vx_result* result,
+                   vx_frame* frames, uint32_t max_frames, uint32_t* n_frames) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!pos || !dir || !result) return fail(VX_ERR_INVALID_ARGUMENT, "debug_trace: null argument");
+    if (max_frames > 1024) max_frames = 1024;
+    if (!frames) max_frames = 0;
+    if (!ctx->d_trace_result) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_trace_result), sizeof(vx_result)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_trace_count), sizeof(uint32_t)));
+    }
+    if (ctx->trace_cap < max_frames || !ctx->d_trace_frames) {
+        if (ctx->d_trace_frames) (void)hipFree(ctx->d_trace_frames);
+        ctx->d_trace_frames = nullptr;
+        const uint32_t cap = max_frames < 128 ? 128 : max_frames;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_trace_frames), size_t(cap) * sizeof(vx_frame)));
+        ctx->trace_cap = cap;
+    }
+    TraceArgs a;
+    std::memcpy(a.pos, pos, sizeof a.pos);
+    std::memcpy(a.dir, dir, sizeof a.dir);
+    a.max_dst = max_dst;
+    a.cast_translucent = cast_translucent;
+    const uint32_t levels = stack_levels(ctx);
+    const size_t lds = size_t(levels) * 64 * 9;
+    const DevScene sc = scene_of(ctx);
+    if (ctx->svo_type == VX_SVO_ESVO)
+        hipLaunchKernelGGL((trace_kernel<VX_SVO_ESVO>), dim3(1), dim3(64), lds, ctx->stream, sc, a, ctx->d_trace_result, ctx->d_trace_frames, max_frames,
+                           ctx->d_trace_count, levels);
+    else
+        hipLaunchKernelGGL((trace_kernel<VX_SVO_CSVO>), dim3(1), dim3(64), lds, ctx->stream, sc, a, ctx->d_trace_result, ctx->d_trace_frames, max_frames,
+                           ctx->d_trace_count, levels);
+    HIP_TRY(hipGetLastError());
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(result, ctx->d_trace_result, sizeof(vx_result), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&n, ctx->d_trace_count, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (frames && max_frames) {
+        const uint32_t k = n < max_frames ? n : max_frames;
+        if (k) HIP_TRY(hipMemcpy(frames, ctx->d_trace_frames, size_t(k) * sizeof(vx_frame), hipMemcpyDeviceToHost));
+    }
+    if (n_frames) *n_frames = n;
+    return VX_OK;
+}
+
+int vx_sync(vx_context* ctx) {
+    if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VX_OK;
+}
+
+int vx_assemble_tiles(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
+                      float* out_rgba32f) {
+    if (!ctx || !tiles || !out_rgba32f || !tile_count || !width || !height || (stride_floats & 3))
+        return fail(VX_ERR_INVALID_ARGUMENT, "assemble_tiles: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const dim3 grid((width + 15) / 16, (height + 15) / 16), block(256);
+    hipLaunchKernelGGL(assemble_kernel, grid, block, 0, ctx->stream, reinterpret_cast<const float4*>(tiles), stride_floats / 4, tile_count, width, height,
+                       (width + kTile - 1) / kTile, reinterpret_cast<float4*>(out_rgba32f));
+    HIP_TRY(hipGetLastError());
+    return VX_OK;
+}
+
+int vx_profile_enable(vx_context* ctx, int enabled) {
+    if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    ctx->profile = enabled != 0;
+    return VX_OK;
+}
+
+int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches) {
+    if (!ctx || !kernel_ms_sum || !launches) return fail(VX_ERR_INVALID_ARGUMENT, "profile_read: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double sum = 0.0;
+    for (auto& l : ctx->launches) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, l.start, l.stop));
+        sum += ms;
+        ctx->event_pool.push_back(l);
+    }
+    *kernel_ms_sum = sum;
+    *launches = uint32_t(ctx->launches.size());
+    ctx->launches.clear();
+    return VX_OK;
+}
+
+void* vx_stream(vx_context* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+int vx_device(const vx_context* ctx) { return ctx ? ctx->device : -1; }
+
+}  // extern "C"

@@ -1,0 +1,672 @@
+// Device-side ray path for gfx950: SVO traversal (ESVO and CSVO node formats), software texture sampler,
+// shading, sky. Written for wave64 / LDS-resident per-ray stacks; no MFMA (nothing here is a contraction).
+//
+// What it computes is the reference's GLSL (assets/shaders/svo.esvo.glsl:50-393, svo.csvo.glsl:151-509,
+// world.glsl:27-141, picker.glsl:30-51); how it computes it is not a translation: per-ray stacks live in LDS
+// in a [level][thread] layout (bank = lane, conflict-free at any mix of levels), the ESVO child descriptor is
+// kept in a register between PUSH/POP instead of being re-fetched every iteration, CSVO bytes are read with
+// single unaligned dword loads, divisions by powers of two are multiplications.
+//
+// Numerics contract (checked bit for bit against oracle/svo_oracle.c): fp32 only, no implicit contraction
+// (-ffp-contract=off); the plane-distance expressions use explicit fmaf exactly where the oracle does.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "voxel_hip.h"
+
+namespace vxd {
+
+constexpr int kMaxSteps = 1000;       // svo.esvo.glsl:18
+constexpr int kMaxScale = 23;         // svo.esvo.glsl:21
+constexpr float kEps = 1.1920929e-7f;  // exp2(-23), svo.esvo.glsl:24
+constexpr uint32_t kInvalidPtr = 0xffffffffu;
+
+struct DevTextures {
+    const uint8_t* base;      // mip chain, level l at base + level_offset[l], layout [layer][y][x][4]
+    uint32_t width, height, layers, levels;
+    uint32_t level_offset[16];
+};
+
+struct DevScene {
+    const uint8_t* world;     // device copy of the mapped world buffer, byte 0 = f32 octree_scale
+    uint64_t world_bytes;     // readable bytes (reads are clamped into it)
+    const vx_material* materials;
+    uint32_t n_materials;
+    DevTextures tex;
+};
+
+struct Result {
+    float t;
+    uint32_t value;
+    int face_id;
+    float pos[3];
+    float uv[2];
+    float color[4];
+    float lod;
+    bool inside_voxel;
+};
+
+struct Counters {  // per-thread, reduced by the instrumented kernel
+    uint32_t rays, iterations, pushes, leaf_tests, leaf_tests_trilinear, boundaries, csvo_header_bytes, csvo_pointer_bytes;
+};
+
+// Per-ray traversal stack in LDS, [level][thread]: every lane's slot for a level sits in its own bank.
+struct Stack {
+    uint32_t* ptr;   // octant / node pointer
+    float* t_max;
+    uint8_t* aux;    // ESVO: parent_octant_idx, CSVO: depth
+    uint32_t stride; // threads per block
+    uint32_t tid;
+    uint32_t levels; // allocated levels; deeper (corrupt) data is clamped into the last one instead of leaving LDS
+    __device__ __forceinline__ uint32_t slot(int scale) const {
+        uint32_t lv = uint32_t(kMaxScale - 1 - scale);
+        lv = lv < levels ? lv : levels - 1;
+        return lv * stride + tid;
+    }
+};
+
+__device__ __forceinline__ float gmin(float x, float y) { return y < x ? y : x; }  // GLSL min
+__device__ __forceinline__ float gmax(float x, float y) { return x < y ? y : x; }  // GLSL max
+__device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+__device__ __forceinline__ uint32_t low_bits(int n) { return n >= 32 ? 0xffffffffu : (n <= 0 ? 0u : ((1u << n) - 1u)); }
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float(uint32_t(e + 127) << 23); }
+__device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
+    const float t = gclamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+// ---- world buffer access --------------------------------------------------------------------------------
+
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+// ESVO: descriptors[] starts at byte 4 (svo.esvo.glsl:3-6)
+__device__ __forceinline__ uint32_t esvo_word(const DevScene& sc, uint32_t index) {
+    uint64_t off = 4ull + uint64_t(index) * 4ull;
+    const uint64_t last = sc.world_bytes - 4;
+    off = off > last ? last : off;
+    return *reinterpret_cast<const uint32_t*>(sc.world + off);
+}
+
+// CSVO: descriptors[] starts at byte 8 and is addressed in bytes (svo.csvo.glsl:1-5, 25-49)
+__device__ __forceinline__ uint32_t csvo_u32(const DevScene& sc, uint32_t byte_ptr) {
+    uint64_t off = 8ull + byte_ptr;
+    const uint64_t last = sc.world_bytes - 4;
+    off = off > last ? last : off;
+    return *reinterpret_cast<const u32_unaligned*>(sc.world + off);
+}
+__device__ __forceinline__ uint32_t csvo_u16(const DevScene& sc, uint32_t p) { return csvo_u32(sc, p) & 0xffffu; }
+__device__ __forceinline__ uint32_t csvo_u8(const DevScene& sc, uint32_t byte_ptr) {
+    uint64_t off = 8ull + byte_ptr;
+    const uint64_t last = sc.world_bytes - 1;
+    off = off > last ? last : off;
+    return sc.world[off];
+}
+
+// bytes taken by the pointer-table entries a 2-bit-per-child mask selects: tag 0,1,2,3 -> 0,1,2,4 bytes
+__device__ __forceinline__ uint32_t csvo_tag_bytes(uint32_t m) {
+    return __popc(m & 0x5555u) + 2u * __popc(m & 0xAAAAu) + __popc(m & (m >> 1) & 0x5555u);
+}
+
+// read_next_ptr (svo.csvo.glsl:53-116)
+__device__ __forceinline__ uint32_t csvo_next_ptr(const DevScene& sc, uint32_t ptr, uint32_t depth, uint32_t idx, bool& crossed,
+                                                  uint32_t& header_bytes, uint32_t& pointer_bytes) {
+    crossed = false;
+    if (depth > 3) {
+        header_bytes = 2;
+        const uint32_t header = csvo_u16(sc, ptr);
+        const uint32_t child = (header >> (idx * 2)) & 3u;
+        if (child == 0) return kInvalidPtr;
+        const uint32_t offset = csvo_tag_bytes(header & ((1u << (idx * 2)) - 1u));
+        const uint32_t ptr_bytes = csvo_tag_bytes(header);
+        uint32_t ptr_offset = csvo_u32(sc, ptr + 2 + offset);
+        ptr_offset &= low_bits(int(1u << (child - 1)) * 8);
+        pointer_bytes = (1u << child) >> 1;
+        if (ptr_offset & (1u << 31)) {
+            crossed = true;
+            return ptr_offset ^ (1u << 31);
+        }
+        return ptr + 2 + ptr_bytes + ptr_offset;
+    }
+    header_bytes = 1;
+    const uint32_t header = csvo_u8(sc, ptr);
+    if (((header >> idx) & 1u) == 0) return kInvalidPtr;
+    const uint32_t offset = __popc(header & ((1u << idx) - 1u));
+    if (depth == 3) {
+        pointer_bytes = 1;
+        return ptr + 1 + __popc(header) + csvo_u8(sc, ptr + 1 + offset);
+    }
+    pointer_bytes = 0;
+    return ptr + 3 + offset;
+}
+
+// read_leaf (svo.csvo.glsl:119-133)
+__device__ __forceinline__ uint32_t csvo_read_leaf(const DevScene& sc, uint32_t material_section_ptr, uint32_t pre_leaf_ptr, uint32_t ptr,
+                                                   uint32_t idx) {
+    const uint32_t material_section_offset = csvo_u16(sc, pre_leaf_ptr + 1);
+    const int leaf_index = int(ptr - (pre_leaf_ptr + 3));
+    const int bit_mark = leaf_index * 8 + int(idx);
+    const uint32_t v0 = csvo_u32(sc, pre_leaf_ptr + 3) & low_bits(bit_mark < 32 ? bit_mark : 32);
+    const uint32_t v1 = csvo_u32(sc, pre_leaf_ptr + 7) & low_bits(bit_mark - 32 > 0 ? bit_mark - 32 : 0);
+    const uint32_t preceding = __popc(v0) + __popc(v1);
+    return csvo_u32(sc, material_section_ptr + material_section_offset * 4 + preceding * 4);
+}
+
+__device__ __forceinline__ vx_material material_at(const DevScene& sc, uint32_t value) {
+    vx_material m;
+    if (value < sc.n_materials) {
+        // 32-byte rows: two 16-byte loads
+        const uint4* p = reinterpret_cast<const uint4*>(sc.materials + value);
+        const uint4 a = p[0], b = p[1];
+        m.specular_pow = __uint_as_float(a.x); m.specular_strength = __uint_as_float(a.y);
+        m.tex_top = int(a.z); m.tex_side = int(a.w); m.tex_bottom = int(b.x);
+        m.tex_top_normal = int(b.y); m.tex_side_normal = int(b.z); m.tex_bottom_normal = int(b.w);
+    } else {
+        m.specular_pow = m.specular_strength = 0.0f;
+        m.tex_top = m.tex_side = m.tex_bottom = m.tex_top_normal = m.tex_side_normal = m.tex_bottom_normal = 0;
+    }
+    return m;
+}
+
+// ---- software sampler: textureLod(sampler2DArray) with the state of texture_array.rs:200-203 ---------------
+//   MAG NEAREST, MIN LINEAR_MIPMAP_LINEAR, WRAP_S CLAMP_TO_EDGE, WRAP_T REPEAT (never set -> GL default)
+
+__device__ __forceinline__ void texel(const DevTextures& t, uint32_t level, uint32_t layer, int x, int y, float out[4]) {
+    uint32_t w = t.width >> level, h = t.height >> level;
+    w = w ? w : 1;
+    h = h ? h : 1;
+    x = x < 0 ? 0 : x;
+    x = x > int(w) - 1 ? int(w) - 1 : x;
+    y %= int(h);
+    y = y < 0 ? y + int(h) : y;
+    const uint32_t rgba = *reinterpret_cast<const uint32_t*>(t.base + t.level_offset[level] + ((size_t(layer) * h + uint32_t(y)) * w + uint32_t(x)) * 4);
+    out[0] = float(rgba & 0xffu) / 255.0f;
+    out[1] = float((rgba >> 8) & 0xffu) / 255.0f;
+    out[2] = float((rgba >> 16) & 0xffu) / 255.0f;
+    out[3] = float(rgba >> 24) / 255.0f;
+}
+
+__device__ __forceinline__ void sample_linear(const DevTextures& t, uint32_t level, uint32_t layer, float u, float v, float out[4]) {
+    uint32_t w = t.width >> level, h = t.height >> level;
+    w = w ? w : 1;
+    h = h ? h : 1;
+    const float x = u * float(w) - 0.5f, y = v * float(h) - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    const int i0 = int(fx), j0 = int(fy);
+    float c00[4], c10[4], c01[4], c11[4];
+    texel(t, level, layer, i0, j0, c00);
+    texel(t, level, layer, i0 + 1, j0, c10);
+    texel(t, level, layer, i0, j0 + 1, c01);
+    texel(t, level, layer, i0 + 1, j0 + 1, c11);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float lo = c00[k] * (1.0f - ax) + c10[k] * ax;
+        const float hi = c01[k] * (1.0f - ax) + c11[k] * ax;
+        out[k] = lo * (1.0f - ay) + hi * ay;
+    }
+}
+
+__device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float v, float layer_f, float lod, float rgba[4]) {
+    if (t.levels == 0 || t.layers == 0) {
+        rgba[0] = rgba[1] = rgba[2] = rgba[3] = 0.0f;
+        return;
+    }
+    const float lf = floorf(layer_f + 0.5f);
+    const uint32_t layer = lf <= 0.0f ? 0u : (lf >= float(t.layers - 1) ? t.layers - 1 : uint32_t(lf));
+    if (!(lod > 0.0f)) {  // magnification: NEAREST on the base level
+        uint32_t w = t.width, h = t.height;
+        texel(t, 0, layer, int(floorf(u * float(w))), int(floorf(v * float(h))), rgba);
+        return;
+    }
+    const float q = float(t.levels - 1);
+    const float lam = lod > q ? q : lod;
+    const float fl = floorf(lam);
+    const uint32_t d1 = uint32_t(fl);
+    const uint32_t d2 = d1 + 1 > t.levels - 1 ? t.levels - 1 : d1 + 1;
+    const float frac = lam - fl;
+    float a[4], b[4];
+    sample_linear(t, d1, layer, u, v, a);
+    sample_linear(t, d2, layer, u, v, b);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rgba[k] = a[k] * (1.0f - frac) + b[k] * frac;
+}
+
+// ---- intersect_octree ---------------------------------------------------------------------------------------
+
+template <int SVO, bool TRACE, bool STATS>
+__device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst, bool cast_translucent,
+                                          const Stack& st, Result& res, uint32_t& steps, vx_frame* frames, uint32_t max_frames,
+                                          uint32_t& n_frames, Counters* ctr) {
+    constexpr bool CSVO = SVO == VX_SVO_CSVO;
+    const float octree_scale = *reinterpret_cast<const float*>(sc.world);
+    const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 1/2^-d = 2^d, exact
+
+    if (STATS) ctr->rays++;
+
+    float rox = ro_in[0] * octree_scale, roy = ro_in[1] * octree_scale, roz = ro_in[2] * octree_scale;
+    max_dst *= octree_scale;
+
+    res.t = -1.0f;
+    res.value = 0;
+    res.face_id = 0;
+    res.pos[0] = res.pos[1] = res.pos[2] = 0.0f;
+    res.uv[0] = res.uv[1] = 0.0f;
+    res.color[0] = res.color[1] = res.color[2] = res.color[3] = 0.0f;
+    res.lod = 0.0f;
+    res.inside_voxel = false;
+
+    rox += 1.0f; roy += 1.0f; roz += 1.0f;
+
+    uint32_t ptr = CSVO ? *reinterpret_cast<const uint32_t*>(sc.world + 4) : 0u;
+    uint32_t parent_octant_idx = 0;
+    int scale = kMaxScale - 1;
+    float scale_exp2 = 0.5f;
+
+    uint32_t last_leaf_value = 0xffffffffu;
+    int adjacent_leaf_count = 0;
+
+    float rdx = rd_in[0], rdy = rd_in[1], rdz = rd_in[2];
+    const uint32_t eps_bits = __float_as_uint(kEps) & 0x7fffffffu;
+    if (fabsf(rdx) < kEps) rdx = __uint_as_float(eps_bits | (__float_as_uint(rdx) & 0x80000000u));
+    if (fabsf(rdy) < kEps) rdy = __uint_as_float(eps_bits | (__float_as_uint(rdy) & 0x80000000u));
+    if (fabsf(rdz) < kEps) rdz = __uint_as_float(eps_bits | (__float_as_uint(rdz) & 0x80000000u));
+
+    const float tcx = 1.0f / -fabsf(rdx), tcy = 1.0f / -fabsf(rdy), tcz = 1.0f / -fabsf(rdz);
+    float tbx = tcx * rox, tby = tcy * roy, tbz = tcz * roz;
+
+    int octant_mask = 0;
+    if (rdx > 0.0f) { octant_mask ^= 1; tbx = __builtin_fmaf(3.0f, tcx, -tbx); }
+    if (rdy > 0.0f) { octant_mask ^= 2; tby = __builtin_fmaf(3.0f, tcy, -tby); }
+    if (rdz > 0.0f) { octant_mask ^= 4; tbz = __builtin_fmaf(3.0f, tcz, -tbz); }
+
+    float t_min = gmax(gmax(__builtin_fmaf(2.0f, tcx, -tbx), __builtin_fmaf(2.0f, tcy, -tby)), __builtin_fmaf(2.0f, tcz, -tbz));
+    t_min = gmax(0.0f, t_min);
+    float t_max = gmin(gmin(tcx - tbx, tcy - tby), tcz - tbz);
+    float h = t_max;
+
+    int idx = 0;
+    float px = 1.0f, py = 1.0f, pz = 1.0f;
+    if (t_min < __builtin_fmaf(1.5f, tcx, -tbx)) { idx ^= 1; px = 1.5f; }
+    if (t_min < __builtin_fmaf(1.5f, tcy, -tby)) { idx ^= 2; py = 1.5f; }
+    if (t_min < __builtin_fmaf(1.5f, tcz, -tbz)) { idx ^= 4; pz = 1.5f; }
+
+    // CSVO state (svo.csvo.glsl:252-258)
+    uint32_t depth = 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu);
+    uint32_t material_section_ptr = kInvalidPtr;
+    uint32_t pre_leaf_pointer = kInvalidPtr;
+
+    // ESVO: the masks of the child being examined depend only on (ptr, parent_octant_idx); fetch them when
+    // those change (start, PUSH, POP) instead of every iteration (svo.esvo.glsl:168-173 reloads each time).
+    uint32_t descriptor = 0;
+    if (!CSVO) descriptor = esvo_word(sc, ptr);
+
+    for (int i = 0; i < kMaxSteps; ++i) {
+        if (max_dst >= 0.0f && t_min > max_dst) break;
+        ++steps;
+        if (STATS) ctr->iterations++;
+
+        const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
+        const float tc_max = gmin(gmin(tcrx, tcry), tcrz);
+
+        const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
+
+        bool is_child, is_leaf, crossed_boundary = false;
+        uint32_t next_ptr = 0, iter_ptr_bytes = 0;
+        if (!CSVO) {
+            is_child = (descriptor & (0x100u << octant_idx)) != 0;
+            is_leaf = (descriptor & (1u << octant_idx)) != 0;
+        } else {
+            uint32_t hb = 0;
+            next_ptr = csvo_next_ptr(sc, ptr, depth, octant_idx, crossed_boundary, hb, iter_ptr_bytes);
+            is_child = next_ptr != kInvalidPtr;
+            is_leaf = is_child && depth < 2;
+            if (depth == 2) pre_leaf_pointer = ptr;
+            if (STATS) ctr->csvo_header_bytes += hb;
+        }
+
+        if (TRACE) {
+            if (n_frames < max_frames) {
+                vx_frame& f = frames[n_frames];
+                f.t_min = t_min * inv_scale;
+                f.ptr = ptr;
+                f.idx = octant_idx;
+                f.parent_octant_idx = CSVO ? depth : parent_octant_idx;
+                f.scale = scale;
+                f.is_child = is_child;
+                f.is_leaf = is_leaf;
+                f.crossed_boundary = crossed_boundary;
+                f.next_ptr = CSVO ? next_ptr : 0u;
+            }
+            ++n_frames;
+        }
+
+        bool advance = true;
+        if (is_child && t_min <= t_max) {
+            if (is_leaf && t_min == 0.0f) res.inside_voxel = true;
+
+            if (is_leaf && t_min > 0.0f) {
+                // ---- HIT (svo.esvo.glsl:185-265) ----
+                if (STATS) ctr->leaf_tests++;
+                uint32_t value;
+                if (!CSVO) {
+                    uint32_t np = esvo_word(sc, ptr + 4 + parent_octant_idx);
+                    if (np & (1u << 31)) np = ptr + 4 + parent_octant_idx + (np & 0x7fffffffu);
+                    value = esvo_word(sc, np + 4 + octant_idx);
+                } else {
+                    value = csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx);
+                }
+
+                const float ex = __builtin_fmaf(px + scale_exp2, tcx, -tbx);
+                const float ey = __builtin_fmaf(py + scale_exp2, tcy, -tby);
+                const float ez = __builtin_fmaf(pz + scale_exp2, tcz, -tbz);
+                const float tc_min = gmax(gmax(ex, ey), ez);
+
+                float qx = px, qy = py, qz = pz;
+                if (octant_mask & 1) qx = 3.0f - scale_exp2 - qx;
+                if (octant_mask & 2) qy = 3.0f - scale_exp2 - qy;
+                if (octant_mask & 4) qz = 3.0f - scale_exp2 - qz;
+
+                const float inv_s = __uint_as_float(0x7f000000u - __float_as_uint(scale_exp2));  // exact 1/scale_exp2
+                int face_id;
+                float uvx, uvy;
+                if (tc_min == ex) {
+                    face_id = int((__float_as_uint(rdx) >> 31) & 1u);
+                    uvx = (__builtin_fmaf(rdz, ex, roz) - qz) * inv_s;
+                    uvy = (__builtin_fmaf(rdy, ex, roy) - qy) * inv_s;
+                    if (rdx > 0.0f) uvx = 1.0f - uvx;
+                } else if (tc_min == ey) {
+                    face_id = 2 | int((__float_as_uint(rdy) >> 31) & 1u);
+                    uvx = (__builtin_fmaf(rdx, ey, rox) - qx) * inv_s;
+                    uvy = (__builtin_fmaf(rdz, ey, roz) - qz) * inv_s;
+                    if (rdy > 0.0f) uvy = 1.0f - uvy;
+                } else {
+                    face_id = 4 | int((__float_as_uint(rdz) >> 31) & 1u);
+                    uvx = (__builtin_fmaf(rdx, ez, rox) - qx) * inv_s;
+                    uvy = (__builtin_fmaf(rdy, ez, roy) - qy) * inv_s;
+                    if (rdz < 0.0f) uvx = 1.0f - uvx;
+                }
+
+                const vx_material mat = material_at(sc, value);
+                int tex_id = mat.tex_side;
+                if (face_id == 3) tex_id = mat.tex_top;
+                else if (face_id == 2) tex_id = mat.tex_bottom;
+
+                const float dst = t_min * inv_scale;
+                const float tex_lod = smoothstepf(15.0f, 25.0f, dst) * (dst - 15.0f) * 0.05f;
+                if (STATS && tex_lod > 0.0f) ctr->leaf_tests_trilinear++;
+
+                float tex_color[4];
+                texture_lod(sc.tex, uvx, uvy, float(tex_id), tex_lod, tex_color);
+
+                const bool first_of_kind = adjacent_leaf_count == 0 || value != last_leaf_value;
+                if ((tex_color[3] > 0.0f || !cast_translucent) && first_of_kind) {
+                    res.t = dst;
+                    res.face_id = face_id;
+                    res.uv[0] = uvx; res.uv[1] = uvy;
+                    res.value = value;
+                    res.color[0] = tex_color[0]; res.color[1] = tex_color[1]; res.color[2] = tex_color[2]; res.color[3] = tex_color[3];
+                    res.lod = tex_lod;
+                    const float hx = gmin(gmax(__builtin_fmaf(t_min, rdx, rox), qx + kEps), qx + scale_exp2 - kEps);
+                    const float hy = gmin(gmax(__builtin_fmaf(t_min, rdy, roy), qy + kEps), qy + scale_exp2 - kEps);
+                    const float hz = gmin(gmax(__builtin_fmaf(t_min, rdz, roz), qz + kEps), qz + scale_exp2 - kEps);
+                    res.pos[0] = (hx - 1.0f) * inv_scale;
+                    res.pos[1] = (hy - 1.0f) * inv_scale;
+                    res.pos[2] = (hz - 1.0f) * inv_scale;
+                    return;
+                }
+                ++adjacent_leaf_count;
+                last_leaf_value = value;
+            } else {
+                const float half_scale = scale_exp2 * 0.5f;
+                const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
+                            tcenz = __builtin_fmaf(half_scale, tcz, tcrz);
+                const float tv_max = gmin(t_max, tc_max);
+
+                if (t_min <= tv_max) {
+                    // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
+                    if (STATS) ctr->pushes++;
+                    if (tc_max < h) {
+                        const uint32_t s = st.slot(scale);
+                        st.ptr[s] = ptr;
+                        st.aux[s] = uint8_t(CSVO ? depth : parent_octant_idx);
+                        st.t_max[s] = t_max;
+                    }
+                    h = tc_max;
+
+                    if (!CSVO) {
+                        uint32_t np = esvo_word(sc, ptr + 4 + parent_octant_idx);
+                        if (np & (1u << 31)) np = ptr + 4 + parent_octant_idx + (np & 0x7fffffffu);
+                        ptr = np;
+                        parent_octant_idx = octant_idx;
+                        descriptor = esvo_word(sc, ptr + (parent_octant_idx >> 1));
+                        if (parent_octant_idx & 1u) descriptor >>= 16;
+                    } else {
+                        if (STATS) ctr->csvo_pointer_bytes += iter_ptr_bytes;
+                        --depth;
+                        ptr = next_ptr;
+                        if (crossed_boundary) {
+                            if (STATS) ctr->boundaries++;
+                            const uint32_t child_lod = csvo_u8(sc, ptr);
+                            const uint32_t material_bytes = csvo_u32(sc, ptr + 1);
+                            ptr += 5;
+                            material_section_ptr = ptr;
+                            ptr += material_bytes;
+                            depth = child_lod;
+                        }
+                    }
+
+                    --scale;
+                    scale_exp2 = half_scale;
+
+                    idx = 0;
+                    if (t_min < tcenx) { idx ^= 1; px += scale_exp2; }
+                    if (t_min < tceny) { idx ^= 2; py += scale_exp2; }
+                    if (t_min < tcenz) { idx ^= 4; pz += scale_exp2; }
+
+                    t_max = tv_max;
+                    advance = false;
+                }
+            }
+        } else {
+            adjacent_leaf_count = 0;
+            last_leaf_value = 0xffffffffu;
+        }
+        if (!advance) continue;
+
+        // ---- ADVANCE (svo.esvo.glsl:324-331) ----
+        int step_mask = 0;
+        if (tc_max >= tcrx) { step_mask ^= 1; px -= scale_exp2; }
+        if (tc_max >= tcry) { step_mask ^= 2; py -= scale_exp2; }
+        if (tc_max >= tcrz) { step_mask ^= 4; pz -= scale_exp2; }
+
+        t_min = tc_max;
+        idx ^= step_mask;
+
+        if ((idx & step_mask) != 0) {
+            // ---- POP (svo.esvo.glsl:347-390) ----
+            uint32_t differing_bits = 0;
+            if (step_mask & 1) differing_bits |= __float_as_uint(px) ^ __float_as_uint(px + scale_exp2);
+            if (step_mask & 2) differing_bits |= __float_as_uint(py) ^ __float_as_uint(py + scale_exp2);
+            if (step_mask & 4) differing_bits |= __float_as_uint(pz) ^ __float_as_uint(pz + scale_exp2);
+
+            scale = differing_bits ? 31 - __clz(differing_bits) : -1;
+            if (scale >= kMaxScale || scale < 0) return;
+            scale_exp2 = pow2i(scale - kMaxScale);
+
+            const uint32_t s = st.slot(scale);
+            ptr = st.ptr[s];
+            if (CSVO) depth = st.aux[s]; else parent_octant_idx = st.aux[s];
+            t_max = st.t_max[s];
+            if (!CSVO) {
+                descriptor = esvo_word(sc, ptr + (parent_octant_idx >> 1));
+                if (parent_octant_idx & 1u) descriptor >>= 16;
+            }
+
+            const int shx = __float_as_int(px) >> scale, shy = __float_as_int(py) >> scale, shz = __float_as_int(pz) >> scale;
+            px = __int_as_float(shx << scale);
+            py = __int_as_float(shy << scale);
+            pz = __int_as_float(shz << scale);
+            idx = (shx & 1) | ((shy & 1) << 1) | ((shz & 1) << 2);
+
+            h = 0.0f;
+        }
+    }
+}
+
+// ---- world.glsl -----------------------------------------------------------------------------------------------
+
+struct RenderParams {
+    vx_uniforms u;
+    float tan_half_fovy;   // tanf(fovy * 0.5f), evaluated on the host (world.glsl:115)
+    uint32_t width, height;
+    uint32_t tiles_x, tiles_y;
+    uint32_t tile_rank, tile_count, n_local_tiles;
+};
+
+__device__ __forceinline__ float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void normalize3(const float v[3], float out[3]) {
+    const float len = sqrtf(dot3(v, v));
+    out[0] = v[0] / len; out[1] = v[1] / len; out[2] = v[2] / len;
+}
+
+// world.glsl:110-129
+__device__ __forceinline__ void primary_ray(const RenderParams& p, uint32_t x, uint32_t y, float ro[3], float rd[3]) {
+    float uvx = float(x) / float(p.width), uvy = float(y) / float(p.height);
+    uvx = uvx * 2.0f - 1.0f;
+    uvy = uvy * 2.0f - 1.0f;
+    uvx *= p.u.aspect;
+    uvx *= p.tan_half_fovy;
+    uvy *= p.tan_half_fovy;
+    const float* m = p.u.view;
+    const float ow = m[3] * 0.0f + m[7] * 0.0f + m[11] * 0.0f + m[15] * 1.0f;
+    const float lw = m[3] * uvx + m[7] * uvy + m[11] * -1.0f + m[15] * 1.0f;
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        ro[r] = (m[r] * 0.0f + m[4 + r] * 0.0f + m[8 + r] * 0.0f + m[12 + r] * 1.0f) / ow;
+        const float l = (m[r] * uvx + m[4 + r] * uvy + m[8 + r] * -1.0f + m[12 + r] * 1.0f) / lw;
+        d[r] = l - ro[r];
+    }
+    normalize3(d, rd);
+}
+
+// world.glsl:92-108
+__device__ __forceinline__ void sky_color(const float rd[3], float out[3]) {
+    const float SKY[3] = {135.0f / 255.0f, 206.0f / 255.0f, 235.0f / 255.0f};
+    const float flat[3] = {rd[0], 0.0f, rd[2]};
+    float p[3];
+    normalize3(flat, p);
+    const float a = acosf(dot3(rd, p) / fabsf(sqrtf(dot3(rd, rd))) * fabsf(sqrtf(dot3(p, p))));
+    float grad = a / 1.570796f;
+    grad = 1.0f - powf(1.0f - grad, 3.0f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float horizon = 1.0f * (1.0f - 0.3f) + SKY[k] * 0.3f;
+        out[k] = horizon * (1.0f - grad) + SKY[k] * grad;
+    }
+}
+
+__constant__ float kFaceNormals[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};    // svo.glsl:2-9
+__constant__ float kFaceTangents[6][3] = {{0, 0, 1}, {0, 0, -1}, {1, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {1, 0, 0}};    // svo.glsl:12-19
+__constant__ float kFaceBitangents[6][3] = {{0, 1, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 1}, {0, 1, 0}, {0, 1, 0}};    // svo.glsl:22-29
+
+// trace_ray + sky (world.glsl:27-90, 132-138) for one pixel
+template <int SVO, bool STATS>
+__device__ __forceinline__ void shade_pixel(const DevScene& sc, const RenderParams& p, uint32_t x, uint32_t y, const Stack& st, float color[4],
+                                            vx_hit* rec, Counters* ctr, uint32_t* lit, uint32_t* shadow_rays) {
+    float ro[3], rd[3];
+    primary_ray(p, x, y, ro, rd);
+
+    Result res;
+    uint32_t steps = 0, nf = 0;
+    intersect<SVO, false, STATS>(sc, ro, rd, -1.0f, true, st, res, steps, nullptr, 0, nf, ctr);
+
+    const bool hit = res.t != -1.0f;
+    uint32_t flags = hit ? 1u : 0u;
+    float shadow_t = -1.0f;
+    color[0] = color[1] = color[2] = color[3] = 0.0f;
+
+    bool done = res.t < 0.0f;
+    if (!done) {
+        if (floorf(res.pos[0]) == floorf(p.u.highlight_pos[0]) && floorf(res.pos[1]) == floorf(p.u.highlight_pos[1]) &&
+            floorf(res.pos[2]) == floorf(p.u.highlight_pos[2])) {
+            const float lx = fabsf(res.uv[0] - 0.5f) * 2.0f, ly = fabsf(res.uv[1] - 0.5f) * 2.0f;
+            if (gmax(lx, ly) > 1.0f - 1.0f / 16.0f) {
+                color[0] = color[1] = color[2] = color[3] = 1.0f;
+                flags |= 8u;
+                done = true;
+            }
+        }
+    }
+    if (!done) {
+        if (STATS) ++*lit;
+        const vx_material mat = material_at(sc, res.value);
+        int tex_normal_id = mat.tex_side_normal;
+        if (res.face_id == 3) tex_normal_id = mat.tex_top_normal;
+        else if (res.face_id == 2) tex_normal_id = mat.tex_bottom_normal;
+
+        float normal[3] = {kFaceNormals[res.face_id][0], kFaceNormals[res.face_id][1], kFaceNormals[res.face_id][2]};
+        if (tex_normal_id != -1) {
+            float s[4];
+            texture_lod(sc.tex, res.uv[0], res.uv[1], float(tex_normal_id), res.lod, s);
+            const float tex[3] = {s[0] * 2.0f - 1.0f, s[2] * 2.0f - 1.0f, s[1] * 2.0f - 1.0f};  // .xzy
+            float n[3];
+            normalize3(tex, n);
+            const float base[3] = {normal[0], normal[1], normal[2]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) normal[k] = n[0] * kFaceTangents[res.face_id][k] + n[1] * base[k] + n[2] * kFaceBitangents[res.face_id][k];
+        }
+
+        const float neg_l[3] = {-p.u.light_dir[0], -p.u.light_dir[1], -p.u.light_dir[2]};
+        const float diffuse = gmax(dot3(normal, neg_l), 0.0f);
+
+        const float vd[3] = {res.pos[0] - p.u.cam_pos[0], res.pos[1] - p.u.cam_pos[1], res.pos[2] - p.u.cam_pos[2]};
+        float view_dir[3];
+        normalize3(vd, view_dir);
+        const float dn = dot3(normal, neg_l);
+        float reflect_dir[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) reflect_dir[k] = neg_l[k] - 2.0f * dn * normal[k];
+        const float specular = powf(gmax(dot3(view_dir, reflect_dir), 0.0f), mat.specular_pow) * mat.specular_strength;
+
+        float shadow = 1.0f;
+        if (p.u.render_shadows && res.t < p.u.shadow_distance) {
+            const float so[3] = {res.pos[0] + normal[0] * 0.001f, res.pos[1] + normal[1] * 0.001f, res.pos[2] + normal[2] * 0.001f};
+            Result sres;
+            if (STATS) ++*shadow_rays;
+            intersect<SVO, false, STATS>(sc, so, neg_l, -1.0f, true, st, sres, steps, nullptr, 0, nf, ctr);
+            shadow = sres.t < 0.0f ? 1.0f : 0.0f;
+            flags |= 2u;
+            if (!(sres.t < 0.0f)) flags |= 4u;
+            shadow_t = sres.t;
+        }
+
+        const float light = gclamp(p.u.ambient + (diffuse + specular) * shadow, 0.0f, 1.0f);
+        color[0] = res.color[0] * light;
+        color[1] = res.color[1] * light;
+        color[2] = res.color[2] * light;
+        color[3] = res.color[3];
+    }
+
+    if (!hit) {
+        float sky[3];
+        sky_color(rd, sky);
+        color[0] = sky[0]; color[1] = sky[1]; color[2] = sky[2]; color[3] = 1.0f;
+    }
+
+    if (rec) {
+        rec->t = res.t;
+        rec->value = res.value;
+        rec->face_id = res.face_id;
+        rec->flags = flags;
+        rec->pos[0] = res.pos[0]; rec->pos[1] = res.pos[1]; rec->pos[2] = res.pos[2];
+        rec->lod = res.lod;
+        rec->uv[0] = res.uv[0]; rec->uv[1] = res.uv[1];
+        rec->shadow_t = shadow_t;
+        rec->steps = steps;
+    }
+}
+
+}  // namespace vxd

@@ -1,0 +1,240 @@
+"""ctypes binding of libvoxelhip.so (include/voxel_hip.h) shaped like the reference's `graphics::Svo`
+(src/graphics/svo.rs:56-256): new / update / render / raycast / get_stats.
+
+This is harness code. It adds nothing to the path: every method is one or two C-ABI calls, and every failure
+of the native library raises -- there is no fallback of any kind.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from .build import lib_path
+
+VX_OK = 0
+VX_MEM_HOST, VX_MEM_DEVICE = 0, 1
+TILE = 32
+
+MATERIAL_DTYPE = np.dtype([("specular_pow", "<f4"), ("specular_strength", "<f4"), ("tex_top", "<i4"), ("tex_side", "<i4"), ("tex_bottom", "<i4"),
+                           ("tex_top_normal", "<i4"), ("tex_side_normal", "<i4"), ("tex_bottom_normal", "<i4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("value", "<u4"), ("face_id", "<i4"), ("flags", "<u4"), ("pos", "<f4", 3), ("lod", "<f4"), ("uv", "<f4", 2),
+                      ("shadow_t", "<f4"), ("steps", "<u4")])
+PICKER_TASK_DTYPE = np.dtype([("max_dst", "<f4"), ("_p0", "<f4", 3), ("pos", "<f4", 3), ("_p1", "<f4"), ("dir", "<f4", 3), ("_p2", "<f4")])
+PICKER_RESULT_DTYPE = np.dtype([("dst", "<f4"), ("inside_voxel", "<u4"), ("_p0", "<f4", 2), ("pos", "<f4", 3), ("_p1", "<f4"), ("normal", "<f4", 3),
+                                ("_p2", "<f4")])
+FRAME_DTYPE = np.dtype([("t_min", "<f4"), ("ptr", "<u4"), ("idx", "<u4"), ("parent_octant_idx", "<u4"), ("scale", "<i4"), ("is_child", "<i4"),
+                        ("is_leaf", "<i4"), ("crossed_boundary", "<i4"), ("next_ptr", "<u4")])
+assert HIT_DTYPE.itemsize == 48 and PICKER_TASK_DTYPE.itemsize == 48 and PICKER_RESULT_DTYPE.itemsize == 48 and FRAME_DTYPE.itemsize == 36
+
+COUNTER_FIELDS = ["rays", "iterations", "pushes", "leaf_tests", "leaf_tests_trilinear", "boundaries", "csvo_header_bytes", "csvo_pointer_bytes",
+                  "pixels", "lit_pixels", "shadow_rays"]
+
+
+class Uniforms(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("fovy", C.c_float), ("aspect", C.c_float), ("ambient", C.c_float), ("light_dir", C.c_float * 3),
+                ("cam_pos", C.c_float * 3), ("render_shadows", C.c_int32), ("shadow_distance", C.c_float), ("highlight_pos", C.c_float * 3)]
+
+
+class Range(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("length", C.c_uint64)]
+
+
+class Target(C.Structure):
+    _fields_ = [("rgba32f", C.c_void_p), ("hits", C.c_void_p), ("memory", C.c_int32), ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("t", C.c_float), ("value", C.c_uint32), ("face_id", C.c_int32), ("pos", C.c_float * 3), ("uv", C.c_float * 2),
+                ("color", C.c_float * 4), ("lod", C.c_float), ("inside_voxel", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("used_bytes", C.c_uint64), ("capacity_bytes", C.c_uint64), ("depth", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in COUNTER_FIELDS]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in COUNTER_FIELDS}
+
+
+# every symbol include/voxel_hip.h declares: (restype, argtypes)
+_vp, _u32, _u64, _sz, _int = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t, C.c_int
+SYMBOLS = {
+    "vx_create": (_int, [_int, _sz, _int, C.POINTER(_vp)]),
+    "vx_destroy": (None, [_vp]),
+    "vx_set_materials": (_int, [_vp, _vp, _u32]),
+    "vx_set_textures": (_int, [_vp, _vp, _u32, _u32, _u32, _u32]),
+    "vx_staging_ptr": (_vp, [_vp]),
+    "vx_capacity": (_sz, [_vp]),
+    "vx_commit": (_int, [_vp, _u32, _vp, _u32, _u64]),
+    "vx_commit_all": (_int, [_vp, _u32, _u64]),
+    "vx_get_stats": (_int, [_vp, C.POINTER(Stats)]),
+    "vx_render": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, C.POINTER(Target)]),
+    "vx_raycast": (_int, [_vp, _vp, _u32, _vp]),
+    "vx_debug_trace": (_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.c_float, _int, C.POINTER(Result), _vp, _u32, C.POINTER(_u32)]),
+    "vx_sync": (_int, [_vp]),
+    "vx_assemble_tiles": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
+    "vx_local_tile_count": (_u32, [_u32, _u32, _u32, _u32]),
+    "vx_render_counters": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, _u32, _u32, C.POINTER(Counters)]),
+    "vx_profile_enable": (_int, [_vp, _int]),
+    "vx_profile_read": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32)]),
+    "vx_stream": (_vp, [_vp]),
+    "vx_device": (_int, [_vp]),
+    "vx_last_error": (C.c_char_p, []),
+    "vx_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class VoxelHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libvoxelhip.so; raises if it (or any declared symbol) is missing -- never falls back."""
+    global _lib
+    if _lib is None:
+        L = C.CDLL(str(lib_path("libvoxelhip.so")))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != VX_OK:
+        raise VoxelHipError(f"libvoxelhip error {rc}: {lib().vx_last_error().decode()}")
+
+
+def make_uniforms(view, fovy, aspect, ambient, light_dir, cam_pos, render_shadows, shadow_distance, highlight_pos=None):
+    u = Uniforms()
+    u.view = (C.c_float * 16)(*[float(x) for x in view])
+    u.fovy, u.aspect, u.ambient = float(fovy), float(aspect), float(ambient)
+    u.light_dir = (C.c_float * 3)(*[float(x) for x in light_dir])
+    u.cam_pos = (C.c_float * 3)(*[float(x) for x in cam_pos])
+    u.render_shadows = int(render_shadows)
+    u.shadow_distance = float(shadow_distance)
+    hp = highlight_pos if highlight_pos is not None else (math.nan,) * 3  # NaN when nothing is selected (svo.rs:211)
+    u.highlight_pos = (C.c_float * 3)(*[float(x) for x in hp])
+    return u
+
+
+def local_tile_count(width, height, rank, count):
+    return lib().vx_local_tile_count(width, height, rank, count)
+
+
+class Svo:
+    """`graphics::Svo` over the C ABI."""
+
+    def __init__(self, svo_type, capacity_bytes, device=0):
+        self._h = _vp()
+        self.svo_type = svo_type
+        _check(lib().vx_create(svo_type, capacity_bytes, device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # -- resources ---------------------------------------------------------------------------------------
+    def set_materials(self, materials):
+        m = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
+        _check(lib().vx_set_materials(self._h, m.ctypes.data_as(_vp), m.size))
+
+    def set_textures(self, base_rgba8, mip_levels):
+        """base_rgba8: uint8 [layers][h][w][4], row 0 = bottom (already flipped like TextureArrayBuilder does)."""
+        t = np.ascontiguousarray(base_rgba8, dtype=np.uint8)
+        layers, h, w, c = t.shape
+        assert c == 4
+        _check(lib().vx_set_textures(self._h, t.ctypes.data_as(_vp), w, h, layers, mip_levels))
+
+    # -- Svo::update (svo.rs:171-189) ---------------------------------------------------------------------
+    def update(self, world):
+        ranges = world.updated_ranges()
+        cap = lib().vx_capacity(self._h)
+        staging = lib().vx_staging_ptr(self._h)
+        world.write_changes_to(staging + 4, cap - 1, True)
+        arr = (Range * max(len(ranges), 1))()
+        for i, (s, n) in enumerate(ranges):
+            arr[i].start, arr[i].length = s, n
+        _check(lib().vx_commit(self._h, world.depth, C.cast(arr, _vp), len(ranges), world.size_in_bytes))
+
+    def upload_frame(self, frame_words, depth):
+        """Copies a complete mapped-buffer image ([f32 scale][header][arena]) into staging and commits all of it."""
+        raw = np.ascontiguousarray(frame_words).view(np.uint8)
+        cap = lib().vx_capacity(self._h)
+        if raw.size > cap:
+            raise VoxelHipError("frame larger than the world buffer")
+        C.memmove(lib().vx_staging_ptr(self._h), raw.ctypes.data, raw.size)
+        header = 20 if self.svo_type == 1 else 4
+        _check(lib().vx_commit_all(self._h, depth, max(raw.size - 4 - header, 0)))
+
+    def get_stats(self):
+        s = Stats()
+        _check(lib().vx_get_stats(self._h, C.byref(s)))
+        return dict(used_bytes=int(s.used_bytes), capacity_bytes=int(s.capacity_bytes), depth=int(s.depth))
+
+    # -- Svo::render (svo.rs:196-229) ---------------------------------------------------------------------
+    def render(self, uniforms, width, height, want_hits=False, tile_rank=0, tile_count=1):
+        """Returns (image float32 [h][w][4] row 0 = bottom, hits or None); tile-sharded calls return compact tile lists."""
+        if tile_count > 1:
+            n = local_tile_count(width, height, tile_rank, tile_count)
+            img = np.zeros((n, TILE, TILE, 4), dtype=np.float32)
+            hits = np.zeros((n, TILE, TILE), dtype=HIT_DTYPE) if want_hits else None
+        else:
+            img = np.zeros((height, width, 4), dtype=np.float32)
+            hits = np.zeros((height, width), dtype=HIT_DTYPE) if want_hits else None
+        t = Target(img.ctypes.data, hits.ctypes.data if want_hits else None, VX_MEM_HOST, tile_rank, tile_count)
+        _check(lib().vx_render(self._h, C.byref(uniforms), width, height, C.byref(t)))
+        return img, hits
+
+    def render_device(self, uniforms, width, height, out_ptr, hits_ptr=None, tile_rank=0, tile_count=1):
+        """Asynchronous render into device memory (e.g. a torch tensor's data_ptr()); pair with sync()."""
+        t = Target(out_ptr, hits_ptr, VX_MEM_DEVICE, tile_rank, tile_count)
+        _check(lib().vx_render(self._h, C.byref(uniforms), width, height, C.byref(t)))
+
+    def render_counters(self, uniforms, width, height, tile_rank=0, tile_count=1):
+        c = Counters()
+        _check(lib().vx_render_counters(self._h, C.byref(uniforms), width, height, tile_rank, tile_count, C.byref(c)))
+        return c.as_dict()
+
+    # -- Svo::raycast (svo.rs:233-255) --------------------------------------------------------------------
+    def raycast(self, tasks):
+        tasks = np.ascontiguousarray(tasks, dtype=PICKER_TASK_DTYPE)
+        out = np.zeros(tasks.size, dtype=PICKER_RESULT_DTYPE)
+        _check(lib().vx_raycast(self._h, tasks.ctypes.data_as(_vp), tasks.size, out.ctypes.data_as(_vp)))
+        return out
+
+    def debug_trace(self, pos, direction, max_dst, cast_translucent, max_frames=100):
+        p = (C.c_float * 3)(*[float(x) for x in pos])
+        d = (C.c_float * 3)(*[float(x) for x in direction])
+        res = Result()
+        frames = np.zeros(max(max_frames, 1), dtype=FRAME_DTYPE)
+        n = _u32(0)
+        _check(lib().vx_debug_trace(self._h, C.byref(p), C.byref(d), max_dst, int(cast_translucent), C.byref(res), frames.ctypes.data_as(_vp),
+                                    max_frames, C.byref(n)))
+        return res, frames[:min(n.value, max_frames)], n.value
+
+    def assemble_tiles(self, tiles_ptr, stride_floats, tile_count, width, height, out_ptr):
+        _check(lib().vx_assemble_tiles(self._h, tiles_ptr, stride_floats, tile_count, width, height, out_ptr))
+
+    def sync(self):
+        _check(lib().vx_sync(self._h))
+
+    def profile_enable(self, on=True):
+        _check(lib().vx_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, n = C.c_double(0), _u32(0)
+        _check(lib().vx_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    @property
+    def stream(self):
+        return lib().vx_stream(self._h)
