@@ -183,10 +183,13 @@ def main():
         rows_budget = int(len(probe_rows) * 2 * args.cpu_seconds / max(probe_s, 1e-6))
         cc = orc.Counters()
         if rows_budget >= H:
+            # the whole frame fits the budget: repeat it until about cpu_seconds of CPU work have been timed
+            reps = max(1, min(200, rows_budget // H))
             t0 = time.perf_counter()
-            scene.render(ou, W, H, want_hits=False, counters=cc, threads=cores)
+            for _ in range(reps):
+                scene.render(ou, W, H, want_hits=False, counters=cc, threads=cores)
             cpu_s = time.perf_counter() - t0
-            sample = f"whole {W}x{H} frame"
+            sample = f"{reps} x the whole {W}x{H} frame"
         else:
             bands = 8
             band_h = max(rows_budget // bands, 1)

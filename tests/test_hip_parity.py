@@ -158,7 +158,7 @@ def test_random_world_picker_rays(hip, golden, fmt, seed, svo_pos, n_blocks):
     got = svo.raycast(tasks)
     exp = scene.picker(tasks.view(orc.PICKER_TASK_DTYPE), threads=4)
     assert got.tobytes() == exp.tobytes()
-    assert (exp["dst"] > 0).sum() > (0 if n_blocks == 0 else n // 20)
+    assert (exp["dst"] > 0).sum() > (0 if n_blocks == 0 else 50)  # the comparison above is not vacuous
 
 
 # ---- full frames: shading, shadows, translucency, trilinear sampling -------------------------------------------------
