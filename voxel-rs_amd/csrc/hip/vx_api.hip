@@ -28,11 +28,14 @@ constexpr uint32_t kTile = 32;         // multi-GPU sharding unit (pixels per ed
 constexpr uint32_t kBlockEdge = 16;    // one 256-thread workgroup shades 16x16 pixels: 4 waves x (8x8)
 constexpr uint32_t kBlockThreads = 256;
 
-__device__ __forceinline__ Stack make_stack(unsigned char* smem, uint32_t levels, uint32_t threads, uint32_t tid) {
+__device__ __forceinline__ Stack make_stack(unsigned char* smem, uint32_t levels, uint32_t threads, uint32_t tid, StackSpill& spill) {
     Stack st;
+    st.spill_ptr = spill.ptr;
+    st.spill_t_max = spill.t_max;
+    st.spill_aux = spill.aux;
     st.ptr = reinterpret_cast<uint32_t*>(smem);
     st.t_max = reinterpret_cast<float*>(smem + size_t(levels) * threads * 4);
-    st.aux = smem + size_t(levels) * threads * 8;
+    st.aux = reinterpret_cast<int16_t*>(smem + size_t(levels) * threads * 8);
     st.stride = threads;
     st.tid = tid;
     st.levels = levels;
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(DevScene sc, Rend
                                                                unsigned long long* __restrict__ counters, uint32_t levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
-    const Stack st = make_stack(smem, levels, kBlockThreads, tid);
+    StackSpill spill;
+    const Stack st = make_stack(smem, levels, kBlockThreads, tid, spill);
 
     // block -> (local tile, 16x16 sub-block) -> pixel
     const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
@@ -74,7 +78,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(DevScene sc, Rend
     const uint32_t in_x = (sub & 1u) * kBlockEdge + (wave & 1u) * 8 + lx;  // position inside the 32x32 tile
     const uint32_t in_y = (sub >> 1) * kBlockEdge + (wave >> 1) * 8 + ly;
     const uint32_t x = tx * kTile + in_x, y = ty * kTile + in_y;
-    const bool active = tile < p.tiles_x * p.tiles_y && x < p.width && y < p.height;
+    const bool tile_valid = tile < p.tiles_x * p.tiles_y;
+    const bool active = tile_valid && x < p.width && y < p.height;
 
     Counters ctr = {};
     uint32_t lit = 0, shadow_rays = 0;
@@ -85,6 +90,11 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(DevScene sc, Rend
         const size_t index = p.tile_count > 1 ? size_t(local_tile) * (kTile * kTile) + in_y * kTile + in_x : size_t(y) * p.width + x;
         if (out) out[index] = make_float4(color[0], color[1], color[2], color[3]);
         if (HITS) hits[index] = rec;
+    } else if (tile_valid && p.tile_count > 1) {
+        // pixels of an edge tile that fall outside the image: keep the compact tile list fully defined
+        const size_t index = size_t(local_tile) * (kTile * kTile) + in_y * kTile + in_x;
+        if (out) out[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (HITS) memset(&hits[index], 0, sizeof(vx_hit));
     }
 
     if (STATS) {
@@ -103,7 +113,8 @@ template <int SVO>
 __global__ __launch_bounds__(64) void picker_kernel(DevScene sc, const vx_picker_task* __restrict__ tasks, uint32_t n,
                                                     vx_picker_result* __restrict__ results, uint32_t levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Stack st = make_stack(smem, levels, 64, threadIdx.x);
+    StackSpill spill;
+    const Stack st = make_stack(smem, levels, 64, threadIdx.x, spill);
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     // picker.glsl:30-51
@@ -134,7 +145,8 @@ template <int SVO>
 __global__ __launch_bounds__(64) void trace_kernel(DevScene sc, TraceArgs a, vx_result* __restrict__ result, vx_frame* __restrict__ frames,
                                                    uint32_t max_frames, uint32_t* __restrict__ n_frames, uint32_t levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Stack st = make_stack(smem, levels, 64, threadIdx.x);
+    StackSpill spill;
+    const Stack st = make_stack(smem, levels, 64, threadIdx.x, spill);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Result res;
     uint32_t steps = 0, nf = 0;
@@ -259,7 +271,7 @@ int check_ready(vx_context* ctx) {
 template <bool HITS, bool STATS>
 int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hits, unsigned long long* counters) {
     const uint32_t levels = stack_levels(ctx);
-    const size_t lds = size_t(levels) * kBlockThreads * 9;
+    const size_t lds = size_t(levels) * kBlockThreads * 10;
     const dim3 grid(p.n_local_tiles * 4), block(kBlockThreads);
     if (grid.x == 0) return VX_OK;
     const DevScene sc = scene_of(ctx);
@@ -554,7 +566,7 @@ int vx_raycast(vx_context* ctx, const vx_picker_task* tasks, uint32_t count, vx_
     }
     HIP_TRY(hipMemcpyAsync(ctx->d_tasks, tasks, size_t(count) * sizeof(vx_picker_task), hipMemcpyHostToDevice, ctx->stream));
     const uint32_t levels = stack_levels(ctx);
-    const size_t lds = size_t(levels) * 64 * 9;
+    const size_t lds = size_t(levels) * 64 * 10;
     const DevScene sc = scene_of(ctx);
     const dim3 grid((count + 63) / 64), block(64);
     if (ctx->svo_type == VX_SVO_ESVO)
@@ -592,7 +604,7 @@ int vx_debug_trace(vx_context* ctx, const float pos[3], const float dir[3], floa
     a.max_dst = max_dst;
     a.cast_translucent = cast_translucent;
     const uint32_t levels = stack_levels(ctx);
-    const size_t lds = size_t(levels) * 64 * 9;
+    const size_t lds = size_t(levels) * 64 * 10;
     const DevScene sc = scene_of(ctx);
     if (ctx->svo_type == VX_SVO_ESVO)
         hipLaunchKernelGGL((trace_kernel<VX_SVO_ESVO>), dim3(1), dim3(64), lds, ctx->stream, sc, a, ctx->d_trace_result, ctx->d_trace_frames, max_frames,

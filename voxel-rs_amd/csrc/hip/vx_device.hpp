@@ -11,7 +11,9 @@
 // (-ffp-contract=off); the plane-distance expressions use explicit fmaf exactly where the oracle does.
 #pragma once
 
+#ifndef VX_DEVICE_ON_HOST
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "voxel_hip.h"
@@ -52,19 +54,51 @@ struct Counters {  // per-thread, reduced by the instrumented kernel
     uint32_t rays, iterations, pushes, leaf_tests, leaf_tests_trilinear, boundaries, csvo_header_bytes, csvo_pointer_bytes;
 };
 
-// Per-ray traversal stack in LDS, [level][thread]: every lane's slot for a level sits in its own bank.
+// Per-ray traversal stack. Levels the octree can legitimately reach (depth + 1) live in LDS, [level][thread]:
+// every lane's slot for a level sits in its own bank, whatever mix of levels the lanes are on. A ray that starts
+// INSIDE a voxel makes the reference descend "below" the leaves, interpreting leaf bytes as nodes
+// (svo.esvo.glsl:183-185 / svo.csvo.glsl:293-295 only treat a leaf as a hit when t_min > 0); its stack arrays hold
+// MAX_SCALE + 1 entries (svo.esvo.glsl:28-30), so those pushes are kept too -- in a per-thread spill array that
+// ordinary rays never touch.
 struct Stack {
     uint32_t* ptr;   // octant / node pointer
     float* t_max;
-    uint8_t* aux;    // ESVO: parent_octant_idx, CSVO: depth
+    int16_t* aux;    // ESVO: parent_octant_idx; CSVO: depth, which spans [-23, 255] once a ray is below the leaves
+                     // (svo.csvo.glsl:398 keeps decrementing a uint): sign-extended 16 bits restore the same pattern
     uint32_t stride; // threads per block
     uint32_t tid;
-    uint32_t levels; // allocated levels; deeper (corrupt) data is clamped into the last one instead of leaving LDS
-    __device__ __forceinline__ uint32_t slot(int scale) const {
-        uint32_t lv = uint32_t(kMaxScale - 1 - scale);
-        lv = lv < levels ? lv : levels - 1;
-        return lv * stride + tid;
+    uint32_t levels; // levels held in LDS
+    uint32_t* spill_ptr;  // [kMaxScale] per-thread
+    float* spill_t_max;
+    int16_t* spill_aux;
+
+    __device__ __forceinline__ void push(int scale, uint32_t p, int16_t a, float t) const {
+        const uint32_t lv = uint32_t(kMaxScale - 1 - scale);
+        if (lv < levels) {
+            const uint32_t s = lv * stride + tid;
+            ptr[s] = p; aux[s] = a; t_max[s] = t;
+        } else if (lv < uint32_t(kMaxScale)) {
+            spill_ptr[lv] = p; spill_aux[lv] = a; spill_t_max[lv] = t;
+        }
     }
+    __device__ __forceinline__ void pop(int scale, uint32_t& p, int16_t& a, float& t) const {
+        const uint32_t lv = uint32_t(kMaxScale - 1 - scale);
+        if (lv < levels) {
+            const uint32_t s = lv * stride + tid;
+            p = ptr[s]; a = aux[s]; t = t_max[s];
+        } else if (lv < uint32_t(kMaxScale)) {
+            p = spill_ptr[lv]; a = spill_aux[lv]; t = spill_t_max[lv];
+        } else {
+            p = 0; a = 0; t = 0.0f;
+        }
+    }
+};
+
+// per-thread backing store for Stack::spill_* (lives in scratch; touched only by rays that start inside a voxel)
+struct StackSpill {
+    uint32_t ptr[kMaxScale];
+    float t_max[kMaxScale];
+    int16_t aux[kMaxScale];
 };
 
 __device__ __forceinline__ float gmin(float x, float y) { return y < x ? y : x; }  // GLSL min
@@ -428,10 +462,7 @@ __device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[
                     // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
                     if (STATS) ctr->pushes++;
                     if (tc_max < h) {
-                        const uint32_t s = st.slot(scale);
-                        st.ptr[s] = ptr;
-                        st.aux[s] = uint8_t(CSVO ? depth : parent_octant_idx);
-                        st.t_max[s] = t_max;
+                        st.push(scale, ptr, int16_t(CSVO ? depth : parent_octant_idx), t_max);
                     }
                     h = tc_max;
 
@@ -495,10 +526,9 @@ __device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[
             if (scale >= kMaxScale || scale < 0) return;
             scale_exp2 = pow2i(scale - kMaxScale);
 
-            const uint32_t s = st.slot(scale);
-            ptr = st.ptr[s];
-            if (CSVO) depth = st.aux[s]; else parent_octant_idx = st.aux[s];
-            t_max = st.t_max[s];
+            int16_t aux;
+            st.pop(scale, ptr, aux, t_max);
+            if (CSVO) depth = uint32_t(int32_t(aux)); else parent_octant_idx = uint32_t(aux);
             if (!CSVO) {
                 descriptor = esvo_word(sc, ptr + (parent_octant_idx >> 1));
                 if (parent_octant_idx & 1u) descriptor >>= 16;
