@@ -21,6 +21,7 @@ static inline float __int_as_float(int32_t u) { float f; std::memcpy(&f, &u, 4);
 #define VX_DEVICE_ON_HOST 1
 #include "vx_device.hpp"
 
+namespace vxd { unsigned char* vx_smem = nullptr; }
 using namespace vxd;
 
 extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t world_bytes, const vx_material* mats, uint32_t n_mats,
@@ -30,13 +31,11 @@ extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t worl
     sc.world = world; sc.world_bytes = world_bytes; sc.materials = mats; sc.n_materials = n_mats;
     sc.tex.base = tex; sc.tex.width = tw; sc.tex.height = th; sc.tex.layers = layers; sc.tex.levels = levels;
     for (uint32_t l = 0; l < levels && l < 16; ++l) sc.tex.level_offset[l] = level_offset[l];
-    std::vector<uint32_t> sp(32);
-    std::vector<float> stm(32);
-    std::vector<int16_t> sa(32);
-    Stack st;
+    std::vector<unsigned char> lds(7 * 10 + 64);
+    vx_smem = lds.data();
     StackSpill spill;
-    st.ptr = sp.data(); st.t_max = stm.data(); st.aux = sa.data(); st.stride = 1; st.tid = 0; st.levels = 7;
-    st.spill_ptr = spill.ptr; st.spill_t_max = spill.t_max; st.spill_aux = spill.aux;
+    Stack st;
+    st.stride = 1; st.tid = 0; st.levels = 7; st.spill = &spill;
     for (uint32_t i = 0; i < n; ++i) {
         Result res;
         uint32_t steps = 0, nf = 0;

@@ -159,6 +159,17 @@ def test_random_world_picker_rays(hip, golden, fmt, seed, svo_pos, n_blocks):
     exp = scene.picker(tasks.view(orc.PICKER_TASK_DTYPE), threads=4)
     assert got.tobytes() == exp.tobytes()
     assert (exp["dst"] > 0).sum() > (0 if n_blocks == 0 else 50)  # the comparison above is not vacuous
+    # origins inside the chunk: with 6000 blocks about one ray in seven starts INSIDE a voxel, where the reference keeps
+    # descending below the leaf level (svo.esvo.glsl:183-185) -- the stack's spill levels are what this exercises
+    tasks["pos"] = (np.asarray(svo_pos, dtype=np.float32) * 32 + rng.uniform(0, 32, size=(n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    tasks["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tasks["max_dst"] = -1.0
+    got = svo.raycast(tasks)
+    exp = scene.picker(tasks.view(orc.PICKER_TASK_DTYPE), threads=4)
+    assert got.tobytes() == exp.tobytes()
+    if n_blocks >= 6000:
+        assert exp["inside_voxel"].sum() > 100
 
 
 # ---- full frames: shading, shadows, translucency, trilinear sampling -------------------------------------------------
@@ -322,3 +333,34 @@ def test_error_behaviour(hip):
     assert rc == 4 and b"not large enough" in hip.lib().vx_last_error()
     with pytest.raises(hip.VoxelHipError):
         hip.Svo(3, 1 << 16)
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_kernel_versions_agree(hip, fmt, monkeypatch):
+    """The persistent wavefront kernel (default) and the one-thread-per-pixel kernel write identical images and hit
+    records, for several refill/service thresholds (they only reorder work between lanes)."""
+    from voxel_rs_amd import scenes
+
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(8, threads=4)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    w, h = 250, 130
+    u = scenes.bench_camera(8, st["h_max"], w, h)
+    results = []
+    for env in ({"VX_RENDER_KERNEL": "1"}, {"VX_RENDER_KERNEL": "2"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"},
+                {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "64", "VX_SERVICE_MIN": "64"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"}):
+        for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+        svo.set_materials(mats)
+        svo.set_textures(tex, 6)
+        svo.update(world)
+        img, hits = svo.render(u, w, h, want_hits=True)
+        img2, _ = svo.render(u, w, h)
+        assert img2.tobytes() == img.tobytes()
+        results.append((img.tobytes(), hits.tobytes(), svo.render_counters(u, w, h)))
+        svo.close()
+    for r in results[1:]:
+        assert r[0] == results[0][0] and r[1] == results[0][1] and r[2] == results[0][2]

@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -28,17 +29,12 @@ constexpr uint32_t kTile = 32;         // multi-GPU sharding unit (pixels per ed
 constexpr uint32_t kBlockEdge = 16;    // one 256-thread workgroup shades 16x16 pixels: 4 waves x (8x8)
 constexpr uint32_t kBlockThreads = 256;
 
-__device__ __forceinline__ Stack make_stack(unsigned char* smem, uint32_t levels, uint32_t threads, uint32_t tid, StackSpill& spill) {
+__device__ __forceinline__ Stack make_stack(uint32_t levels, uint32_t threads, uint32_t tid, StackSpill& spill) {
     Stack st;
-    st.spill_ptr = spill.ptr;
-    st.spill_t_max = spill.t_max;
-    st.spill_aux = spill.aux;
-    st.ptr = reinterpret_cast<uint32_t*>(smem);
-    st.t_max = reinterpret_cast<float*>(smem + size_t(levels) * threads * 4);
-    st.aux = reinterpret_cast<int16_t*>(smem + size_t(levels) * threads * 8);
     st.stride = threads;
     st.tid = tid;
     st.levels = levels;
+    st.spill = &spill;
     return st;
 }
 
@@ -62,10 +58,9 @@ __device__ __forceinline__ void lane_to_xy(uint32_t lane, uint32_t& x, uint32_t&
 template <int SVO, bool HITS, bool STATS>
 __global__ __launch_bounds__(kBlockThreads) void render_kernel(DevScene sc, RenderParams p, float4* __restrict__ out, vx_hit* __restrict__ hits,
                                                                unsigned long long* __restrict__ counters, uint32_t levels) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
     StackSpill spill;
-    const Stack st = make_stack(smem, levels, kBlockThreads, tid, spill);
+    const Stack st = make_stack(levels, kBlockThreads, tid, spill);
 
     // block -> (local tile, 16x16 sub-block) -> pixel
     const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
@@ -109,12 +104,187 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(DevScene sc, Rend
     }
 }
 
+// ---- v2: persistent wavefront kernel ---------------------------------------------------------------------------
+//
+// One workgroup = one wave64 that keeps its 64 lanes fed from a global queue of 8x8-pixel sub-tiles. A lane's ray is a
+// small state machine (Trav): IDLE -> TRAV (primary) -> [LEAF -> TRAV]* -> DONE -> shade -> TRAV (shadow) -> ... ->
+// DONE -> pixel written -> IDLE. The expensive, rare phases (leaf test = material row + texture sample; shading; ray
+// set-up) are not executed the moment one lane needs them: lanes park, and the wave services them when a ballot
+// shows that `service_min` lanes are waiting (or nobody is left traversing); idle lanes are re-filled with new pixels
+// when `refill_min` of them are free. The common descend/advance/pop step therefore runs with most lanes active
+// instead of the ~30 % the one-thread-per-pixel kernel reached (profiles/round1/v1_*).
+enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3 };
+
+struct PersistentArgs {
+    uint32_t* work_counter;   // next sub-tile; zeroed before every launch
+    uint32_t total_subtiles;  // n_local_tiles * 16
+    uint32_t refill_min, service_min;
+};
+
+template <int SVO, bool HITS, bool STATS>
+__global__ __launch_bounds__(64) void render_persistent(DevScene sc, RenderParams p, PersistentArgs a, float4* __restrict__ out,
+                                                        vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, uint32_t levels) {
+    const uint32_t lane = threadIdx.x;
+    StackSpill spill;
+    const Stack st = make_stack(levels, 64, lane, spill);
+
+    Trav<SVO> tr;
+    Result res;
+    int state = kIdle;
+    bool shadow_ray = false;
+    uint32_t out_index = 0, px_x = 0, px_y = 0;
+    float keep_color[4] = {0, 0, 0, 0}, keep_ds = 0.0f;
+    vx_hit rec;            // HITS only
+    uint32_t steps = 0;    // HITS only
+    Counters ctr = {};
+    uint32_t n_pixels = 0, lit = 0, shadow_rays = 0;
+    uint32_t nf = 0;
+
+    uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
+    bool queue_empty = false;
+
+    for (;;) {
+        // ---- refill idle lanes from the sub-tile queue ----
+        unsigned long long idle_mask = __ballot(state == kIdle);
+        if (!queue_empty && idle_mask && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
+            for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
+                if (cursor >= 64) {
+                    uint32_t t = 0;
+                    if (lane == 0) t = atomicAdd(a.work_counter, 1u);
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    if (t >= a.total_subtiles) {
+                        queue_empty = true;
+                        break;
+                    }
+                    sub = t;
+                    cursor = 0;
+                }
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
+                const uint32_t k = cursor + rank;
+                if (state == kIdle && k < 64) {
+                    // sub-tile -> pixel: 32x32 tile (sharding unit), 4x4 sub-tiles in Morton order, 8x8 pixels in Morton order
+                    const uint32_t local_tile = sub >> 4, s = sub & 15u;
+                    const uint32_t tile = local_tile * p.tile_count + p.tile_rank;
+                    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+                    const uint32_t sx = (s & 1u) | ((s >> 1) & 2u), sy = ((s >> 1) & 1u) | ((s >> 2) & 2u);
+                    uint32_t lx, ly;
+                    lane_to_xy(k, lx, ly);
+                    const uint32_t in_x = sx * 8 + lx, in_y = sy * 8 + ly;
+                    px_x = tx * kTile + in_x;
+                    px_y = ty * kTile + in_y;
+                    out_index = p.tile_count > 1 ? local_tile * (kTile * kTile) + in_y * kTile + in_x : px_y * p.width + px_x;
+                    if (px_x < p.width && px_y < p.height) {
+                        float ro[3], rd[3];
+                        primary_ray(p, px_x, px_y, ro, rd);
+                        tr.init(sc, ro, rd, -1.0f);
+                        state = kTrav;
+                        shadow_ray = false;
+                        steps = 0;
+                        if (STATS) { ctr.rays++; ++n_pixels; }
+                    } else if (p.tile_count > 1) {
+                        // padding pixel of an edge tile: keep the compact tile list fully defined
+                        if (out) out[out_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (HITS) memset(&hits[out_index], 0, sizeof(vx_hit));
+                    }
+                }
+                const uint32_t n_idle = uint32_t(__popcll(idle_mask));
+                cursor += n_idle < 64 - cursor ? n_idle : 64 - cursor;
+                idle_mask = __ballot(state == kIdle);
+            }
+        }
+        if (__ballot(state != kIdle) == 0) {
+            if (queue_empty) break;
+            continue;
+        }
+
+        // ---- traverse until enough lanes wait for service ----
+        for (;;) {
+            if (state == kTrav) {
+                const TravStatus s = tr.template step<false, STATS>(sc, st, nullptr, 0, nf, STATS ? &ctr : nullptr);
+                if (s == kTravAtLeaf) state = kLeaf;
+                else if (s == kTravFinished) {
+                    result_miss(res, tr.inside_voxel);
+                    state = kDone;
+                }
+            }
+            const unsigned long long trav = __ballot(state == kTrav);
+            const unsigned long long serv = __ballot(state == kLeaf || state == kDone);
+            if (trav == 0 || uint32_t(__popcll(serv)) >= a.service_min) break;
+        }
+
+        // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
+        if (state == kLeaf) state = tr.template leaf_test<STATS>(sc, true, res, STATS ? &ctr : nullptr) ? kDone : kTrav;
+
+        // ---- finished rays ----
+        if (state == kDone) {
+            float color[4];
+            bool write = true;
+            if (!shadow_ray) {
+                PrimaryOutcome o;
+                shade_primary(sc, p, res, o);
+                if (HITS) {
+                    rec.t = res.t; rec.value = res.value; rec.face_id = res.face_id; rec.flags = o.flags;
+                    rec.pos[0] = res.pos[0]; rec.pos[1] = res.pos[1]; rec.pos[2] = res.pos[2];
+                    rec.lod = res.lod; rec.uv[0] = res.uv[0]; rec.uv[1] = res.uv[1];
+                    rec.shadow_t = -1.0f;
+                    steps = tr.iter;
+                }
+                if (res.t == -1.0f) {  // no hit: sky (world.glsl:135-138)
+                    float ro[3], rd[3], sky[3];
+                    primary_ray(p, px_x, px_y, ro, rd);
+                    sky_color(rd, sky);
+                    color[0] = sky[0]; color[1] = sky[1]; color[2] = sky[2]; color[3] = 1.0f;
+                } else {
+                    if (STATS && !(o.flags & 8u)) ++lit;
+                    color[0] = o.color[0]; color[1] = o.color[1]; color[2] = o.color[2]; color[3] = o.color[3];
+                    if (!o.final_color) {
+                        keep_color[0] = o.color[0]; keep_color[1] = o.color[1]; keep_color[2] = o.color[2]; keep_color[3] = o.color[3];
+                        keep_ds = o.ds;
+                        const float neg_l[3] = {-p.u.light_dir[0], -p.u.light_dir[1], -p.u.light_dir[2]};
+                        tr.init(sc, o.shadow_origin, neg_l, -1.0f);
+                        shadow_ray = true;
+                        state = kTrav;
+                        write = false;
+                        if (STATS) { ctr.rays++; ++shadow_rays; }
+                    }
+                }
+            } else {
+                color[0] = keep_color[0]; color[1] = keep_color[1]; color[2] = keep_color[2]; color[3] = keep_color[3];
+                apply_light(p, color, keep_ds, res.t < 0.0f ? 1.0f : 0.0f);
+                if (HITS) {
+                    if (!(res.t < 0.0f)) rec.flags |= 4u;
+                    rec.shadow_t = res.t;
+                    steps += tr.iter;
+                }
+            }
+            if (write) {
+                if (out) out[out_index] = make_float4(color[0], color[1], color[2], color[3]);
+                if (HITS) {
+                    rec.steps = steps;
+                    hits[out_index] = rec;
+                }
+                state = kIdle;
+            }
+        }
+    }
+
+    if (STATS) {
+        uint32_t v[11] = {ctr.rays, ctr.iterations, ctr.pushes, ctr.leaf_tests, ctr.leaf_tests_trilinear, ctr.boundaries, ctr.csvo_header_bytes,
+                          ctr.csvo_pointer_bytes, n_pixels, lit, shadow_rays};
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            unsigned long long sum = v[k];
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+            if (lane == 0 && sum) atomicAdd(&counters[k], sum);
+        }
+    }
+}
+
 template <int SVO>
 __global__ __launch_bounds__(64) void picker_kernel(DevScene sc, const vx_picker_task* __restrict__ tasks, uint32_t n,
                                                     vx_picker_result* __restrict__ results, uint32_t levels) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     StackSpill spill;
-    const Stack st = make_stack(smem, levels, 64, threadIdx.x, spill);
+    const Stack st = make_stack(levels, 64, threadIdx.x, spill);
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     // picker.glsl:30-51
@@ -144,9 +314,8 @@ struct TraceArgs {
 template <int SVO>
 __global__ __launch_bounds__(64) void trace_kernel(DevScene sc, TraceArgs a, vx_result* __restrict__ result, vx_frame* __restrict__ frames,
                                                    uint32_t max_frames, uint32_t* __restrict__ n_frames, uint32_t levels) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     StackSpill spill;
-    const Stack st = make_stack(smem, levels, 64, threadIdx.x, spill);
+    const Stack st = make_stack(levels, 64, threadIdx.x, spill);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Result res;
     uint32_t steps = 0, nf = 0;
@@ -224,6 +393,12 @@ struct vx_context {
     vx_result* d_trace_result = nullptr;  vx_frame* d_trace_frames = nullptr;  uint32_t* d_trace_count = nullptr;  uint32_t trace_cap = 0;
     unsigned long long* d_counters = nullptr;
 
+    uint32_t* d_work_counter = nullptr;
+    int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
+    uint32_t refill_min = 16, service_min = 12;
+    int cu_count = 256;
+    int persistent_blocks[2][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
+
     bool profile = false;
     std::vector<ProfiledLaunch> launches;
     std::vector<ProfiledLaunch> event_pool;
@@ -276,6 +451,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
     if (grid.x == 0) return VX_OK;
     const DevScene sc = scene_of(ctx);
 
+    if (ctx->kernel_version != 1) HIP_TRY(hipMemsetAsync(ctx->d_work_counter, 0, sizeof(uint32_t), ctx->stream));  // sub-tile queue head
     ProfiledLaunch ev{};
     if (ctx->profile) {
         if (!ctx->event_pool.empty()) {
@@ -287,10 +463,36 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         }
         HIP_TRY(hipEventRecord(ev.start, ctx->stream));
     }
-    if (ctx->svo_type == VX_SVO_ESVO)
-        hipLaunchKernelGGL((render_kernel<VX_SVO_ESVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters, levels);
-    else
-        hipLaunchKernelGGL((render_kernel<VX_SVO_CSVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters, levels);
+    if (ctx->kernel_version == 1) {
+        if (ctx->svo_type == VX_SVO_ESVO)
+            hipLaunchKernelGGL((render_kernel<VX_SVO_ESVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters, levels);
+        else
+            hipLaunchKernelGGL((render_kernel<VX_SVO_CSVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters, levels);
+    } else {
+        // persistent waves: as many 64-thread workgroups as the device keeps resident, fed from the sub-tile queue
+        const size_t wave_lds = size_t(levels) * 64 * 10;
+        int& per_cu = ctx->persistent_blocks[ctx->svo_type == VX_SVO_CSVO][HITS][STATS];
+        if (per_cu == 0) {
+            int n = 0;
+            const void* fn = ctx->svo_type == VX_SVO_ESVO ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, STATS>)
+                                                            : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, HITS, STATS>);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, wave_lds) != hipSuccess || n <= 0) n = 8;
+            per_cu = n;
+        }
+        PersistentArgs a;
+        a.work_counter = ctx->d_work_counter;
+        a.total_subtiles = p.n_local_tiles * 16;
+        a.refill_min = ctx->refill_min;
+        a.service_min = ctx->service_min;
+        uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(per_cu);
+        if (waves > a.total_subtiles) waves = a.total_subtiles;
+        if (ctx->svo_type == VX_SVO_ESVO)
+            hipLaunchKernelGGL((render_persistent<VX_SVO_ESVO, HITS, STATS>), dim3(waves), dim3(64), wave_lds, ctx->stream, sc, p, a,
+                               reinterpret_cast<float4*>(out), hits, counters, levels);
+        else
+            hipLaunchKernelGGL((render_persistent<VX_SVO_CSVO, HITS, STATS>), dim3(waves), dim3(64), wave_lds, ctx->stream, sc, p, a,
+                               reinterpret_cast<float4*>(out), hits, counters, levels);
+    }
     HIP_TRY(hipGetLastError());
     if (ctx->profile) {
         HIP_TRY(hipEventRecord(ev.stop, ctx->stream));
@@ -368,6 +570,19 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     CREATE_TRY(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&c->render_done, hipEventDisableTiming));
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
+    {
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, device));
+        c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
+        if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
+        if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
+        if (c->refill_min < 1) c->refill_min = 1;
+        if (c->refill_min > 64) c->refill_min = 64;
+        if (c->service_min < 1) c->service_min = 1;
+        if (c->service_min > 64) c->service_min = 64;
+    }
     // one all-zero material and a 1x1 transparent-black texture so that rendering works before any registry is set
     const vx_material zero_mat = {0, 0, -1, -1, -1, -1, -1, -1};
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_materials), sizeof zero_mat));
@@ -387,7 +602,7 @@ void vx_destroy(vx_context* c) {
     for (auto& l : c->event_pool) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     if (c->staging) (void)hipHostFree(c->staging);
     void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_image, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
-                   c->d_trace_count, c->d_counters};
+                   c->d_trace_count, c->d_counters, c->d_work_counter};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (c->upload_done) (void)hipEventDestroy(c->upload_done);

@@ -60,38 +60,31 @@ struct Counters {  // per-thread, reduced by the instrumented kernel
 // (svo.esvo.glsl:183-185 / svo.csvo.glsl:293-295 only treat a leaf as a hit when t_min > 0); its stack arrays hold
 // MAX_SCALE + 1 entries (svo.esvo.glsl:28-30), so those pushes are kept too -- in a per-thread spill array that
 // ordinary rays never touch.
-struct Stack {
-    uint32_t* ptr;   // octant / node pointer
-    float* t_max;
-    int16_t* aux;    // ESVO: parent_octant_idx; CSVO: depth, which spans [-23, 255] once a ray is below the leaves
-                     // (svo.csvo.glsl:398 keeps decrementing a uint): sign-extended 16 bits restore the same pattern
-    uint32_t stride; // threads per block
-    uint32_t tid;
-    uint32_t levels; // levels held in LDS
-    uint32_t* spill_ptr;  // [kMaxScale] per-thread
-    float* spill_t_max;
-    int16_t* spill_aux;
+#ifndef VX_DEVICE_ON_HOST
+// the one dynamic-LDS array of every kernel in this library (16-byte aligned base, cdna guide G17)
+extern __shared__ __attribute__((aligned(16))) unsigned char vx_smem[];
+#else
+extern unsigned char* vx_smem;
+#endif
 
-    __device__ __forceinline__ void push(int scale, uint32_t p, int16_t a, float t) const {
-        const uint32_t lv = uint32_t(kMaxScale - 1 - scale);
-        if (lv < levels) {
-            const uint32_t s = lv * stride + tid;
-            ptr[s] = p; aux[s] = a; t_max[s] = t;
-        } else if (lv < uint32_t(kMaxScale)) {
-            spill_ptr[lv] = p; spill_aux[lv] = a; spill_t_max[lv] = t;
-        }
-    }
-    __device__ __forceinline__ void pop(int scale, uint32_t& p, int16_t& a, float& t) const {
-        const uint32_t lv = uint32_t(kMaxScale - 1 - scale);
-        if (lv < levels) {
-            const uint32_t s = lv * stride + tid;
-            p = ptr[s]; a = aux[s]; t = t_max[s];
-        } else if (lv < uint32_t(kMaxScale)) {
-            p = spill_ptr[lv]; a = spill_aux[lv]; t = spill_t_max[lv];
-        } else {
-            p = 0; a = 0; t = 0.0f;
-        }
-    }
+struct StackSpill;
+
+struct Stack {
+    // LDS image: u32 ptr[levels][threads] | f32 t_max[levels][threads] | i16 aux[levels][threads], addressed by byte
+    // offsets into vx_smem (no generic pointers: LDS and scratch accesses stay in their own address spaces)
+    uint32_t stride;  // threads sharing the LDS image
+    uint32_t tid;
+    uint32_t levels;  // levels held in LDS
+    StackSpill* spill;
+
+    __device__ __forceinline__ uint32_t* lds_ptr(uint32_t s) const { return reinterpret_cast<uint32_t*>(vx_smem) + s; }
+    __device__ __forceinline__ float* lds_t_max(uint32_t s) const { return reinterpret_cast<float*>(vx_smem + size_t(levels) * stride * 4) + s; }
+    __device__ __forceinline__ int16_t* lds_aux(uint32_t s) const { return reinterpret_cast<int16_t*>(vx_smem + size_t(levels) * stride * 8) + s; }
+
+    // aux = ESVO: parent_octant_idx; CSVO: depth, which spans [-23, 255] once a ray is below the leaves
+    // (svo.csvo.glsl:398 keeps decrementing a uint): sign-extended 16 bits restore the same 32-bit pattern
+    __device__ __forceinline__ void push(int scale, uint32_t p, int16_t a, float t) const;
+    __device__ __forceinline__ void pop(int scale, uint32_t& p, int16_t& a, float& t) const;
 };
 
 // per-thread backing store for Stack::spill_* (lives in scratch; touched only by rays that start inside a voxel)
@@ -100,6 +93,28 @@ struct StackSpill {
     float t_max[kMaxScale];
     int16_t aux[kMaxScale];
 };
+
+__device__ __forceinline__ void Stack::push(int scale, uint32_t p, int16_t a, float t) const {
+    const uint32_t lv = uint32_t(kMaxScale - 1 - scale);
+    if (lv < levels) {
+        const uint32_t s = lv * stride + tid;
+        *lds_ptr(s) = p; *lds_aux(s) = a; *lds_t_max(s) = t;
+    } else if (lv < uint32_t(kMaxScale)) {
+        spill->ptr[lv] = p; spill->aux[lv] = a; spill->t_max[lv] = t;
+    }
+}
+
+__device__ __forceinline__ void Stack::pop(int scale, uint32_t& p, int16_t& a, float& t) const {
+    const uint32_t lv = uint32_t(kMaxScale - 1 - scale);
+    if (lv < levels) {
+        const uint32_t s = lv * stride + tid;
+        p = *lds_ptr(s); a = *lds_aux(s); t = *lds_t_max(s);
+    } else if (lv < uint32_t(kMaxScale)) {
+        p = spill->ptr[lv]; a = spill->aux[lv]; t = spill->t_max[lv];
+    } else {
+        p = 0; a = 0; t = 0.0f;
+    }
+}
 
 __device__ __forceinline__ float gmin(float x, float y) { return y < x ? y : x; }  // GLSL min
 __device__ __forceinline__ float gmax(float x, float y) { return x < y ? y : x; }  // GLSL max
@@ -267,246 +282,86 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
     for (int k = 0; k < 4; ++k) rgba[k] = a[k] * (1.0f - frac) + b[k] * frac;
 }
 
-// ---- intersect_octree ---------------------------------------------------------------------------------------
+// ---- intersect_octree as a resumable per-lane state machine ------------------------------------------------------
+//
+// The reference's loop body has three very different costs: the common descend/advance/pop step, the rare leaf test
+// (material row + texture sample, svo.esvo.glsl:185-265) and termination. Run as written, one lane at a leaf stalls
+// the other 63. Here one ray is a `Trav` whose step() performs exactly one loop iteration of the reference and
+// reports when the ray is AT a leaf instead of testing it, so a wavefront can park such lanes and test them
+// together (render kernel), while the picker / debug kernels simply call step() and leaf_test() back to back.
 
-template <int SVO, bool TRACE, bool STATS>
-__device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst, bool cast_translucent,
-                                          const Stack& st, Result& res, uint32_t& steps, vx_frame* frames, uint32_t max_frames,
-                                          uint32_t& n_frames, Counters* ctr) {
-    constexpr bool CSVO = SVO == VX_SVO_CSVO;
-    const float octree_scale = *reinterpret_cast<const float*>(sc.world);
-    const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 1/2^-d = 2^d, exact
+enum TravStatus : int { kTravContinue = 0, kTravAtLeaf = 1, kTravFinished = 2 };
 
-    if (STATS) ctr->rays++;
+template <int SVO>
+struct Trav {
+    static constexpr bool CSVO = SVO == VX_SVO_CSVO;
 
-    float rox = ro_in[0] * octree_scale, roy = ro_in[1] * octree_scale, roz = ro_in[2] * octree_scale;
-    max_dst *= octree_scale;
+    float rox, roy, roz, rdx, rdy, rdz;   // origin in [1,2) space, epsilon-clamped direction
+    float tcx, tcy, tcz, tbx, tby, tbz;   // t(x) = x * t_coef - t_bias per axis
+    float px, py, pz;                     // current octant corner
+    float t_min, t_max, h, scale_exp2;
+    float max_dst;                        // already scaled to [0,1]; < 0 = unlimited
+    uint32_t ptr;
+    uint32_t aux;                         // ESVO: parent_octant_idx, CSVO: depth
+    uint32_t node;                        // ESVO: masks of the child being examined (cached); CSVO: pointer of the child at the leaf
+    uint32_t material_section_ptr, pre_leaf_pointer;  // CSVO only
+    uint32_t last_leaf_value;
+    int adjacent_leaf_count;
+    int scale, idx, octant_mask;
+    uint32_t iter;                        // loop iterations executed (the reference's `i`)
+    bool pending_advance;                 // a rejected leaf still owes the ADVANCE/POP half of its iteration
+    bool inside_voxel;
 
-    res.t = -1.0f;
-    res.value = 0;
-    res.face_id = 0;
-    res.pos[0] = res.pos[1] = res.pos[2] = 0.0f;
-    res.uv[0] = res.uv[1] = 0.0f;
-    res.color[0] = res.color[1] = res.color[2] = res.color[3] = 0.0f;
-    res.lod = 0.0f;
-    res.inside_voxel = false;
+    __device__ __forceinline__ void init(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst_in) {
+        const float octree_scale = *reinterpret_cast<const float*>(sc.world);
+        rox = ro_in[0] * octree_scale; roy = ro_in[1] * octree_scale; roz = ro_in[2] * octree_scale;
+        max_dst = max_dst_in * octree_scale;
+        rox += 1.0f; roy += 1.0f; roz += 1.0f;
 
-    rox += 1.0f; roy += 1.0f; roz += 1.0f;
+        ptr = CSVO ? *reinterpret_cast<const uint32_t*>(sc.world + 4) : 0u;
+        aux = CSVO ? 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu) : 0u;  // svo.csvo.glsl:254
+        scale = kMaxScale - 1;
+        scale_exp2 = 0.5f;
+        last_leaf_value = 0xffffffffu;
+        adjacent_leaf_count = 0;
+        material_section_ptr = kInvalidPtr;
+        pre_leaf_pointer = kInvalidPtr;
+        iter = 0;
+        pending_advance = false;
+        inside_voxel = false;
 
-    uint32_t ptr = CSVO ? *reinterpret_cast<const uint32_t*>(sc.world + 4) : 0u;
-    uint32_t parent_octant_idx = 0;
-    int scale = kMaxScale - 1;
-    float scale_exp2 = 0.5f;
+        rdx = rd_in[0]; rdy = rd_in[1]; rdz = rd_in[2];
+        const uint32_t eps_bits = __float_as_uint(kEps) & 0x7fffffffu;
+        if (fabsf(rdx) < kEps) rdx = __uint_as_float(eps_bits | (__float_as_uint(rdx) & 0x80000000u));
+        if (fabsf(rdy) < kEps) rdy = __uint_as_float(eps_bits | (__float_as_uint(rdy) & 0x80000000u));
+        if (fabsf(rdz) < kEps) rdz = __uint_as_float(eps_bits | (__float_as_uint(rdz) & 0x80000000u));
 
-    uint32_t last_leaf_value = 0xffffffffu;
-    int adjacent_leaf_count = 0;
+        tcx = 1.0f / -fabsf(rdx); tcy = 1.0f / -fabsf(rdy); tcz = 1.0f / -fabsf(rdz);
+        tbx = tcx * rox; tby = tcy * roy; tbz = tcz * roz;
 
-    float rdx = rd_in[0], rdy = rd_in[1], rdz = rd_in[2];
-    const uint32_t eps_bits = __float_as_uint(kEps) & 0x7fffffffu;
-    if (fabsf(rdx) < kEps) rdx = __uint_as_float(eps_bits | (__float_as_uint(rdx) & 0x80000000u));
-    if (fabsf(rdy) < kEps) rdy = __uint_as_float(eps_bits | (__float_as_uint(rdy) & 0x80000000u));
-    if (fabsf(rdz) < kEps) rdz = __uint_as_float(eps_bits | (__float_as_uint(rdz) & 0x80000000u));
+        octant_mask = 0;
+        if (rdx > 0.0f) { octant_mask ^= 1; tbx = __builtin_fmaf(3.0f, tcx, -tbx); }
+        if (rdy > 0.0f) { octant_mask ^= 2; tby = __builtin_fmaf(3.0f, tcy, -tby); }
+        if (rdz > 0.0f) { octant_mask ^= 4; tbz = __builtin_fmaf(3.0f, tcz, -tbz); }
 
-    const float tcx = 1.0f / -fabsf(rdx), tcy = 1.0f / -fabsf(rdy), tcz = 1.0f / -fabsf(rdz);
-    float tbx = tcx * rox, tby = tcy * roy, tbz = tcz * roz;
+        t_min = gmax(gmax(__builtin_fmaf(2.0f, tcx, -tbx), __builtin_fmaf(2.0f, tcy, -tby)), __builtin_fmaf(2.0f, tcz, -tbz));
+        t_min = gmax(0.0f, t_min);
+        t_max = gmin(gmin(tcx - tbx, tcy - tby), tcz - tbz);
+        h = t_max;
 
-    int octant_mask = 0;
-    if (rdx > 0.0f) { octant_mask ^= 1; tbx = __builtin_fmaf(3.0f, tcx, -tbx); }
-    if (rdy > 0.0f) { octant_mask ^= 2; tby = __builtin_fmaf(3.0f, tcy, -tby); }
-    if (rdz > 0.0f) { octant_mask ^= 4; tbz = __builtin_fmaf(3.0f, tcz, -tbz); }
+        idx = 0;
+        px = 1.0f; py = 1.0f; pz = 1.0f;
+        if (t_min < __builtin_fmaf(1.5f, tcx, -tbx)) { idx ^= 1; px = 1.5f; }
+        if (t_min < __builtin_fmaf(1.5f, tcy, -tby)) { idx ^= 2; py = 1.5f; }
+        if (t_min < __builtin_fmaf(1.5f, tcz, -tbz)) { idx ^= 4; pz = 1.5f; }
 
-    float t_min = gmax(gmax(__builtin_fmaf(2.0f, tcx, -tbx), __builtin_fmaf(2.0f, tcy, -tby)), __builtin_fmaf(2.0f, tcz, -tbz));
-    t_min = gmax(0.0f, t_min);
-    float t_max = gmin(gmin(tcx - tbx, tcy - tby), tcz - tbz);
-    float h = t_max;
+        // ESVO: the masks of the child being examined depend only on (ptr, parent_octant_idx); they are fetched when
+        // those change (here, PUSH, POP) instead of every iteration (svo.esvo.glsl:168-173 reloads each time).
+        node = CSVO ? 0u : esvo_word(sc, ptr);
+    }
 
-    int idx = 0;
-    float px = 1.0f, py = 1.0f, pz = 1.0f;
-    if (t_min < __builtin_fmaf(1.5f, tcx, -tbx)) { idx ^= 1; px = 1.5f; }
-    if (t_min < __builtin_fmaf(1.5f, tcy, -tby)) { idx ^= 2; py = 1.5f; }
-    if (t_min < __builtin_fmaf(1.5f, tcz, -tbz)) { idx ^= 4; pz = 1.5f; }
-
-    // CSVO state (svo.csvo.glsl:252-258)
-    uint32_t depth = 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu);
-    uint32_t material_section_ptr = kInvalidPtr;
-    uint32_t pre_leaf_pointer = kInvalidPtr;
-
-    // ESVO: the masks of the child being examined depend only on (ptr, parent_octant_idx); fetch them when
-    // those change (start, PUSH, POP) instead of every iteration (svo.esvo.glsl:168-173 reloads each time).
-    uint32_t descriptor = 0;
-    if (!CSVO) descriptor = esvo_word(sc, ptr);
-
-    for (int i = 0; i < kMaxSteps; ++i) {
-        if (max_dst >= 0.0f && t_min > max_dst) break;
-        ++steps;
-        if (STATS) ctr->iterations++;
-
-        const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
-        const float tc_max = gmin(gmin(tcrx, tcry), tcrz);
-
-        const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
-
-        bool is_child, is_leaf, crossed_boundary = false;
-        uint32_t next_ptr = 0, iter_ptr_bytes = 0;
-        if (!CSVO) {
-            is_child = (descriptor & (0x100u << octant_idx)) != 0;
-            is_leaf = (descriptor & (1u << octant_idx)) != 0;
-        } else {
-            uint32_t hb = 0;
-            next_ptr = csvo_next_ptr(sc, ptr, depth, octant_idx, crossed_boundary, hb, iter_ptr_bytes);
-            is_child = next_ptr != kInvalidPtr;
-            is_leaf = is_child && depth < 2;
-            if (depth == 2) pre_leaf_pointer = ptr;
-            if (STATS) ctr->csvo_header_bytes += hb;
-        }
-
-        if (TRACE) {
-            if (n_frames < max_frames) {
-                vx_frame& f = frames[n_frames];
-                f.t_min = t_min * inv_scale;
-                f.ptr = ptr;
-                f.idx = octant_idx;
-                f.parent_octant_idx = CSVO ? depth : parent_octant_idx;
-                f.scale = scale;
-                f.is_child = is_child;
-                f.is_leaf = is_leaf;
-                f.crossed_boundary = crossed_boundary;
-                f.next_ptr = CSVO ? next_ptr : 0u;
-            }
-            ++n_frames;
-        }
-
-        bool advance = true;
-        if (is_child && t_min <= t_max) {
-            if (is_leaf && t_min == 0.0f) res.inside_voxel = true;
-
-            if (is_leaf && t_min > 0.0f) {
-                // ---- HIT (svo.esvo.glsl:185-265) ----
-                if (STATS) ctr->leaf_tests++;
-                uint32_t value;
-                if (!CSVO) {
-                    uint32_t np = esvo_word(sc, ptr + 4 + parent_octant_idx);
-                    if (np & (1u << 31)) np = ptr + 4 + parent_octant_idx + (np & 0x7fffffffu);
-                    value = esvo_word(sc, np + 4 + octant_idx);
-                } else {
-                    value = csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx);
-                }
-
-                const float ex = __builtin_fmaf(px + scale_exp2, tcx, -tbx);
-                const float ey = __builtin_fmaf(py + scale_exp2, tcy, -tby);
-                const float ez = __builtin_fmaf(pz + scale_exp2, tcz, -tbz);
-                const float tc_min = gmax(gmax(ex, ey), ez);
-
-                float qx = px, qy = py, qz = pz;
-                if (octant_mask & 1) qx = 3.0f - scale_exp2 - qx;
-                if (octant_mask & 2) qy = 3.0f - scale_exp2 - qy;
-                if (octant_mask & 4) qz = 3.0f - scale_exp2 - qz;
-
-                const float inv_s = __uint_as_float(0x7f000000u - __float_as_uint(scale_exp2));  // exact 1/scale_exp2
-                int face_id;
-                float uvx, uvy;
-                if (tc_min == ex) {
-                    face_id = int((__float_as_uint(rdx) >> 31) & 1u);
-                    uvx = (__builtin_fmaf(rdz, ex, roz) - qz) * inv_s;
-                    uvy = (__builtin_fmaf(rdy, ex, roy) - qy) * inv_s;
-                    if (rdx > 0.0f) uvx = 1.0f - uvx;
-                } else if (tc_min == ey) {
-                    face_id = 2 | int((__float_as_uint(rdy) >> 31) & 1u);
-                    uvx = (__builtin_fmaf(rdx, ey, rox) - qx) * inv_s;
-                    uvy = (__builtin_fmaf(rdz, ey, roz) - qz) * inv_s;
-                    if (rdy > 0.0f) uvy = 1.0f - uvy;
-                } else {
-                    face_id = 4 | int((__float_as_uint(rdz) >> 31) & 1u);
-                    uvx = (__builtin_fmaf(rdx, ez, rox) - qx) * inv_s;
-                    uvy = (__builtin_fmaf(rdy, ez, roy) - qy) * inv_s;
-                    if (rdz < 0.0f) uvx = 1.0f - uvx;
-                }
-
-                const vx_material mat = material_at(sc, value);
-                int tex_id = mat.tex_side;
-                if (face_id == 3) tex_id = mat.tex_top;
-                else if (face_id == 2) tex_id = mat.tex_bottom;
-
-                const float dst = t_min * inv_scale;
-                const float tex_lod = smoothstepf(15.0f, 25.0f, dst) * (dst - 15.0f) * 0.05f;
-                if (STATS && tex_lod > 0.0f) ctr->leaf_tests_trilinear++;
-
-                float tex_color[4];
-                texture_lod(sc.tex, uvx, uvy, float(tex_id), tex_lod, tex_color);
-
-                const bool first_of_kind = adjacent_leaf_count == 0 || value != last_leaf_value;
-                if ((tex_color[3] > 0.0f || !cast_translucent) && first_of_kind) {
-                    res.t = dst;
-                    res.face_id = face_id;
-                    res.uv[0] = uvx; res.uv[1] = uvy;
-                    res.value = value;
-                    res.color[0] = tex_color[0]; res.color[1] = tex_color[1]; res.color[2] = tex_color[2]; res.color[3] = tex_color[3];
-                    res.lod = tex_lod;
-                    const float hx = gmin(gmax(__builtin_fmaf(t_min, rdx, rox), qx + kEps), qx + scale_exp2 - kEps);
-                    const float hy = gmin(gmax(__builtin_fmaf(t_min, rdy, roy), qy + kEps), qy + scale_exp2 - kEps);
-                    const float hz = gmin(gmax(__builtin_fmaf(t_min, rdz, roz), qz + kEps), qz + scale_exp2 - kEps);
-                    res.pos[0] = (hx - 1.0f) * inv_scale;
-                    res.pos[1] = (hy - 1.0f) * inv_scale;
-                    res.pos[2] = (hz - 1.0f) * inv_scale;
-                    return;
-                }
-                ++adjacent_leaf_count;
-                last_leaf_value = value;
-            } else {
-                const float half_scale = scale_exp2 * 0.5f;
-                const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
-                            tcenz = __builtin_fmaf(half_scale, tcz, tcrz);
-                const float tv_max = gmin(t_max, tc_max);
-
-                if (t_min <= tv_max) {
-                    // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
-                    if (STATS) ctr->pushes++;
-                    if (tc_max < h) {
-                        st.push(scale, ptr, int16_t(CSVO ? depth : parent_octant_idx), t_max);
-                    }
-                    h = tc_max;
-
-                    if (!CSVO) {
-                        uint32_t np = esvo_word(sc, ptr + 4 + parent_octant_idx);
-                        if (np & (1u << 31)) np = ptr + 4 + parent_octant_idx + (np & 0x7fffffffu);
-                        ptr = np;
-                        parent_octant_idx = octant_idx;
-                        descriptor = esvo_word(sc, ptr + (parent_octant_idx >> 1));
-                        if (parent_octant_idx & 1u) descriptor >>= 16;
-                    } else {
-                        if (STATS) ctr->csvo_pointer_bytes += iter_ptr_bytes;
-                        --depth;
-                        ptr = next_ptr;
-                        if (crossed_boundary) {
-                            if (STATS) ctr->boundaries++;
-                            const uint32_t child_lod = csvo_u8(sc, ptr);
-                            const uint32_t material_bytes = csvo_u32(sc, ptr + 1);
-                            ptr += 5;
-                            material_section_ptr = ptr;
-                            ptr += material_bytes;
-                            depth = child_lod;
-                        }
-                    }
-
-                    --scale;
-                    scale_exp2 = half_scale;
-
-                    idx = 0;
-                    if (t_min < tcenx) { idx ^= 1; px += scale_exp2; }
-                    if (t_min < tceny) { idx ^= 2; py += scale_exp2; }
-                    if (t_min < tcenz) { idx ^= 4; pz += scale_exp2; }
-
-                    t_max = tv_max;
-                    advance = false;
-                }
-            }
-        } else {
-            adjacent_leaf_count = 0;
-            last_leaf_value = 0xffffffffu;
-        }
-        if (!advance) continue;
-
-        // ---- ADVANCE (svo.esvo.glsl:324-331) ----
+    // ADVANCE + POP (svo.esvo.glsl:324-390). Returns false when the ray left the octree.
+    __device__ __forceinline__ bool advance(const DevScene& sc, const Stack& st, float tcrx, float tcry, float tcrz, float tc_max) {
         int step_mask = 0;
         if (tc_max >= tcrx) { step_mask ^= 1; px -= scale_exp2; }
         if (tc_max >= tcry) { step_mask ^= 2; py -= scale_exp2; }
@@ -516,22 +371,21 @@ __device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[
         idx ^= step_mask;
 
         if ((idx & step_mask) != 0) {
-            // ---- POP (svo.esvo.glsl:347-390) ----
             uint32_t differing_bits = 0;
             if (step_mask & 1) differing_bits |= __float_as_uint(px) ^ __float_as_uint(px + scale_exp2);
             if (step_mask & 2) differing_bits |= __float_as_uint(py) ^ __float_as_uint(py + scale_exp2);
             if (step_mask & 4) differing_bits |= __float_as_uint(pz) ^ __float_as_uint(pz + scale_exp2);
 
             scale = differing_bits ? 31 - __clz(differing_bits) : -1;
-            if (scale >= kMaxScale || scale < 0) return;
+            if (scale >= kMaxScale || scale < 0) return false;
             scale_exp2 = pow2i(scale - kMaxScale);
 
-            int16_t aux;
-            st.pop(scale, ptr, aux, t_max);
-            if (CSVO) depth = uint32_t(int32_t(aux)); else parent_octant_idx = uint32_t(aux);
+            int16_t a;
+            st.pop(scale, ptr, a, t_max);
+            aux = CSVO ? uint32_t(int32_t(a)) : uint32_t(a);
             if (!CSVO) {
-                descriptor = esvo_word(sc, ptr + (parent_octant_idx >> 1));
-                if (parent_octant_idx & 1u) descriptor >>= 16;
+                node = esvo_word(sc, ptr + (aux >> 1));
+                if (aux & 1u) node >>= 16;
             }
 
             const int shx = __float_as_int(px) >> scale, shy = __float_as_int(py) >> scale, shz = __float_as_int(pz) >> scale;
@@ -539,10 +393,223 @@ __device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[
             py = __int_as_float(shy << scale);
             pz = __int_as_float(shz << scale);
             idx = (shx & 1) | ((shy & 1) << 1) | ((shz & 1) << 2);
-
             h = 0.0f;
         }
+        return true;
     }
+
+    // One iteration of the reference's loop (svo.esvo.glsl:152-391 / svo.csvo.glsl:261-508) minus the leaf test.
+    template <bool TRACE, bool STATS>
+    __device__ __forceinline__ TravStatus step(const DevScene& sc, const Stack& st, vx_frame* frames, uint32_t max_frames, uint32_t& n_frames,
+                                               Counters* ctr) {
+        if (pending_advance) {
+            // second half of an iteration whose leaf was rejected by leaf_test()
+            pending_advance = false;
+            const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
+            return advance(sc, st, tcrx, tcry, tcrz, gmin(gmin(tcrx, tcry), tcrz)) ? kTravContinue : kTravFinished;
+        }
+        if (iter >= uint32_t(kMaxSteps)) return kTravFinished;
+        if (max_dst >= 0.0f && t_min > max_dst) return kTravFinished;
+        ++iter;
+        if (STATS) ctr->iterations++;
+
+        const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
+        const float tc_max = gmin(gmin(tcrx, tcry), tcrz);
+        const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
+
+        bool is_child, is_leaf, crossed_boundary = false;
+        uint32_t next_ptr = 0, iter_ptr_bytes = 0;
+        if (!CSVO) {
+            is_child = (node & (0x100u << octant_idx)) != 0;
+            is_leaf = (node & (1u << octant_idx)) != 0;
+        } else {
+            uint32_t hb = 0;
+            next_ptr = csvo_next_ptr(sc, ptr, aux, octant_idx, crossed_boundary, hb, iter_ptr_bytes);
+            is_child = next_ptr != kInvalidPtr;
+            is_leaf = is_child && aux < 2;
+            if (aux == 2) pre_leaf_pointer = ptr;
+            if (STATS) ctr->csvo_header_bytes += hb;
+        }
+
+        if (TRACE) {
+            if (n_frames < max_frames) {
+                const float octree_scale = *reinterpret_cast<const float*>(sc.world);
+                vx_frame& f = frames[n_frames];
+                f.t_min = t_min * __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));
+                f.ptr = ptr;
+                f.idx = octant_idx;
+                f.parent_octant_idx = aux;
+                f.scale = scale;
+                f.is_child = is_child;
+                f.is_leaf = is_leaf;
+                f.crossed_boundary = crossed_boundary;
+                f.next_ptr = CSVO ? next_ptr : 0u;
+            }
+            ++n_frames;
+        }
+
+        if (is_child && t_min <= t_max) {
+            if (is_leaf && t_min == 0.0f) inside_voxel = true;
+            if (is_leaf && t_min > 0.0f) return kTravAtLeaf;  // leaf_test() decides; state is left untouched
+
+            const float half_scale = scale_exp2 * 0.5f;
+            const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
+                        tcenz = __builtin_fmaf(half_scale, tcz, tcrz);
+            const float tv_max = gmin(t_max, tc_max);
+            if (t_min <= tv_max) {
+                // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
+                if (STATS) ctr->pushes++;
+                if (tc_max < h) st.push(scale, ptr, int16_t(aux), t_max);
+                h = tc_max;
+                if (!CSVO) {
+                    uint32_t np = esvo_word(sc, ptr + 4 + aux);
+                    if (np & (1u << 31)) np = ptr + 4 + aux + (np & 0x7fffffffu);
+                    ptr = np;
+                    aux = octant_idx;
+                    node = esvo_word(sc, ptr + (aux >> 1));
+                    if (aux & 1u) node >>= 16;
+                } else {
+                    if (STATS) ctr->csvo_pointer_bytes += iter_ptr_bytes;
+                    --aux;
+                    ptr = next_ptr;
+                    if (crossed_boundary) {
+                        if (STATS) ctr->boundaries++;
+                        const uint32_t child_lod = csvo_u8(sc, ptr);
+                        const uint32_t material_bytes = csvo_u32(sc, ptr + 1);
+                        ptr += 5;
+                        material_section_ptr = ptr;
+                        ptr += material_bytes;
+                        aux = child_lod;
+                    }
+                }
+                --scale;
+                scale_exp2 = half_scale;
+                idx = 0;
+                if (t_min < tcenx) { idx ^= 1; px += scale_exp2; }
+                if (t_min < tceny) { idx ^= 2; py += scale_exp2; }
+                if (t_min < tcenz) { idx ^= 4; pz += scale_exp2; }
+                t_max = tv_max;
+                return kTravContinue;
+            }
+        } else {
+            adjacent_leaf_count = 0;
+            last_leaf_value = 0xffffffffu;
+        }
+        return advance(sc, st, tcrx, tcry, tcrz, tc_max) ? kTravContinue : kTravFinished;
+    }
+
+    // HIT phase (svo.esvo.glsl:185-265) for a ray whose step() returned kTravAtLeaf. Returns true when the leaf is
+    // the result (res filled in); otherwise records the translucent leaf and arms the ADVANCE half of the iteration.
+    template <bool STATS>
+    __device__ __forceinline__ bool leaf_test(const DevScene& sc, bool cast_translucent, Result& res, Counters* ctr) {
+        if (STATS) ctr->leaf_tests++;
+        const float octree_scale = *reinterpret_cast<const float*>(sc.world);
+        const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 2^depth, exact
+        const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
+        uint32_t value;
+        if (!CSVO) {
+            uint32_t np = esvo_word(sc, ptr + 4 + aux);
+            if (np & (1u << 31)) np = ptr + 4 + aux + (np & 0x7fffffffu);
+            value = esvo_word(sc, np + 4 + octant_idx);
+        } else {
+            value = csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx);
+        }
+
+        const float ex = __builtin_fmaf(px + scale_exp2, tcx, -tbx);
+        const float ey = __builtin_fmaf(py + scale_exp2, tcy, -tby);
+        const float ez = __builtin_fmaf(pz + scale_exp2, tcz, -tbz);
+        const float tc_min = gmax(gmax(ex, ey), ez);
+
+        float qx = px, qy = py, qz = pz;  // un-mirrored voxel corner
+        if (octant_mask & 1) qx = 3.0f - scale_exp2 - qx;
+        if (octant_mask & 2) qy = 3.0f - scale_exp2 - qy;
+        if (octant_mask & 4) qz = 3.0f - scale_exp2 - qz;
+
+        const float inv_s = __uint_as_float(0x7f000000u - __float_as_uint(scale_exp2));  // exact 1/scale_exp2
+        int face_id;
+        float uvx, uvy;
+        if (tc_min == ex) {
+            face_id = int((__float_as_uint(rdx) >> 31) & 1u);
+            uvx = (__builtin_fmaf(rdz, ex, roz) - qz) * inv_s;
+            uvy = (__builtin_fmaf(rdy, ex, roy) - qy) * inv_s;
+            if (rdx > 0.0f) uvx = 1.0f - uvx;
+        } else if (tc_min == ey) {
+            face_id = 2 | int((__float_as_uint(rdy) >> 31) & 1u);
+            uvx = (__builtin_fmaf(rdx, ey, rox) - qx) * inv_s;
+            uvy = (__builtin_fmaf(rdz, ey, roz) - qz) * inv_s;
+            if (rdy > 0.0f) uvy = 1.0f - uvy;
+        } else {
+            face_id = 4 | int((__float_as_uint(rdz) >> 31) & 1u);
+            uvx = (__builtin_fmaf(rdx, ez, rox) - qx) * inv_s;
+            uvy = (__builtin_fmaf(rdy, ez, roy) - qy) * inv_s;
+            if (rdz < 0.0f) uvx = 1.0f - uvx;
+        }
+
+        const vx_material mat = material_at(sc, value);
+        int tex_id = mat.tex_side;
+        if (face_id == 3) tex_id = mat.tex_top;
+        else if (face_id == 2) tex_id = mat.tex_bottom;
+
+        const float dst = t_min * inv_scale;
+        const float tex_lod = smoothstepf(15.0f, 25.0f, dst) * (dst - 15.0f) * 0.05f;
+        if (STATS && tex_lod > 0.0f) ctr->leaf_tests_trilinear++;
+
+        float tex_color[4];
+        texture_lod(sc.tex, uvx, uvy, float(tex_id), tex_lod, tex_color);
+
+        const bool first_of_kind = adjacent_leaf_count == 0 || value != last_leaf_value;
+        if ((tex_color[3] > 0.0f || !cast_translucent) && first_of_kind) {
+            res.t = dst;
+            res.face_id = face_id;
+            res.uv[0] = uvx; res.uv[1] = uvy;
+            res.value = value;
+            res.color[0] = tex_color[0]; res.color[1] = tex_color[1]; res.color[2] = tex_color[2]; res.color[3] = tex_color[3];
+            res.lod = tex_lod;
+            const float hx = gmin(gmax(__builtin_fmaf(t_min, rdx, rox), qx + kEps), qx + scale_exp2 - kEps);
+            const float hy = gmin(gmax(__builtin_fmaf(t_min, rdy, roy), qy + kEps), qy + scale_exp2 - kEps);
+            const float hz = gmin(gmax(__builtin_fmaf(t_min, rdz, roz), qz + kEps), qz + scale_exp2 - kEps);
+            res.pos[0] = (hx - 1.0f) * inv_scale;
+            res.pos[1] = (hy - 1.0f) * inv_scale;
+            res.pos[2] = (hz - 1.0f) * inv_scale;
+            res.inside_voxel = inside_voxel;
+            return true;
+        }
+        ++adjacent_leaf_count;
+        last_leaf_value = value;
+        pending_advance = true;
+        return false;
+    }
+};
+
+__device__ __forceinline__ void result_miss(Result& res, bool inside_voxel) {
+    res.t = -1.0f;
+    res.value = 0;
+    res.face_id = 0;
+    res.pos[0] = res.pos[1] = res.pos[2] = 0.0f;
+    res.uv[0] = res.uv[1] = 0.0f;
+    res.color[0] = res.color[1] = res.color[2] = res.color[3] = 0.0f;
+    res.lod = 0.0f;
+    res.inside_voxel = inside_voxel;
+}
+
+// Whole-ray form (picker and debug kernels; the v1 render kernel): step and test back to back.
+template <int SVO, bool TRACE, bool STATS>
+__device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst, bool cast_translucent,
+                                          const Stack& st, Result& res, uint32_t& steps, vx_frame* frames, uint32_t max_frames,
+                                          uint32_t& n_frames, Counters* ctr) {
+    if (STATS) ctr->rays++;
+    Trav<SVO> tr;
+    tr.init(sc, ro_in, rd_in, max_dst);
+    for (;;) {
+        const TravStatus s = tr.template step<TRACE, STATS>(sc, st, frames, max_frames, n_frames, ctr);
+        if (s == kTravContinue) continue;
+        if (s == kTravAtLeaf && tr.template leaf_test<STATS>(sc, cast_translucent, res, ctr)) break;
+        if (s == kTravFinished) {
+            result_miss(res, tr.inside_voxel);
+            break;
+        }
+    }
+    steps += tr.iter;
 }
 
 // ---- world.glsl -----------------------------------------------------------------------------------------------
@@ -601,6 +668,82 @@ __device__ __forceinline__ void sky_color(const float rd[3], float out[3]) {
 __constant__ float kFaceNormals[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};    // svo.glsl:2-9
 __constant__ float kFaceTangents[6][3] = {{0, 0, 1}, {0, 0, -1}, {1, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {1, 0, 0}};    // svo.glsl:12-19
 __constant__ float kFaceBitangents[6][3] = {{0, 1, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 1}, {0, 1, 0}, {0, 1, 0}};    // svo.glsl:22-29
+
+// world.glsl:87-88
+__device__ __forceinline__ void apply_light(const RenderParams& p, float color[4], float ds, float shadow) {
+    const float light = gclamp(p.u.ambient + ds * shadow, 0.0f, 1.0f);
+    color[0] *= light; color[1] *= light; color[2] *= light;
+}
+
+// What trace_ray does with a finished PRIMARY ray (world.glsl:31-84), split from the traversal so that a wavefront
+// can run it for several lanes at once. Outcome: either the pixel's final colour, or "cast this shadow ray" plus
+// the two values needed after it (surface colour and diffuse+specular).
+struct PrimaryOutcome {
+    bool final_color;     // color[] is the pixel's value; no shadow ray
+    float color[4];       // final colour, or the surface colour to be lit
+    float ds;             // diffuse + specular
+    float shadow_origin[3];
+    uint32_t flags;       // vx_hit flags accumulated so far
+};
+
+__device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderParams& p, const Result& res, PrimaryOutcome& o) {
+    o.flags = res.t != -1.0f ? 1u : 0u;
+    o.final_color = true;
+    o.ds = 0.0f;
+    o.color[0] = o.color[1] = o.color[2] = o.color[3] = 0.0f;
+    o.shadow_origin[0] = o.shadow_origin[1] = o.shadow_origin[2] = 0.0f;
+    if (res.t < 0.0f) return;  // miss: the caller paints the sky
+
+    if (floorf(res.pos[0]) == floorf(p.u.highlight_pos[0]) && floorf(res.pos[1]) == floorf(p.u.highlight_pos[1]) &&
+        floorf(res.pos[2]) == floorf(p.u.highlight_pos[2])) {
+        const float lx = fabsf(res.uv[0] - 0.5f) * 2.0f, ly = fabsf(res.uv[1] - 0.5f) * 2.0f;
+        if (gmax(lx, ly) > 1.0f - 1.0f / 16.0f) {
+            o.color[0] = o.color[1] = o.color[2] = o.color[3] = 1.0f;
+            o.flags |= 8u;
+            return;
+        }
+    }
+
+    const vx_material mat = material_at(sc, res.value);
+    int tex_normal_id = mat.tex_side_normal;
+    if (res.face_id == 3) tex_normal_id = mat.tex_top_normal;
+    else if (res.face_id == 2) tex_normal_id = mat.tex_bottom_normal;
+
+    float normal[3] = {kFaceNormals[res.face_id][0], kFaceNormals[res.face_id][1], kFaceNormals[res.face_id][2]};
+    if (tex_normal_id != -1) {
+        float s[4];
+        texture_lod(sc.tex, res.uv[0], res.uv[1], float(tex_normal_id), res.lod, s);
+        const float tex[3] = {s[0] * 2.0f - 1.0f, s[2] * 2.0f - 1.0f, s[1] * 2.0f - 1.0f};  // .xzy
+        float n[3];
+        normalize3(tex, n);
+        const float base[3] = {normal[0], normal[1], normal[2]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) normal[k] = n[0] * kFaceTangents[res.face_id][k] + n[1] * base[k] + n[2] * kFaceBitangents[res.face_id][k];
+    }
+
+    const float neg_l[3] = {-p.u.light_dir[0], -p.u.light_dir[1], -p.u.light_dir[2]};
+    const float diffuse = gmax(dot3(normal, neg_l), 0.0f);
+    const float vd[3] = {res.pos[0] - p.u.cam_pos[0], res.pos[1] - p.u.cam_pos[1], res.pos[2] - p.u.cam_pos[2]};
+    float view_dir[3];
+    normalize3(vd, view_dir);
+    const float dn = dot3(normal, neg_l);
+    float reflect_dir[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) reflect_dir[k] = neg_l[k] - 2.0f * dn * normal[k];
+    const float specular = powf(gmax(dot3(view_dir, reflect_dir), 0.0f), mat.specular_pow) * mat.specular_strength;
+
+    o.ds = diffuse + specular;
+    o.color[0] = res.color[0]; o.color[1] = res.color[1]; o.color[2] = res.color[2]; o.color[3] = res.color[3];
+    if (p.u.render_shadows && res.t < p.u.shadow_distance) {
+        o.final_color = false;
+        o.flags |= 2u;
+        o.shadow_origin[0] = res.pos[0] + normal[0] * 0.001f;
+        o.shadow_origin[1] = res.pos[1] + normal[1] * 0.001f;
+        o.shadow_origin[2] = res.pos[2] + normal[2] * 0.001f;
+    } else {
+        apply_light(p, o.color, o.ds, 1.0f);
+    }
+}
 
 // trace_ray + sky (world.glsl:27-90, 132-138) for one pixel
 template <int SVO, bool STATS>
