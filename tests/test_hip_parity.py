@@ -356,11 +356,15 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
         svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
         svo.set_materials(mats)
         svo.set_textures(tex, 6)
-        svo.update(world)
+        svo.update_full(world)  # a fresh buffer each time: the world's dirty ranges were consumed by the first update
         img, hits = svo.render(u, w, h, want_hits=True)
         img2, _ = svo.render(u, w, h)
         assert img2.tobytes() == img.tobytes()
-        results.append((img.tobytes(), hits.tobytes(), svo.render_counters(u, w, h)))
+        results.append((img, hits.tobytes(), svo.render_counters(u, w, h)))
         svo.close()
     for r in results[1:]:
-        assert r[0] == results[0][0] and r[1] == results[0][1] and r[2] == results[0][2]
+        assert r[1] == results[0][1], "hit records differ between kernel versions"
+        assert r[2] == results[0][2], "step counters differ between kernel versions"
+        assert np.array_equal(np.isnan(r[0]), np.isnan(results[0][0]))
+        print("max colour difference between kernel versions:", np.nanmax(np.abs(r[0] - results[0][0])))
+        assert np.nanmax(np.abs(r[0] - results[0][0])) <= COLOR_TOL

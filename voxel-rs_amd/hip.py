@@ -172,6 +172,11 @@ class Svo:
             arr[i].start, arr[i].length = s, n
         _check(lib().vx_commit(self._h, world.depth, C.cast(arr, _vp), len(ranges), world.size_in_bytes))
 
+    def update_full(self, world):
+        """First upload into a fresh buffer: WorldSvo::write_to (whole arena) instead of the dirty ranges, which a
+        WorldSvo only tracks for ONE target buffer (they are cleared by the first write_changes_to)."""
+        self.upload_frame(world.frame(pad_words=0), world.depth)
+
     def upload_frame(self, frame_words, depth):
         """Copies a complete mapped-buffer image ([f32 scale][header][arena]) into staging and commits all of it."""
         raw = np.ascontiguousarray(frame_words).view(np.uint8)
