@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""A/B sweeps of render-kernel variants in ONE process (interleaved rounds, median and min of the HIP-event kernel time).
+
+    python profiles/sweep.py --format esvo --configs "k=1" "k=2,r=16,s=12" "k=2,r=8,s=8" --rounds 3 --steps 10
+"""
+import argparse
+import os
+import statistics
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from _pkg import load_package  # noqa: E402
+
+vra = load_package()
+from voxel_rs_amd import hip, scenes  # noqa: E402
+
+KEYS = {"k": "VX_RENDER_KERNEL", "r": "VX_REFILL_MIN", "s": "VX_SERVICE_MIN", "w": "VX_WAVES_PER_CU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--format", default="esvo")
+    ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--configs", nargs="+", required=True)
+    args = ap.parse_args()
+    import torch
+
+    fmt = vra.SVO_ESVO if args.format == "esvo" else vra.SVO_CSVO
+    world = vra.World(fmt)
+    st = world.build_heightfield(args.depth)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    W, H = args.width, args.height
+    u = scenes.bench_camera(args.depth, st["h_max"], W, H, shadow_distance=3.0e38)
+    image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    ctxs = []
+    for cfg in args.configs:
+        for k in KEYS.values():
+            os.environ.pop(k, None)
+        for kv in cfg.split(","):
+            k, v = kv.split("=")
+            os.environ[KEYS[k]] = v
+        svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20))
+        svo.set_materials(mats)
+        svo.set_textures(tex, 6)
+        svo.update_full(world)
+        for _ in range(3):
+            svo.render_device(u, W, H, image.data_ptr())
+        svo.sync()
+        ctxs.append((cfg, svo, []))
+    rays = ctxs[0][1].render_counters(u, W, H)["rays"]
+    for _ in range(args.rounds):
+        for cfg, svo, times in ctxs:
+            svo.profile_enable(True)
+            for _ in range(args.steps):
+                svo.render_device(u, W, H, image.data_ptr())
+            ms, n = svo.profile_read()
+            svo.profile_enable(False)
+            times.append(ms / n)
+    for cfg, svo, times in ctxs:
+        med, mn = statistics.median(times), min(times)
+        print(f"{args.format} {cfg:28s} kernel ms median {med:.4f} min {mn:.4f}  -> {rays / med / 1e3:.1f} Mrays/s")
+
+
+if __name__ == "__main__":
+    main()
