@@ -11,6 +11,7 @@
 #define __constant__ static const
 #define __restrict__
 struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 static inline uint32_t __popc(uint32_t v) { return uint32_t(__builtin_popcount(v)); }
 static inline int __clz(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
@@ -27,10 +28,16 @@ using namespace vxd;
 extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t world_bytes, const vx_material* mats, uint32_t n_mats,
                                const uint8_t* tex, uint32_t tw, uint32_t th, uint32_t layers, uint32_t levels, const uint32_t* level_offset,
                                const vx_picker_task* tasks, uint32_t n, vx_picker_result* results, int cast_translucent) {
-    DevScene sc;
-    sc.world = world; sc.world_bytes = world_bytes; sc.materials = mats; sc.n_materials = n_mats;
-    sc.tex.base = tex; sc.tex.width = tw; sc.tex.height = th; sc.tex.layers = layers; sc.tex.levels = levels;
-    for (uint32_t l = 0; l < levels && l < 16; ++l) sc.tex.level_offset[l] = level_offset[l];
+    SceneArgs sa = {};
+    sa.world = world; sa.world_bytes = uint32_t(world_bytes); sa.materials = mats; sa.n_materials = n_mats;
+    sa.tex = tex; sa.tex_bytes = 0;
+    sa.width = tw; sa.height = th; sa.layers = layers; sa.levels = levels;
+    for (uint32_t l = 0; l < levels && l < 16; ++l) {
+        sa.level_offset[l] = level_offset[l];
+        const uint32_t w = (tw >> l) ? (tw >> l) : 1, h = (th >> l) ? (th >> l) : 1;
+        sa.tex_bytes = level_offset[l] + layers * w * h * 4;
+    }
+    const DevScene sc = make_scene(sa);
     std::vector<unsigned char> lds(7 * 10 + 64);
     vx_smem = lds.data();
     StackSpill spill;

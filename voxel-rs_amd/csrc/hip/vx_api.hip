@@ -56,8 +56,9 @@ __device__ __forceinline__ void lane_to_xy(uint32_t lane, uint32_t& x, uint32_t&
 }
 
 template <int SVO, bool HITS, bool STATS>
-__global__ __launch_bounds__(kBlockThreads) void render_kernel(DevScene sc, RenderParams p, float4* __restrict__ out, vx_hit* __restrict__ hits,
+__global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, RenderParams p, float4* __restrict__ out, vx_hit* __restrict__ hits,
                                                                unsigned long long* __restrict__ counters, uint32_t levels) {
+    const DevScene sc = make_scene(sa);
     const uint32_t tid = threadIdx.x;
     StackSpill spill;
     const Stack st = make_stack(levels, kBlockThreads, tid, spill);
@@ -122,8 +123,9 @@ struct PersistentArgs {
 };
 
 template <int SVO, bool HITS, bool STATS>
-__global__ __launch_bounds__(64) void render_persistent(DevScene sc, RenderParams p, PersistentArgs a, float4* __restrict__ out,
+__global__ __launch_bounds__(64) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, uint32_t levels) {
+    const DevScene sc = make_scene(sa);
     const uint32_t lane = threadIdx.x;
     StackSpill spill;
     const Stack st = make_stack(levels, 64, lane, spill);
@@ -281,8 +283,9 @@ __global__ __launch_bounds__(64) void render_persistent(DevScene sc, RenderParam
 }
 
 template <int SVO>
-__global__ __launch_bounds__(64) void picker_kernel(DevScene sc, const vx_picker_task* __restrict__ tasks, uint32_t n,
+__global__ __launch_bounds__(64) void picker_kernel(SceneArgs sa, const vx_picker_task* __restrict__ tasks, uint32_t n,
                                                     vx_picker_result* __restrict__ results, uint32_t levels) {
+    const DevScene sc = make_scene(sa);
     StackSpill spill;
     const Stack st = make_stack(levels, 64, threadIdx.x, spill);
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -312,8 +315,9 @@ struct TraceArgs {
 };
 
 template <int SVO>
-__global__ __launch_bounds__(64) void trace_kernel(DevScene sc, TraceArgs a, vx_result* __restrict__ result, vx_frame* __restrict__ frames,
+__global__ __launch_bounds__(64) void trace_kernel(SceneArgs sa, TraceArgs a, vx_result* __restrict__ result, vx_frame* __restrict__ frames,
                                                    uint32_t max_frames, uint32_t* __restrict__ n_frames, uint32_t levels) {
+    const DevScene sc = make_scene(sa);
     StackSpill spill;
     const Stack st = make_stack(levels, 64, threadIdx.x, spill);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -384,7 +388,8 @@ struct vx_context {
     vx_material* d_materials = nullptr;
     uint32_t n_materials = 0;
     uint8_t* d_tex = nullptr;
-    DevTextures tex = {};
+    uint32_t tex_bytes = 0;
+    struct { uint32_t width, height, layers, levels, level_offset[16]; } tex = {};
 
     // scratch
     float* d_image = nullptr;  size_t d_image_bytes = 0;
@@ -416,13 +421,16 @@ uint32_t stack_levels(const vx_context* c) {
     return l;
 }
 
-DevScene scene_of(const vx_context* c) {
-    DevScene s;
+SceneArgs scene_of(const vx_context* c) {
+    SceneArgs s = {};
     s.world = c->d_world;
-    s.world_bytes = c->capacity;
+    s.world_bytes = uint32_t(c->capacity);
     s.materials = c->d_materials;
     s.n_materials = c->n_materials;
-    s.tex = c->tex;
+    s.tex = c->d_tex;
+    s.tex_bytes = c->tex_bytes;
+    s.width = c->tex.width; s.height = c->tex.height; s.layers = c->tex.layers; s.levels = c->tex.levels;
+    for (int l = 0; l < 16; ++l) s.level_offset[l] = c->tex.level_offset[l];
     return s;
 }
 
@@ -449,7 +457,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
     const size_t lds = size_t(levels) * kBlockThreads * 10;
     const dim3 grid(p.n_local_tiles * 4), block(kBlockThreads);
     if (grid.x == 0) return VX_OK;
-    const DevScene sc = scene_of(ctx);
+    const SceneArgs sc = scene_of(ctx);
 
     if (ctx->kernel_version != 1) HIP_TRY(hipMemsetAsync(ctx->d_work_counter, 0, sizeof(uint32_t), ctx->stream));  // sub-tile queue head
     ProfiledLaunch ev{};
@@ -538,6 +546,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     *out = nullptr;
     if (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO) return fail(VX_ERR_INVALID_ARGUMENT, "svo_type must be VX_SVO_ESVO or VX_SVO_CSVO");
     if (capacity_bytes < 64) return fail(VX_ERR_INVALID_ARGUMENT, "capacity_bytes too small");
+    if (capacity_bytes >= (size_t(1) << 32) - 64)
+        return fail(VX_ERR_CAPACITY, "world buffers of 4 GiB and more are not supported yet (32-bit buffer-resource offsets)");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(VX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= n) return fail(VX_ERR_NO_DEVICE, "device index out of range");
@@ -634,7 +644,7 @@ int vx_set_textures(vx_context* ctx, const uint8_t* rgba8, uint32_t width, uint3
     if (levels < 1) levels = 1;
     if (levels > 16) levels = 16;
 
-    DevTextures t = {};
+    decltype(ctx->tex) t = {};
     t.width = width; t.height = height; t.layers = layers; t.levels = levels;
     size_t total = 0;
     for (uint32_t l = 0; l < levels; ++l) {
@@ -667,7 +677,7 @@ int vx_set_textures(vx_context* ctx, const uint8_t* rgba8, uint32_t width, uint3
     ctx->d_tex = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_tex), total));
     HIP_TRY(hipMemcpy(ctx->d_tex, chain.data(), total, hipMemcpyHostToDevice));
-    t.base = ctx->d_tex;
+    ctx->tex_bytes = uint32_t(total);
     ctx->tex = t;
     return VX_OK;
 }
@@ -782,7 +792,7 @@ int vx_raycast(vx_context* ctx, const vx_picker_task* tasks, uint32_t count, vx_
     HIP_TRY(hipMemcpyAsync(ctx->d_tasks, tasks, size_t(count) * sizeof(vx_picker_task), hipMemcpyHostToDevice, ctx->stream));
     const uint32_t levels = stack_levels(ctx);
     const size_t lds = size_t(levels) * 64 * 10;
-    const DevScene sc = scene_of(ctx);
+    const SceneArgs sc = scene_of(ctx);
     const dim3 grid((count + 63) / 64), block(64);
     if (ctx->svo_type == VX_SVO_ESVO)
         hipLaunchKernelGGL((picker_kernel<VX_SVO_ESVO>), grid, block, lds, ctx->stream, sc, ctx->d_tasks, count, ctx->d_results, levels);
@@ -820,7 +830,7 @@ int vx_debug_trace(vx_context* ctx, const float pos[3], const float dir[3], floa
     a.cast_translucent = cast_translucent;
     const uint32_t levels = stack_levels(ctx);
     const size_t lds = size_t(levels) * 64 * 10;
-    const DevScene sc = scene_of(ctx);
+    const SceneArgs sc = scene_of(ctx);
     if (ctx->svo_type == VX_SVO_ESVO)
         hipLaunchKernelGGL((trace_kernel<VX_SVO_ESVO>), dim3(1), dim3(64), lds, ctx->stream, sc, a, ctx->d_trace_result, ctx->d_trace_frames, max_frames,
                            ctx->d_trace_count, levels);

@@ -25,19 +25,65 @@ constexpr int kMaxScale = 23;         // svo.esvo.glsl:21
 constexpr float kEps = 1.1920929e-7f;  // exp2(-23), svo.esvo.glsl:24
 constexpr uint32_t kInvalidPtr = 0xffffffffu;
 
+// Buffer resources (128-bit V#) for everything the rays read: 32-bit byte offsets instead of 64-bit pointers and the
+// hardware's range check instead of explicit clamps -- an out-of-range read returns 0, which is also what the CPU
+// oracle defines for reads beyond the world buffer, unknown block ids and missing texels.
+#ifndef VX_DEVICE_ON_HOST
+typedef __amdgpu_buffer_rsrc_t buf_t;
+__device__ __forceinline__ buf_t make_buf(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, int(bytes), 0x00020000);
+}
+__device__ __forceinline__ uint32_t buf_u32(buf_t b, uint32_t off) { return uint32_t(__builtin_amdgcn_raw_buffer_load_b32(b, int(off), 0, 0)); }
+__device__ __forceinline__ uint32_t buf_u8(buf_t b, uint32_t off) { return uint32_t(__builtin_amdgcn_raw_buffer_load_b8(b, int(off), 0, 0)); }
+__device__ __forceinline__ uint4 buf_u128(buf_t b, uint32_t off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(b, int(off), 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+#else
+struct buf_t { const uint8_t* p; uint32_t bytes; };
+inline buf_t make_buf(const void* p, uint32_t bytes) { return buf_t{static_cast<const uint8_t*>(p), bytes}; }
+inline uint32_t buf_u32(buf_t b, uint32_t off) { uint32_t v = 0; if (uint64_t(off) + 4 <= b.bytes) std::memcpy(&v, b.p + off, 4); return v; }
+inline uint32_t buf_u8(buf_t b, uint32_t off) { return off < b.bytes ? b.p[off] : 0u; }
+inline uint4 buf_u128(buf_t b, uint32_t off) { uint4 v = {0, 0, 0, 0}; if (uint64_t(off) + 16 <= b.bytes) std::memcpy(&v, b.p + off, 16); return v; }
+#endif
+
 struct DevTextures {
-    const uint8_t* base;      // mip chain, level l at base + level_offset[l], layout [layer][y][x][4]
+    buf_t buf;                // mip chain, level l at level_offset[l], layout [layer][y][x][4]
+    uint32_t width, height, layers, levels;
+    const uint32_t* level_offset;  // [16], stays in the kernel-argument segment (no private copy: it is indexed per lane)
+};
+
+struct DevScene {
+    buf_t world;              // device copy of the mapped world buffer, byte 0 = f32 octree_scale (< 4 GiB)
+    buf_t materials;          // vx_material rows
+    float octree_scale;       // = world[0], read once per launch by the host-side wrapper of the kernel arguments
+    uint32_t root_ptr;        // CSVO: world[1]
+    DevTextures tex;
+};
+
+// what the host passes to a kernel; expanded into a DevScene (descriptors in SGPRs) at kernel entry
+struct SceneArgs {
+    const uint8_t* world;
+    uint32_t world_bytes;
+    const vx_material* materials;
+    uint32_t n_materials;
+    const uint8_t* tex;
+    uint32_t tex_bytes;
     uint32_t width, height, layers, levels;
     uint32_t level_offset[16];
 };
 
-struct DevScene {
-    const uint8_t* world;     // device copy of the mapped world buffer, byte 0 = f32 octree_scale
-    uint64_t world_bytes;     // readable bytes (reads are clamped into it)
-    const vx_material* materials;
-    uint32_t n_materials;
-    DevTextures tex;
-};
+__device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
+    DevScene sc;
+    sc.world = make_buf(a.world, a.world_bytes);
+    sc.materials = make_buf(a.materials, a.n_materials * uint32_t(sizeof(vx_material)));
+    sc.tex.buf = make_buf(a.tex, a.tex_bytes);
+    sc.tex.width = a.width; sc.tex.height = a.height; sc.tex.layers = a.layers; sc.tex.levels = a.levels;
+    sc.tex.level_offset = a.level_offset;
+    sc.octree_scale = __uint_as_float(buf_u32(sc.world, 0));
+    sc.root_ptr = buf_u32(sc.world, 4);
+    return sc;
+}
 
 struct Result {
     float t;
@@ -128,30 +174,18 @@ __device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
 
 // ---- world buffer access --------------------------------------------------------------------------------
 
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-
 // ESVO: descriptors[] starts at byte 4 (svo.esvo.glsl:3-6)
 __device__ __forceinline__ uint32_t esvo_word(const DevScene& sc, uint32_t index) {
-    uint64_t off = 4ull + uint64_t(index) * 4ull;
-    const uint64_t last = sc.world_bytes - 4;
-    off = off > last ? last : off;
-    return *reinterpret_cast<const uint32_t*>(sc.world + off);
+    index = index < 0x3ffffffeu ? index : 0x3ffffffeu;  // keep 4 + 4*index from wrapping: wild indices must read 0, not alias
+    return buf_u32(sc.world, 4u + index * 4u);
 }
 
-// CSVO: descriptors[] starts at byte 8 and is addressed in bytes (svo.csvo.glsl:1-5, 25-49)
-__device__ __forceinline__ uint32_t csvo_u32(const DevScene& sc, uint32_t byte_ptr) {
-    uint64_t off = 8ull + byte_ptr;
-    const uint64_t last = sc.world_bytes - 4;
-    off = off > last ? last : off;
-    return *reinterpret_cast<const u32_unaligned*>(sc.world + off);
-}
+// CSVO: descriptors[] starts at byte 8 and is addressed in bytes (svo.csvo.glsl:1-5, 25-49); the hardware reads
+// unaligned dwords directly, so read_uint's two-loads-and-shift collapses into one load
+__device__ __forceinline__ uint32_t csvo_clamp(uint32_t byte_ptr) { return byte_ptr < 0xfffffff0u ? byte_ptr : 0xfffffff0u; }  // no wrap of 8 + ptr
+__device__ __forceinline__ uint32_t csvo_u32(const DevScene& sc, uint32_t byte_ptr) { return buf_u32(sc.world, 8u + csvo_clamp(byte_ptr)); }
 __device__ __forceinline__ uint32_t csvo_u16(const DevScene& sc, uint32_t p) { return csvo_u32(sc, p) & 0xffffu; }
-__device__ __forceinline__ uint32_t csvo_u8(const DevScene& sc, uint32_t byte_ptr) {
-    uint64_t off = 8ull + byte_ptr;
-    const uint64_t last = sc.world_bytes - 1;
-    off = off > last ? last : off;
-    return sc.world[off];
-}
+__device__ __forceinline__ uint32_t csvo_u8(const DevScene& sc, uint32_t byte_ptr) { return buf_u8(sc.world, 8u + csvo_clamp(byte_ptr)); }
 
 // bytes taken by the pointer-table entries a 2-bit-per-child mask selects: tag 0,1,2,3 -> 0,1,2,4 bytes
 __device__ __forceinline__ uint32_t csvo_tag_bytes(uint32_t m) {
@@ -203,18 +237,13 @@ __device__ __forceinline__ uint32_t csvo_read_leaf(const DevScene& sc, uint32_t 
 }
 
 __device__ __forceinline__ vx_material material_at(const DevScene& sc, uint32_t value) {
+    // 32-byte rows: two 16-byte loads; block ids beyond the table read as an all-zero row (range-checked by the V#)
+    const uint32_t off = value < 0x07ffffffu ? value * 32u : 0xffffffe0u;
+    const uint4 a = buf_u128(sc.materials, off), b = buf_u128(sc.materials, off + 16u);
     vx_material m;
-    if (value < sc.n_materials) {
-        // 32-byte rows: two 16-byte loads
-        const uint4* p = reinterpret_cast<const uint4*>(sc.materials + value);
-        const uint4 a = p[0], b = p[1];
-        m.specular_pow = __uint_as_float(a.x); m.specular_strength = __uint_as_float(a.y);
-        m.tex_top = int(a.z); m.tex_side = int(a.w); m.tex_bottom = int(b.x);
-        m.tex_top_normal = int(b.y); m.tex_side_normal = int(b.z); m.tex_bottom_normal = int(b.w);
-    } else {
-        m.specular_pow = m.specular_strength = 0.0f;
-        m.tex_top = m.tex_side = m.tex_bottom = m.tex_top_normal = m.tex_side_normal = m.tex_bottom_normal = 0;
-    }
+    m.specular_pow = __uint_as_float(a.x); m.specular_strength = __uint_as_float(a.y);
+    m.tex_top = int(a.z); m.tex_side = int(a.w); m.tex_bottom = int(b.x);
+    m.tex_top_normal = int(b.y); m.tex_side_normal = int(b.z); m.tex_bottom_normal = int(b.w);
     return m;
 }
 
@@ -229,7 +258,7 @@ __device__ __forceinline__ void texel(const DevTextures& t, uint32_t level, uint
     x = x > int(w) - 1 ? int(w) - 1 : x;
     y %= int(h);
     y = y < 0 ? y + int(h) : y;
-    const uint32_t rgba = *reinterpret_cast<const uint32_t*>(t.base + t.level_offset[level] + ((size_t(layer) * h + uint32_t(y)) * w + uint32_t(x)) * 4);
+    const uint32_t rgba = buf_u32(t.buf, t.level_offset[level] + ((layer * h + uint32_t(y)) * w + uint32_t(x)) * 4u);
     out[0] = float(rgba & 0xffu) / 255.0f;
     out[1] = float((rgba >> 8) & 0xffu) / 255.0f;
     out[2] = float((rgba >> 16) & 0xffu) / 255.0f;
@@ -313,12 +342,12 @@ struct Trav {
     bool inside_voxel;
 
     __device__ __forceinline__ void init(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst_in) {
-        const float octree_scale = *reinterpret_cast<const float*>(sc.world);
+        const float octree_scale = sc.octree_scale;
         rox = ro_in[0] * octree_scale; roy = ro_in[1] * octree_scale; roz = ro_in[2] * octree_scale;
         max_dst = max_dst_in * octree_scale;
         rox += 1.0f; roy += 1.0f; roz += 1.0f;
 
-        ptr = CSVO ? *reinterpret_cast<const uint32_t*>(sc.world + 4) : 0u;
+        ptr = CSVO ? sc.root_ptr : 0u;
         aux = CSVO ? 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu) : 0u;  // svo.csvo.glsl:254
         scale = kMaxScale - 1;
         scale_exp2 = 0.5f;
@@ -433,7 +462,7 @@ struct Trav {
 
         if (TRACE) {
             if (n_frames < max_frames) {
-                const float octree_scale = *reinterpret_cast<const float*>(sc.world);
+                const float octree_scale = sc.octree_scale;
                 vx_frame& f = frames[n_frames];
                 f.t_min = t_min * __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));
                 f.ptr = ptr;
@@ -503,7 +532,7 @@ struct Trav {
     template <bool STATS>
     __device__ __forceinline__ bool leaf_test(const DevScene& sc, bool cast_translucent, Result& res, Counters* ctr) {
         if (STATS) ctr->leaf_tests++;
-        const float octree_scale = *reinterpret_cast<const float*>(sc.world);
+        const float octree_scale = sc.octree_scale;
         const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 2^depth, exact
         const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
         uint32_t value;
