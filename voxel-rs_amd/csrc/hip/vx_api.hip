@@ -122,8 +122,8 @@ struct PersistentArgs {
     uint32_t refill_min, service_min;
 };
 
-template <int SVO, bool HITS, bool STATS>
-__global__ __launch_bounds__(64) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
+template <int SVO, bool HITS, bool STATS, int MINW = 1>
+__global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, uint32_t levels) {
     const DevScene sc = make_scene(sa);
     const uint32_t lane = threadIdx.x;
@@ -400,7 +400,8 @@ struct vx_context {
 
     uint32_t* d_work_counter = nullptr;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
-    uint32_t refill_min = 16, service_min = 12;
+    uint32_t refill_min = 8, service_min = 28;
+    int min_waves = 1;                    // experiment: __launch_bounds__ waves-per-SIMD variant of the plain render kernel
     int cu_count = 256;
     int persistent_blocks[2][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
 
@@ -479,11 +480,18 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
     } else {
         // persistent waves: as many 64-thread workgroups as the device keeps resident, fed from the sub-tile queue
         const size_t wave_lds = size_t(levels) * 64 * 10;
+        const bool esvo = ctx->svo_type == VX_SVO_ESVO;
+        const void* fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, STATS>)
+                              : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, HITS, STATS>);
+        int mw = 1;
+        if (!HITS && !STATS) {
+            if (ctx->min_waves == 4) { mw = 4; fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 4>) : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 4>); }
+            if (ctx->min_waves == 5) { mw = 5; fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 5>) : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 5>); }
+            if (ctx->min_waves == 6) { mw = 6; fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 6>) : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 6>); }
+        }
         int& per_cu = ctx->persistent_blocks[ctx->svo_type == VX_SVO_CSVO][HITS][STATS];
         if (per_cu == 0) {
             int n = 0;
-            const void* fn = ctx->svo_type == VX_SVO_ESVO ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, STATS>)
-                                                            : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, HITS, STATS>);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, wave_lds) != hipSuccess || n <= 0) n = 8;
             per_cu = n;
         }
@@ -494,12 +502,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.service_min = ctx->service_min;
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
-        if (ctx->svo_type == VX_SVO_ESVO)
-            hipLaunchKernelGGL((render_persistent<VX_SVO_ESVO, HITS, STATS>), dim3(waves), dim3(64), wave_lds, ctx->stream, sc, p, a,
-                               reinterpret_cast<float4*>(out), hits, counters, levels);
-        else
-            hipLaunchKernelGGL((render_persistent<VX_SVO_CSVO, HITS, STATS>), dim3(waves), dim3(64), wave_lds, ctx->stream, sc, p, a,
-                               reinterpret_cast<float4*>(out), hits, counters, levels);
+        void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, const_cast<uint32_t*>(&levels)};
+        (void)mw;
+        HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
     if (ctx->profile) {
@@ -586,6 +591,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
         c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
+        if (const char* e = std::getenv("VX_MIN_WAVES")) c->min_waves = std::atoi(e);
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
         if (c->refill_min < 1) c->refill_min = 1;
