@@ -28,7 +28,7 @@ for d in sorted(glob.glob(out+'/pmc*/')):
         for r in csv.DictReader(open(f)):
             acc[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k,v in acc.items():
-            if 'render_kernel' not in k: continue
+            if 'render_' not in k: continue
             print('== pmc', k)
             for c,vals in v.items():
                 print('   %-32s n=%d mean=%.6g' % (c, len(vals), sum(vals)/len(vals)))
