@@ -105,6 +105,31 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
     }
 }
 
+// ---- traversal image builder (ESVO) ---------------------------------------------------------------------------------
+//
+// Re-lays the reference's 12-word octants (4 header words + 8 body words, src/world/hds/esvo.rs:74-101) out as 64-byte
+// octants of eight {lo, hi} entries: lo = what the body word holds (relative pointers resolved to an octant index, bit 31
+// kept as their tag; absolute chunk pointers and leaf values verbatim), hi = the masks the header holds for that child.
+// Descending into a child then costs ONE 8-byte load (pointer and masks together) instead of the reference's two
+// dependent loads, and a leaf value is one load instead of two. One thread per (octant, child): reads are 4-byte
+// strided, writes are fully coalesced 8-byte stores. Runs on the upload stream for the dirty ranges of a commit.
+__global__ __launch_bounds__(256) void esvo_image_kernel(const uint32_t* __restrict__ arena, uint64_t first_octant, uint64_t n_octants,
+                                                         uint2* __restrict__ image) {
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n_octants * 8) return;
+    const uint64_t k = first_octant + (i >> 3);
+    const uint32_t j = uint32_t(i & 7);
+    const uint32_t* o = arena + k * 12;
+    const uint32_t masks = (o[j >> 1] >> ((j & 1u) * 16u)) & 0xffffu;
+    uint32_t lo = o[4 + j];
+    if (lo & 0x80000000u) {
+        // relative to this body word, in descriptors[] index space (octant k starts at word 5 + 12 k)
+        const uint64_t target_word = 12ull * k + 4 + j + (lo & 0x7fffffffu);
+        lo = 0x80000000u | uint32_t(target_word / 12);
+    }
+    image[k * 8 + j] = make_uint2(lo, masks);
+}
+
 // ---- v2: persistent wavefront kernel ---------------------------------------------------------------------------
 //
 // One workgroup = one wave64 that keeps its 64 lanes fed from a global queue of 8x8-pixel sub-tiles. A lane's ray is a
@@ -136,6 +161,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     bool shadow_ray = false;
     uint32_t out_index = 0, px_x = 0, px_y = 0;
     float keep_color[4] = {0, 0, 0, 0}, keep_ds = 0.0f;
+    float shadow_origin[3] = {0, 0, 0};  // image traversal only: needed if the shadow ray must be re-run on the reference buffer
     vx_hit rec;            // HITS only
     uint32_t steps = 0;    // HITS only
     Counters ctr = {};
@@ -207,6 +233,20 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 else if (s == kTravFinished) {
                     result_miss(res, tr.inside_voxel);
                     state = kDone;
+                } else if (SVO == VX_SVO_IMAGE && s == kTravNeedsReference) {
+                    // The ray starts inside a voxel: the reference now walks leaf data as if it were nodes
+                    // (svo.esvo.glsl:183-185). Reproduce that exactly by re-running this one ray on the reference-format buffer.
+                    float ro[3], rd[3];
+                    if (!shadow_ray) {
+                        primary_ray(p, px_x, px_y, ro, rd);
+                    } else {
+                        ro[0] = shadow_origin[0]; ro[1] = shadow_origin[1]; ro[2] = shadow_origin[2];
+                        rd[0] = -p.u.light_dir[0]; rd[1] = -p.u.light_dir[1]; rd[2] = -p.u.light_dir[2];
+                    }
+                    uint32_t it = 0;
+                    intersect<VX_SVO_ESVO, false, false>(sc, ro, rd, -1.0f, true, st, res, it, nullptr, 0, nf, nullptr);
+                    tr.iter = it;
+                    state = kDone;
                 }
             }
             const unsigned long long trav = __ballot(state == kTrav);
@@ -243,6 +283,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                         keep_color[0] = o.color[0]; keep_color[1] = o.color[1]; keep_color[2] = o.color[2]; keep_color[3] = o.color[3];
                         keep_ds = o.ds;
                         const float neg_l[3] = {-p.u.light_dir[0], -p.u.light_dir[1], -p.u.light_dir[2]};
+                        if (SVO == VX_SVO_IMAGE) { shadow_origin[0] = o.shadow_origin[0]; shadow_origin[1] = o.shadow_origin[1]; shadow_origin[2] = o.shadow_origin[2]; }
                         tr.init(sc, o.shadow_origin, neg_l, -1.0f);
                         shadow_ray = true;
                         state = kTrav;
@@ -392,18 +433,22 @@ struct vx_context {
     struct { uint32_t width, height, layers, levels, level_offset[16]; } tex = {};
 
     // scratch
-    float* d_image = nullptr;  size_t d_image_bytes = 0;
+    float* d_frame = nullptr;  size_t d_frame_bytes = 0;
     vx_hit* d_hits = nullptr;  size_t d_hits_bytes = 0;
     vx_picker_task* d_tasks = nullptr;  vx_picker_result* d_results = nullptr;  uint32_t picker_cap = 0;
     vx_result* d_trace_result = nullptr;  vx_frame* d_trace_frames = nullptr;  uint32_t* d_trace_count = nullptr;  uint32_t trace_cap = 0;
     unsigned long long* d_counters = nullptr;
 
     uint32_t* d_work_counter = nullptr;
+    uint8_t* d_image = nullptr;           // ESVO traversal image (64-byte octants)
+    size_t image_capacity = 0;
+    bool image_enabled = true, image_ok = false;
+    uint32_t image_root = 0, image_root_masks = 0;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
     uint32_t refill_min = 8, service_min = 28;
     int min_waves = 1;                    // experiment: __launch_bounds__ waves-per-SIMD variant of the plain render kernel
     int cu_count = 256;
-    int persistent_blocks[2][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
+    int persistent_blocks[3][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
 
     bool profile = false;
     std::vector<ProfiledLaunch> launches;
@@ -432,6 +477,10 @@ SceneArgs scene_of(const vx_context* c) {
     s.tex_bytes = c->tex_bytes;
     s.width = c->tex.width; s.height = c->tex.height; s.layers = c->tex.layers; s.levels = c->tex.levels;
     for (int l = 0; l < 16; ++l) s.level_offset[l] = c->tex.level_offset[l];
+    s.image = c->d_image;
+    s.image_bytes = c->image_ok ? uint32_t(c->image_capacity) : 0u;
+    s.image_root = c->image_root;
+    s.image_root_masks = c->image_root_masks;
     return s;
 }
 
@@ -483,13 +532,17 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         const bool esvo = ctx->svo_type == VX_SVO_ESVO;
         const void* fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, STATS>)
                               : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, HITS, STATS>);
+        // ESVO worlds are rendered from the traversal image; the instrumented variant stays on the reference layout so that
+        // its step counters are the reference's own
+        const bool use_image = esvo && ctx->image_ok && !STATS;
+        if (use_image) fn = reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false>);
         int mw = 1;
-        if (!HITS && !STATS) {
+        if (!HITS && !STATS && !use_image) {
             if (ctx->min_waves == 4) { mw = 4; fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 4>) : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 4>); }
             if (ctx->min_waves == 5) { mw = 5; fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 5>) : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 5>); }
             if (ctx->min_waves == 6) { mw = 6; fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 6>) : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 6>); }
         }
-        int& per_cu = ctx->persistent_blocks[ctx->svo_type == VX_SVO_CSVO][HITS][STATS];
+        int& per_cu = ctx->persistent_blocks[use_image ? 2 : (ctx->svo_type == VX_SVO_CSVO)][HITS][STATS];
         if (per_cu == 0) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, wave_lds) != hipSuccess || n <= 0) n = 8;
@@ -592,12 +645,22 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("VX_MIN_WAVES")) c->min_waves = std::atoi(e);
+        if (const char* e = std::getenv("VX_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
         if (c->refill_min < 1) c->refill_min = 1;
         if (c->refill_min > 64) c->refill_min = 64;
         if (c->service_min < 1) c->service_min = 1;
         if (c->service_min > 64) c->service_min = 64;
+    }
+    if (svo_type == VX_SVO_ESVO && c->image_enabled && c->kernel_version != 1) {
+        c->image_capacity = (c->capacity / 48 + 1) * 64;
+        if (c->image_capacity < (size_t(1) << 32) - 64) {
+            CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_image), c->image_capacity));
+            CREATE_TRY(hipMemset(c->d_image, 0, c->image_capacity));
+        } else {
+            c->image_enabled = false;
+        }
     }
     // one all-zero material and a 1x1 transparent-black texture so that rendering works before any registry is set
     const vx_material zero_mat = {0, 0, -1, -1, -1, -1, -1, -1};
@@ -617,8 +680,8 @@ void vx_destroy(vx_context* c) {
     for (auto& l : c->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     for (auto& l : c->event_pool) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     if (c->staging) (void)hipHostFree(c->staging);
-    void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_image, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
-                   c->d_trace_count, c->d_counters, c->d_work_counter};
+    void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_frame, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
+                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (c->upload_done) (void)hipEventDestroy(c->upload_done);
@@ -712,6 +775,29 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
         const uint64_t off = head + ranges[i].start;
         HIP_TRY(hipMemcpyAsync(ctx->d_world + off, ctx->staging + off, ranges[i].length, hipMemcpyHostToDevice, ctx->upload_stream));
     }
+    if (ctx->d_image && ctx->image_enabled) {
+        // refresh the traversal image for the octants the dirty ranges cover (a range is a whole chunk or the root octree:
+        // always a multiple of one 48-byte octant; anything else means the arena does not hold octants -> no image)
+        bool ok = true;
+        for (uint32_t i = 0; i < count && ok; ++i) ok = ranges[i].start % 48 == 0 && ranges[i].length % 48 == 0;
+        uint32_t pre[5];
+        std::memcpy(pre, ctx->staging + 4, sizeof pre);
+        ok = ok && pre[4] >= 5 && (pre[4] - 5) % 12 == 0;
+        if (ok) {
+            for (uint32_t i = 0; i < count; ++i) {
+                const uint64_t n_oct = ranges[i].length / 48;
+                if (!n_oct) continue;
+                const uint64_t threads = n_oct * 8;
+                hipLaunchKernelGGL(esvo_image_kernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, ctx->upload_stream,
+                                   reinterpret_cast<const uint32_t*>(ctx->d_world + head), ranges[i].start / 48, n_oct,
+                                   reinterpret_cast<uint2*>(ctx->d_image));
+            }
+            HIP_TRY(hipGetLastError());
+            ctx->image_root = (pre[4] - 5) / 12;
+            ctx->image_root_masks = pre[0] & 0xffffu;
+        }
+        ctx->image_ok = ok;
+    }
     HIP_TRY(hipEventRecord(ctx->upload_done, ctx->upload_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_done, 0));
     // the caller may rewrite the staging mirror as soon as we return: wait for the copies to have read it
@@ -744,8 +830,8 @@ int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint
     float* out = static_cast<float*>(target->rgba32f);
     vx_hit* hits = target->hits;
     if (target->memory == VX_MEM_HOST) {
-        if (int rc = ensure(reinterpret_cast<void**>(&ctx->d_image), &ctx->d_image_bytes, pixels * 16)) return rc;
-        out = ctx->d_image;
+        if (int rc = ensure(reinterpret_cast<void**>(&ctx->d_frame), &ctx->d_frame_bytes, pixels * 16)) return rc;
+        out = ctx->d_frame;
         if (hits) {
             if (int rc = ensure(reinterpret_cast<void**>(&ctx->d_hits), &ctx->d_hits_bytes, pixels * sizeof(vx_hit))) return rc;
             hits = ctx->d_hits;
@@ -754,7 +840,7 @@ int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint
     const int rc = hits ? launch_render<true, false>(ctx, p, out, hits, nullptr) : launch_render<false, false>(ctx, p, out, nullptr, nullptr);
     if (rc) return rc;
     if (target->memory == VX_MEM_HOST) {
-        HIP_TRY(hipMemcpyAsync(target->rgba32f, ctx->d_image, pixels * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(target->rgba32f, ctx->d_frame, pixels * 16, hipMemcpyDeviceToHost, ctx->stream));
         if (target->hits) HIP_TRY(hipMemcpyAsync(target->hits, ctx->d_hits, pixels * sizeof(vx_hit), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }

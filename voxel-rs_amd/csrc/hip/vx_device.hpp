@@ -39,12 +39,17 @@ __device__ __forceinline__ uint4 buf_u128(buf_t b, uint32_t off) {
     const auto v = __builtin_amdgcn_raw_buffer_load_b128(b, int(off), 0, 0);
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
+__device__ __forceinline__ uint2 buf_u64(buf_t b, uint32_t off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(b, int(off), 0, 0);
+    return make_uint2(v[0], v[1]);
+}
 #else
 struct buf_t { const uint8_t* p; uint32_t bytes; };
 inline buf_t make_buf(const void* p, uint32_t bytes) { return buf_t{static_cast<const uint8_t*>(p), bytes}; }
 inline uint32_t buf_u32(buf_t b, uint32_t off) { uint32_t v = 0; if (uint64_t(off) + 4 <= b.bytes) std::memcpy(&v, b.p + off, 4); return v; }
 inline uint32_t buf_u8(buf_t b, uint32_t off) { return off < b.bytes ? b.p[off] : 0u; }
 inline uint4 buf_u128(buf_t b, uint32_t off) { uint4 v = {0, 0, 0, 0}; if (uint64_t(off) + 16 <= b.bytes) std::memcpy(&v, b.p + off, 16); return v; }
+inline uint2 buf_u64(buf_t b, uint32_t off) { uint2 v = {0, 0}; if (uint64_t(off) + 8 <= b.bytes) std::memcpy(&v, b.p + off, 8); return v; }
 #endif
 
 struct DevTextures {
@@ -56,9 +61,15 @@ struct DevTextures {
 struct DevScene {
     buf_t world;              // device copy of the mapped world buffer, byte 0 = f32 octree_scale (< 4 GiB)
     buf_t materials;          // vx_material rows
-    float octree_scale;       // = world[0], read once per launch by the host-side wrapper of the kernel arguments
+    float octree_scale;       // = world[0]
     uint32_t root_ptr;        // CSVO: world[1]
     DevTextures tex;
+    // Traversal image (VX_SVO_IMAGE): the GPU-native re-layout of the octree built at commit time. One octant =
+    // 64 bytes = 8 entries {lo, hi}: lo = child octant index | 1<<31, or the original absolute word pointer of a
+    // chunk (bit 31 clear), or the leaf value; hi = (child_mask << 8 | leaf_mask) of that child.
+    buf_t image;
+    uint32_t image_root;      // octant index of the root octree's first octant
+    uint32_t image_root_masks;
 };
 
 // what the host passes to a kernel; expanded into a DevScene (descriptors in SGPRs) at kernel entry
@@ -71,6 +82,8 @@ struct SceneArgs {
     uint32_t tex_bytes;
     uint32_t width, height, layers, levels;
     uint32_t level_offset[16];
+    const uint8_t* image;
+    uint32_t image_bytes, image_root, image_root_masks;
 };
 
 __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
@@ -82,6 +95,9 @@ __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
     sc.tex.level_offset = a.level_offset;
     sc.octree_scale = __uint_as_float(buf_u32(sc.world, 0));
     sc.root_ptr = buf_u32(sc.world, 4);
+    sc.image = make_buf(a.image, a.image_bytes);
+    sc.image_root = a.image_root;
+    sc.image_root_masks = a.image_root_masks;
     return sc;
 }
 
@@ -179,6 +195,16 @@ __device__ __forceinline__ uint32_t esvo_word(const DevScene& sc, uint32_t index
     index = index < 0x3ffffffeu ? index : 0x3ffffffeu;  // keep 4 + 4*index from wrapping: wild indices must read 0, not alias
     return buf_u32(sc.world, 4u + index * 4u);
 }
+
+// traversal image: entry `child` of octant `octant` (8 bytes)
+#define VX_SVO_IMAGE 3
+__device__ __forceinline__ uint2 image_entry(const DevScene& sc, uint32_t octant, uint32_t child) {
+    octant = octant < 0x03fffffeu ? octant : 0x03fffffeu;  // no wrap of octant * 64
+    return buf_u64(sc.image, octant * 64u + child * 8u);
+}
+// pointer stored in an entry -> octant index: relative pointers were resolved when the image was built (bit 31 set);
+// absolute ones are the reference's word indices into descriptors[] (5-word preamble, 12-word octants)
+__device__ __forceinline__ uint32_t image_child_octant(uint32_t lo) { return (lo & 0x80000000u) ? (lo & 0x7fffffffu) : (lo - 5u) / 12u; }
 
 // CSVO: descriptors[] starts at byte 8 and is addressed in bytes (svo.csvo.glsl:1-5, 25-49); the hardware reads
 // unaligned dwords directly, so read_uint's two-loads-and-shift collapses into one load
@@ -319,20 +345,23 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
 // reports when the ray is AT a leaf instead of testing it, so a wavefront can park such lanes and test them
 // together (render kernel), while the picker / debug kernels simply call step() and leaf_test() back to back.
 
-enum TravStatus : int { kTravContinue = 0, kTravAtLeaf = 1, kTravFinished = 2 };
+// kTravNeedsReference: only from the image traversal -- the ray starts inside a voxel, where the reference goes on to
+// interpret leaf data as nodes; such a ray is re-run on the reference-format buffer (see render_persistent).
+enum TravStatus : int { kTravContinue = 0, kTravAtLeaf = 1, kTravFinished = 2, kTravNeedsReference = 3 };
 
 template <int SVO>
 struct Trav {
     static constexpr bool CSVO = SVO == VX_SVO_CSVO;
+    static constexpr bool IMG = SVO == VX_SVO_IMAGE;
 
     float rox, roy, roz, rdx, rdy, rdz;   // origin in [1,2) space, epsilon-clamped direction
     float tcx, tcy, tcz, tbx, tby, tbz;   // t(x) = x * t_coef - t_bias per axis
     float px, py, pz;                     // current octant corner
     float t_min, t_max, h, scale_exp2;
     float max_dst;                        // already scaled to [0,1]; < 0 = unlimited
-    uint32_t ptr;
-    uint32_t aux;                         // ESVO: parent_octant_idx, CSVO: depth
-    uint32_t node;                        // ESVO: masks of the child being examined (cached); CSVO: pointer of the child at the leaf
+    uint32_t ptr;                         // ESVO/CSVO: as in the reference; image: the octant whose children are examined
+    uint32_t aux;                         // ESVO: parent_octant_idx, CSVO: depth, image: unused
+    uint32_t node;                        // ESVO/image: masks of the octant being examined (cached)
     uint32_t material_section_ptr, pre_leaf_pointer;  // CSVO only
     uint32_t last_leaf_value;
     int adjacent_leaf_count;
@@ -347,7 +376,7 @@ struct Trav {
         max_dst = max_dst_in * octree_scale;
         rox += 1.0f; roy += 1.0f; roz += 1.0f;
 
-        ptr = CSVO ? sc.root_ptr : 0u;
+        ptr = CSVO ? sc.root_ptr : (IMG ? sc.image_root : 0u);
         aux = CSVO ? 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu) : 0u;  // svo.csvo.glsl:254
         scale = kMaxScale - 1;
         scale_exp2 = 0.5f;
@@ -386,7 +415,7 @@ struct Trav {
 
         // ESVO: the masks of the child being examined depend only on (ptr, parent_octant_idx); they are fetched when
         // those change (here, PUSH, POP) instead of every iteration (svo.esvo.glsl:168-173 reloads each time).
-        node = CSVO ? 0u : esvo_word(sc, ptr);
+        node = CSVO ? 0u : (IMG ? sc.image_root_masks : esvo_word(sc, ptr));
     }
 
     // ADVANCE + POP (svo.esvo.glsl:324-390). Returns false when the ray left the octree.
@@ -411,10 +440,14 @@ struct Trav {
 
             int16_t a;
             st.pop(scale, ptr, a, t_max);
-            aux = CSVO ? uint32_t(int32_t(a)) : uint32_t(a);
-            if (!CSVO) {
-                node = esvo_word(sc, ptr + (aux >> 1));
-                if (aux & 1u) node >>= 16;
+            if (IMG) {
+                node = uint32_t(uint16_t(a));
+            } else {
+                aux = CSVO ? uint32_t(int32_t(a)) : uint32_t(a);
+                if (!CSVO) {
+                    node = esvo_word(sc, ptr + (aux >> 1));
+                    if (aux & 1u) node >>= 16;
+                }
             }
 
             const int shx = __float_as_int(px) >> scale, shy = __float_as_int(py) >> scale, shz = __float_as_int(pz) >> scale;
@@ -480,6 +513,7 @@ struct Trav {
         if (is_child && t_min <= t_max) {
             if (is_leaf && t_min == 0.0f) inside_voxel = true;
             if (is_leaf && t_min > 0.0f) return kTravAtLeaf;  // leaf_test() decides; state is left untouched
+            if (IMG && is_leaf) return kTravNeedsReference;     // t_min == 0: the ray starts inside this voxel
 
             const float half_scale = scale_exp2 * 0.5f;
             const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
@@ -488,9 +522,13 @@ struct Trav {
             if (t_min <= tv_max) {
                 // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
                 if (STATS) ctr->pushes++;
-                if (tc_max < h) st.push(scale, ptr, int16_t(aux), t_max);
+                if (tc_max < h) st.push(scale, ptr, int16_t(IMG ? node : aux), t_max);
                 h = tc_max;
-                if (!CSVO) {
+                if (IMG) {
+                    const uint2 e = image_entry(sc, ptr, octant_idx);
+                    ptr = image_child_octant(e.x);
+                    node = e.y & 0xffffu;
+                } else if (!CSVO) {
                     uint32_t np = esvo_word(sc, ptr + 4 + aux);
                     if (np & (1u << 31)) np = ptr + 4 + aux + (np & 0x7fffffffu);
                     ptr = np;
@@ -536,7 +574,9 @@ struct Trav {
         const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 2^depth, exact
         const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
         uint32_t value;
-        if (!CSVO) {
+        if (IMG) {
+            value = image_entry(sc, ptr, octant_idx).x;
+        } else if (!CSVO) {
             uint32_t np = esvo_word(sc, ptr + 4 + aux);
             if (np & (1u << 31)) np = ptr + 4 + aux + (np & 0x7fffffffu);
             value = esvo_word(sc, np + 4 + octant_idx);
