@@ -101,10 +101,8 @@ extern "C" void devhost_picker_image(const uint8_t* world, uint64_t world_bytes,
             if (s == kTravAtLeaf && tr.leaf_test<false>(sc, cast_translucent != 0, res, nullptr)) break;
             if (s == kTravFinished) { result_miss(res, tr.inside_voxel); break; }
             if (s == kTravNeedsReference) {
-                uint32_t it = 0;
-                intersect<VX_SVO_ESVO, false, false>(sc, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, cast_translucent != 0, st, res, it, nullptr, 0, nf, nullptr);
+                tr.init(sc, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, true);
                 ++*n_fallbacks;
-                break;
             }
         }
         vx_picker_result r;

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     state = kDone;
                 } else if (SVO == VX_SVO_IMAGE && s == kTravNeedsReference) {
                     // The ray starts inside a voxel: the reference now walks leaf data as if it were nodes
-                    // (svo.esvo.glsl:183-185). Reproduce that exactly by re-running this one ray on the reference-format buffer.
+                    // (svo.esvo.glsl:183-185). Reproduce that exactly by restarting this one ray on the reference-format buffer.
                     float ro[3], rd[3];
                     if (!shadow_ray) {
                         primary_ray(p, px_x, px_y, ro, rd);
@@ -243,10 +243,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                         ro[0] = shadow_origin[0]; ro[1] = shadow_origin[1]; ro[2] = shadow_origin[2];
                         rd[0] = -p.u.light_dir[0]; rd[1] = -p.u.light_dir[1]; rd[2] = -p.u.light_dir[2];
                     }
-                    uint32_t it = 0;
-                    intersect<VX_SVO_ESVO, false, false>(sc, ro, rd, -1.0f, true, st, res, it, nullptr, 0, nf, nullptr);
-                    tr.iter = it;
-                    state = kDone;
+                    tr.init(sc, ro, rd, -1.0f, /*reference=*/true);  // stays in kTrav: same loop, reference-format paths
                 }
             }
             const unsigned long long trav = __ballot(state == kTrav);

@@ -369,14 +369,19 @@ struct Trav {
     uint32_t iter;                        // loop iterations executed (the reference's `i`)
     bool pending_advance;                 // a rejected leaf still owes the ADVANCE/POP half of its iteration
     bool inside_voxel;
+    bool ref_mode;                        // image traversal only: this ray walks the reference-format buffer instead (see below)
 
-    __device__ __forceinline__ void init(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst_in) {
+    // true while this lane reads the traversal image; a Trav<VX_SVO_IMAGE> in ref_mode behaves exactly like Trav<VX_SVO_ESVO>
+    __device__ __forceinline__ bool img() const { return IMG && !ref_mode; }
+
+    __device__ __forceinline__ void init(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst_in, bool reference = false) {
+        ref_mode = IMG && reference;
         const float octree_scale = sc.octree_scale;
         rox = ro_in[0] * octree_scale; roy = ro_in[1] * octree_scale; roz = ro_in[2] * octree_scale;
         max_dst = max_dst_in * octree_scale;
         rox += 1.0f; roy += 1.0f; roz += 1.0f;
 
-        ptr = CSVO ? sc.root_ptr : (IMG ? sc.image_root : 0u);
+        ptr = CSVO ? sc.root_ptr : (img() ? sc.image_root : 0u);
         aux = CSVO ? 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu) : 0u;  // svo.csvo.glsl:254
         scale = kMaxScale - 1;
         scale_exp2 = 0.5f;
@@ -415,7 +420,7 @@ struct Trav {
 
         // ESVO: the masks of the child being examined depend only on (ptr, parent_octant_idx); they are fetched when
         // those change (here, PUSH, POP) instead of every iteration (svo.esvo.glsl:168-173 reloads each time).
-        node = CSVO ? 0u : (IMG ? sc.image_root_masks : esvo_word(sc, ptr));
+        node = CSVO ? 0u : (img() ? sc.image_root_masks : esvo_word(sc, ptr));
     }
 
     // ADVANCE + POP (svo.esvo.glsl:324-390). Returns false when the ray left the octree.
@@ -440,7 +445,7 @@ struct Trav {
 
             int16_t a;
             st.pop(scale, ptr, a, t_max);
-            if (IMG) {
+            if (img()) {
                 node = uint32_t(uint16_t(a));
             } else {
                 aux = CSVO ? uint32_t(int32_t(a)) : uint32_t(a);
@@ -513,7 +518,7 @@ struct Trav {
         if (is_child && t_min <= t_max) {
             if (is_leaf && t_min == 0.0f) inside_voxel = true;
             if (is_leaf && t_min > 0.0f) return kTravAtLeaf;  // leaf_test() decides; state is left untouched
-            if (IMG && is_leaf) return kTravNeedsReference;     // t_min == 0: the ray starts inside this voxel
+            if (img() && is_leaf) return kTravNeedsReference;   // t_min == 0: the ray starts inside this voxel
 
             const float half_scale = scale_exp2 * 0.5f;
             const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
@@ -522,9 +527,9 @@ struct Trav {
             if (t_min <= tv_max) {
                 // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
                 if (STATS) ctr->pushes++;
-                if (tc_max < h) st.push(scale, ptr, int16_t(IMG ? node : aux), t_max);
+                if (tc_max < h) st.push(scale, ptr, int16_t(img() ? node : aux), t_max);
                 h = tc_max;
-                if (IMG) {
+                if (img()) {
                     const uint2 e = image_entry(sc, ptr, octant_idx);
                     ptr = image_child_octant(e.x);
                     node = e.y & 0xffffu;
@@ -574,7 +579,7 @@ struct Trav {
         const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 2^depth, exact
         const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
         uint32_t value;
-        if (IMG) {
+        if (img()) {
             value = image_entry(sc, ptr, octant_idx).x;
         } else if (!CSVO) {
             uint32_t np = esvo_word(sc, ptr + 4 + aux);
