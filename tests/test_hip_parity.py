@@ -347,9 +347,9 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     w, h = 250, 130
     u = scenes.bench_camera(8, st["h_max"], w, h)
     results = []
-    for env in ({"VX_RENDER_KERNEL": "1"}, {"VX_RENDER_KERNEL": "2"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"},
+    for env in ({"VX_RENDER_KERNEL": "1"}, {"VX_RENDER_KERNEL": "2"}, {"VX_RENDER_KERNEL": "2", "VX_IMAGE": "1"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"},
                 {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "64", "VX_SERVICE_MIN": "64"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"}):
-        for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN"):
+        for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_IMAGE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -439,7 +439,7 @@ struct vx_context {
     uint32_t* d_work_counter = nullptr;
     uint8_t* d_image = nullptr;           // ESVO traversal image (64-byte octants)
     size_t image_capacity = 0;
-    bool image_enabled = true, image_ok = false;
+    bool image_enabled = false, image_ok = false;  // opt-in (VX_IMAGE=1) until it beats the reference-layout kernel (profiles/round1)
     uint32_t image_root = 0, image_root_masks = 0;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
     uint32_t refill_min = 8, service_min = 28;
