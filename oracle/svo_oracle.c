@@ -543,7 +543,10 @@ static void sky_color(const float rd[3], float out[3]) { /* world.glsl:92-108 */
     for (int k = 0; k < 3; ++k) HORIZON[k] = 1.0f * (1.0f - 0.3f) + SKY[k] * 0.3f;
     float flat[3] = {rd[0], 0.0f, rd[2]}, p[3];
     normalize3(flat, p);
-    float a = acosf(dot3(rd, p) / fabsf(sqrtf(dot3(rd, rd))) * fabsf(sqrtf(dot3(p, p))));
+    /* acos is undefined beyond [-1,1] in GLSL; at the horizon rounding pushes the argument an ulp above 1. The reference's
+     * expected image (assets/tests/graphics_svo_render_expected.png) shows the horizon row as plain horizon colour,
+     * i.e. its driver returns acos(1+) = 0, which clamping reproduces. */
+    float a = acosf(gclamp(dot3(rd, p) / fabsf(sqrtf(dot3(rd, rd))) * fabsf(sqrtf(dot3(p, p))), -1.0f, 1.0f));
     float grad = a / 1.570796f;
     grad = 1.0f - powf(1.0f - grad, 3.0f);
     for (int k = 0; k < 3; ++k) out[k] = HORIZON[k] * (1.0f - grad) + SKY[k] * grad;

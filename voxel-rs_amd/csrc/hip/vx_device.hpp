@@ -729,7 +729,8 @@ __device__ __forceinline__ void sky_color(const float rd[3], float out[3]) {
     const float flat[3] = {rd[0], 0.0f, rd[2]};
     float p[3];
     normalize3(flat, p);
-    const float a = acosf(dot3(rd, p) / fabsf(sqrtf(dot3(rd, rd))) * fabsf(sqrtf(dot3(p, p))));
+    // argument clamped like the oracle does: the reference's expected image has no undefined (acos(1+)) horizon pixels
+    const float a = acosf(gclamp(dot3(rd, p) / fabsf(sqrtf(dot3(rd, rd))) * fabsf(sqrtf(dot3(p, p))), -1.0f, 1.0f));
     float grad = a / 1.570796f;
     grad = 1.0f - powf(1.0f - grad, 3.0f);
 #pragma unroll
