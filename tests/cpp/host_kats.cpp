@@ -14,6 +14,7 @@
 #include "esvo.hpp"
 #include "octree.hpp"
 #include "range_buffer.hpp"
+#include "worldsvo.hpp"
 
 using namespace vx;
 
@@ -548,6 +549,93 @@ static void chunk_storage_depth_and_blocks() {  // chunk.rs:60-90, 110-131
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// world <-> SVO space, chunk shifting  (src/systems/worldsvo.rs:226-386, 505-558)
+// ---------------------------------------------------------------------------------------------------------
+
+using vx::systems::SvoCoordSpace;
+
+static void coord_space_positive() {  // worldsvo.rs:513-524
+    SvoCoordSpace cs{ChunkPos{4, 5, 12}, 2};
+    const Vec3 world{std::fma(32.0f, 5.0f, 16.25f), std::fma(32.0f, 3.0f, 4.25f), std::fma(32.0f, 10.0f, 20.5f)};
+    const Vec3 svo = cs.cnv_block_pos(world);
+    CHECK((svo == Vec3{std::fma(32.0f, 3.0f, 16.25f), std::fma(32.0f, 0.0f, 4.25f), std::fma(32.0f, 0.0f, 20.5f)}));
+    CHECK(cs.cnv_svo_pos(svo) == world);
+}
+
+static void coord_space_negative() {  // worldsvo.rs:526-537
+    SvoCoordSpace cs{ChunkPos{-1, -1, -1}, 2};
+    const Vec3 world{-16.25f, -4.25f, -20.5f};
+    const Vec3 svo = cs.cnv_block_pos(world);
+    CHECK((svo == Vec3{std::fma(32.0f, 2.0f, 15.75f), std::fma(32.0f, 2.0f, 27.75f), std::fma(32.0f, 2.0f, 11.5f)}));
+    CHECK(cs.cnv_svo_pos(svo) == world);
+}
+
+static void coord_space_cnv_chunk_pos() {  // worldsvo.rs:539-557
+    SvoCoordSpace cs{ChunkPos{0, 0, 0}, 1};
+    auto eq = [](std::optional<Position> p, Position q) { return p && *p == q; };
+    CHECK(eq(cs.cnv_chunk_pos(ChunkPos{-1, 0, 0}), Position{0, 1, 1}));
+    CHECK(eq(cs.cnv_chunk_pos(ChunkPos{0, 0, 0}), Position{1, 1, 1}));
+    CHECK(eq(cs.cnv_chunk_pos(ChunkPos{1, 0, 0}), Position{2, 1, 1}));
+    CHECK(!cs.cnv_chunk_pos(ChunkPos{-2, 0, 0}));
+    CHECK(!cs.cnv_chunk_pos(ChunkPos{2, 0, 0}));
+    CHECK(!cs.cnv_chunk_pos(ChunkPos{1, 0, 1}));
+}
+
+struct ShiftFixture {
+    std::unordered_map<ChunkPos, LeafId, ChunkPosHash> leaf_ids;
+    Esvo<EsvoU32Leaf> world;
+    LeafId c0, c1, c2;
+    ShiftFixture() {
+        c0 = world.set_leaf(Position{0, 1, 1}, EsvoU32Leaf{1}, true).first; leaf_ids[ChunkPos{-1, 0, 0}] = c0;
+        c1 = world.set_leaf(Position{1, 1, 1}, EsvoU32Leaf{2}, true).first; leaf_ids[ChunkPos{0, 0, 0}] = c1;
+        c2 = world.set_leaf(Position{2, 1, 1}, EsvoU32Leaf{3}, true).first; leaf_ids[ChunkPos{1, 0, 0}] = c2;
+    }
+    uint32_t at(uint32_t x) const { const EsvoU32Leaf* l = world.get_leaf(Position{x, 1, 1}); return l ? l->value : 0; }
+    bool ids_are(std::initializer_list<std::pair<ChunkPos, LeafId>> want) const {
+        if (leaf_ids.size() != want.size()) return false;
+        for (auto& kv : want) {
+            auto it = leaf_ids.find(kv.first);
+            if (it == leaf_ids.end() || it->second != kv.second) return false;
+        }
+        return true;
+    }
+};
+
+static void shift_chunks_x_positive() {  // worldsvo.rs:247-300
+    ShiftFixture f;
+    CHECK(f.at(0) == 1 && f.at(1) == 2 && f.at(2) == 3);
+    vx::systems::shift_chunks(SvoCoordSpace{ChunkPos{1, 0, 0}, 1}, f.leaf_ids, f.world);
+    CHECK(f.ids_are({{ChunkPos{0, 0, 0}, f.c0}, {ChunkPos{1, 0, 0}, f.c1}}));
+    CHECK(f.at(0) == 2 && f.at(1) == 3 && f.at(2) == 0);
+    vx::systems::shift_chunks(SvoCoordSpace{ChunkPos{2, 0, 0}, 1}, f.leaf_ids, f.world);
+    CHECK(f.ids_are({{ChunkPos{1, 0, 0}, f.c0}}));
+    CHECK(f.at(0) == 3 && f.at(1) == 0 && f.at(2) == 0);
+    vx::systems::shift_chunks(SvoCoordSpace{ChunkPos{3, 0, 0}, 1}, f.leaf_ids, f.world);
+    CHECK(f.leaf_ids.empty());
+    CHECK(f.at(0) == 0 && f.at(1) == 0 && f.at(2) == 0);
+}
+
+static void shift_chunks_x_negative() {  // worldsvo.rs:302-355
+    ShiftFixture f;
+    vx::systems::shift_chunks(SvoCoordSpace{ChunkPos{-1, 0, 0}, 1}, f.leaf_ids, f.world);
+    CHECK(f.ids_are({{ChunkPos{-1, 0, 0}, f.c1}, {ChunkPos{0, 0, 0}, f.c2}}));
+    CHECK(f.at(0) == 0 && f.at(1) == 1 && f.at(2) == 2);
+    vx::systems::shift_chunks(SvoCoordSpace{ChunkPos{-2, 0, 0}, 1}, f.leaf_ids, f.world);
+    CHECK(f.ids_are({{ChunkPos{-1, 0, 0}, f.c2}}));
+    CHECK(f.at(0) == 0 && f.at(1) == 0 && f.at(2) == 1);
+    vx::systems::shift_chunks(SvoCoordSpace{ChunkPos{-3, 0, 0}, 1}, f.leaf_ids, f.world);
+    CHECK(f.leaf_ids.empty());
+    CHECK(f.at(0) == 0 && f.at(1) == 0 && f.at(2) == 0);
+}
+
+static void shift_chunks_x_out_of_range() {  // worldsvo.rs:357-385
+    ShiftFixture f;
+    vx::systems::shift_chunks(SvoCoordSpace{ChunkPos{3, 0, 0}, 1}, f.leaf_ids, f.world);
+    CHECK(f.leaf_ids.empty());
+    CHECK(f.at(0) == 0 && f.at(1) == 0 && f.at(2) == 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 
 int main(int argc, char** argv) {
     const std::map<std::string, std::function<void()>> cases = {
@@ -572,6 +660,12 @@ int main(int argc, char** argv) {
         {"chunk_pos_from_block_pos", chunk_pos_from_block_pos},
         {"block_pos_roundtrip", block_pos_roundtrip},
         {"chunk_storage_depth_and_blocks", chunk_storage_depth_and_blocks},
+        {"coord_space_positive", coord_space_positive},
+        {"coord_space_negative", coord_space_negative},
+        {"coord_space_cnv_chunk_pos", coord_space_cnv_chunk_pos},
+        {"shift_chunks_x_positive", shift_chunks_x_positive},
+        {"shift_chunks_x_negative", shift_chunks_x_negative},
+        {"shift_chunks_x_out_of_range", shift_chunks_x_out_of_range},
     };
     if (argc >= 2 && std::string(argv[1]) == "--list") {
         for (auto& c : cases) std::printf("%s\n", c.first.c_str());

@@ -168,6 +168,29 @@ def main():
                   dict(dst=0.5, inside_voxel=True, pos=[1.0, 0.5, 0.5], normal=[-1.0, 0.0, 0.0]),
                   dict(dst=-1.0, inside_voxel=False, pos=[0.0, 0.0, 0.0], normal=[0.0, 0.0, 0.0])])
 
+    # picker batch (de)serialisation tables, src/graphics/svo_picker.rs:311-418 and :422-536
+    psrc = Path("/root/reference/src/graphics/svo_picker.rs").read_text()
+    ser = section(psrc, "fn picker_batch_serialization()", "fn picker_batch_deserialization()")
+    tasks = [dict(max_dst=float(m.group(1)), pos=nums(m.group(2)), dir=nums(m.group(3))) for m in re.finditer(
+        r"PickerTask \{ max_dst: ([0-9.]+), pos: AlignedPoint3\(Point3::new\(([^)]*)\)\), dir: AlignedVec3\(Vector3::new\(([^)]*)\)\) \}", ser)]
+    tasks = tasks[1:]  # the first literal is the buffer's default fill value, not an expected task
+    assert len(tasks) == 80, len(tasks)
+    des = psrc[psrc.index("fn picker_batch_deserialization()"):]
+    results = [dict(dst=float(m.group(1)), inside_voxel=m.group(2) == "true", pos=nums(m.group(3)), normal=nums(m.group(4))) for m in re.finditer(
+        r"PickerResult \{ dst: (-?[0-9.]+), inside_voxel: (\w+), pos: AlignedPoint3\(Point3::new\(([^)]*)\)\), normal: AlignedVec3\(Vector3::new\(([^)]*)\)\) \}", des)]
+    assert len(results) == 80, len(results)
+    batch = dict(aabbs=[dict(pos=[0.5, 0.0, 0.5], offset=[-0.5, 0.0, -0.5], extents=[1.0, 1.0, 1.0]),
+                        dict(pos=[0.0, 0.0, 0.0], offset=[0.0, 0.0, 0.0], extents=[1.5, 1.5, 1.5])])
+    out["picker_batch"] = dict(
+        source="src/graphics/svo_picker.rs:311-536",
+        serialization=dict(rays=[dict(pos=[1.0, 0.0, 1.0], dir=[0.0, 1.0, 0.0], max_dst=20.0), dict(pos=[2.0, 0.0, 2.0], dir=[1.0, 0.0, 0.0], max_dst=40.0)],
+                           aabbs=batch["aabbs"], expected_tasks=tasks),
+        deserialization=dict(rays=[dict(pos=[0.0, 0.0, 0.0], dir=[-1.0, 0.0, 0.0], max_dst=20.0), dict(pos=[0.0, 0.0, 0.0], dir=[1.0, 0.0, 0.0], max_dst=20.0)],
+                             aabbs=batch["aabbs"], results=results,
+                             expected_rays=[dict(dst=-1.0, inside_voxel=False, pos=[0.0, 0.0, 0.0], normal=[0.0, 0.0, 0.0]),
+                                            dict(dst=10.0, inside_voxel=True, pos=[-1.0, 0.0, 0.0], normal=[10.0, 0.0, 0.0])],
+                             expected_aabbs=[dict(neg=[8.0, 7.0, 8.0], pos=[2.0, 4.0, 1.0]), dict(neg=[9.0, 8.0, 7.0], pos=[1.0, 4.0, 3.0])]))
+
     OUT.write_text(json.dumps(out, indent=1))
     print("wrote", OUT, OUT.stat().st_size, "bytes")
 

@@ -3,6 +3,9 @@
 // hands to `graphics::Svo::update` (src/graphics/svo.rs:171-189).
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -10,7 +13,11 @@
 #include "chunk.hpp"
 #include "csvo.hpp"
 #include "esvo.hpp"
+#include "graphics_svo.hpp"
 #include "scene.hpp"
+#include "svo_picker.hpp"
+#include "svo_registry.hpp"
+#include "worldsvo.hpp"
 
 using namespace vx;
 
@@ -133,5 +140,156 @@ uint64_t vxh_scene_build_heightfield(void* wp, uint32_t depth, uint32_t seed, ui
 }
 
 uint32_t vxh_scene_height(uint32_t depth, uint32_t seed, uint32_t x, uint32_t z) { return heightfield_height(depth, seed, x, z); }
+
+// ---- picker batches (src/graphics/svo_picker.rs) --------------------------------------------------------------------
+
+namespace {
+PickerBatch make_batch(const float* rays, uint32_t n_rays, const float* aabbs, uint32_t n_aabbs) {
+    PickerBatch b;
+    for (uint32_t i = 0; i < n_rays; ++i) {
+        const float* r = rays + 7 * i;  // pos, dir, max_dst
+        b.add_ray(Vec3{r[0], r[1], r[2]}, Vec3{r[3], r[4], r[5]}, r[6]);
+    }
+    for (uint32_t i = 0; i < n_aabbs; ++i) {
+        const float* a = aabbs + 9 * i;  // pos, offset, extents
+        b.add_aabb(Aabb{Vec3{a[0], a[1], a[2]}, Vec3{a[3], a[4], a[5]}, Vec3{a[6], a[7], a[8]}});
+    }
+    return b;
+}
+}  // namespace
+
+// PickerBatch::serialize_tasks; returns the task count (writes at most `max`)
+uint32_t vxh_picker_serialize(const float* rays, uint32_t n_rays, const float* aabbs, uint32_t n_aabbs, vx_picker_task* out, uint32_t max) {
+    std::vector<vx_picker_task> tasks;
+    make_batch(rays, n_rays, aabbs, n_aabbs).serialize_tasks(tasks);
+    for (size_t i = 0; i < tasks.size() && i < max; ++i) out[i] = tasks[i];
+    return uint32_t(tasks.size());
+}
+
+// PickerBatch::deserialize_results: out_rays = n_rays x {dst, inside, pos[3], normal[3]}, out_aabbs = n_aabbs x {neg[3], pos[3]}
+void vxh_picker_deserialize(const float* rays, uint32_t n_rays, const float* aabbs, uint32_t n_aabbs, const vx_picker_result* results,
+                            float* out_rays, float* out_aabbs) {
+    PickerBatchResult res;
+    make_batch(rays, n_rays, aabbs, n_aabbs).deserialize_results(results, res);
+    for (size_t i = 0; i < res.rays.size(); ++i) {
+        const RayResult& r = res.rays[i];
+        const float v[8] = {r.dst, r.inside_voxel ? 1.0f : 0.0f, r.pos.x, r.pos.y, r.pos.z, r.normal.x, r.normal.y, r.normal.z};
+        std::memcpy(out_rays + 8 * i, v, sizeof v);
+    }
+    for (size_t i = 0; i < res.aabbs.size(); ++i) {
+        const AabbResult& a = res.aabbs[i];
+        const float v[6] = {a.neg.x, a.neg.y, a.neg.z, a.pos.x, a.pos.y, a.pos.z};
+        std::memcpy(out_aabbs + 6 * i, v, sizeof v);
+    }
+}
+
+// ---- graphics::Svo end to end (src/graphics/svo.rs:342-449), needs a GPU -----------------------------------------------
+
+// The reference's `render` test through the C++ mirror: registry from PNG files, one uncompacted chunk, Svo::new(.., 10 MB),
+// update, render 640x490, as_image, diff_images against the expected PNG. Returns 0 and the diff fraction, or -1 (see `err`).
+int vxh_reference_render_test(int svo_type, const char* texture_dir, const char* expected_png, const char* actual_png_out, double* diff, char* err,
+                              size_t err_len) {
+    try {
+        const std::string dir = texture_dir;
+        VoxelRegistry reg;
+        reg.add_texture("stone", dir + "/stone.png").add_texture("stone_normal", dir + "/stone_n.png").add_texture("dirt", dir + "/dirt.png")
+            .add_texture("dirt_normal", dir + "/dirt_n.png").add_texture("grass_side", dir + "/grass_side.png")
+            .add_texture("grass_side_normal", dir + "/grass_side_n.png").add_texture("grass_top", dir + "/grass_top.png")
+            .add_texture("grass_top_normal", dir + "/grass_top_n.png")
+            .add_material(0, Material())
+            .add_material(1, Material().specular(70.0f, 0.4f).all_sides("stone").with_normals())
+            .add_material(2, Material().specular(14.0f, 0.4f).top("grass_top").side("grass_side").bottom("dirt").with_normals());
+
+        Chunk chunk(ChunkPos{0, 0, 0}, 5);
+        for (uint32_t x = 0; x < 5; ++x)
+            for (uint32_t z = 0; z < 5; ++z) chunk.set_block(x, 0, z, 1);
+        for (uint32_t z : {1u, 3u})
+            for (auto xy : {std::pair<uint32_t, uint32_t>{1, 1}, {3, 1}, {1, 3}, {3, 3}}) chunk.set_block(xy.first, xy.second, z, 2);
+
+        graphics::Svo svo(reg, svo_type == 1 ? graphics::SvoType::Esvo : graphics::SvoType::Csvo, 10);
+        Esvo<EsvoSerializedChunk> esvo;
+        Csvo csvo;
+        if (svo_type == 1) {
+            esvo.set_leaf(Position{0, 0, 0}, EsvoSerializedChunk(chunk), true);
+            esvo.serialize();
+            graphics::WorldSvoRef<Esvo<EsvoSerializedChunk>> ref(esvo);
+            svo.update(ref);
+        } else {
+            csvo.set_leaf(Position{0, 0, 0}, CsvoSerializedChunk(chunk), true);
+            csvo.serialize();
+            graphics::WorldSvoRef<Csvo> ref(csvo);
+            svo.update(ref);
+        }
+        const int w = 640, h = 490;
+        graphics::Framebuffer fb(w, h);
+        fb.clear(0, 0, 0, 1);
+        graphics::RenderParams p;
+        p.ambient_intensity = 0.3f;
+        p.light_dir = graphics::normalize(Vec3{-1, -1, -1});
+        p.cam_pos = Vec3{2.5f, 2.5f, 7.5f};
+        p.cam_fwd = Vec3{0, 0, -1};
+        p.cam_up = Vec3{0, 1, 0};
+        p.fov_y_rad = 72.0f * 3.14159265358979323846f / 180.0f;
+        p.aspect_ratio = float(w) / float(h);
+        p.selected_voxel = Vec3{1, 1, 3};
+        p.render_shadows = true;
+        p.shadow_distance = 500.0f;
+        svo.render(p, fb);
+        const Image8 actual = fb.as_image();
+        if (actual_png_out && *actual_png_out) png_write(actual_png_out, actual);
+        Image8 expected;
+        std::string e;
+        if (!png_read(expected_png, expected, e)) throw std::runtime_error(e);
+        *diff = graphics::diff_images(actual, expected);
+        const graphics::Stats st = svo.get_stats();
+        if (st.depth != 6 || st.capacity_bytes != 10u * 1000 * 1000) throw std::runtime_error("unexpected stats");
+        return 0;
+    } catch (const std::exception& ex) {
+        if (err && err_len) std::snprintf(err, err_len, "%s", ex.what());
+        return -1;
+    }
+}
+
+// worldsvo::Svo end to end: chunks at world positions around `center`, raycasts in WORLD space straight down at (x, z)
+// pairs from height y0; out = n x {dst, pos.y}. Exercises coordinate conversion both ways, chunk shifting and updates.
+int vxh_mapper_raycast_test(int svo_type, uint32_t render_distance, const int32_t* chunk_pos, const uint32_t* floor_height, uint32_t n_chunks,
+                            const int32_t centers[6], const float* xz, uint32_t n_rays, float y0, float* out_first, float* out_second, char* err,
+                            size_t err_len) {
+    try {
+        VoxelRegistry reg;
+        reg.add_material(0, Material()).add_material(1, Material());
+        graphics::Svo gfx(reg, svo_type == 1 ? graphics::SvoType::Esvo : graphics::SvoType::Csvo, 64);
+        auto run = [&](auto& mapper) {
+            for (uint32_t i = 0; i < n_chunks; ++i) {
+                Chunk c(ChunkPos{chunk_pos[3 * i], chunk_pos[3 * i + 1], chunk_pos[3 * i + 2]}, 5);
+                c.fill_with([&](uint32_t, uint32_t y, uint32_t) -> std::optional<BlockId> { return y < floor_height[i] ? std::optional<BlockId>(1u) : std::nullopt; });
+                mapper.set_chunk(c);
+            }
+            for (int pass = 0; pass < 2; ++pass) {
+                mapper.update(ChunkPos{centers[3 * pass], centers[3 * pass + 1], centers[3 * pass + 2]});
+                PickerBatch batch;
+                for (uint32_t i = 0; i < n_rays; ++i) batch.add_ray(Vec3{xz[2 * i], y0, xz[2 * i + 1]}, Vec3{0, -1, 0}, -1.0f);
+                PickerBatchResult res;
+                mapper.raycast(batch, res);
+                float* out = pass == 0 ? out_first : out_second;
+                for (uint32_t i = 0; i < n_rays; ++i) {
+                    out[2 * i] = res.rays[i].dst;
+                    out[2 * i + 1] = res.rays[i].pos.y;
+                }
+            }
+        };
+        if (svo_type == 1) {
+            systems::Svo<Esvo<EsvoSerializedChunk>, EsvoSerializedChunk> mapper(gfx, render_distance);
+            run(mapper);
+        } else {
+            systems::Svo<Csvo, CsvoSerializedChunk> mapper(gfx, render_distance);
+            run(mapper);
+        }
+        return 0;
+    } catch (const std::exception& ex) {
+        if (err && err_len) std::snprintf(err, err_len, "%s", ex.what());
+        return -1;
+    }
+}
 
 }  // extern "C"

@@ -44,6 +44,10 @@ def lib():
             "vxh_world_updated_ranges": (sz, [vp, vp, sz]),
             "vxh_world_frame": (sz, [vp, vp, sz]),
             "vxh_scene_build_heightfield": (u64, [vp, u32, u32, u32, vp, vp]),
+            "vxh_picker_serialize": (u32, [vp, u32, vp, u32, vp, u32]),
+            "vxh_picker_deserialize": (None, [vp, u32, vp, u32, vp, vp, vp]),
+            "vxh_reference_render_test": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, sz]),
+            "vxh_mapper_raycast_test": (C.c_int, [C.c_int, u32, vp, vp, u32, vp, vp, u32, C.c_float, vp, vp, C.c_char_p, sz]),
             "vxh_scene_height": (u32, [u32, u32, u32, u32]),
         }
         for name, (res, args) in sig.items():
@@ -166,3 +170,61 @@ class World:
 
 def scene_height(depth, seed, x, z):
     return lib().vxh_scene_height(depth, seed, x, z)
+
+
+PICKER_TASK_DTYPE = np.dtype([("max_dst", "<f4"), ("_p0", "<f4", 3), ("pos", "<f4", 3), ("_p1", "<f4"), ("dir", "<f4", 3), ("_p2", "<f4")])
+PICKER_RESULT_DTYPE = np.dtype([("dst", "<f4"), ("inside_voxel", "<u4"), ("_p0", "<f4", 2), ("pos", "<f4", 3), ("_p1", "<f4"), ("normal", "<f4", 3),
+                                ("_p2", "<f4")])
+
+
+def _batch_arrays(rays, aabbs):
+    r = np.array([list(x["pos"]) + list(x["dir"]) + [x["max_dst"]] for x in rays], dtype=np.float32).reshape(-1, 7)
+    a = np.array([list(x["pos"]) + list(x["offset"]) + list(x["extents"]) for x in aabbs], dtype=np.float32).reshape(-1, 9)
+    return np.ascontiguousarray(r), np.ascontiguousarray(a)
+
+
+def picker_serialize(rays, aabbs):
+    """PickerBatch::serialize_tasks (src/graphics/svo_picker.rs:63-80)."""
+    r, a = _batch_arrays(rays, aabbs)
+    n = lib().vxh_picker_serialize(r.ctypes.data_as(C.c_void_p), len(rays), a.ctypes.data_as(C.c_void_p), len(aabbs), None, 0)
+    out = np.zeros(n, dtype=PICKER_TASK_DTYPE)
+    lib().vxh_picker_serialize(r.ctypes.data_as(C.c_void_p), len(rays), a.ctypes.data_as(C.c_void_p), len(aabbs), out.ctypes.data_as(C.c_void_p), n)
+    return out
+
+
+def picker_deserialize(rays, aabbs, results):
+    """PickerBatch::deserialize_results (svo_picker.rs:84-104): (rays n x 8 floats, aabbs n x 6 floats)."""
+    r, a = _batch_arrays(rays, aabbs)
+    res = np.ascontiguousarray(results, dtype=PICKER_RESULT_DTYPE)
+    out_r = np.zeros((len(rays), 8), dtype=np.float32)
+    out_a = np.zeros((len(aabbs), 6), dtype=np.float32)
+    lib().vxh_picker_deserialize(r.ctypes.data_as(C.c_void_p), len(rays), a.ctypes.data_as(C.c_void_p), len(aabbs), res.ctypes.data_as(C.c_void_p),
+                                 out_r.ctypes.data_as(C.c_void_p), out_a.ctypes.data_as(C.c_void_p))
+    return out_r, out_a
+
+
+def reference_render_test(svo_type, texture_dir, expected_png, actual_png_out=""):
+    """src/graphics/svo.rs:342-399 through the C++ mirror of graphics::Svo (needs a GPU). Returns the diff fraction."""
+    diff = C.c_double(0)
+    err = C.create_string_buffer(512)
+    rc = lib().vxh_reference_render_test(svo_type, str(texture_dir).encode(), str(expected_png).encode(), str(actual_png_out).encode(), C.byref(diff), err, 512)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return diff.value
+
+
+def mapper_raycast_test(svo_type, render_distance, chunks, centers, xz, y0):
+    """worldsvo::Svo end to end (needs a GPU). chunks: [(cx, cy, cz, floor_height)], centers: two ChunkPos. Returns two (n, 2) arrays {dst, pos.y}."""
+    cp = np.ascontiguousarray([c[:3] for c in chunks], dtype=np.int32)
+    fh = np.ascontiguousarray([c[3] for c in chunks], dtype=np.uint32)
+    cen = np.ascontiguousarray(centers, dtype=np.int32).reshape(6)
+    pts = np.ascontiguousarray(xz, dtype=np.float32).reshape(-1, 2)
+    a = np.zeros((len(pts), 2), dtype=np.float32)
+    b = np.zeros((len(pts), 2), dtype=np.float32)
+    err = C.create_string_buffer(512)
+    rc = lib().vxh_mapper_raycast_test(svo_type, render_distance, cp.ctypes.data_as(C.c_void_p), fh.ctypes.data_as(C.c_void_p), len(chunks),
+                                       cen.ctypes.data_as(C.c_void_p), pts.ctypes.data_as(C.c_void_p), len(pts), y0, a.ctypes.data_as(C.c_void_p),
+                                       b.ctypes.data_as(C.c_void_p), err, 512)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return a, b
