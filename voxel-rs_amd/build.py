@@ -29,3 +29,13 @@ def lib_path(name):
     if not p.exists():
         raise FileNotFoundError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C voxel-rs_amd)")
     return p
+
+
+def share_hip_runtime_with_torch():
+    """The PyTorch wheel bundles its own libamdhip64 (same SONAME as /opt/rocm's). Whichever copy is loaded first serves the
+    whole process; loading ours first and torch's later puts two HIP runtimes in one process and torch then reports
+    "No HIP GPUs". When torch is installed, import it before any of our libraries so that both share one runtime."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass

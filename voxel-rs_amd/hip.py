@@ -9,7 +9,7 @@ import math
 
 import numpy as np
 
-from .build import lib_path
+from .build import lib_path, share_hip_runtime_with_torch
 
 VX_OK = 0
 VX_MEM_HOST, VX_MEM_DEVICE = 0, 1
@@ -97,13 +97,7 @@ def lib():
     """Loads libvoxelhip.so; raises if it (or any declared symbol) is missing -- never falls back."""
     global _lib
     if _lib is None:
-        # The PyTorch wheel bundles its own libamdhip64 (same SONAME as /opt/rocm's). Whichever copy is loaded first
-        # serves the whole process; loading ours first and torch's later puts two HIP runtimes in one process and
-        # torch then reports "No HIP GPUs". When torch is present, let it load first so both share one runtime.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        share_hip_runtime_with_torch()
         L = C.CDLL(str(lib_path("libvoxelhip.so")))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from .build import lib_path
+from .build import lib_path, share_hip_runtime_with_torch
 
 SVO_ESVO = 1  # SvoType::Esvo, shader define "1" (src/graphics/svo.rs:35)
 SVO_CSVO = 2  # SvoType::Csvo, shader define "2" (src/graphics/svo.rs:36)
@@ -21,6 +21,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        share_hip_runtime_with_torch()  # libvoxelhost links libvoxelhip, which links the HIP runtime
         L = C.CDLL(str(lib_path("libvoxelhost.so")))
         vp, u32, i32, u64, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_uint64, C.c_size_t
         sig = {
