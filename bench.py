@@ -102,28 +102,27 @@ def main():
     my_rays = counters["rays"]
     my_bytes = algorithmic_bytes(args.format, counters)
 
-    n_local = hip.local_tile_count(W, H, rank, world_size)
-    n_max = max(hip.local_tile_count(W, H, r, world_size) for r in range(world_size))
     if world_size > 1:
-        tiles = torch.zeros((n_max, 32, 32, 4), dtype=torch.float32, device="cuda")
-        gathered = torch.zeros((world_size, n_max, 32, 32, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
-        image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+        from voxel_rs_amd.sharding import FrameSharder
+
         vx_stream = torch.cuda.ExternalStream(svo.stream)
+
+        def render_tiles(tiles):
+            svo.render_device(uniforms, W, H, tiles.data_ptr(), tile_rank=rank, tile_count=world_size)
+
+        def assemble(gathered, image):
+            svo.assemble_tiles(gathered.data_ptr(), gathered.shape[1] * 32 * 32 * 4, world_size, W, H, image.data_ptr())
+
+        # the collective runs on torch's stream: order it after the render stream, and the assembly after the collective
+        sharder = FrameSharder(W, H, rank, world_size, dist, "cuda", render_tiles, assemble,
+                               before_gather=lambda: torch.cuda.current_stream().wait_stream(vx_stream),
+                               after_gather=lambda: vx_stream.wait_stream(torch.cuda.current_stream()))
+        step = sharder.step
     else:
         image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
 
-    def step():
-        if world_size == 1:
+        def step():
             svo.render_device(uniforms, W, H, image.data_ptr())
-            return
-        svo.render_device(uniforms, W, H, tiles.data_ptr(), tile_rank=rank, tile_count=world_size)
-        cur = torch.cuda.current_stream()
-        cur.wait_stream(vx_stream)
-        # the one exchange step of the path: finished tiles -> rank 0, each peer over its own xGMI link
-        dist.gather(tiles, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-        if rank == 0:
-            vx_stream.wait_stream(cur)
-            svo.assemble_tiles(gathered.data_ptr(), n_max * 32 * 32 * 4, world_size, W, H, image.data_ptr())
 
     def barrier():
         svo.sync()
