@@ -113,11 +113,29 @@ def main():
         def assemble(gathered, image):
             svo.assemble_tiles(gathered.data_ptr(), gathered.shape[1] * 32 * 32 * 4, world_size, W, H, image.data_ptr())
 
-        # the collective runs on torch's stream: order it after the render stream, and the assembly after the collective
-        sharder = FrameSharder(W, H, rank, world_size, dist, "cuda", render_tiles, assemble,
-                               before_gather=lambda: torch.cuda.current_stream().wait_stream(vx_stream),
-                               after_gather=lambda: vx_stream.wait_stream(torch.cuda.current_stream()))
-        step = sharder.step
+        # The renderer has its own stream and the collective runs on torch's. With two tile buffers, render k+1 may start
+        # once collective k-1 (the previous user of its buffer) is done; waiting for ALL prior collectives is a superset.
+        # An event per buffer would be tighter; stream-level waits keep this simple and are correct.
+        gather_done = [torch.cuda.Event(), torch.cuda.Event()]
+        state = {"i": 0}
+
+        def before_render():
+            gather_done[state["i"] % 2].wait(vx_stream)  # the collective that last read this tile buffer (no-op until recorded)
+
+        def before_gather():
+            torch.cuda.current_stream().wait_stream(vx_stream)
+
+        def after_gather_all():
+            gather_done[state["i"] % 2].record(torch.cuda.current_stream())
+            state["i"] += 1
+
+        sharder = FrameSharder(W, H, rank, world_size, dist, "cuda", render_tiles, assemble, before_render=before_render,
+                               before_gather=before_gather, after_gather=lambda: vx_stream.wait_stream(torch.cuda.current_stream()))
+        _step = sharder.step
+
+        def step():
+            _step()
+            after_gather_all()
     else:
         image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
 

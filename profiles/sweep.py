@@ -16,7 +16,7 @@ from _pkg import load_package  # noqa: E402
 vra = load_package()
 from voxel_rs_amd import hip, scenes  # noqa: E402
 
-KEYS = {"k": "VX_RENDER_KERNEL", "r": "VX_REFILL_MIN", "s": "VX_SERVICE_MIN", "m": "VX_MIN_WAVES", "i": "VX_IMAGE"}
+KEYS = {"k": "VX_RENDER_KERNEL", "r": "VX_REFILL_MIN", "s": "VX_SERVICE_MIN", "m": "VX_MIN_WAVES", "i": "VX_IMAGE", "w": "VX_WAVES_PER_CU"}
 
 
 def main():

@@ -443,6 +443,7 @@ struct vx_context {
     uint32_t image_root = 0, image_root_masks = 0;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
     uint32_t refill_min = 8, service_min = 28;
+    int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int min_waves = 1;                    // experiment: __launch_bounds__ waves-per-SIMD variant of the plain render kernel
     int cu_count = 256;
     int persistent_blocks[3][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
@@ -550,7 +551,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.total_subtiles = p.n_local_tiles * 16;
         a.refill_min = ctx->refill_min;
         a.service_min = ctx->service_min;
-        uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(per_cu);
+        uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, const_cast<uint32_t*>(&levels)};
         (void)mw;
@@ -642,6 +643,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("VX_MIN_WAVES")) c->min_waves = std::atoi(e);
+        if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
         if (const char* e = std::getenv("VX_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));

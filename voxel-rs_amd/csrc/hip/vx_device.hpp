@@ -423,127 +423,16 @@ struct Trav {
         node = CSVO ? 0u : (img() ? sc.image_root_masks : esvo_word(sc, ptr));
     }
 
-    // One iteration of the reference's loop (svo.esvo.glsl:152-391 / svo.csvo.glsl:261-508) minus the leaf test.
-    //
-    // Written as straight-line, predicated code: in a wavefront some lanes PUSH while others ADVANCE in the same
-    // iteration, so branching on the phase would run both bodies back to back at half occupancy each. Here every
-    // lane evaluates both cheap arithmetic updates and SELECTS; only the memory operations (stack write + child
-    // fetch for PUSH, stack read + masks for POP) sit under a condition. The per-lane sequence of fp32 operations
-    // that reaches the state is exactly the reference's, so results stay bit-identical.
-    template <bool TRACE, bool STATS>
-    __device__ __forceinline__ TravStatus step(const DevScene& sc, const Stack& st, vx_frame* frames, uint32_t max_frames, uint32_t& n_frames,
-                                               Counters* ctr) {
-        // a rejected leaf (leaf_test) still owes the ADVANCE/POP half of its iteration: no checks, no new iteration
-        const bool resume = pending_advance;
-        pending_advance = false;
-        if (!resume) {
-            if (iter >= uint32_t(kMaxSteps)) return kTravFinished;
-            if (max_dst >= 0.0f && t_min > max_dst) return kTravFinished;
-            ++iter;
-            if (STATS) ctr->iterations++;
-        }
+    // ADVANCE + POP (svo.esvo.glsl:324-390). Returns false when the ray left the octree.
+    __device__ __forceinline__ bool advance(const DevScene& sc, const Stack& st, float tcrx, float tcry, float tcrz, float tc_max) {
+        int step_mask = 0;
+        if (tc_max >= tcrx) { step_mask ^= 1; px -= scale_exp2; }
+        if (tc_max >= tcry) { step_mask ^= 2; py -= scale_exp2; }
+        if (tc_max >= tcrz) { step_mask ^= 4; pz -= scale_exp2; }
 
-        const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
-        const float tc_max = gmin(gmin(tcrx, tcry), tcrz);
-        const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
+        t_min = tc_max;
+        idx ^= step_mask;
 
-        bool is_child = false, is_leaf = false, crossed_boundary = false;
-        uint32_t next_ptr = 0, iter_ptr_bytes = 0;
-        if (!resume) {
-            if (!CSVO) {
-                is_child = (node & (0x100u << octant_idx)) != 0;
-                is_leaf = (node & (1u << octant_idx)) != 0;
-            } else {
-                uint32_t hb = 0;
-                next_ptr = csvo_next_ptr(sc, ptr, aux, octant_idx, crossed_boundary, hb, iter_ptr_bytes);
-                is_child = next_ptr != kInvalidPtr;
-                is_leaf = is_child && aux < 2;
-                if (aux == 2) pre_leaf_pointer = ptr;
-                if (STATS) ctr->csvo_header_bytes += hb;
-            }
-            if (TRACE) {
-                if (n_frames < max_frames) {
-                    vx_frame& f = frames[n_frames];
-                    f.t_min = t_min * __uint_as_float(0x7f000000u - __float_as_uint(sc.octree_scale));
-                    f.ptr = ptr;
-                    f.idx = octant_idx;
-                    f.parent_octant_idx = aux;
-                    f.scale = scale;
-                    f.is_child = is_child;
-                    f.is_leaf = is_leaf;
-                    f.crossed_boundary = crossed_boundary;
-                    f.next_ptr = CSVO ? next_ptr : 0u;
-                }
-                ++n_frames;
-            }
-        }
-
-        const bool hit = is_child && t_min <= t_max;  // false when resuming
-        if (hit && is_leaf) {
-            if (t_min > 0.0f) return kTravAtLeaf;         // leaf_test() decides; state is left untouched
-            inside_voxel = true;                          // t_min == 0: the ray starts inside this voxel ...
-            if (img()) return kTravNeedsReference;        // ... and the reference goes on to walk the leaf as a node
-        }
-        if (!resume && !hit) {
-            adjacent_leaf_count = 0;
-            last_leaf_value = 0xffffffffu;
-        }
-
-        // ---- PUSH or ADVANCE: decide, do the memory part of PUSH, then select the arithmetic ----
-        const float half_scale = scale_exp2 * 0.5f;
-        const float tv_max = gmin(t_max, tc_max);
-        const bool push = hit && t_min <= tv_max;
-
-        if (push) {  // svo.esvo.glsl:280-311, svo.csvo.glsl:387-426
-            if (STATS) ctr->pushes++;
-            if (tc_max < h) st.push(scale, ptr, int16_t(img() ? node : aux), t_max);
-            if (img()) {
-                const uint2 e = image_entry(sc, ptr, octant_idx);
-                ptr = image_child_octant(e.x);
-                node = e.y & 0xffffu;
-            } else if (!CSVO) {
-                uint32_t np = esvo_word(sc, ptr + 4 + aux);
-                if (np & (1u << 31)) np = ptr + 4 + aux + (np & 0x7fffffffu);
-                ptr = np;
-                aux = octant_idx;
-                node = esvo_word(sc, ptr + (aux >> 1));
-                if (aux & 1u) node >>= 16;
-            } else {
-                if (STATS) ctr->csvo_pointer_bytes += iter_ptr_bytes;
-                --aux;
-                ptr = next_ptr;
-                if (crossed_boundary) {
-                    if (STATS) ctr->boundaries++;
-                    const uint32_t child_lod = csvo_u8(sc, ptr);
-                    const uint32_t material_bytes = csvo_u32(sc, ptr + 1);
-                    ptr += 5;
-                    material_section_ptr = ptr;
-                    ptr += material_bytes;
-                    aux = child_lod;
-                }
-            }
-        }
-
-        // PUSH: child index and corner from the centre planes (svo.esvo.glsl:299-305)
-        const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
-                    tcenz = __builtin_fmaf(half_scale, tcz, tcrz);
-        const bool bx = t_min < tcenx, by = t_min < tceny, bz = t_min < tcenz;
-        // ADVANCE: step mask and corner from the exit planes (svo.esvo.glsl:324-331)
-        const bool sx = tc_max >= tcrx, sy = tc_max >= tcry, sz = tc_max >= tcrz;
-        const int step_mask = push ? 0 : (int(sx) | (int(sy) << 1) | (int(sz) << 2));
-        const int push_idx = int(bx) | (int(by) << 1) | (int(bz) << 2);
-
-        px = push ? (bx ? px + half_scale : px) : (sx ? px - scale_exp2 : px);
-        py = push ? (by ? py + half_scale : py) : (sy ? py - scale_exp2 : py);
-        pz = push ? (bz ? pz + half_scale : pz) : (sz ? pz - scale_exp2 : pz);
-        idx = push ? push_idx : (idx ^ step_mask);
-        h = push ? tc_max : h;
-        t_max = push ? tv_max : t_max;
-        t_min = push ? t_min : tc_max;
-        scale = push ? scale - 1 : scale;
-        scale_exp2 = push ? half_scale : scale_exp2;
-
-        // ---- POP (svo.esvo.glsl:347-390): the step left the parent octant ----
         if ((idx & step_mask) != 0) {
             uint32_t differing_bits = 0;
             if (step_mask & 1) differing_bits |= __float_as_uint(px) ^ __float_as_uint(px + scale_exp2);
@@ -551,7 +440,7 @@ struct Trav {
             if (step_mask & 4) differing_bits |= __float_as_uint(pz) ^ __float_as_uint(pz + scale_exp2);
 
             scale = differing_bits ? 31 - __clz(differing_bits) : -1;
-            if (scale >= kMaxScale || scale < 0) return kTravFinished;  // left the octree
+            if (scale >= kMaxScale || scale < 0) return false;
             scale_exp2 = pow2i(scale - kMaxScale);
 
             int16_t a;
@@ -573,7 +462,112 @@ struct Trav {
             idx = (shx & 1) | ((shy & 1) << 1) | ((shz & 1) << 2);
             h = 0.0f;
         }
-        return kTravContinue;
+        return true;
+    }
+
+    // One iteration of the reference's loop (svo.esvo.glsl:152-391 / svo.csvo.glsl:261-508) minus the leaf test.
+    template <bool TRACE, bool STATS>
+    __device__ __forceinline__ TravStatus step(const DevScene& sc, const Stack& st, vx_frame* frames, uint32_t max_frames, uint32_t& n_frames,
+                                               Counters* ctr) {
+        if (pending_advance) {
+            // second half of an iteration whose leaf was rejected by leaf_test()
+            pending_advance = false;
+            const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
+            return advance(sc, st, tcrx, tcry, tcrz, gmin(gmin(tcrx, tcry), tcrz)) ? kTravContinue : kTravFinished;
+        }
+        if (iter >= uint32_t(kMaxSteps)) return kTravFinished;
+        if (max_dst >= 0.0f && t_min > max_dst) return kTravFinished;
+        ++iter;
+        if (STATS) ctr->iterations++;
+
+        const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
+        const float tc_max = gmin(gmin(tcrx, tcry), tcrz);
+        const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
+
+        bool is_child, is_leaf, crossed_boundary = false;
+        uint32_t next_ptr = 0, iter_ptr_bytes = 0;
+        if (!CSVO) {
+            is_child = (node & (0x100u << octant_idx)) != 0;
+            is_leaf = (node & (1u << octant_idx)) != 0;
+        } else {
+            uint32_t hb = 0;
+            next_ptr = csvo_next_ptr(sc, ptr, aux, octant_idx, crossed_boundary, hb, iter_ptr_bytes);
+            is_child = next_ptr != kInvalidPtr;
+            is_leaf = is_child && aux < 2;
+            if (aux == 2) pre_leaf_pointer = ptr;
+            if (STATS) ctr->csvo_header_bytes += hb;
+        }
+
+        if (TRACE) {
+            if (n_frames < max_frames) {
+                const float octree_scale = sc.octree_scale;
+                vx_frame& f = frames[n_frames];
+                f.t_min = t_min * __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));
+                f.ptr = ptr;
+                f.idx = octant_idx;
+                f.parent_octant_idx = aux;
+                f.scale = scale;
+                f.is_child = is_child;
+                f.is_leaf = is_leaf;
+                f.crossed_boundary = crossed_boundary;
+                f.next_ptr = CSVO ? next_ptr : 0u;
+            }
+            ++n_frames;
+        }
+
+        if (is_child && t_min <= t_max) {
+            if (is_leaf && t_min == 0.0f) inside_voxel = true;
+            if (is_leaf && t_min > 0.0f) return kTravAtLeaf;  // leaf_test() decides; state is left untouched
+            if (img() && is_leaf) return kTravNeedsReference;   // t_min == 0: the ray starts inside this voxel
+
+            const float half_scale = scale_exp2 * 0.5f;
+            const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
+                        tcenz = __builtin_fmaf(half_scale, tcz, tcrz);
+            const float tv_max = gmin(t_max, tc_max);
+            if (t_min <= tv_max) {
+                // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
+                if (STATS) ctr->pushes++;
+                if (tc_max < h) st.push(scale, ptr, int16_t(img() ? node : aux), t_max);
+                h = tc_max;
+                if (img()) {
+                    const uint2 e = image_entry(sc, ptr, octant_idx);
+                    ptr = image_child_octant(e.x);
+                    node = e.y & 0xffffu;
+                } else if (!CSVO) {
+                    uint32_t np = esvo_word(sc, ptr + 4 + aux);
+                    if (np & (1u << 31)) np = ptr + 4 + aux + (np & 0x7fffffffu);
+                    ptr = np;
+                    aux = octant_idx;
+                    node = esvo_word(sc, ptr + (aux >> 1));
+                    if (aux & 1u) node >>= 16;
+                } else {
+                    if (STATS) ctr->csvo_pointer_bytes += iter_ptr_bytes;
+                    --aux;
+                    ptr = next_ptr;
+                    if (crossed_boundary) {
+                        if (STATS) ctr->boundaries++;
+                        const uint32_t child_lod = csvo_u8(sc, ptr);
+                        const uint32_t material_bytes = csvo_u32(sc, ptr + 1);
+                        ptr += 5;
+                        material_section_ptr = ptr;
+                        ptr += material_bytes;
+                        aux = child_lod;
+                    }
+                }
+                --scale;
+                scale_exp2 = half_scale;
+                idx = 0;
+                if (t_min < tcenx) { idx ^= 1; px += scale_exp2; }
+                if (t_min < tceny) { idx ^= 2; py += scale_exp2; }
+                if (t_min < tcenz) { idx ^= 4; pz += scale_exp2; }
+                t_max = tv_max;
+                return kTravContinue;
+            }
+        } else {
+            adjacent_leaf_count = 0;
+            last_leaf_value = 0xffffffffu;
+        }
+        return advance(sc, st, tcrx, tcry, tcrz, tc_max) ? kTravContinue : kTravFinished;
     }
 
     // HIT phase (svo.esvo.glsl:185-265) for a ray whose step() returned kTravAtLeaf. Returns true when the leaf is

@@ -54,29 +54,38 @@ class FrameSharder:
 
     render_tiles(tiles_tensor): fills this rank's compact tile list (asynchronously on the renderer's stream is fine).
     assemble(gathered_tensor, image_tensor): rank 0 only.
-    before_gather / after_gather: stream-ordering hooks (GPU: make the collective's stream wait for the render stream and
-    back); no-ops on CPU.
+    Stream-ordering hooks (GPU: the renderer has its own stream, the collective runs on torch's; no-ops on CPU):
+      before_render -- the renderer must not overwrite a tile list the previous collective using it is still sending;
+      before_gather -- the collective waits for the render;  after_gather -- the assembly waits for the collective.
+    Tile lists and gather buffers are double-buffered so that frame k+1's render overlaps frame k's gather/assembly.
     """
 
-    def __init__(self, width, height, rank, world, dist, device, render_tiles, assemble, before_gather=None, after_gather=None):
+    def __init__(self, width, height, rank, world, dist, device, render_tiles, assemble, before_render=None, before_gather=None,
+                 after_gather=None, buffers=2):
         import torch
 
         self.width, self.height, self.rank, self.world, self.dist = width, height, rank, world, dist
         self.render_tiles, self.assemble = render_tiles, assemble
-        self.before_gather = before_gather or (lambda: None)
-        self.after_gather = after_gather or (lambda: None)
+        noop = lambda: None  # noqa: E731
+        self.before_render, self.before_gather, self.after_gather = before_render or noop, before_gather or noop, after_gather or noop
         self.n_local = len(local_tile_ids(width, height, rank, world))
         self.n_max = max(len(local_tile_ids(width, height, r, world)) for r in range(world))
-        self.tiles = torch.zeros((self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device)
-        self.gathered = torch.zeros((world, self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) if rank == 0 else None
+        self.tiles = [torch.zeros((self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) for _ in range(buffers)]
+        self.gathered = [torch.zeros((world, self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) if rank == 0 else None
+                         for _ in range(buffers)]
         self.image = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if rank == 0 else None
+        self.frame = 0
 
     def step(self):
-        self.render_tiles(self.tiles)
+        b = self.frame % len(self.tiles)
+        self.frame += 1
+        tiles, gathered = self.tiles[b], self.gathered[b]
+        self.before_render()
+        self.render_tiles(tiles)
         self.before_gather()
         # the one exchange step of the path: finished tiles -> rank 0
-        self.dist.gather(self.tiles, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
+        self.dist.gather(tiles, list(gathered.unbind(0)) if self.rank == 0 else None, dst=0)
         if self.rank == 0:
             self.after_gather()
-            self.assemble(self.gathered, self.image)
+            self.assemble(gathered, self.image)
         return self.image
