@@ -39,16 +39,17 @@ extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t worl
         sa.tex_bytes = level_offset[l] + layers * w * h * 4;
     }
     const DevScene sc = make_scene(sa);
-    std::vector<unsigned char> lds(7 * 10 + 64);
+    std::vector<unsigned char> lds(Stack<1>::kBytes + 64);
+    // Stack<1>::slot0 is "negative" (it is relative to scale 0 of a full-height plane): bias the base so that the sums land in lds
     vx_smem = lds.data();
     StackSpill spill;
-    Stack st;
-    st.stride = 1; st.tid = 0; st.levels = 7; st.spill = &spill;
+    Stack<1> st;
+    st.init(0, &spill);
     for (uint32_t i = 0; i < n; ++i) {
         Result res;
-        uint32_t steps = 0, nf = 0;
-        if (svo_type == 1) intersect<1, false, false>(sc, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, cast_translucent != 0, st, res, steps, nullptr, 0, nf, nullptr);
-        else intersect<2, false, false>(sc, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, cast_translucent != 0, st, res, steps, nullptr, 0, nf, nullptr);
+        uint32_t steps = 0;
+        if (svo_type == 1) intersect<1, false, false, true>(sc, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, cast_translucent != 0, st, res, steps, nullptr, nullptr);
+        else intersect<2, false, false, true>(sc, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, cast_translucent != 0, st, res, steps, nullptr, nullptr);
         vx_picker_result r;
         std::memset(&r, 0, sizeof r);
         if (res.t > 0.0f) {
@@ -60,58 +61,3 @@ extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t worl
     }
 }
 
-// Image traversal on the host: builds the 64-byte-octant image with the same per-entry rule as esvo_image_kernel and runs
-// Trav<VX_SVO_IMAGE>, falling back to the reference-format traversal exactly like render_persistent does.
-extern "C" void devhost_picker_image(const uint8_t* world, uint64_t world_bytes, const vx_material* mats, uint32_t n_mats, const uint8_t* tex,
-                                     uint32_t tw, uint32_t th, uint32_t layers, const vx_picker_task* tasks, uint32_t n,
-                                     vx_picker_result* results, int cast_translucent, uint32_t* n_fallbacks) {
-    const uint32_t* arena = reinterpret_cast<const uint32_t*>(world + 24);
-    const uint64_t n_oct = (world_bytes - 24) / 48;
-    std::vector<uint2> image(n_oct * 8);
-    for (uint64_t k = 0; k < n_oct; ++k)
-        for (uint32_t j = 0; j < 8; ++j) {
-            const uint32_t* o = arena + k * 12;
-            const uint32_t masks = (o[j >> 1] >> ((j & 1u) * 16u)) & 0xffffu;
-            uint32_t lo = o[4 + j];
-            if (lo & 0x80000000u) lo = 0x80000000u | uint32_t((12ull * k + 4 + j + (lo & 0x7fffffffu)) / 12);
-            image[k * 8 + j] = uint2{lo, masks};
-        }
-    uint32_t pre[5];
-    std::memcpy(pre, world + 4, sizeof pre);
-    SceneArgs sa = {};
-    sa.world = world; sa.world_bytes = uint32_t(world_bytes); sa.materials = mats; sa.n_materials = n_mats;
-    sa.tex = tex; sa.tex_bytes = layers * tw * th * 4; sa.width = tw; sa.height = th; sa.layers = layers; sa.levels = 1;
-    sa.image = reinterpret_cast<const uint8_t*>(image.data()); sa.image_bytes = uint32_t(image.size() * 8);
-    sa.image_root = (pre[4] - 5) / 12; sa.image_root_masks = pre[0] & 0xffffu;
-    const DevScene sc = make_scene(sa);
-    std::vector<unsigned char> lds(7 * 10 + 64);
-    vx_smem = lds.data();
-    StackSpill spill;
-    Stack st;
-    st.stride = 1; st.tid = 0; st.levels = 7; st.spill = &spill;
-    *n_fallbacks = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        Result res;
-        uint32_t nf = 0;
-        Trav<VX_SVO_IMAGE> tr;
-        tr.init(sc, tasks[i].pos, tasks[i].dir, tasks[i].max_dst);
-        for (;;) {
-            const TravStatus s = tr.step<false, false>(sc, st, nullptr, 0, nf, nullptr);
-            if (s == kTravContinue) continue;
-            if (s == kTravAtLeaf && tr.leaf_test<false>(sc, cast_translucent != 0, res, nullptr)) break;
-            if (s == kTravFinished) { result_miss(res, tr.inside_voxel); break; }
-            if (s == kTravNeedsReference) {
-                tr.init(sc, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, true);
-                ++*n_fallbacks;
-            }
-        }
-        vx_picker_result r;
-        std::memset(&r, 0, sizeof r);
-        if (res.t > 0.0f) {
-            r.dst = res.t; r.inside_voxel = res.inside_voxel;
-            std::memcpy(r.pos, res.pos, 12);
-            std::memcpy(r.normal, kFaceNormals[res.face_id], 12);
-        } else r.dst = -1.0f;
-        results[i] = r;
-    }
-}

@@ -29,15 +29,6 @@ constexpr uint32_t kTile = 32;         // multi-GPU sharding unit (pixels per ed
 constexpr uint32_t kBlockEdge = 16;    // one 256-thread workgroup shades 16x16 pixels: 4 waves x (8x8)
 constexpr uint32_t kBlockThreads = 256;
 
-__device__ __forceinline__ Stack make_stack(uint32_t levels, uint32_t threads, uint32_t tid, StackSpill& spill) {
-    Stack st;
-    st.stride = threads;
-    st.tid = tid;
-    st.levels = levels;
-    st.spill = &spill;
-    return st;
-}
-
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2). Remap so that each XCD shades a
 // contiguous run of screen blocks and its L2 keeps that region's octree nodes (speed only, never correctness).
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
@@ -57,11 +48,12 @@ __device__ __forceinline__ void lane_to_xy(uint32_t lane, uint32_t& x, uint32_t&
 
 template <int SVO, bool HITS, bool STATS>
 __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, RenderParams p, float4* __restrict__ out, vx_hit* __restrict__ hits,
-                                                               unsigned long long* __restrict__ counters, uint32_t levels) {
+                                                               unsigned long long* __restrict__ counters) {
     const DevScene sc = make_scene(sa);
     const uint32_t tid = threadIdx.x;
     StackSpill spill;
-    const Stack st = make_stack(levels, kBlockThreads, tid, spill);
+    Stack<kBlockThreads> st;
+    st.init(tid, &spill);
 
     // block -> (local tile, 16x16 sub-block) -> pixel
     const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
@@ -105,31 +97,6 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
     }
 }
 
-// ---- traversal image builder (ESVO) ---------------------------------------------------------------------------------
-//
-// Re-lays the reference's 12-word octants (4 header words + 8 body words, src/world/hds/esvo.rs:74-101) out as 64-byte
-// octants of eight {lo, hi} entries: lo = what the body word holds (relative pointers resolved to an octant index, bit 31
-// kept as their tag; absolute chunk pointers and leaf values verbatim), hi = the masks the header holds for that child.
-// Descending into a child then costs ONE 8-byte load (pointer and masks together) instead of the reference's two
-// dependent loads, and a leaf value is one load instead of two. One thread per (octant, child): reads are 4-byte
-// strided, writes are fully coalesced 8-byte stores. Runs on the upload stream for the dirty ranges of a commit.
-__global__ __launch_bounds__(256) void esvo_image_kernel(const uint32_t* __restrict__ arena, uint64_t first_octant, uint64_t n_octants,
-                                                         uint2* __restrict__ image) {
-    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= n_octants * 8) return;
-    const uint64_t k = first_octant + (i >> 3);
-    const uint32_t j = uint32_t(i & 7);
-    const uint32_t* o = arena + k * 12;
-    const uint32_t masks = (o[j >> 1] >> ((j & 1u) * 16u)) & 0xffffu;
-    uint32_t lo = o[4 + j];
-    if (lo & 0x80000000u) {
-        // relative to this body word, in descriptors[] index space (octant k starts at word 5 + 12 k)
-        const uint64_t target_word = 12ull * k + 4 + j + (lo & 0x7fffffffu);
-        lo = 0x80000000u | uint32_t(target_word / 12);
-    }
-    image[k * 8 + j] = make_uint2(lo, masks);
-}
-
 // ---- v2: persistent wavefront kernel ---------------------------------------------------------------------------
 //
 // One workgroup = one wave64 that keeps its 64 lanes fed from a global queue of 8x8-pixel sub-tiles. A lane's ray is a
@@ -139,7 +106,7 @@ __global__ __launch_bounds__(256) void esvo_image_kernel(const uint32_t* __restr
 // shows that `service_min` lanes are waiting (or nobody is left traversing); idle lanes are re-filled with new pixels
 // when `refill_min` of them are free. The common descend/advance/pop step therefore runs with most lanes active
 // instead of the ~30 % the one-thread-per-pixel kernel reached (profiles/round1/v1_*).
-enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3 };
+enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4 };
 
 struct PersistentArgs {
     uint32_t* work_counter;   // next sub-tile; zeroed before every launch
@@ -149,11 +116,12 @@ struct PersistentArgs {
 
 template <int SVO, bool HITS, bool STATS, int MINW = 1>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
-                                                        vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, uint32_t levels) {
+                                                        vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters) {
     const DevScene sc = make_scene(sa);
     const uint32_t lane = threadIdx.x;
     StackSpill spill;
-    const Stack st = make_stack(levels, 64, lane, spill);
+    Stack<64> st;
+    st.init(lane, &spill);
 
     Trav<SVO> tr;
     Result res;
@@ -161,12 +129,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     bool shadow_ray = false;
     uint32_t out_index = 0, px_x = 0, px_y = 0;
     float keep_color[4] = {0, 0, 0, 0}, keep_ds = 0.0f;
-    float shadow_origin[3] = {0, 0, 0};  // image traversal only: needed if the shadow ray must be re-run on the reference buffer
     vx_hit rec;            // HITS only
     uint32_t steps = 0;    // HITS only
     Counters ctr = {};
     uint32_t n_pixels = 0, lit = 0, shadow_rays = 0;
-    uint32_t nf = 0;
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
     bool queue_empty = false;
@@ -226,33 +192,25 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         }
 
         // ---- traverse until enough lanes wait for service ----
+        const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle)));  // idle lanes are not waiting for anything
         for (;;) {
             if (state == kTrav) {
-                const TravStatus s = tr.template step<false, STATS>(sc, st, nullptr, 0, nf, STATS ? &ctr : nullptr);
-                if (s == kTravAtLeaf) state = kLeaf;
-                else if (s == kTravFinished) {
-                    result_miss(res, tr.inside_voxel);
-                    state = kDone;
-                } else if (SVO == VX_SVO_IMAGE && s == kTravNeedsReference) {
-                    // The ray starts inside a voxel: the reference now walks leaf data as if it were nodes
-                    // (svo.esvo.glsl:183-185). Reproduce that exactly by restarting this one ray on the reference-format buffer.
-                    float ro[3], rd[3];
-                    if (!shadow_ray) {
-                        primary_ray(p, px_x, px_y, ro, rd);
-                    } else {
-                        ro[0] = shadow_origin[0]; ro[1] = shadow_origin[1]; ro[2] = shadow_origin[2];
-                        rd[0] = -p.u.light_dir[0]; rd[1] = -p.u.light_dir[1]; rd[2] = -p.u.light_dir[2];
-                    }
-                    tr.init(sc, ro, rd, -1.0f, /*reference=*/true);  // stays in kTrav: same loop, reference-format paths
-                }
+                const TravStatus s = tr.template step<false, STATS, false>(sc, st, nullptr, STATS ? &ctr : nullptr);
+                state = s == kTravContinue ? kTrav : (s == kTravAtLeaf ? kLeaf : kMissed);
             }
             const unsigned long long trav = __ballot(state == kTrav);
-            const unsigned long long serv = __ballot(state == kLeaf || state == kDone);
-            if (trav == 0 || uint32_t(__popcll(serv)) >= a.service_min) break;
+            if (trav == 0 || 64u - uint32_t(__popcll(trav)) >= park_limit) break;
         }
 
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
-        if (state == kLeaf) state = tr.template leaf_test<STATS>(sc, true, res, STATS ? &ctr : nullptr) ? kDone : kTrav;
+        if (state == kLeaf) {
+            const LeafOutcome o = tr.template leaf_test<false, STATS>(sc, st, true, res, nullptr, STATS ? &ctr : nullptr);
+            state = o == kLeafHit ? kDone : (o == kLeafPassed ? kTrav : kMissed);
+        }
+        if (state == kMissed) {
+            result_miss(res, tr.inside_voxel);
+            state = kDone;
+        }
 
         // ---- finished rays ----
         if (state == kDone) {
@@ -280,7 +238,6 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                         keep_color[0] = o.color[0]; keep_color[1] = o.color[1]; keep_color[2] = o.color[2]; keep_color[3] = o.color[3];
                         keep_ds = o.ds;
                         const float neg_l[3] = {-p.u.light_dir[0], -p.u.light_dir[1], -p.u.light_dir[2]};
-                        if (SVO == VX_SVO_IMAGE) { shadow_origin[0] = o.shadow_origin[0]; shadow_origin[1] = o.shadow_origin[1]; shadow_origin[2] = o.shadow_origin[2]; }
                         tr.init(sc, o.shadow_origin, neg_l, -1.0f);
                         shadow_ray = true;
                         state = kTrav;
@@ -322,17 +279,18 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
 template <int SVO>
 __global__ __launch_bounds__(64) void picker_kernel(SceneArgs sa, const vx_picker_task* __restrict__ tasks, uint32_t n,
-                                                    vx_picker_result* __restrict__ results, uint32_t levels) {
+                                                    vx_picker_result* __restrict__ results) {
     const DevScene sc = make_scene(sa);
     StackSpill spill;
-    const Stack st = make_stack(levels, 64, threadIdx.x, spill);
+    Stack<64> st;
+    st.init(threadIdx.x, &spill);
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     // picker.glsl:30-51
     const vx_picker_task task = tasks[i];
     Result res;
-    uint32_t steps = 0, nf = 0;
-    intersect<SVO, false, false>(sc, task.pos, task.dir, task.max_dst, false, st, res, steps, nullptr, 0, nf, nullptr);
+    uint32_t steps = 0;
+    intersect<SVO, false, false, true>(sc, task.pos, task.dir, task.max_dst, false, st, res, steps, nullptr, nullptr);
     vx_picker_result r;
     memset(&r, 0, sizeof r);
     if (res.t > 0.0f) {
@@ -354,14 +312,17 @@ struct TraceArgs {
 
 template <int SVO>
 __global__ __launch_bounds__(64) void trace_kernel(SceneArgs sa, TraceArgs a, vx_result* __restrict__ result, vx_frame* __restrict__ frames,
-                                                   uint32_t max_frames, uint32_t* __restrict__ n_frames, uint32_t levels) {
+                                                   uint32_t max_frames, uint32_t* __restrict__ n_frames) {
     const DevScene sc = make_scene(sa);
     StackSpill spill;
-    const Stack st = make_stack(levels, 64, threadIdx.x, spill);
+    Stack<64> st;
+    st.init(threadIdx.x, &spill);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Result res;
-    uint32_t steps = 0, nf = 0;
-    intersect<SVO, true, false>(sc, a.pos, a.dir, a.max_dst, a.cast_translucent != 0, st, res, steps, frames, max_frames, nf, nullptr);
+    uint32_t steps = 0;
+    TraceSink tk;
+    tk.frames = frames; tk.max_frames = max_frames; tk.n_frames = 0;
+    intersect<SVO, true, false, true>(sc, a.pos, a.dir, a.max_dst, a.cast_translucent != 0, st, res, steps, (TracePtr)&tk, nullptr);
     vx_result r;
     r.t = res.t; r.value = res.value; r.face_id = res.face_id;
     r.pos[0] = res.pos[0]; r.pos[1] = res.pos[1]; r.pos[2] = res.pos[2];
@@ -370,7 +331,7 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneArgs sa, TraceArgs a, vx
     r.lod = res.lod;
     r.inside_voxel = res.inside_voxel ? 1 : 0;
     *result = r;
-    *n_frames = nf;
+    *n_frames = tk.n_frames;
 }
 
 // scatter gathered compact tile lists back into a row-major image (one thread per pixel, float4 stores)
@@ -437,16 +398,11 @@ struct vx_context {
     unsigned long long* d_counters = nullptr;
 
     uint32_t* d_work_counter = nullptr;
-    uint8_t* d_image = nullptr;           // ESVO traversal image (64-byte octants)
-    size_t image_capacity = 0;
-    bool image_enabled = false, image_ok = false;  // opt-in (VX_IMAGE=1) until it beats the reference-layout kernel (profiles/round1)
-    uint32_t image_root = 0, image_root_masks = 0;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
     uint32_t refill_min = 8, service_min = 28;
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
-    int min_waves = 1;                    // experiment: __launch_bounds__ waves-per-SIMD variant of the plain render kernel
     int cu_count = 256;
-    int persistent_blocks[3][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
+    int persistent_blocks[2][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
 
     bool profile = false;
     std::vector<ProfiledLaunch> launches;
@@ -456,14 +412,6 @@ struct vx_context {
 namespace {
 
 uint32_t header_bytes(const vx_context* c) { return c->svo_type == VX_SVO_ESVO ? 20u : 4u; }
-
-// slots a ray's stack can need: one per level above the leaves, +1 spare; clamped into the algorithm's range
-uint32_t stack_levels(const vx_context* c) {
-    uint32_t l = c->stats.depth + 1;
-    if (l < 2) l = 2;
-    if (l > uint32_t(kMaxScale)) l = kMaxScale;
-    return l;
-}
 
 SceneArgs scene_of(const vx_context* c) {
     SceneArgs s = {};
@@ -475,10 +423,6 @@ SceneArgs scene_of(const vx_context* c) {
     s.tex_bytes = c->tex_bytes;
     s.width = c->tex.width; s.height = c->tex.height; s.layers = c->tex.layers; s.levels = c->tex.levels;
     for (int l = 0; l < 16; ++l) s.level_offset[l] = c->tex.level_offset[l];
-    s.image = c->d_image;
-    s.image_bytes = c->image_ok ? uint32_t(c->image_capacity) : 0u;
-    s.image_root = c->image_root;
-    s.image_root_masks = c->image_root_masks;
     return s;
 }
 
@@ -501,8 +445,7 @@ int check_ready(vx_context* ctx) {
 
 template <bool HITS, bool STATS>
 int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hits, unsigned long long* counters) {
-    const uint32_t levels = stack_levels(ctx);
-    const size_t lds = size_t(levels) * kBlockThreads * 10;
+    const size_t lds = Stack<kBlockThreads>::kBytes;
     const dim3 grid(p.n_local_tiles * 4), block(kBlockThreads);
     if (grid.x == 0) return VX_OK;
     const SceneArgs sc = scene_of(ctx);
@@ -521,26 +464,16 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
     }
     if (ctx->kernel_version == 1) {
         if (ctx->svo_type == VX_SVO_ESVO)
-            hipLaunchKernelGGL((render_kernel<VX_SVO_ESVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters, levels);
+            hipLaunchKernelGGL((render_kernel<VX_SVO_ESVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters);
         else
-            hipLaunchKernelGGL((render_kernel<VX_SVO_CSVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters, levels);
+            hipLaunchKernelGGL((render_kernel<VX_SVO_CSVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters);
     } else {
         // persistent waves: as many 64-thread workgroups as the device keeps resident, fed from the sub-tile queue
-        const size_t wave_lds = size_t(levels) * 64 * 10;
+        const size_t wave_lds = Stack<64>::kBytes;
         const bool esvo = ctx->svo_type == VX_SVO_ESVO;
         const void* fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, STATS>)
                               : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, HITS, STATS>);
-        // ESVO worlds are rendered from the traversal image; the instrumented variant stays on the reference layout so that
-        // its step counters are the reference's own
-        const bool use_image = esvo && ctx->image_ok && !STATS;
-        if (use_image) fn = reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false>);
-        int mw = 1;
-        if (!HITS && !STATS && !use_image) {
-            if (ctx->min_waves == 4) { mw = 4; fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 4>) : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 4>); }
-            if (ctx->min_waves == 5) { mw = 5; fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 5>) : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 5>); }
-            if (ctx->min_waves == 6) { mw = 6; fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 6>) : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 6>); }
-        }
-        int& per_cu = ctx->persistent_blocks[use_image ? 2 : (ctx->svo_type == VX_SVO_CSVO)][HITS][STATS];
+        int& per_cu = ctx->persistent_blocks[esvo ? 0 : 1][HITS][STATS];
         if (per_cu == 0) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, wave_lds) != hipSuccess || n <= 0) n = 8;
@@ -553,8 +486,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.service_min = ctx->service_min;
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
-        void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, const_cast<uint32_t*>(&levels)};
-        (void)mw;
+        void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
@@ -642,24 +574,13 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
         c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
-        if (const char* e = std::getenv("VX_MIN_WAVES")) c->min_waves = std::atoi(e);
         if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
-        if (const char* e = std::getenv("VX_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
         if (c->refill_min < 1) c->refill_min = 1;
         if (c->refill_min > 64) c->refill_min = 64;
         if (c->service_min < 1) c->service_min = 1;
         if (c->service_min > 64) c->service_min = 64;
-    }
-    if (svo_type == VX_SVO_ESVO && c->image_enabled && c->kernel_version != 1) {
-        c->image_capacity = (c->capacity / 48 + 1) * 64;
-        if (c->image_capacity < (size_t(1) << 32) - 64) {
-            CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_image), c->image_capacity));
-            CREATE_TRY(hipMemset(c->d_image, 0, c->image_capacity));
-        } else {
-            c->image_enabled = false;
-        }
     }
     // one all-zero material and a 1x1 transparent-black texture so that rendering works before any registry is set
     const vx_material zero_mat = {0, 0, -1, -1, -1, -1, -1, -1};
@@ -680,7 +601,7 @@ void vx_destroy(vx_context* c) {
     for (auto& l : c->event_pool) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     if (c->staging) (void)hipHostFree(c->staging);
     void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_frame, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
-                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image};
+                   c->d_trace_count, c->d_counters, c->d_work_counter};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (c->upload_done) (void)hipEventDestroy(c->upload_done);
@@ -774,29 +695,6 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
         const uint64_t off = head + ranges[i].start;
         HIP_TRY(hipMemcpyAsync(ctx->d_world + off, ctx->staging + off, ranges[i].length, hipMemcpyHostToDevice, ctx->upload_stream));
     }
-    if (ctx->d_image && ctx->image_enabled) {
-        // refresh the traversal image for the octants the dirty ranges cover (a range is a whole chunk or the root octree:
-        // always a multiple of one 48-byte octant; anything else means the arena does not hold octants -> no image)
-        bool ok = true;
-        for (uint32_t i = 0; i < count && ok; ++i) ok = ranges[i].start % 48 == 0 && ranges[i].length % 48 == 0;
-        uint32_t pre[5];
-        std::memcpy(pre, ctx->staging + 4, sizeof pre);
-        ok = ok && pre[4] >= 5 && (pre[4] - 5) % 12 == 0;
-        if (ok) {
-            for (uint32_t i = 0; i < count; ++i) {
-                const uint64_t n_oct = ranges[i].length / 48;
-                if (!n_oct) continue;
-                const uint64_t threads = n_oct * 8;
-                hipLaunchKernelGGL(esvo_image_kernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, ctx->upload_stream,
-                                   reinterpret_cast<const uint32_t*>(ctx->d_world + head), ranges[i].start / 48, n_oct,
-                                   reinterpret_cast<uint2*>(ctx->d_image));
-            }
-            HIP_TRY(hipGetLastError());
-            ctx->image_root = (pre[4] - 5) / 12;
-            ctx->image_root_masks = pre[0] & 0xffffu;
-        }
-        ctx->image_ok = ok;
-    }
     HIP_TRY(hipEventRecord(ctx->upload_done, ctx->upload_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_done, 0));
     // the caller may rewrite the staging mirror as soon as we return: wait for the copies to have read it
@@ -881,14 +779,13 @@ int vx_raycast(vx_context* ctx, const vx_picker_task* tasks, uint32_t count, vx_
         ctx->picker_cap = cap;
     }
     HIP_TRY(hipMemcpyAsync(ctx->d_tasks, tasks, size_t(count) * sizeof(vx_picker_task), hipMemcpyHostToDevice, ctx->stream));
-    const uint32_t levels = stack_levels(ctx);
-    const size_t lds = size_t(levels) * 64 * 10;
+    const size_t lds = Stack<64>::kBytes;
     const SceneArgs sc = scene_of(ctx);
     const dim3 grid((count + 63) / 64), block(64);
     if (ctx->svo_type == VX_SVO_ESVO)
-        hipLaunchKernelGGL((picker_kernel<VX_SVO_ESVO>), grid, block, lds, ctx->stream, sc, ctx->d_tasks, count, ctx->d_results, levels);
+        hipLaunchKernelGGL((picker_kernel<VX_SVO_ESVO>), grid, block, lds, ctx->stream, sc, ctx->d_tasks, count, ctx->d_results);
     else
-        hipLaunchKernelGGL((picker_kernel<VX_SVO_CSVO>), grid, block, lds, ctx->stream, sc, ctx->d_tasks, count, ctx->d_results, levels);
+        hipLaunchKernelGGL((picker_kernel<VX_SVO_CSVO>), grid, block, lds, ctx->stream, sc, ctx->d_tasks, count, ctx->d_results);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->render_done, ctx->stream));
     ctx->render_recorded = true;
@@ -919,15 +816,14 @@ int vx_debug_trace(vx_context* ctx, const float pos[3], const float dir[3], floa
     std::memcpy(a.dir, dir, sizeof a.dir);
     a.max_dst = max_dst;
     a.cast_translucent = cast_translucent;
-    const uint32_t levels = stack_levels(ctx);
-    const size_t lds = size_t(levels) * 64 * 10;
+    const size_t lds = Stack<64>::kBytes;
     const SceneArgs sc = scene_of(ctx);
     if (ctx->svo_type == VX_SVO_ESVO)
         hipLaunchKernelGGL((trace_kernel<VX_SVO_ESVO>), dim3(1), dim3(64), lds, ctx->stream, sc, a, ctx->d_trace_result, ctx->d_trace_frames, max_frames,
-                           ctx->d_trace_count, levels);
+                           ctx->d_trace_count);
     else
         hipLaunchKernelGGL((trace_kernel<VX_SVO_CSVO>), dim3(1), dim3(64), lds, ctx->stream, sc, a, ctx->d_trace_result, ctx->d_trace_frames, max_frames,
-                           ctx->d_trace_count, levels);
+                           ctx->d_trace_count);
     HIP_TRY(hipGetLastError());
     uint32_t n = 0;
     HIP_TRY(hipMemcpyAsync(result, ctx->d_trace_result, sizeof(vx_result), hipMemcpyDeviceToHost, ctx->stream));

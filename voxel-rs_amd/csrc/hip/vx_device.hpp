@@ -64,12 +64,6 @@ struct DevScene {
     float octree_scale;       // = world[0]
     uint32_t root_ptr;        // CSVO: world[1]
     DevTextures tex;
-    // Traversal image (VX_SVO_IMAGE): the GPU-native re-layout of the octree built at commit time. One octant =
-    // 64 bytes = 8 entries {lo, hi}: lo = child octant index | 1<<31, or the original absolute word pointer of a
-    // chunk (bit 31 clear), or the leaf value; hi = (child_mask << 8 | leaf_mask) of that child.
-    buf_t image;
-    uint32_t image_root;      // octant index of the root octree's first octant
-    uint32_t image_root_masks;
 };
 
 // what the host passes to a kernel; expanded into a DevScene (descriptors in SGPRs) at kernel entry
@@ -82,8 +76,6 @@ struct SceneArgs {
     uint32_t tex_bytes;
     uint32_t width, height, layers, levels;
     uint32_t level_offset[16];
-    const uint8_t* image;
-    uint32_t image_bytes, image_root, image_root_masks;
 };
 
 __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
@@ -95,9 +87,6 @@ __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
     sc.tex.level_offset = a.level_offset;
     sc.octree_scale = __uint_as_float(buf_u32(sc.world, 0));
     sc.root_ptr = buf_u32(sc.world, 4);
-    sc.image = make_buf(a.image, a.image_bytes);
-    sc.image_root = a.image_root;
-    sc.image_root_masks = a.image_root_masks;
     return sc;
 }
 
@@ -116,71 +105,89 @@ struct Counters {  // per-thread, reduced by the instrumented kernel
     uint32_t rays, iterations, pushes, leaf_tests, leaf_tests_trilinear, boundaries, csvo_header_bytes, csvo_pointer_bytes;
 };
 
-// Per-ray traversal stack. Levels the octree can legitimately reach (depth + 1) live in LDS, [level][thread]:
-// every lane's slot for a level sits in its own bank, whatever mix of levels the lanes are on. A ray that starts
-// INSIDE a voxel makes the reference descend "below" the leaves, interpreting leaf bytes as nodes
-// (svo.esvo.glsl:183-185 / svo.csvo.glsl:293-295 only treat a leaf as a hit when t_min > 0); its stack arrays hold
-// MAX_SCALE + 1 entries (svo.esvo.glsl:28-30), so those pushes are kept too -- in a per-thread spill array that
-// ordinary rays never touch.
+// Per-ray traversal stack. The levels an octree of depth <= kLdsLevels - 1 can legitimately reach live in LDS as three
+// u32 planes [plane][level][thread]: every lane's slot for a level sits in its own bank whatever mix of levels the lanes
+// are on, and the planes are a compile-time distance apart, so one address register serves all three accesses (the
+// first two fuse into ds_write2st64_b32 / ds_read2st64_b32). A ray that starts INSIDE a voxel makes the reference
+// descend "below" the leaves, interpreting leaf bytes as nodes (svo.esvo.glsl:183-185 / svo.csvo.glsl:293-295 only
+// treat a leaf as a hit when t_min > 0); its stack arrays hold MAX_SCALE + 1 entries (svo.esvo.glsl:28-30), so those
+// pushes are kept too -- in a per-thread spill array that ordinary rays never touch.
+constexpr int kLdsLevels = 14;
+constexpr int kLdsBaseScale = kMaxScale - kLdsLevels;  // scales [kLdsBaseScale, 22] are LDS resident
+
+// LDS and scratch are reached through address-space-qualified pointers only: a generic pointer would turn every stack
+// access into a flat_ instruction plus an aperture test.
 #ifndef VX_DEVICE_ON_HOST
 // the one dynamic-LDS array of every kernel in this library (16-byte aligned base, cdna guide G17)
 extern __shared__ __attribute__((aligned(16))) unsigned char vx_smem[];
+#define VX_AS_LDS __attribute__((address_space(3)))
+#define VX_AS_PRIVATE __attribute__((address_space(5)))
 #else
 extern unsigned char* vx_smem;
+#define VX_AS_LDS
+#define VX_AS_PRIVATE
 #endif
 
-struct StackSpill;
-
-struct Stack {
-    // LDS image: u32 ptr[levels][threads] | f32 t_max[levels][threads] | i16 aux[levels][threads], addressed by byte
-    // offsets into vx_smem (no generic pointers: LDS and scratch accesses stay in their own address spaces)
-    uint32_t stride;  // threads sharing the LDS image
-    uint32_t tid;
-    uint32_t levels;  // levels held in LDS
-    StackSpill* spill;
-
-    __device__ __forceinline__ uint32_t* lds_ptr(uint32_t s) const { return reinterpret_cast<uint32_t*>(vx_smem) + s; }
-    __device__ __forceinline__ float* lds_t_max(uint32_t s) const { return reinterpret_cast<float*>(vx_smem + size_t(levels) * stride * 4) + s; }
-    __device__ __forceinline__ int16_t* lds_aux(uint32_t s) const { return reinterpret_cast<int16_t*>(vx_smem + size_t(levels) * stride * 8) + s; }
-
-    // aux = ESVO: parent_octant_idx; CSVO: depth, which spans [-23, 255] once a ray is below the leaves
-    // (svo.csvo.glsl:398 keeps decrementing a uint): sign-extended 16 bits restore the same 32-bit pattern
-    __device__ __forceinline__ void push(int scale, uint32_t p, int16_t a, float t) const;
-    __device__ __forceinline__ void pop(int scale, uint32_t& p, int16_t& a, float& t) const;
-};
-
-// per-thread backing store for Stack::spill_* (lives in scratch; touched only by rays that start inside a voxel)
+// per-thread backing store for the levels below the LDS-resident ones (lives in scratch)
 struct StackSpill {
     uint32_t ptr[kMaxScale];
     float t_max[kMaxScale];
-    int16_t aux[kMaxScale];
+    uint32_t aux[kMaxScale];
 };
 
-__device__ __forceinline__ void Stack::push(int scale, uint32_t p, int16_t a, float t) const {
-    const uint32_t lv = uint32_t(kMaxScale - 1 - scale);
-    if (lv < levels) {
-        const uint32_t s = lv * stride + tid;
-        *lds_ptr(s) = p; *lds_aux(s) = a; *lds_t_max(s) = t;
-    } else if (lv < uint32_t(kMaxScale)) {
-        spill->ptr[lv] = p; spill->aux[lv] = a; spill->t_max[lv] = t;
-    }
-}
+// What a slot holds -- ESVO: {own-octant pointer, t_max, child masks}; CSVO: {node byte pointer, t_max, depth << 16 | header}.
+template <int THREADS>
+struct Stack {
+    static constexpr uint32_t kPlane = uint32_t(kLdsLevels) * THREADS * 4;  // bytes between planes
+    static constexpr uint32_t kBytes = 3 * kPlane;                          // dynamic LDS a block of THREADS threads needs
+    uint32_t slot0;  // byte offset of this thread's slot for scale 0 of a (virtual) full-height plane; may be "negative"
+    VX_AS_PRIVATE StackSpill* spill;
 
-__device__ __forceinline__ void Stack::pop(int scale, uint32_t& p, int16_t& a, float& t) const {
-    const uint32_t lv = uint32_t(kMaxScale - 1 - scale);
-    if (lv < levels) {
-        const uint32_t s = lv * stride + tid;
-        p = *lds_ptr(s); a = *lds_aux(s); t = *lds_t_max(s);
-    } else if (lv < uint32_t(kMaxScale)) {
-        p = spill->ptr[lv]; a = spill->aux[lv]; t = spill->t_max[lv];
-    } else {
-        p = 0; a = 0; t = 0.0f;
+    __device__ __forceinline__ void init(uint32_t tid, StackSpill* sp) {
+        slot0 = tid * 4u - uint32_t(kLdsBaseScale) * THREADS * 4u;
+        spill = (VX_AS_PRIVATE StackSpill*)sp;
     }
-}
+    __device__ __forceinline__ VX_AS_LDS uint32_t* at(uint32_t byte) const { return (VX_AS_LDS uint32_t*)((VX_AS_LDS unsigned char*)vx_smem + byte); }
+
+    __device__ __forceinline__ void push(int scale, uint32_t p, float t, uint32_t a) const {
+        if (uint32_t(scale - kLdsBaseScale) < uint32_t(kLdsLevels)) {
+            const uint32_t s = uint32_t(scale) * (THREADS * 4u) + slot0;
+            *at(s) = p; *at(s + kPlane) = __float_as_uint(t); *at(s + 2 * kPlane) = a;
+        } else if (uint32_t(scale) < uint32_t(kMaxScale)) {
+            spill->ptr[scale] = p; spill->t_max[scale] = t; spill->aux[scale] = a;
+        }
+    }
+    // scale is in [0, kMaxScale) here (the caller has already left the octree otherwise)
+    __device__ __forceinline__ void pop(int scale, uint32_t& p, float& t, uint32_t& a) const {
+        if (uint32_t(scale - kLdsBaseScale) < uint32_t(kLdsLevels)) {
+            const uint32_t s = uint32_t(scale) * (THREADS * 4u) + slot0;
+            p = *at(s); t = __uint_as_float(*at(s + kPlane)); a = *at(s + 2 * kPlane);
+        } else {
+            p = spill->ptr[scale]; t = spill->t_max[scale]; a = spill->aux[scale];
+        }
+    }
+};
 
 __device__ __forceinline__ float gmin(float x, float y) { return y < x ? y : x; }  // GLSL min
 __device__ __forceinline__ float gmax(float x, float y) { return x < y ? y : x; }  // GLSL max
 __device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+// min / max of three plane distances. The operands are never NaN or -0 for finite rays (p >= 1, t_coef != 0: see
+// Trav::init), where the hardware's single v_min3/v_max3 and the GLSL chain agree bit for bit.
+#ifndef VX_DEVICE_ON_HOST
+__device__ __forceinline__ float gmin3(float x, float y, float z) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ float gmax3(float x, float y, float z) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+#else
+inline float gmin3(float x, float y, float z) { return gmin(gmin(x, y), z); }
+inline float gmax3(float x, float y, float z) { return gmax(gmax(x, y), z); }
+#endif
 __device__ __forceinline__ uint32_t low_bits(int n) { return n >= 32 ? 0xffffffffu : (n <= 0 ? 0u : ((1u << n) - 1u)); }
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float(uint32_t(e + 127) << 23); }
 __device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
@@ -195,16 +202,6 @@ __device__ __forceinline__ uint32_t esvo_word(const DevScene& sc, uint32_t index
     index = index < 0x3ffffffeu ? index : 0x3ffffffeu;  // keep 4 + 4*index from wrapping: wild indices must read 0, not alias
     return buf_u32(sc.world, 4u + index * 4u);
 }
-
-// traversal image: entry `child` of octant `octant` (8 bytes)
-#define VX_SVO_IMAGE 3
-__device__ __forceinline__ uint2 image_entry(const DevScene& sc, uint32_t octant, uint32_t child) {
-    octant = octant < 0x03fffffeu ? octant : 0x03fffffeu;  // no wrap of octant * 64
-    return buf_u64(sc.image, octant * 64u + child * 8u);
-}
-// pointer stored in an entry -> octant index: relative pointers were resolved when the image was built (bit 31 set);
-// absolute ones are the reference's word indices into descriptors[] (5-word preamble, 12-word octants)
-__device__ __forceinline__ uint32_t image_child_octant(uint32_t lo) { return (lo & 0x80000000u) ? (lo & 0x7fffffffu) : (lo - 5u) / 12u; }
 
 // CSVO: descriptors[] starts at byte 8 and is addressed in bytes (svo.csvo.glsl:1-5, 25-49); the hardware reads
 // unaligned dwords directly, so read_uint's two-loads-and-shift collapses into one load
@@ -344,45 +341,61 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
 // the other 63. Here one ray is a `Trav` whose step() performs exactly one loop iteration of the reference and
 // reports when the ray is AT a leaf instead of testing it, so a wavefront can park such lanes and test them
 // together (render kernel), while the picker / debug kernels simply call step() and leaf_test() back to back.
+//
+// What a Trav keeps between iterations is chosen so that an iteration that neither descends nor pops touches no memory:
+//   ESVO  the reference identifies the node being examined as (ptr, parent_octant_idx) = "slot of my parent's octant"
+//         and, every iteration, re-reads that slot's masks; on PUSH it reads the slot's pointer and then, dependent
+//         on it, the child's masks (svo.esvo.glsl:168-173, 283-290). Here the node is identified by `ptr` = the
+//         pointer to its OWN octant (what the reference calls the child pointer) plus `node` = its masks. Both
+//         words a PUSH needs (child pointer, child masks) are then in the octant at `ptr`: two independent loads.
+//         A leaf's value is one load, and POP restores the masks from the stack instead of re-reading them.
+//         Same words, same values -- only read once, and earlier. (ptr, parent_octant_idx) are still tracked for
+//         the debug trace, which reports them per iteration.
+//   CSVO  the node header (1 or 2 bytes, svo.csvo.glsl:53-116) is read when the node is entered and kept in `node`
+//         (and on the stack); the pointer-table entry is only read by the iteration that descends through it.
+enum TravStatus : int { kTravContinue = 0, kTravAtLeaf = 1, kTravFinished = 2 };
+enum LeafOutcome : int { kLeafHit = 0, kLeafPassed = 1, kLeafPassedAndFinished = 2 };
 
-// kTravNeedsReference: only from the image traversal -- the ray starts inside a voxel, where the reference goes on to
-// interpret leaf data as nodes; such a ray is re-run on the reference-format buffer (see render_persistent).
-enum TravStatus : int { kTravContinue = 0, kTravAtLeaf = 1, kTravFinished = 2, kTravNeedsReference = 3 };
+// Debug-trace state (trace kernel only): the output frames, and the reference's (ptr, parent_octant_idx) view of the
+// ESVO cursor with its own shadow stack.
+struct TraceSink {
+    vx_frame* frames;
+    uint32_t max_frames, n_frames;
+    uint32_t ref_ptr, ref_aux;
+    uint32_t stack_ptr[kMaxScale];
+    uint8_t stack_aux[kMaxScale];
+};
+
+typedef VX_AS_PRIVATE TraceSink* TracePtr;
 
 template <int SVO>
 struct Trav {
     static constexpr bool CSVO = SVO == VX_SVO_CSVO;
-    static constexpr bool IMG = SVO == VX_SVO_IMAGE;
 
     float rox, roy, roz, rdx, rdy, rdz;   // origin in [1,2) space, epsilon-clamped direction
     float tcx, tcy, tcz, tbx, tby, tbz;   // t(x) = x * t_coef - t_bias per axis
     float px, py, pz;                     // current octant corner
     float t_min, t_max, h, scale_exp2;
     float max_dst;                        // already scaled to [0,1]; < 0 = unlimited
-    uint32_t ptr;                         // ESVO/CSVO: as in the reference; image: the octant whose children are examined
-    uint32_t aux;                         // ESVO: parent_octant_idx, CSVO: depth, image: unused
-    uint32_t node;                        // ESVO/image: masks of the octant being examined (cached)
+    uint32_t ptr;                         // ESVO: word index of the examined node's own octant; CSVO: its byte pointer
+    uint32_t node;                        // ESVO: child_mask << 8 | leaf_mask of the examined node; CSVO: its header
+    uint32_t depth;                       // CSVO only (svo.csvo.glsl:254); wraps below 0 exactly like the reference's uint
     uint32_t material_section_ptr, pre_leaf_pointer;  // CSVO only
     uint32_t last_leaf_value;
     int adjacent_leaf_count;
     int scale, idx, octant_mask;
     uint32_t iter;                        // loop iterations executed (the reference's `i`)
-    bool pending_advance;                 // a rejected leaf still owes the ADVANCE/POP half of its iteration
     bool inside_voxel;
-    bool ref_mode;                        // image traversal only: this ray walks the reference-format buffer instead (see below)
 
-    // true while this lane reads the traversal image; a Trav<VX_SVO_IMAGE> in ref_mode behaves exactly like Trav<VX_SVO_ESVO>
-    __device__ __forceinline__ bool img() const { return IMG && !ref_mode; }
+    __device__ __forceinline__ uint32_t csvo_header(const DevScene& sc) const { return depth > 3 ? csvo_u16(sc, ptr) : csvo_u8(sc, ptr); }
 
-    __device__ __forceinline__ void init(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst_in, bool reference = false) {
-        ref_mode = IMG && reference;
+    template <bool TRACE = false>
+    __device__ __forceinline__ void init(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst_in, TracePtr tk = nullptr) {
         const float octree_scale = sc.octree_scale;
         rox = ro_in[0] * octree_scale; roy = ro_in[1] * octree_scale; roz = ro_in[2] * octree_scale;
         max_dst = max_dst_in * octree_scale;
         rox += 1.0f; roy += 1.0f; roz += 1.0f;
 
-        ptr = CSVO ? sc.root_ptr : (img() ? sc.image_root : 0u);
-        aux = CSVO ? 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu) : 0u;  // svo.csvo.glsl:254
         scale = kMaxScale - 1;
         scale_exp2 = 0.5f;
         last_leaf_value = 0xffffffffu;
@@ -390,7 +403,6 @@ struct Trav {
         material_section_ptr = kInvalidPtr;
         pre_leaf_pointer = kInvalidPtr;
         iter = 0;
-        pending_advance = false;
         inside_voxel = false;
 
         rdx = rd_in[0]; rdy = rd_in[1]; rdz = rd_in[2];
@@ -418,13 +430,24 @@ struct Trav {
         if (t_min < __builtin_fmaf(1.5f, tcy, -tby)) { idx ^= 2; py = 1.5f; }
         if (t_min < __builtin_fmaf(1.5f, tcz, -tbz)) { idx ^= 4; pz = 1.5f; }
 
-        // ESVO: the masks of the child being examined depend only on (ptr, parent_octant_idx); they are fetched when
-        // those change (here, PUSH, POP) instead of every iteration (svo.esvo.glsl:168-173 reloads each time).
-        node = CSVO ? 0u : (img() ? sc.image_root_masks : esvo_word(sc, ptr));
+        if (CSVO) {
+            ptr = sc.root_ptr;
+            depth = 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu);  // svo.csvo.glsl:254
+            node = csvo_header(sc);
+        } else {
+            // the reference starts at (ptr 0, parent_octant_idx 0): the preamble is an octant whose only child is the root
+            depth = 0;
+            node = esvo_word(sc, 0);
+            const uint32_t w = esvo_word(sc, 4);
+            ptr = (w & 0x80000000u) ? 4u + (w & 0x7fffffffu) : w;
+            if (TRACE) { tk->ref_ptr = 0; tk->ref_aux = 0; }
+        }
     }
 
     // ADVANCE + POP (svo.esvo.glsl:324-390). Returns false when the ray left the octree.
-    __device__ __forceinline__ bool advance(const DevScene& sc, const Stack& st, float tcrx, float tcry, float tcrz, float tc_max) {
+    template <bool TRACE, class ST>
+    __device__ __forceinline__ bool advance(const DevScene& sc, const ST& st, float tcrx, float tcry, float tcrz, float tc_max, TracePtr tk) {
+        (void)sc;
         int step_mask = 0;
         if (tc_max >= tcrx) { step_mask ^= 1; px -= scale_exp2; }
         if (tc_max >= tcry) { step_mask ^= 2; py -= scale_exp2; }
@@ -433,6 +456,7 @@ struct Trav {
         t_min = tc_max;
         idx ^= step_mask;
 
+        bool inside = true;
         if ((idx & step_mask) != 0) {
             uint32_t differing_bits = 0;
             if (step_mask & 1) differing_bits |= __float_as_uint(px) ^ __float_as_uint(px + scale_exp2);
@@ -440,154 +464,163 @@ struct Trav {
             if (step_mask & 4) differing_bits |= __float_as_uint(pz) ^ __float_as_uint(pz + scale_exp2);
 
             scale = differing_bits ? 31 - __clz(differing_bits) : -1;
-            if (scale >= kMaxScale || scale < 0) return false;
-            scale_exp2 = pow2i(scale - kMaxScale);
+            inside = uint32_t(scale) < uint32_t(kMaxScale);
+            if (inside) {
+                scale_exp2 = pow2i(scale - kMaxScale);
 
-            int16_t a;
-            st.pop(scale, ptr, a, t_max);
-            if (img()) {
-                node = uint32_t(uint16_t(a));
-            } else {
-                aux = CSVO ? uint32_t(int32_t(a)) : uint32_t(a);
-                if (!CSVO) {
-                    node = esvo_word(sc, ptr + (aux >> 1));
-                    if (aux & 1u) node >>= 16;
+                uint32_t a;
+                st.pop(scale, ptr, t_max, a);
+                if (CSVO) {
+                    node = a & 0xffffu;
+                    depth = uint32_t(int32_t(a) >> 16);  // sign-extended: depth spans [-23, 255] once a ray is below the leaves
+                } else {
+                    node = a;
+                    if (TRACE) { tk->ref_ptr = tk->stack_ptr[scale]; tk->ref_aux = tk->stack_aux[scale]; }
                 }
-            }
 
-            const int shx = __float_as_int(px) >> scale, shy = __float_as_int(py) >> scale, shz = __float_as_int(pz) >> scale;
-            px = __int_as_float(shx << scale);
-            py = __int_as_float(shy << scale);
-            pz = __int_as_float(shz << scale);
-            idx = (shx & 1) | ((shy & 1) << 1) | ((shz & 1) << 2);
-            h = 0.0f;
+                const int shx = __float_as_int(px) >> scale, shy = __float_as_int(py) >> scale, shz = __float_as_int(pz) >> scale;
+                px = __int_as_float(shx << scale);
+                py = __int_as_float(shy << scale);
+                pz = __int_as_float(shz << scale);
+                idx = (shx & 1) | ((shy & 1) << 1) | ((shz & 1) << 2);
+                h = 0.0f;
+            }
         }
-        return true;
+        return inside;
     }
 
     // One iteration of the reference's loop (svo.esvo.glsl:152-391 / svo.csvo.glsl:261-508) minus the leaf test.
-    template <bool TRACE, bool STATS>
-    __device__ __forceinline__ TravStatus step(const DevScene& sc, const Stack& st, vx_frame* frames, uint32_t max_frames, uint32_t& n_frames,
-                                               Counters* ctr) {
-        if (pending_advance) {
-            // second half of an iteration whose leaf was rejected by leaf_test()
-            pending_advance = false;
-            const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
-            return advance(sc, st, tcrx, tcry, tcrz, gmin(gmin(tcrx, tcry), tcrz)) ? kTravContinue : kTravFinished;
-        }
-        if (iter >= uint32_t(kMaxSteps)) return kTravFinished;
-        if (max_dst >= 0.0f && t_min > max_dst) return kTravFinished;
+    // LIMIT = the ray has a maximum distance (picker); render rays are unlimited and skip the test.
+    template <bool TRACE, bool STATS, bool LIMIT, class ST>
+    __device__ __forceinline__ TravStatus step(const DevScene& sc, const ST& st, TracePtr tk, Counters* ctr) {
+        bool live = iter < uint32_t(kMaxSteps);
+        if (LIMIT) live = live && !(max_dst >= 0.0f && t_min > max_dst);
+        if (!live) return kTravFinished;
         ++iter;
         if (STATS) ctr->iterations++;
 
         const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
-        const float tc_max = gmin(gmin(tcrx, tcry), tcrz);
+        const float tc_max = gmin3(tcrx, tcry, tcrz);
         const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
 
-        bool is_child, is_leaf, crossed_boundary = false;
-        uint32_t next_ptr = 0, iter_ptr_bytes = 0;
+        bool is_child, is_leaf;
+        uint32_t tag = 0;  // CSVO internal nodes: the child's 2-bit pointer-width tag
         if (!CSVO) {
             is_child = (node & (0x100u << octant_idx)) != 0;
             is_leaf = (node & (1u << octant_idx)) != 0;
         } else {
-            uint32_t hb = 0;
-            next_ptr = csvo_next_ptr(sc, ptr, aux, octant_idx, crossed_boundary, hb, iter_ptr_bytes);
-            is_child = next_ptr != kInvalidPtr;
-            is_leaf = is_child && aux < 2;
-            if (aux == 2) pre_leaf_pointer = ptr;
-            if (STATS) ctr->csvo_header_bytes += hb;
+            if (depth > 3) {
+                tag = (node >> (octant_idx * 2)) & 3u;
+                is_child = tag != 0;
+            } else {
+                is_child = ((node >> octant_idx) & 1u) != 0;
+            }
+            is_leaf = is_child && depth < 2;
+            if (depth == 2) pre_leaf_pointer = ptr;
+            if (STATS) ctr->csvo_header_bytes += depth > 3 ? 2u : 1u;
         }
 
         if (TRACE) {
-            if (n_frames < max_frames) {
+            if (tk->n_frames < tk->max_frames) {
                 const float octree_scale = sc.octree_scale;
-                vx_frame& f = frames[n_frames];
+                vx_frame& f = tk->frames[tk->n_frames];
                 f.t_min = t_min * __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));
-                f.ptr = ptr;
+                f.ptr = CSVO ? ptr : tk->ref_ptr;
                 f.idx = octant_idx;
-                f.parent_octant_idx = aux;
+                f.parent_octant_idx = CSVO ? depth : tk->ref_aux;
                 f.scale = scale;
                 f.is_child = is_child;
                 f.is_leaf = is_leaf;
-                f.crossed_boundary = crossed_boundary;
-                f.next_ptr = CSVO ? next_ptr : 0u;
+                bool crossed = false;
+                uint32_t hb = 0, pb = 0;
+                f.next_ptr = CSVO ? csvo_next_ptr(sc, ptr, depth, octant_idx, crossed, hb, pb) : 0u;
+                f.crossed_boundary = crossed;
             }
-            ++n_frames;
+            ++tk->n_frames;
         }
 
-        if (is_child && t_min <= t_max) {
-            if (is_leaf && t_min == 0.0f) inside_voxel = true;
-            if (is_leaf && t_min > 0.0f) return kTravAtLeaf;  // leaf_test() decides; state is left untouched
-            if (img() && is_leaf) return kTravNeedsReference;   // t_min == 0: the ray starts inside this voxel
-
-            const float half_scale = scale_exp2 * 0.5f;
-            const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
-                        tcenz = __builtin_fmaf(half_scale, tcz, tcrz);
-            const float tv_max = gmin(t_max, tc_max);
-            if (t_min <= tv_max) {
-                // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
-                if (STATS) ctr->pushes++;
-                if (tc_max < h) st.push(scale, ptr, int16_t(img() ? node : aux), t_max);
-                h = tc_max;
-                if (img()) {
-                    const uint2 e = image_entry(sc, ptr, octant_idx);
-                    ptr = image_child_octant(e.x);
-                    node = e.y & 0xffffu;
-                } else if (!CSVO) {
-                    uint32_t np = esvo_word(sc, ptr + 4 + aux);
-                    if (np & (1u << 31)) np = ptr + 4 + aux + (np & 0x7fffffffu);
-                    ptr = np;
-                    aux = octant_idx;
-                    node = esvo_word(sc, ptr + (aux >> 1));
-                    if (aux & 1u) node >>= 16;
-                } else {
-                    if (STATS) ctr->csvo_pointer_bytes += iter_ptr_bytes;
-                    --aux;
-                    ptr = next_ptr;
-                    if (crossed_boundary) {
-                        if (STATS) ctr->boundaries++;
-                        const uint32_t child_lod = csvo_u8(sc, ptr);
-                        const uint32_t material_bytes = csvo_u32(sc, ptr + 1);
-                        ptr += 5;
-                        material_section_ptr = ptr;
-                        ptr += material_bytes;
-                        aux = child_lod;
-                    }
-                }
-                --scale;
-                scale_exp2 = half_scale;
-                idx = 0;
-                if (t_min < tcenx) { idx ^= 1; px += scale_exp2; }
-                if (t_min < tceny) { idx ^= 2; py += scale_exp2; }
-                if (t_min < tcenz) { idx ^= 4; pz += scale_exp2; }
-                t_max = tv_max;
-                return kTravContinue;
-            }
-        } else {
+        const bool descend = is_child && t_min <= t_max;
+        if (!descend) {
             adjacent_leaf_count = 0;
             last_leaf_value = 0xffffffffu;
         }
-        return advance(sc, st, tcrx, tcry, tcrz, tc_max) ? kTravContinue : kTravFinished;
+        if (descend && is_leaf) {
+            if (t_min > 0.0f) return kTravAtLeaf;  // leaf_test() decides; the cursor is left untouched
+            if (t_min == 0.0f) inside_voxel = true;
+        }
+        const float tv_max = gmin(t_max, tc_max);
+        if (descend && t_min <= tv_max) {
+            // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
+            if (STATS) ctr->pushes++;
+            const float half_scale = scale_exp2 * 0.5f;
+            const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
+                        tcenz = __builtin_fmaf(half_scale, tcz, tcrz);
+            if (!CSVO) {
+                const uint32_t body = ptr + 4 + octant_idx;
+                const uint32_t w = esvo_word(sc, body), hd = esvo_word(sc, ptr + (octant_idx >> 1));
+                if (tc_max < h) {
+                    st.push(scale, ptr, t_max, node);
+                    if (TRACE) { tk->stack_ptr[scale] = tk->ref_ptr; tk->stack_aux[scale] = uint8_t(tk->ref_aux); }
+                }
+                if (TRACE) { tk->ref_ptr = ptr; tk->ref_aux = octant_idx; }
+                ptr = (w & 0x80000000u) ? body + (w & 0x7fffffffu) : w;
+                node = (octant_idx & 1u) ? hd >> 16 : hd;
+            } else {
+                if (tc_max < h) st.push(scale, ptr, t_max, (depth << 16) | node);
+                // read_next_ptr (svo.csvo.glsl:53-116) with the header already at hand
+                uint32_t next_ptr;
+                bool crossed = false;
+                if (depth > 3) {
+                    const uint32_t offset = csvo_tag_bytes(node & ((1u << (octant_idx * 2)) - 1u));
+                    uint32_t e = csvo_u32(sc, ptr + 2 + offset) & low_bits(int(1u << (tag - 1)) * 8);
+                    if (STATS) ctr->csvo_pointer_bytes += (1u << tag) >> 1;
+                    crossed = (e & 0x80000000u) != 0;
+                    next_ptr = crossed ? e ^ 0x80000000u : ptr + 2 + csvo_tag_bytes(node) + e;
+                } else {
+                    const uint32_t offset = __popc(node & ((1u << octant_idx) - 1u));
+                    if (depth == 3) {
+                        if (STATS) ctr->csvo_pointer_bytes += 1;
+                        next_ptr = ptr + 1 + __popc(node) + csvo_u8(sc, ptr + 1 + offset);
+                    } else {
+                        next_ptr = ptr + 3 + offset;
+                    }
+                }
+                --depth;
+                ptr = next_ptr;
+                if (crossed) {
+                    if (STATS) ctr->boundaries++;
+                    const uint32_t child_lod = csvo_u8(sc, ptr);
+                    const uint32_t material_bytes = csvo_u32(sc, ptr + 1);
+                    ptr += 5;
+                    material_section_ptr = ptr;
+                    ptr += material_bytes;
+                    depth = child_lod;
+                }
+                node = csvo_header(sc);
+            }
+            h = tc_max;
+            --scale;
+            scale_exp2 = half_scale;
+            idx = 0;
+            if (t_min < tcenx) { idx ^= 1; px += scale_exp2; }
+            if (t_min < tceny) { idx ^= 2; py += scale_exp2; }
+            if (t_min < tcenz) { idx ^= 4; pz += scale_exp2; }
+            t_max = tv_max;
+            return kTravContinue;
+        }
+        return advance<TRACE>(sc, st, tcrx, tcry, tcrz, tc_max, tk) ? kTravContinue : kTravFinished;
     }
 
-    // HIT phase (svo.esvo.glsl:185-265) for a ray whose step() returned kTravAtLeaf. Returns true when the leaf is
-    // the result (res filled in); otherwise records the translucent leaf and arms the ADVANCE half of the iteration.
-    template <bool STATS>
-    __device__ __forceinline__ bool leaf_test(const DevScene& sc, bool cast_translucent, Result& res, Counters* ctr) {
+    // HIT phase (svo.esvo.glsl:185-265) for a ray whose step() returned kTravAtLeaf. kLeafHit: the leaf is the result
+    // (res filled in). Otherwise the translucent leaf is recorded and the ADVANCE half of the iteration is run.
+    template <bool TRACE, bool STATS, class ST>
+    __device__ __forceinline__ LeafOutcome leaf_test(const DevScene& sc, const ST& st, bool cast_translucent, Result& res, TracePtr tk,
+                                                     Counters* ctr) {
         if (STATS) ctr->leaf_tests++;
         const float octree_scale = sc.octree_scale;
         const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 2^depth, exact
         const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
-        uint32_t value;
-        if (img()) {
-            value = image_entry(sc, ptr, octant_idx).x;
-        } else if (!CSVO) {
-            uint32_t np = esvo_word(sc, ptr + 4 + aux);
-            if (np & (1u << 31)) np = ptr + 4 + aux + (np & 0x7fffffffu);
-            value = esvo_word(sc, np + 4 + octant_idx);
-        } else {
-            value = csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx);
-        }
+        const uint32_t value = CSVO ? csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx) : esvo_word(sc, ptr + 4 + octant_idx);
 
         const float ex = __builtin_fmaf(px + scale_exp2, tcx, -tbx);
         const float ey = __builtin_fmaf(py + scale_exp2, tcy, -tby);
@@ -646,12 +679,13 @@ struct Trav {
             res.pos[1] = (hy - 1.0f) * inv_scale;
             res.pos[2] = (hz - 1.0f) * inv_scale;
             res.inside_voxel = inside_voxel;
-            return true;
+            return kLeafHit;
         }
         ++adjacent_leaf_count;
         last_leaf_value = value;
-        pending_advance = true;
-        return false;
+        // the rest of this iteration: ADVANCE (svo.esvo.glsl:324 onwards)
+        const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
+        return advance<TRACE>(sc, st, tcrx, tcry, tcrz, gmin3(tcrx, tcry, tcrz), tk) ? kLeafPassed : kLeafPassedAndFinished;
     }
 };
 
@@ -667,17 +701,19 @@ __device__ __forceinline__ void result_miss(Result& res, bool inside_voxel) {
 }
 
 // Whole-ray form (picker and debug kernels; the v1 render kernel): step and test back to back.
-template <int SVO, bool TRACE, bool STATS>
+template <int SVO, bool TRACE, bool STATS, bool LIMIT, class ST>
 __device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst, bool cast_translucent,
-                                          const Stack& st, Result& res, uint32_t& steps, vx_frame* frames, uint32_t max_frames,
-                                          uint32_t& n_frames, Counters* ctr) {
+                                          const ST& st, Result& res, uint32_t& steps, TracePtr tk, Counters* ctr) {
     if (STATS) ctr->rays++;
     Trav<SVO> tr;
-    tr.init(sc, ro_in, rd_in, max_dst);
+    tr.template init<TRACE>(sc, ro_in, rd_in, max_dst, tk);
     for (;;) {
-        const TravStatus s = tr.template step<TRACE, STATS>(sc, st, frames, max_frames, n_frames, ctr);
-        if (s == kTravContinue) continue;
-        if (s == kTravAtLeaf && tr.template leaf_test<STATS>(sc, cast_translucent, res, ctr)) break;
+        TravStatus s = tr.template step<TRACE, STATS, LIMIT>(sc, st, tk, ctr);
+        if (s == kTravAtLeaf) {
+            const LeafOutcome o = tr.template leaf_test<TRACE, STATS>(sc, st, cast_translucent, res, tk, ctr);
+            if (o == kLeafHit) break;
+            s = o == kLeafPassed ? kTravContinue : kTravFinished;
+        }
         if (s == kTravFinished) {
             result_miss(res, tr.inside_voxel);
             break;
@@ -821,15 +857,15 @@ __device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderPa
 }
 
 // trace_ray + sky (world.glsl:27-90, 132-138) for one pixel
-template <int SVO, bool STATS>
-__device__ __forceinline__ void shade_pixel(const DevScene& sc, const RenderParams& p, uint32_t x, uint32_t y, const Stack& st, float color[4],
+template <int SVO, bool STATS, class ST>
+__device__ __forceinline__ void shade_pixel(const DevScene& sc, const RenderParams& p, uint32_t x, uint32_t y, const ST& st, float color[4],
                                             vx_hit* rec, Counters* ctr, uint32_t* lit, uint32_t* shadow_rays) {
     float ro[3], rd[3];
     primary_ray(p, x, y, ro, rd);
 
     Result res;
-    uint32_t steps = 0, nf = 0;
-    intersect<SVO, false, STATS>(sc, ro, rd, -1.0f, true, st, res, steps, nullptr, 0, nf, ctr);
+    uint32_t steps = 0;
+    intersect<SVO, false, STATS, false>(sc, ro, rd, -1.0f, true, st, res, steps, nullptr, ctr);
 
     const bool hit = res.t != -1.0f;
     uint32_t flags = hit ? 1u : 0u;
@@ -884,7 +920,7 @@ __device__ __forceinline__ void shade_pixel(const DevScene& sc, const RenderPara
             const float so[3] = {res.pos[0] + normal[0] * 0.001f, res.pos[1] + normal[1] * 0.001f, res.pos[2] + normal[2] * 0.001f};
             Result sres;
             if (STATS) ++*shadow_rays;
-            intersect<SVO, false, STATS>(sc, so, neg_l, -1.0f, true, st, sres, steps, nullptr, 0, nf, ctr);
+            intersect<SVO, false, STATS, false>(sc, so, neg_l, -1.0f, true, st, sres, steps, nullptr, ctr);
             shadow = sres.t < 0.0f ? 1.0f : 0.0f;
             flags |= 2u;
             if (!(sres.t < 0.0f)) flags |= 4u;
