@@ -411,12 +411,14 @@ struct vx_context {
 
 namespace {
 
+constexpr size_t kWorldPad = 16;
+
 uint32_t header_bytes(const vx_context* c) { return c->svo_type == VX_SVO_ESVO ? 20u : 4u; }
 
 SceneArgs scene_of(const vx_context* c) {
     SceneArgs s = {};
     s.world = c->d_world;
-    s.world_bytes = uint32_t(c->capacity);
+    s.world_bytes = uint32_t(c->capacity + kWorldPad);
     s.materials = c->d_materials;
     s.n_materials = c->n_materials;
     s.tex = c->d_tex;
@@ -561,8 +563,10 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     } while (0)
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->staging), c->capacity, hipHostMallocDefault));
     std::memset(c->staging, 0, c->capacity);
-    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_world), c->capacity));
-    CREATE_TRY(hipMemset(c->d_world, 0, c->capacity));
+    // kWorldPad zero bytes follow the buffer and are inside the descriptor's range: an unaligned dword read that straddles
+    // the end then returns the real bytes plus zeros (what the word-wise reference reads), not an all-zero dword
+    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_world), c->capacity + kWorldPad));
+    CREATE_TRY(hipMemset(c->d_world, 0, c->capacity + kWorldPad));
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));

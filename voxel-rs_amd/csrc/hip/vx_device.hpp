@@ -387,7 +387,17 @@ struct Trav {
     uint32_t iter;                        // loop iterations executed (the reference's `i`)
     bool inside_voxel;
 
-    __device__ __forceinline__ uint32_t csvo_header(const DevScene& sc) const { return depth > 3 ? csvo_u16(sc, ptr) : csvo_u8(sc, ptr); }
+    // CSVO header of the node at `ptr`, normalised to the internal-node form (2 bits per child): the 1-bit-per-child
+    // headers of the three lowest levels are spread to tag 01 per present child, after which child lookup and the
+    // popcount-style table offsets are the same expressions at every depth (popcount(h & below) == tag_bytes(h' & below')).
+    __device__ __forceinline__ uint32_t csvo_header(const DevScene& sc) const {
+        const uint32_t raw = csvo_u32(sc, ptr);
+        uint32_t x = raw & 0xffu;
+        x = (x | (x << 4)) & 0x0f0fu;
+        x = (x | (x << 2)) & 0x3333u;
+        x = (x | (x << 1)) & 0x5555u;
+        return depth > 3 ? raw & 0xffffu : x;
+    }
 
     template <bool TRACE = false>
     __device__ __forceinline__ void init(const DevScene& sc, const float ro_in[3], const float rd_in[3], float max_dst_in, TracePtr tk = nullptr) {
@@ -434,6 +444,7 @@ struct Trav {
             ptr = sc.root_ptr;
             depth = 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu);  // svo.csvo.glsl:254
             node = csvo_header(sc);
+            if (depth == 2) pre_leaf_pointer = ptr;
         } else {
             // the reference starts at (ptr 0, parent_octant_idx 0): the preamble is an octant whose only child is the root
             depth = 0;
@@ -504,19 +515,16 @@ struct Trav {
         const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
 
         bool is_child, is_leaf;
-        uint32_t tag = 0;  // CSVO internal nodes: the child's 2-bit pointer-width tag
+        uint32_t tag = 0;  // CSVO: the child's 2-bit pointer-width tag (01 for every present child of the 1-bit levels)
         if (!CSVO) {
             is_child = (node & (0x100u << octant_idx)) != 0;
             is_leaf = (node & (1u << octant_idx)) != 0;
         } else {
-            if (depth > 3) {
-                tag = (node >> (octant_idx * 2)) & 3u;
-                is_child = tag != 0;
-            } else {
-                is_child = ((node >> octant_idx) & 1u) != 0;
-            }
+            tag = (node >> (octant_idx * 2)) & 3u;
+            is_child = tag != 0;
             is_leaf = is_child && depth < 2;
-            if (depth == 2) pre_leaf_pointer = ptr;
+            // (the reference's per-iteration `if (depth == 2) pre_leaf_pointer = ptr`, svo.csvo.glsl:283, is done once, when
+            // a depth-2 node is entered: nothing else can change either value while the ray is inside that node's subtree)
             if (STATS) ctr->csvo_header_bytes += depth > 3 ? 2u : 1u;
         }
 
@@ -567,23 +575,18 @@ struct Trav {
                 node = (octant_idx & 1u) ? hd >> 16 : hd;
             } else {
                 if (tc_max < h) st.push(scale, ptr, t_max, (depth << 16) | node);
-                // read_next_ptr (svo.csvo.glsl:53-116) with the header already at hand
-                uint32_t next_ptr;
+                // read_next_ptr (svo.csvo.glsl:53-116) with the (normalised) header already at hand: internal nodes
+                // (2-byte header, 1/2/4-byte table entries) and the depth-3 level (1-byte header, 1-byte entries) are the
+                // same computation; the two lowest levels have no table
+                const uint32_t offset = csvo_tag_bytes(node & ((1u << (octant_idx * 2)) - 1u));
+                uint32_t next_ptr = ptr + 3 + offset;
                 bool crossed = false;
-                if (depth > 3) {
-                    const uint32_t offset = csvo_tag_bytes(node & ((1u << (octant_idx * 2)) - 1u));
-                    uint32_t e = csvo_u32(sc, ptr + 2 + offset) & low_bits(int(1u << (tag - 1)) * 8);
+                if (depth >= 3) {
+                    const uint32_t table = ptr + (depth > 3 ? 2u : 1u);
+                    const uint32_t e = csvo_u32(sc, table + offset) & (0xffffffffu >> ((0x001018u >> ((tag - 1) * 8)) & 0xffu));
                     if (STATS) ctr->csvo_pointer_bytes += (1u << tag) >> 1;
                     crossed = (e & 0x80000000u) != 0;
-                    next_ptr = crossed ? e ^ 0x80000000u : ptr + 2 + csvo_tag_bytes(node) + e;
-                } else {
-                    const uint32_t offset = __popc(node & ((1u << octant_idx) - 1u));
-                    if (depth == 3) {
-                        if (STATS) ctr->csvo_pointer_bytes += 1;
-                        next_ptr = ptr + 1 + __popc(node) + csvo_u8(sc, ptr + 1 + offset);
-                    } else {
-                        next_ptr = ptr + 3 + offset;
-                    }
+                    next_ptr = crossed ? e ^ 0x80000000u : table + csvo_tag_bytes(node) + e;
                 }
                 --depth;
                 ptr = next_ptr;
@@ -597,6 +600,7 @@ struct Trav {
                     depth = child_lod;
                 }
                 node = csvo_header(sc);
+                if (depth == 2) pre_leaf_pointer = ptr;
             }
             h = tc_max;
             --scale;
