@@ -129,6 +129,11 @@ typedef struct vx_counters {
     uint64_t rays, iterations, pushes, leaf_tests, leaf_tests_trilinear, boundaries;
     uint64_t csvo_header_bytes, csvo_pointer_bytes;
     uint64_t pixels, lit_pixels, shadow_rays;
+    /* occupancy of the persistent wavefront kernel: trips of its traversal loop summed over waves (iterations / (64 *
+     * wave_steps) = fraction of lanes traversing), service phases run, queue refills (0 for the per-pixel kernel) */
+    uint64_t wave_steps, services, refills;
+    /* the same after a wave found the queue empty (the frame's tail): loop trips and lane-iterations */
+    uint64_t tail_wave_steps, tail_iterations;
 } vx_counters;
 
 /* Where vx_render writes. Tiles are 32x32 pixels, numbered row-major from the bottom-left; a context renders

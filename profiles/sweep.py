@@ -53,7 +53,9 @@ def main():
             svo.render_device(u, W, H, image.data_ptr())
         svo.sync()
         ctxs.append((cfg, svo, []))
-    rays = ctxs[0][1].render_counters(u, W, H)["rays"]
+    counters = ctxs[0][1].render_counters(u, W, H)
+    rays = counters["rays"]
+    print("counters:", {k: int(v) for k, v in counters.items()})
     for _ in range(args.rounds):
         for cfg, svo, times in ctxs:
             svo.profile_enable(True)

@@ -7,6 +7,7 @@
 #include <vector>
 
 #define __device__
+#define __host__
 #define __forceinline__ inline
 #define __constant__ static const
 #define __restrict__

@@ -335,6 +335,9 @@ def test_error_behaviour(hip):
         hip.Svo(3, 1 << 16)
 
 
+OCCUPANCY_COUNTERS = ("wave_steps", "services", "refills", "tail_wave_steps", "tail_iterations")
+
+
 @pytest.mark.parametrize("fmt", FMTS)
 def test_kernel_versions_agree(hip, fmt, monkeypatch):
     """The persistent wavefront kernel (default) and the one-thread-per-pixel kernel write identical images and hit
@@ -347,9 +350,9 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     w, h = 250, 130
     u = scenes.bench_camera(8, st["h_max"], w, h)
     results = []
-    for env in ({"VX_RENDER_KERNEL": "1"}, {"VX_RENDER_KERNEL": "2"}, {"VX_RENDER_KERNEL": "2", "VX_IMAGE": "1"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"},
+    for env in ({"VX_RENDER_KERNEL": "1"}, {"VX_RENDER_KERNEL": "2"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"},
                 {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "64", "VX_SERVICE_MIN": "64"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"}):
-        for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_IMAGE"):
+        for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -360,7 +363,9 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
         img, hits = svo.render(u, w, h, want_hits=True)
         img2, _ = svo.render(u, w, h)
         assert img2.tobytes() == img.tobytes()
-        results.append((img, hits.tobytes(), svo.render_counters(u, w, h)))
+        # (the occupancy counters describe how a kernel scheduled its lanes, not what the rays did)
+        counters = {k: v for k, v in svo.render_counters(u, w, h).items() if k not in OCCUPANCY_COUNTERS}
+        results.append((img, hits.tobytes(), counters))
         svo.close()
     for r in results[1:]:
         assert r[1] == results[0][1], "hit records differ between kernel versions"

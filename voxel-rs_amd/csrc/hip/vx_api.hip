@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     uint32_t steps = 0;    // HITS only
     Counters ctr = {};
     uint32_t n_pixels = 0, lit = 0, shadow_rays = 0;
+    uint32_t wave_steps = 0, services = 0, refills = 0, tail_wave_steps = 0, tail_iterations = 0;  // STATS only, wave-uniform
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
     bool queue_empty = false;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // ---- refill idle lanes from the sub-tile queue ----
         unsigned long long idle_mask = __ballot(state == kIdle);
         if (!queue_empty && idle_mask && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
+            if (STATS) ++refills;
             for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
                 if (cursor >= 64) {
                     uint32_t t = 0;
@@ -199,10 +201,15 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 state = s == kTravContinue ? kTrav : (s == kTravAtLeaf ? kLeaf : kMissed);
             }
             const unsigned long long trav = __ballot(state == kTrav);
+            if (STATS) {
+                ++wave_steps;
+                if (queue_empty) { ++tail_wave_steps; tail_iterations += uint32_t(__popcll(trav)); }
+            }
             if (trav == 0 || 64u - uint32_t(__popcll(trav)) >= park_limit) break;
         }
 
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
+        if (STATS) ++services;
         if (state == kLeaf) {
             const LeafOutcome o = tr.template leaf_test<false, STATS>(sc, st, true, res, nullptr, STATS ? &ctr : nullptr);
             state = o == kLeafHit ? kDone : (o == kLeafPassed ? kTrav : kMissed);
@@ -273,6 +280,13 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             unsigned long long sum = v[k];
             for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
             if (lane == 0 && sum) atomicAdd(&counters[k], sum);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[11], (unsigned long long)wave_steps);
+            atomicAdd(&counters[12], (unsigned long long)services);
+            atomicAdd(&counters[13], (unsigned long long)refills);
+            atomicAdd(&counters[14], (unsigned long long)tail_wave_steps);
+            atomicAdd(&counters[15], (unsigned long long)tail_iterations);
         }
     }
 }
@@ -507,6 +521,9 @@ int fill_params(const vx_uniforms* u, uint32_t w, uint32_t h, uint32_t tile_rank
     if (tile_rank >= tile_count) return fail(VX_ERR_INVALID_ARGUMENT, "tile_rank >= tile_count");
     p.u = *u;
     p.tan_half_fovy = tanf(u->fovy * 0.5f);
+    view_origin(u->view, p.ray_origin);
+    p.affine_view = (u->view[3] == 0.0f && u->view[7] == 0.0f && u->view[11] == 0.0f && u->view[15] == 1.0f && std::isfinite(p.tan_half_fovy) &&
+                     std::isfinite(u->aspect)) ? 1u : 0u;
     p.width = w;
     p.height = h;
     p.tiles_x = (w + kTile - 1) / kTile;
@@ -766,6 +783,8 @@ int vx_render_counters(vx_context* ctx, const vx_uniforms* uniforms, uint32_t wi
     out->rays = h[0]; out->iterations = h[1]; out->pushes = h[2]; out->leaf_tests = h[3]; out->leaf_tests_trilinear = h[4];
     out->boundaries = h[5]; out->csvo_header_bytes = h[6]; out->csvo_pointer_bytes = h[7];
     out->pixels = h[8]; out->lit_pixels = h[9]; out->shadow_rays = h[10];
+    out->wave_steps = h[11]; out->services = h[12]; out->refills = h[13];
+    out->tail_wave_steps = h[14]; out->tail_iterations = h[15];
     return VX_OK;
 }
 

@@ -273,34 +273,53 @@ __device__ __forceinline__ vx_material material_at(const DevScene& sc, uint32_t 
 // ---- software sampler: textureLod(sampler2DArray) with the state of texture_array.rs:200-203 ---------------
 //   MAG NEAREST, MIN LINEAR_MIPMAP_LINEAR, WRAP_S CLAMP_TO_EDGE, WRAP_T REPEAT (never set -> GL default)
 
-__device__ __forceinline__ void texel(const DevTextures& t, uint32_t level, uint32_t layer, int x, int y, float out[4]) {
-    uint32_t w = t.width >> level, h = t.height >> level;
-    w = w ? w : 1;
-    h = h ? h : 1;
-    x = x < 0 ? 0 : x;
-    x = x > int(w) - 1 ? int(w) - 1 : x;
-    y %= int(h);
-    y = y < 0 ? y + int(h) : y;
-    const uint32_t rgba = buf_u32(t.buf, t.level_offset[level] + ((layer * h + uint32_t(y)) * w + uint32_t(x)) * 4u);
-    out[0] = float(rgba & 0xffu) / 255.0f;
-    out[1] = float((rgba >> 8) & 0xffu) / 255.0f;
-    out[2] = float((rgba >> 16) & 0xffu) / 255.0f;
-    out[3] = float(rgba >> 24) / 255.0f;
+// float(b) / 255.0f for b in [0, 255], bit for bit (checked for all 256 values with exact rational arithmetic): one
+// Newton step on b * RN(1/255) instead of the ~10-instruction IEEE division sequence, four times per texel
+__device__ __forceinline__ float unorm8(uint32_t b) {
+    const float x = float(b), r = 1.0f / 255.0f;
+    const float q0 = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q0, 255.0f, x), r, q0);
 }
 
+__device__ __forceinline__ void unpack_rgba8(uint32_t rgba, float out[4]) {
+    out[0] = unorm8(rgba & 0xffu);
+    out[1] = unorm8((rgba >> 8) & 0xffu);
+    out[2] = unorm8((rgba >> 16) & 0xffu);
+    out[3] = unorm8(rgba >> 24);
+}
+
+// one mip level of one layer: dimensions, byte offset of the layer, and the two wrap modes
+struct TexLevel {
+    int w, h;
+    uint32_t base;
+    bool pow2_h;  // wave-uniform: REPEAT is a mask instead of a signed modulo
+    __device__ __forceinline__ TexLevel(const DevTextures& t, uint32_t level, uint32_t layer) {
+        const uint32_t ww = t.width >> level, hh = t.height >> level;
+        w = int(ww ? ww : 1);
+        h = int(hh ? hh : 1);
+        base = t.level_offset[level] + layer * uint32_t(h) * uint32_t(w) * 4u;
+        pow2_h = (t.height & (t.height - 1)) == 0;
+    }
+    __device__ __forceinline__ int clamp_s(int x) const { x = x < 0 ? 0 : x; return x > w - 1 ? w - 1 : x; }
+    __device__ __forceinline__ int repeat_t(int y) const {
+        if (pow2_h) return y & (h - 1);
+        y %= h;
+        return y < 0 ? y + h : y;
+    }
+    __device__ __forceinline__ uint32_t offset(int x, int y) const { return base + (uint32_t(y) * uint32_t(w) + uint32_t(x)) * 4u; }
+};
+
 __device__ __forceinline__ void sample_linear(const DevTextures& t, uint32_t level, uint32_t layer, float u, float v, float out[4]) {
-    uint32_t w = t.width >> level, h = t.height >> level;
-    w = w ? w : 1;
-    h = h ? h : 1;
-    const float x = u * float(w) - 0.5f, y = v * float(h) - 0.5f;
+    const TexLevel L(t, level, layer);
+    const float x = u * float(L.w) - 0.5f, y = v * float(L.h) - 0.5f;
     const float fx = floorf(x), fy = floorf(y);
     const float ax = x - fx, ay = y - fy;
     const int i0 = int(fx), j0 = int(fy);
+    const int x0 = L.clamp_s(i0), x1 = L.clamp_s(i0 + 1), y0 = L.repeat_t(j0), y1 = L.repeat_t(j0 + 1);
+    const uint32_t r00 = buf_u32(t.buf, L.offset(x0, y0)), r10 = buf_u32(t.buf, L.offset(x1, y0));
+    const uint32_t r01 = buf_u32(t.buf, L.offset(x0, y1)), r11 = buf_u32(t.buf, L.offset(x1, y1));
     float c00[4], c10[4], c01[4], c11[4];
-    texel(t, level, layer, i0, j0, c00);
-    texel(t, level, layer, i0 + 1, j0, c10);
-    texel(t, level, layer, i0, j0 + 1, c01);
-    texel(t, level, layer, i0 + 1, j0 + 1, c11);
+    unpack_rgba8(r00, c00); unpack_rgba8(r10, c10); unpack_rgba8(r01, c01); unpack_rgba8(r11, c11);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float lo = c00[k] * (1.0f - ax) + c10[k] * ax;
@@ -317,8 +336,8 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
     const float lf = floorf(layer_f + 0.5f);
     const uint32_t layer = lf <= 0.0f ? 0u : (lf >= float(t.layers - 1) ? t.layers - 1 : uint32_t(lf));
     if (!(lod > 0.0f)) {  // magnification: NEAREST on the base level
-        uint32_t w = t.width, h = t.height;
-        texel(t, 0, layer, int(floorf(u * float(w))), int(floorf(v * float(h))), rgba);
+        const TexLevel L(t, 0, layer);
+        unpack_rgba8(buf_u32(t.buf, L.offset(L.clamp_s(int(floorf(u * float(L.w)))), L.repeat_t(int(floorf(v * float(L.h)))))), rgba);
         return;
     }
     const float q = float(t.levels - 1);
@@ -731,6 +750,8 @@ __device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[
 struct RenderParams {
     vx_uniforms u;
     float tan_half_fovy;   // tanf(fovy * 0.5f), evaluated on the host (world.glsl:115)
+    float ray_origin[3];   // (view * vec4(0,0,0,1)).xyz / .w, the same for every pixel: evaluated on the host (world.glsl:118)
+    uint32_t affine_view;  // the view matrix's last row is (0,0,0,1): the per-pixel perspective divide is a division by exactly 1
     uint32_t width, height;
     uint32_t tiles_x, tiles_y;
     uint32_t tile_rank, tile_count, n_local_tiles;
@@ -742,6 +763,12 @@ __device__ __forceinline__ void normalize3(const float v[3], float out[3]) {
     out[0] = v[0] / len; out[1] = v[1] / len; out[2] = v[2] / len;
 }
 
+// (view * vec4(0,0,0,1)).xyz / .w (world.glsl:118), in the operation order primary_ray uses for the look-at point
+__host__ __device__ inline void view_origin(const float* m, float ro[3]) {
+    const float ow = m[3] * 0.0f + m[7] * 0.0f + m[11] * 0.0f + m[15] * 1.0f;
+    for (int r = 0; r < 3; ++r) ro[r] = (m[r] * 0.0f + m[4 + r] * 0.0f + m[8 + r] * 0.0f + m[12 + r] * 1.0f) / ow;
+}
+
 // world.glsl:110-129
 __device__ __forceinline__ void primary_ray(const RenderParams& p, uint32_t x, uint32_t y, float ro[3], float rd[3]) {
     float uvx = float(x) / float(p.width), uvy = float(y) / float(p.height);
@@ -751,14 +778,22 @@ __device__ __forceinline__ void primary_ray(const RenderParams& p, uint32_t x, u
     uvx *= p.tan_half_fovy;
     uvy *= p.tan_half_fovy;
     const float* m = p.u.view;
-    const float ow = m[3] * 0.0f + m[7] * 0.0f + m[11] * 0.0f + m[15] * 1.0f;
-    const float lw = m[3] * uvx + m[7] * uvy + m[11] * -1.0f + m[15] * 1.0f;
     float d[3];
+    if (p.affine_view) {
+        // lw = 0*uvx + 0*uvy + 0*-1 + 1 is exactly 1 and x / 1 == x: the three divisions drop out
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        ro[r] = (m[r] * 0.0f + m[4 + r] * 0.0f + m[8 + r] * 0.0f + m[12 + r] * 1.0f) / ow;
-        const float l = (m[r] * uvx + m[4 + r] * uvy + m[8 + r] * -1.0f + m[12 + r] * 1.0f) / lw;
-        d[r] = l - ro[r];
+        for (int r = 0; r < 3; ++r) {
+            ro[r] = p.ray_origin[r];
+            d[r] = (m[r] * uvx + m[4 + r] * uvy + m[8 + r] * -1.0f + m[12 + r] * 1.0f) - ro[r];
+        }
+    } else {
+        const float lw = m[3] * uvx + m[7] * uvy + m[11] * -1.0f + m[15] * 1.0f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            ro[r] = p.ray_origin[r];
+            const float l = (m[r] * uvx + m[4 + r] * uvy + m[8 + r] * -1.0f + m[12 + r] * 1.0f) / lw;
+            d[r] = l - ro[r];
+        }
     }
     normalize3(d, rd);
 }

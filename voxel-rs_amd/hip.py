@@ -27,7 +27,7 @@ FRAME_DTYPE = np.dtype([("t_min", "<f4"), ("ptr", "<u4"), ("idx", "<u4"), ("pare
 assert HIT_DTYPE.itemsize == 48 and PICKER_TASK_DTYPE.itemsize == 48 and PICKER_RESULT_DTYPE.itemsize == 48 and FRAME_DTYPE.itemsize == 36
 
 COUNTER_FIELDS = ["rays", "iterations", "pushes", "leaf_tests", "leaf_tests_trilinear", "boundaries", "csvo_header_bytes", "csvo_pointer_bytes",
-                  "pixels", "lit_pixels", "shadow_rays"]
+                  "pixels", "lit_pixels", "shadow_rays", "wave_steps", "services", "refills", "tail_wave_steps", "tail_iterations"]
 
 
 class Uniforms(C.Structure):
