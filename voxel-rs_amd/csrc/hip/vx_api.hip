@@ -127,7 +127,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     Result res;
     int state = kIdle;
     bool shadow_ray = false;
-    uint32_t out_index = 0, px_x = 0, px_y = 0;
+    uint32_t out_index = 0;
+    float primary_rd[3] = {0, 0, 0};  // kept while a primary ray is in flight: the sky needs it if the ray misses (world.glsl:135-138)
     float keep_color[4] = {0, 0, 0, 0}, keep_ds = 0.0f;
     vx_hit rec;            // HITS only
     uint32_t steps = 0;    // HITS only
@@ -139,66 +140,12 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     bool queue_empty = false;
 
     for (;;) {
-        // ---- refill idle lanes from the sub-tile queue ----
-        unsigned long long idle_mask = __ballot(state == kIdle);
-        if (!queue_empty && idle_mask && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
-            if (STATS) ++refills;
-            for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
-                if (cursor >= 64) {
-                    uint32_t t = 0;
-                    if (lane == 0) t = atomicAdd(a.work_counter, 1u);
-                    t = __builtin_amdgcn_readfirstlane(t);
-                    if (t >= a.total_subtiles) {
-                        queue_empty = true;
-                        break;
-                    }
-                    sub = t;
-                    cursor = 0;
-                }
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
-                const uint32_t k = cursor + rank;
-                if (state == kIdle && k < 64) {
-                    // sub-tile -> pixel: 32x32 tile (sharding unit), 4x4 sub-tiles in Morton order, 8x8 pixels in Morton order
-                    const uint32_t local_tile = sub >> 4, s = sub & 15u;
-                    const uint32_t tile = local_tile * p.tile_count + p.tile_rank;
-                    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-                    const uint32_t sx = (s & 1u) | ((s >> 1) & 2u), sy = ((s >> 1) & 1u) | ((s >> 2) & 2u);
-                    uint32_t lx, ly;
-                    lane_to_xy(k, lx, ly);
-                    const uint32_t in_x = sx * 8 + lx, in_y = sy * 8 + ly;
-                    px_x = tx * kTile + in_x;
-                    px_y = ty * kTile + in_y;
-                    out_index = p.tile_count > 1 ? local_tile * (kTile * kTile) + in_y * kTile + in_x : px_y * p.width + px_x;
-                    if (px_x < p.width && px_y < p.height) {
-                        float ro[3], rd[3];
-                        primary_ray(p, px_x, px_y, ro, rd);
-                        tr.init(sc, ro, rd, -1.0f);
-                        state = kTrav;
-                        shadow_ray = false;
-                        steps = 0;
-                        if (STATS) { ctr.rays++; ++n_pixels; }
-                    } else if (p.tile_count > 1) {
-                        // padding pixel of an edge tile: keep the compact tile list fully defined
-                        if (out) out[out_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        if (HITS) memset(&hits[out_index], 0, sizeof(vx_hit));
-                    }
-                }
-                const uint32_t n_idle = uint32_t(__popcll(idle_mask));
-                cursor += n_idle < 64 - cursor ? n_idle : 64 - cursor;
-                idle_mask = __ballot(state == kIdle);
-            }
-        }
-        if (__ballot(state != kIdle) == 0) {
-            if (queue_empty) break;
-            continue;
-        }
-
-        // ---- traverse until enough lanes wait for service ----
+        // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
         const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle)));  // idle lanes are not waiting for anything
         for (;;) {
             if (state == kTrav) {
                 const TravStatus s = tr.template step<false, STATS, false>(sc, st, nullptr, STATS ? &ctr : nullptr);
-                state = s == kTravContinue ? kTrav : (s == kTravAtLeaf ? kLeaf : kMissed);
+                if (s != kTravContinue) state = s == kTravAtLeaf ? kLeaf : kMissed;
             }
             const unsigned long long trav = __ballot(state == kTrav);
             if (STATS) {
@@ -207,17 +154,22 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             }
             if (trav == 0 || 64u - uint32_t(__popcll(trav)) >= park_limit) break;
         }
+        if (STATS) ++services;
 
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
-        if (STATS) ++services;
         if (state == kLeaf) {
             const LeafOutcome o = tr.template leaf_test<false, STATS>(sc, st, true, res, nullptr, STATS ? &ctr : nullptr);
             state = o == kLeafHit ? kDone : (o == kLeafPassed ? kTrav : kMissed);
         }
         if (state == kMissed) {
-            result_miss(res, tr.inside_voxel);
+            result_miss(res, tr.inside_voxel());
             state = kDone;
         }
+
+        // A lane that gets a new ray in this service phase -- the shadow ray of a shaded pixel, or the primary ray of a
+        // freshly assigned pixel -- only records origin and direction; one Trav::init below serves both kinds together.
+        float new_ro[3] = {0, 0, 0}, new_rd[3] = {0, 0, 0};
+        bool new_ray = false;
 
         // ---- finished rays ----
         if (state == kDone) {
@@ -234,9 +186,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     steps = tr.iter;
                 }
                 if (res.t == -1.0f) {  // no hit: sky (world.glsl:135-138)
-                    float ro[3], rd[3], sky[3];
-                    primary_ray(p, px_x, px_y, ro, rd);
-                    sky_color(rd, sky);
+                    float sky[3];
+                    sky_color(primary_rd, sky);
                     color[0] = sky[0]; color[1] = sky[1]; color[2] = sky[2]; color[3] = 1.0f;
                 } else {
                     if (STATS && !(o.flags & 8u)) ++lit;
@@ -244,10 +195,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     if (!o.final_color) {
                         keep_color[0] = o.color[0]; keep_color[1] = o.color[1]; keep_color[2] = o.color[2]; keep_color[3] = o.color[3];
                         keep_ds = o.ds;
-                        const float neg_l[3] = {-p.u.light_dir[0], -p.u.light_dir[1], -p.u.light_dir[2]};
-                        tr.init(sc, o.shadow_origin, neg_l, -1.0f);
+                        new_ro[0] = o.shadow_origin[0]; new_ro[1] = o.shadow_origin[1]; new_ro[2] = o.shadow_origin[2];
+                        new_rd[0] = -p.u.light_dir[0]; new_rd[1] = -p.u.light_dir[1]; new_rd[2] = -p.u.light_dir[2];
+                        new_ray = true;
                         shadow_ray = true;
-                        state = kTrav;
                         write = false;
                         if (STATS) { ctr.rays++; ++shadow_rays; }
                     }
@@ -270,6 +221,61 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 state = kIdle;
             }
         }
+
+        // ---- refill idle lanes from the sub-tile queue ----
+        unsigned long long idle_mask = __ballot(state == kIdle);
+        if (!queue_empty && idle_mask && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
+            if (STATS) ++refills;
+            for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
+                if (cursor >= 64) {
+                    uint32_t t = 0;
+                    if (lane == 0) t = atomicAdd(a.work_counter, 1u);
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    if (t >= a.total_subtiles) {
+                        queue_empty = true;
+                        break;
+                    }
+                    sub = t;
+                    cursor = 0;
+                }
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
+                const uint32_t k = cursor + rank;
+                if (state == kIdle && !new_ray && k < 64) {
+                    // sub-tile -> pixel: 32x32 tile (sharding unit), 4x4 sub-tiles in Morton order, 8x8 pixels in Morton order
+                    const uint32_t local_tile = sub >> 4, s = sub & 15u;
+                    const uint32_t tile = local_tile * p.tile_count + p.tile_rank;
+                    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+                    const uint32_t sx = (s & 1u) | ((s >> 1) & 2u), sy = ((s >> 1) & 1u) | ((s >> 2) & 2u);
+                    uint32_t lx, ly;
+                    lane_to_xy(k, lx, ly);
+                    const uint32_t in_x = sx * 8 + lx, in_y = sy * 8 + ly;
+                    const uint32_t px_x = tx * kTile + in_x, px_y = ty * kTile + in_y;
+                    out_index = p.tile_count > 1 ? local_tile * (kTile * kTile) + in_y * kTile + in_x : px_y * p.width + px_x;
+                    if (px_x < p.width && px_y < p.height) {
+                        primary_ray(p, px_x, px_y, new_ro, new_rd);
+                        primary_rd[0] = new_rd[0]; primary_rd[1] = new_rd[1]; primary_rd[2] = new_rd[2];
+                        new_ray = true;
+                        shadow_ray = false;
+                        steps = 0;
+                        if (STATS) { ctr.rays++; ++n_pixels; }
+                    } else if (p.tile_count > 1) {
+                        // padding pixel of an edge tile: keep the compact tile list fully defined
+                        if (out) out[out_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (HITS) memset(&hits[out_index], 0, sizeof(vx_hit));
+                    }
+                }
+                const uint32_t n_idle = uint32_t(__popcll(idle_mask));
+                cursor += n_idle < 64 - cursor ? n_idle : 64 - cursor;
+                idle_mask = __ballot(state == kIdle && !new_ray);
+            }
+        }
+
+        // ---- ray set-up (svo.esvo.glsl:50-150) for every lane that got a ray above ----
+        if (new_ray) {
+            tr.init(sc, new_ro, new_rd, -1.0f);
+            state = kTrav;
+        }
+        if (__ballot(state != kIdle) == 0 && queue_empty) break;
     }
 
     if (STATS) {
@@ -414,6 +420,7 @@ struct vx_context {
     uint32_t* d_work_counter = nullptr;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
     uint32_t refill_min = 8, service_min = 28;
+    int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int cu_count = 256;
     int persistent_blocks[2][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
@@ -489,6 +496,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         const bool esvo = ctx->svo_type == VX_SVO_ESVO;
         const void* fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, STATS>)
                               : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, HITS, STATS>);
+        if (!HITS && !STATS && ctx->min_waves == 4)
+            fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 4>)
+                      : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 4>);
         int& per_cu = ctx->persistent_blocks[esvo ? 0 : 1][HITS][STATS];
         if (per_cu == 0) {
             int n = 0;
@@ -595,6 +605,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
         c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
+        if (const char* e = std::getenv("VX_MIN_WAVES")) c->min_waves = std::atoi(e);
         if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));

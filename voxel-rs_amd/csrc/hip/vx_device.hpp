@@ -400,11 +400,14 @@ struct Trav {
     uint32_t node;                        // ESVO: child_mask << 8 | leaf_mask of the examined node; CSVO: its header
     uint32_t depth;                       // CSVO only (svo.csvo.glsl:254); wraps below 0 exactly like the reference's uint
     uint32_t material_section_ptr, pre_leaf_pointer;  // CSVO only
+    // svo.esvo.glsl:241-265 keeps adjacent_leaf_count and last_leaf_value; only "count != 0" is ever observed, and the value
+    // is only compared while the count is non-zero, so the reset needs to touch the flag alone
     uint32_t last_leaf_value;
-    int adjacent_leaf_count;
+    uint32_t flags;                       // kInsideVoxel | kHasAdjacentLeaf (one word: no per-flag storage for the optimiser to split)
+    static constexpr uint32_t kInsideVoxel = 1u, kHasAdjacentLeaf = 2u;
+    __device__ __forceinline__ bool inside_voxel() const { return (flags & kInsideVoxel) != 0; }
     int scale, idx, octant_mask;
     uint32_t iter;                        // loop iterations executed (the reference's `i`)
-    bool inside_voxel;
 
     // CSVO header of the node at `ptr`, normalised to the internal-node form (2 bits per child): the 1-bit-per-child
     // headers of the three lowest levels are spread to tag 01 per present child, after which child lookup and the
@@ -428,11 +431,10 @@ struct Trav {
         scale = kMaxScale - 1;
         scale_exp2 = 0.5f;
         last_leaf_value = 0xffffffffu;
-        adjacent_leaf_count = 0;
+        flags = 0;
         material_section_ptr = kInvalidPtr;
         pre_leaf_pointer = kInvalidPtr;
         iter = 0;
-        inside_voxel = false;
 
         rdx = rd_in[0]; rdy = rd_in[1]; rdz = rd_in[2];
         const uint32_t eps_bits = __float_as_uint(kEps) & 0x7fffffffu;
@@ -478,6 +480,7 @@ struct Trav {
     template <bool TRACE, class ST>
     __device__ __forceinline__ bool advance(const DevScene& sc, const ST& st, float tcrx, float tcry, float tcrz, float tc_max, TracePtr tk) {
         (void)sc;
+        const uint32_t ox = __float_as_uint(px), oy = __float_as_uint(py), oz = __float_as_uint(pz);
         int step_mask = 0;
         if (tc_max >= tcrx) { step_mask ^= 1; px -= scale_exp2; }
         if (tc_max >= tcry) { step_mask ^= 2; py -= scale_exp2; }
@@ -488,10 +491,19 @@ struct Trav {
 
         bool inside = true;
         if ((idx & step_mask) != 0) {
-            uint32_t differing_bits = 0;
-            if (step_mask & 1) differing_bits |= __float_as_uint(px) ^ __float_as_uint(px + scale_exp2);
-            if (step_mask & 2) differing_bits |= __float_as_uint(py) ^ __float_as_uint(py + scale_exp2);
-            if (step_mask & 4) differing_bits |= __float_as_uint(pz) ^ __float_as_uint(pz + scale_exp2);
+            // svo.esvo.glsl:345-349: per stepped axis, bits(pos) ^ bits(pos + scale_exp2). While scale >= 0 every coordinate is a
+            // multiple of scale_exp2 >= 2^-23 in [1, 2), the subtraction above was exact and pos + scale_exp2 is the old
+            // coordinate again (unstepped axes contribute 0 on their own); below that (a ray that started inside a voxel and
+            // was taken more than `depth` levels further down) the sums round and are formed as written.
+            uint32_t differing_bits;
+            if (scale >= 0) {
+                differing_bits = (ox ^ __float_as_uint(px)) | (oy ^ __float_as_uint(py)) | (oz ^ __float_as_uint(pz));
+            } else {
+                differing_bits = 0;
+                if (step_mask & 1) differing_bits |= __float_as_uint(px) ^ __float_as_uint(px + scale_exp2);
+                if (step_mask & 2) differing_bits |= __float_as_uint(py) ^ __float_as_uint(py + scale_exp2);
+                if (step_mask & 4) differing_bits |= __float_as_uint(pz) ^ __float_as_uint(pz + scale_exp2);
+            }
 
             scale = differing_bits ? 31 - __clz(differing_bits) : -1;
             inside = uint32_t(scale) < uint32_t(kMaxScale);
@@ -508,11 +520,13 @@ struct Trav {
                     if (TRACE) { tk->ref_ptr = tk->stack_ptr[scale]; tk->ref_aux = tk->stack_aux[scale]; }
                 }
 
-                const int shx = __float_as_int(px) >> scale, shy = __float_as_int(py) >> scale, shz = __float_as_int(pz) >> scale;
-                px = __int_as_float(shx << scale);
-                py = __int_as_float(shy << scale);
-                pz = __int_as_float(shz << scale);
-                idx = (shx & 1) | ((shy & 1) << 1) | ((shz & 1) << 2);
+                // svo.esvo.glsl:372-385: drop the position bits below the new scale; the bit at the scale is the child index
+                const uint32_t bx = __float_as_uint(px), by = __float_as_uint(py), bz = __float_as_uint(pz);
+                const uint32_t keep = 0xffffffffu << scale;
+                px = __uint_as_float(bx & keep);
+                py = __uint_as_float(by & keep);
+                pz = __uint_as_float(bz & keep);
+                idx = int(((bx >> scale) & 1u) | (((by >> scale) & 1u) << 1) | (((bz >> scale) & 1u) << 2));
                 h = 0.0f;
             }
         }
@@ -567,13 +581,10 @@ struct Trav {
         }
 
         const bool descend = is_child && t_min <= t_max;
-        if (!descend) {
-            adjacent_leaf_count = 0;
-            last_leaf_value = 0xffffffffu;
-        }
+        if (!descend) flags &= ~kHasAdjacentLeaf;
         if (descend && is_leaf) {
             if (t_min > 0.0f) return kTravAtLeaf;  // leaf_test() decides; the cursor is left untouched
-            if (t_min == 0.0f) inside_voxel = true;
+            if (t_min == 0.0f) flags |= kInsideVoxel;
         }
         const float tv_max = gmin(t_max, tc_max);
         if (descend && t_min <= tv_max) {
@@ -583,20 +594,20 @@ struct Trav {
             const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
                         tcenz = __builtin_fmaf(half_scale, tcz, tcrz);
             if (!CSVO) {
-                const uint32_t body = ptr + 4 + octant_idx;
-                const uint32_t w = esvo_word(sc, body), hd = esvo_word(sc, ptr + (octant_idx >> 1));
+                // the child's pointer word and the header word with its masks, both in the octant at `ptr`
+                const uint32_t w0 = esvo_word(sc, ptr + 4 + octant_idx), w1 = esvo_word(sc, ptr + (octant_idx >> 1));
                 if (tc_max < h) {
                     st.push(scale, ptr, t_max, node);
                     if (TRACE) { tk->stack_ptr[scale] = tk->ref_ptr; tk->stack_aux[scale] = uint8_t(tk->ref_aux); }
                 }
                 if (TRACE) { tk->ref_ptr = ptr; tk->ref_aux = octant_idx; }
-                ptr = (w & 0x80000000u) ? body + (w & 0x7fffffffu) : w;
-                node = (octant_idx & 1u) ? hd >> 16 : hd;
+                ptr = (w0 & 0x80000000u) ? ptr + 4 + octant_idx + (w0 & 0x7fffffffu) : w0;
+                node = (octant_idx & 1u) ? w1 >> 16 : w1;
             } else {
                 if (tc_max < h) st.push(scale, ptr, t_max, (depth << 16) | node);
-                // read_next_ptr (svo.csvo.glsl:53-116) with the (normalised) header already at hand: internal nodes
-                // (2-byte header, 1/2/4-byte table entries) and the depth-3 level (1-byte header, 1-byte entries) are the
-                // same computation; the two lowest levels have no table
+                // read_next_ptr (svo.csvo.glsl:53-116) with the (normalised) header already at hand: internal nodes (2-byte
+                // header, 1/2/4-byte table entries) and the depth-3 level (1-byte header, 1-byte entries) are the same
+                // computation; the two lowest levels have no table
                 const uint32_t offset = csvo_tag_bytes(node & ((1u << (octant_idx * 2)) - 1u));
                 uint32_t next_ptr = ptr + 3 + offset;
                 bool crossed = false;
@@ -687,7 +698,7 @@ struct Trav {
         float tex_color[4];
         texture_lod(sc.tex, uvx, uvy, float(tex_id), tex_lod, tex_color);
 
-        const bool first_of_kind = adjacent_leaf_count == 0 || value != last_leaf_value;
+        const bool first_of_kind = !(flags & kHasAdjacentLeaf) || value != last_leaf_value;
         if ((tex_color[3] > 0.0f || !cast_translucent) && first_of_kind) {
             res.t = dst;
             res.face_id = face_id;
@@ -701,10 +712,10 @@ struct Trav {
             res.pos[0] = (hx - 1.0f) * inv_scale;
             res.pos[1] = (hy - 1.0f) * inv_scale;
             res.pos[2] = (hz - 1.0f) * inv_scale;
-            res.inside_voxel = inside_voxel;
+            res.inside_voxel = inside_voxel();
             return kLeafHit;
         }
-        ++adjacent_leaf_count;
+        flags |= kHasAdjacentLeaf;
         last_leaf_value = value;
         // the rest of this iteration: ADVANCE (svo.esvo.glsl:324 onwards)
         const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
@@ -738,7 +749,7 @@ __device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[
             s = o == kLeafPassed ? kTravContinue : kTravFinished;
         }
         if (s == kTravFinished) {
-            result_miss(res, tr.inside_voxel);
+            result_miss(res, tr.inside_voxel());
             break;
         }
     }
@@ -807,7 +818,8 @@ __device__ __forceinline__ void sky_color(const float rd[3], float out[3]) {
     // argument clamped like the oracle does: the reference's expected image has no undefined (acos(1+)) horizon pixels
     const float a = acosf(gclamp(dot3(rd, p) / fabsf(sqrtf(dot3(rd, rd))) * fabsf(sqrtf(dot3(p, p))), -1.0f, 1.0f));
     float grad = a / 1.570796f;
-    grad = 1.0f - powf(1.0f - grad, 3.0f);
+    const float g1 = 1.0f - grad;
+    grad = 1.0f - g1 * g1 * g1;  // pow(x, 3.0): two multiplications are within an ulp of any pow() and an order of magnitude cheaper
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float horizon = 1.0f * (1.0f - 0.3f) + SKY[k] * 0.3f;
