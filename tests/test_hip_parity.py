@@ -219,6 +219,57 @@ def test_heightfield_frame(hip, fmt, depth, size):
 
 
 @pytest.mark.parametrize("fmt", FMTS)
+def test_rays_from_inside_voxels_in_a_deep_world(hip, fmt):
+    """Depth 13 (a few chunks far from the origin): the leaves sit on the last LDS-resident stack level, so a ray that
+    starts inside a voxel (every primary ray of a camera buried in a block, and shadow rays that start inside a
+    neighbour) is led below them by leaf data (svo.esvo.glsl:183-185 only accepts a leaf when t_min > 0) and has to be
+    carried through the full, spill-backed stack."""
+    import math
+    from voxel_rs_amd import scenes
+
+    rng = np.random.default_rng(11)
+    world = vra.World(SVO_TYPES[fmt])
+    base = (200, 3, 201)
+    for dx in range(2):
+        for dz in range(2):
+            chunk = vra.Chunk(base[0] + dx, base[1], base[2] + dz, 5)
+            for x in range(32):
+                for z in range(32):
+                    top = 6 + int(rng.integers(0, 6))
+                    for y in range(top):
+                        chunk.set_block(x, y, z, int(rng.choice([1, 2, 3, 7, 9])))
+            for _ in range(200):
+                x, y, z = (int(v) for v in rng.integers(0, 32, size=3))
+                chunk.set_block(x, y, z, int(rng.choice([5, 10, 4])))
+            chunk.compact()
+            world.set_chunk((base[0] + dx, base[1], base[2] + dz), chunk)
+    world.serialize()
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+    assert svo.get_stats()["depth"] == 13
+    w, h = 96, 64
+    ox, oy, oz = (32.0 * c for c in base)
+    wandering = 0
+    for eye, fwd in (((ox + 20.3, oy + 2.4, oz + 30.6), (0.6, 0.35, 0.7)), ((ox + 33.5, oy + 4.5, oz + 12.5), (0.2, 0.9, -0.3)),
+                     ((ox + 9.5, oy + 1.5, oz + 40.5), (-0.5, 0.1, 0.8)), ((ox + 30.0, oy + 20.0, oz + 30.0), (0.5, -0.6, 0.6))):
+        u = scenes.render_params_to_uniforms(eye, fwd, (0.0, 1.0, 0.0), math.radians(72.0), w / h, 0.3, (-1.0, -1.0, -1.0), True, 500.0)
+        img, hits = svo.render(u, w, h, want_hits=True)
+        cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
+        compare_frames(img, hits, cimg, chits)
+        oc = orc.Counters()
+        scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h, want_hits=False, counters=oc)
+        gc = svo.render_counters(u, w, h)
+        for k, v in oc.as_dict().items():
+            assert gc[k] == v, (k, gc[k], v)
+        wandering += int((chits["steps"] > 3 * 13).sum())
+    assert wandering > 100  # not vacuous: many rays go well past a plain root-to-leaf descent
+
+
+@pytest.mark.parametrize("fmt", FMTS)
 def test_translucent_blocks_frame(hip, fmt):
     """Glass panes and leaves in front of terrain: the adjacency/translucency rule (svo.esvo.glsl:241-265) in a frame,
     a highlighted voxel (world.glsl:37-45) and a camera inside the domain looking at nearby geometry (NEAREST sampling)."""

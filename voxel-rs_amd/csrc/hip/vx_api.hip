@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
 // shows that `service_min` lanes are waiting (or nobody is left traversing); idle lanes are re-filled with new pixels
 // when `refill_min` of them are free. The common descend/advance/pop step therefore runs with most lanes active
 // instead of the ~30 % the one-thread-per-pixel kernel reached (profiles/round1/v1_*).
-enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4 };
+enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4, kDeep = 5 };
 
 struct PersistentArgs {
     uint32_t* work_counter;   // next sub-tile; zeroed before every launch
@@ -120,10 +120,17 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     const DevScene sc = make_scene(sa);
     const uint32_t lane = threadIdx.x;
     StackSpill spill;
-    Stack<64> st;
+    Stack<64, false> st;       // all 23 levels: LDS, then the per-lane spill array
+    Stack<64, true> fast_st;   // the same LDS slots, no range checks: what the traversal loop uses
     st.init(lane, &spill);
+    fast_st.init(lane, &spill);
+    // a ray may use fast_st while every level it can pop to is LDS resident
+    constexpr int kFastFloor = kLdsBaseScale - 1;
+    // set in Trav::iter while the lane is not traversing, so that "iter < kMaxSteps" alone says "run one more step"
+    constexpr uint32_t kParked = 0x80000000u;
 
     Trav<SVO> tr;
+    tr.iter = kParked;
     Result res;
     int state = kIdle;
     bool shadow_ray = false;
@@ -143,11 +150,14 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
         const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle)));  // idle lanes are not waiting for anything
         for (;;) {
-            if (state == kTrav) {
-                const TravStatus s = tr.template step<false, STATS, false>(sc, st, nullptr, STATS ? &ctr : nullptr);
-                if (s != kTravContinue) state = s == kTravAtLeaf ? kLeaf : kMissed;
+            if (tr.iter < uint32_t(kMaxSteps)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
+                const TravStatus s = tr.template step<false, STATS, false, Stack<64, true>, false>(sc, fast_st, nullptr, STATS ? &ctr : nullptr);
+                if (s != kTravContinue) {
+                    state = s == kTravAtLeaf ? kLeaf : (s == kTravDeep ? kDeep : kMissed);
+                    tr.iter |= kParked;
+                }
             }
-            const unsigned long long trav = __ballot(state == kTrav);
+            const unsigned long long trav = __ballot(tr.iter < uint32_t(kMaxSteps));
             if (STATS) {
                 ++wave_steps;
                 if (queue_empty) { ++tail_wave_steps; tail_iterations += uint32_t(__popcll(trav)); }
@@ -155,11 +165,29 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             if (trav == 0 || 64u - uint32_t(__popcll(trav)) >= park_limit) break;
         }
         if (STATS) ++services;
+        if (state == kTrav && tr.iter >= uint32_t(kMaxSteps)) {  // the cap ended this ray
+            state = kMissed;
+            tr.iter |= kParked;
+        }
+
+        // ---- rays below the LDS-resident levels (they started inside a voxel and were led on by leaf data): full stack ----
+        if (state == kDeep) {
+            tr.iter &= ~kParked;
+            for (;;) {
+                const TravStatus s = tr.template step<false, STATS, false>(sc, st, nullptr, STATS ? &ctr : nullptr);
+                if (s == kTravContinue && tr.scale < kFastFloor) continue;
+                state = s == kTravContinue ? kTrav : (s == kTravAtLeaf ? kLeaf : kMissed);
+                break;
+            }
+            if (state != kTrav) tr.iter |= kParked;
+        }
 
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
         if (state == kLeaf) {
+            tr.iter &= ~kParked;
             const LeafOutcome o = tr.template leaf_test<false, STATS>(sc, st, true, res, nullptr, STATS ? &ctr : nullptr);
-            state = o == kLeafHit ? kDone : (o == kLeafPassed ? kTrav : kMissed);
+            state = o == kLeafHit ? kDone : (o == kLeafPassed ? (tr.scale >= kFastFloor ? kTrav : kDeep) : kMissed);
+            if (state != kTrav) tr.iter |= kParked;
         }
         if (state == kMissed) {
             result_miss(res, tr.inside_voxel());
@@ -183,7 +211,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     rec.pos[0] = res.pos[0]; rec.pos[1] = res.pos[1]; rec.pos[2] = res.pos[2];
                     rec.lod = res.lod; rec.uv[0] = res.uv[0]; rec.uv[1] = res.uv[1];
                     rec.shadow_t = -1.0f;
-                    steps = tr.iter;
+                    steps = tr.iter & ~kParked;
                 }
                 if (res.t == -1.0f) {  // no hit: sky (world.glsl:135-138)
                     float sky[3];
@@ -209,7 +237,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 if (HITS) {
                     if (!(res.t < 0.0f)) rec.flags |= 4u;
                     rec.shadow_t = res.t;
-                    steps += tr.iter;
+                    steps += tr.iter & ~kParked;
                 }
             }
             if (write) {
@@ -272,7 +300,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
         // ---- ray set-up (svo.esvo.glsl:50-150) for every lane that got a ray above ----
         if (new_ray) {
-            tr.init(sc, new_ro, new_rd, -1.0f);
+            tr.init(sc, new_ro, new_rd, -1.0f);  // iter = 0: not parked
             state = kTrav;
         }
         if (__ballot(state != kIdle) == 0 && queue_empty) break;

@@ -136,8 +136,11 @@ struct StackSpill {
 };
 
 // What a slot holds -- ESVO: {own-octant pointer, t_max, child masks}; CSVO: {node byte pointer, t_max, depth << 16 | header}.
-template <int THREADS>
+// FAST = the caller guarantees LDS-resident scales only (see Trav::step: a ray that is about to leave them reports
+// kTravDeep instead), so push/pop are the bare LDS accesses.
+template <int THREADS, bool FAST = false>
 struct Stack {
+    static constexpr bool kFast = FAST;
     static constexpr uint32_t kPlane = uint32_t(kLdsLevels) * THREADS * 4;  // bytes between planes
     static constexpr uint32_t kBytes = 3 * kPlane;                          // dynamic LDS a block of THREADS threads needs
     uint32_t slot0;  // byte offset of this thread's slot for scale 0 of a (virtual) full-height plane; may be "negative"
@@ -150,7 +153,7 @@ struct Stack {
     __device__ __forceinline__ VX_AS_LDS uint32_t* at(uint32_t byte) const { return (VX_AS_LDS uint32_t*)((VX_AS_LDS unsigned char*)vx_smem + byte); }
 
     __device__ __forceinline__ void push(int scale, uint32_t p, float t, uint32_t a) const {
-        if (uint32_t(scale - kLdsBaseScale) < uint32_t(kLdsLevels)) {
+        if (FAST || uint32_t(scale - kLdsBaseScale) < uint32_t(kLdsLevels)) {
             const uint32_t s = uint32_t(scale) * (THREADS * 4u) + slot0;
             *at(s) = p; *at(s + kPlane) = __float_as_uint(t); *at(s + 2 * kPlane) = a;
         } else if (uint32_t(scale) < uint32_t(kMaxScale)) {
@@ -159,7 +162,7 @@ struct Stack {
     }
     // scale is in [0, kMaxScale) here (the caller has already left the octree otherwise)
     __device__ __forceinline__ void pop(int scale, uint32_t& p, float& t, uint32_t& a) const {
-        if (uint32_t(scale - kLdsBaseScale) < uint32_t(kLdsLevels)) {
+        if (FAST || uint32_t(scale - kLdsBaseScale) < uint32_t(kLdsLevels)) {
             const uint32_t s = uint32_t(scale) * (THREADS * 4u) + slot0;
             p = *at(s); t = __uint_as_float(*at(s + kPlane)); a = *at(s + 2 * kPlane);
         } else {
@@ -372,7 +375,9 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
 //         the debug trace, which reports them per iteration.
 //   CSVO  the node header (1 or 2 bytes, svo.csvo.glsl:53-116) is read when the node is entered and kept in `node`
 //         (and on the stack); the pointer-table entry is only read by the iteration that descends through it.
-enum TravStatus : int { kTravContinue = 0, kTravAtLeaf = 1, kTravFinished = 2 };
+// kTravDeep (fast stacks only): the next PUSH would leave the LDS-resident levels; the cursor is untouched and the caller
+// continues this ray with a full stack.
+enum TravStatus : int { kTravContinue = 0, kTravAtLeaf = 1, kTravFinished = 2, kTravDeep = 3 };
 enum LeafOutcome : int { kLeafHit = 0, kLeafPassed = 1, kLeafPassedAndFinished = 2 };
 
 // Debug-trace state (trace kernel only): the output frames, and the reference's (ptr, parent_octant_idx) view of the
@@ -496,7 +501,7 @@ struct Trav {
             // coordinate again (unstepped axes contribute 0 on their own); below that (a ray that started inside a voxel and
             // was taken more than `depth` levels further down) the sums round and are formed as written.
             uint32_t differing_bits;
-            if (scale >= 0) {
+            if (ST::kFast || scale >= 0) {
                 differing_bits = (ox ^ __float_as_uint(px)) | (oy ^ __float_as_uint(py)) | (oz ^ __float_as_uint(pz));
             } else {
                 differing_bits = 0;
@@ -535,9 +540,10 @@ struct Trav {
 
     // One iteration of the reference's loop (svo.esvo.glsl:152-391 / svo.csvo.glsl:261-508) minus the leaf test.
     // LIMIT = the ray has a maximum distance (picker); render rays are unlimited and skip the test.
-    template <bool TRACE, bool STATS, bool LIMIT, class ST>
+    // CAPPED = test the iteration cap here (a caller that already did passes false).
+    template <bool TRACE, bool STATS, bool LIMIT, class ST, bool CAPPED = true>
     __device__ __forceinline__ TravStatus step(const DevScene& sc, const ST& st, TracePtr tk, Counters* ctr) {
-        bool live = iter < uint32_t(kMaxSteps);
+        bool live = !CAPPED || iter < uint32_t(kMaxSteps);
         if (LIMIT) live = live && !(max_dst >= 0.0f && t_min > max_dst);
         if (!live) return kTravFinished;
         ++iter;
@@ -589,6 +595,14 @@ struct Trav {
         const float tv_max = gmin(t_max, tc_max);
         if (descend && t_min <= tv_max) {
             // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
+            if (ST::kFast && scale < kLdsBaseScale) {  // this PUSH would write a slot below the resident ones: undo and hand over
+                --iter;
+                if (STATS) {
+                    ctr->iterations--;
+                    if (CSVO) ctr->csvo_header_bytes -= depth > 3 ? 2u : 1u;
+                }
+                return kTravDeep;
+            }
             if (STATS) ctr->pushes++;
             const float half_scale = scale_exp2 * 0.5f;
             const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
