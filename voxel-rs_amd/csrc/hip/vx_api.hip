@@ -447,7 +447,7 @@ struct vx_context {
 
     uint32_t* d_work_counter = nullptr;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
-    uint32_t refill_min = 8, service_min = 28;
+    uint32_t refill_min = 4, service_min = 28;
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int cu_count = 256;

@@ -112,7 +112,7 @@ struct Counters {  // per-thread, reduced by the instrumented kernel
 // descend "below" the leaves, interpreting leaf bytes as nodes (svo.esvo.glsl:183-185 / svo.csvo.glsl:293-295 only
 // treat a leaf as a hit when t_min > 0); its stack arrays hold MAX_SCALE + 1 entries (svo.esvo.glsl:28-30), so those
 // pushes are kept too -- in a per-thread spill array that ordinary rays never touch.
-constexpr int kLdsLevels = 14;
+constexpr int kLdsLevels = 13;
 constexpr int kLdsBaseScale = kMaxScale - kLdsLevels;  // scales [kLdsBaseScale, 22] are LDS resident
 
 // LDS and scratch are reached through address-space-qualified pointers only: a generic pointer would turn every stack
