@@ -171,6 +171,13 @@ struct Stack {
     }
 };
 
+// instruction-scheduling fence: nothing is moved across it (orders memory requests against the arithmetic that hides them)
+#ifndef VX_DEVICE_ON_HOST
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#else
+inline void sched_fence() {}
+#endif
+
 __device__ __forceinline__ float gmin(float x, float y) { return y < x ? y : x; }  // GLSL min
 __device__ __forceinline__ float gmax(float x, float y) { return x < y ? y : x; }  // GLSL max
 __device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
@@ -604,30 +611,50 @@ struct Trav {
                 return kTravDeep;
             }
             if (STATS) ctr->pushes++;
+            // Order of the block: (1) request what the descent reads, (2) the stack write and all arithmetic that does not
+            // depend on it -- new scale, child centre distances, first child index and corner -- while the request is in
+            // flight, (3) the dependent part. The scheduling fences keep the compiler from pulling (3) up to the loads.
+            uint32_t w0 = 0, w1 = 0, table = 0, offset = 0;
+            if (!CSVO) {
+                // the child's pointer word and the header word with its masks, both in the octant at `ptr`
+                w0 = esvo_word(sc, ptr + 4 + octant_idx);
+                w1 = esvo_word(sc, ptr + (octant_idx >> 1));
+            } else {
+                // read_next_ptr (svo.csvo.glsl:53-116) with the (normalised) header already at hand: internal nodes (2-byte
+                // header, 1/2/4-byte table entries) and the depth-3 level (1-byte header, 1-byte entries) are the same
+                // computation; the two lowest levels have no table
+                offset = csvo_tag_bytes(node & ((1u << (octant_idx * 2)) - 1u));
+                if (depth >= 3) {
+                    table = ptr + (depth > 3 ? 2u : 1u);
+                    w0 = csvo_u32(sc, table + offset);
+                }
+            }
+            sched_fence();
+            if (tc_max < h) {
+                st.push(scale, ptr, t_max, CSVO ? (depth << 16) | node : node);
+                if (TRACE && !CSVO) { tk->stack_ptr[scale] = tk->ref_ptr; tk->stack_aux[scale] = uint8_t(tk->ref_aux); }
+            }
             const float half_scale = scale_exp2 * 0.5f;
             const float tcenx = __builtin_fmaf(half_scale, tcx, tcrx), tceny = __builtin_fmaf(half_scale, tcy, tcry),
                         tcenz = __builtin_fmaf(half_scale, tcz, tcrz);
+            h = tc_max;
+            --scale;
+            scale_exp2 = half_scale;
+            idx = 0;
+            if (t_min < tcenx) { idx ^= 1; px += scale_exp2; }
+            if (t_min < tceny) { idx ^= 2; py += scale_exp2; }
+            if (t_min < tcenz) { idx ^= 4; pz += scale_exp2; }
+            t_max = tv_max;
+            sched_fence();
             if (!CSVO) {
-                // the child's pointer word and the header word with its masks, both in the octant at `ptr`
-                const uint32_t w0 = esvo_word(sc, ptr + 4 + octant_idx), w1 = esvo_word(sc, ptr + (octant_idx >> 1));
-                if (tc_max < h) {
-                    st.push(scale, ptr, t_max, node);
-                    if (TRACE) { tk->stack_ptr[scale] = tk->ref_ptr; tk->stack_aux[scale] = uint8_t(tk->ref_aux); }
-                }
                 if (TRACE) { tk->ref_ptr = ptr; tk->ref_aux = octant_idx; }
                 ptr = (w0 & 0x80000000u) ? ptr + 4 + octant_idx + (w0 & 0x7fffffffu) : w0;
                 node = (octant_idx & 1u) ? w1 >> 16 : w1;
             } else {
-                if (tc_max < h) st.push(scale, ptr, t_max, (depth << 16) | node);
-                // read_next_ptr (svo.csvo.glsl:53-116) with the (normalised) header already at hand: internal nodes (2-byte
-                // header, 1/2/4-byte table entries) and the depth-3 level (1-byte header, 1-byte entries) are the same
-                // computation; the two lowest levels have no table
-                const uint32_t offset = csvo_tag_bytes(node & ((1u << (octant_idx * 2)) - 1u));
                 uint32_t next_ptr = ptr + 3 + offset;
                 bool crossed = false;
                 if (depth >= 3) {
-                    const uint32_t table = ptr + (depth > 3 ? 2u : 1u);
-                    const uint32_t e = csvo_u32(sc, table + offset) & (0xffffffffu >> ((0x001018u >> ((tag - 1) * 8)) & 0xffu));
+                    const uint32_t e = w0 & (0xffffffffu >> ((0x001018u >> ((tag - 1) * 8)) & 0xffu));
                     if (STATS) ctr->csvo_pointer_bytes += (1u << tag) >> 1;
                     crossed = (e & 0x80000000u) != 0;
                     next_ptr = crossed ? e ^ 0x80000000u : table + csvo_tag_bytes(node) + e;
@@ -646,14 +673,6 @@ struct Trav {
                 node = csvo_header(sc);
                 if (depth == 2) pre_leaf_pointer = ptr;
             }
-            h = tc_max;
-            --scale;
-            scale_exp2 = half_scale;
-            idx = 0;
-            if (t_min < tcenx) { idx ^= 1; px += scale_exp2; }
-            if (t_min < tceny) { idx ^= 2; py += scale_exp2; }
-            if (t_min < tcenz) { idx ^= 4; pz += scale_exp2; }
-            t_max = tv_max;
             return kTravContinue;
         }
         return advance<TRACE>(sc, st, tcrx, tcry, tcrz, tc_max, tk) ? kTravContinue : kTravFinished;
