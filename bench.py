@@ -43,6 +43,15 @@ def algorithmic_bytes(fmt, c):
     return trav + shade
 
 
+def measured_traffic(fmt):
+    """HBM-side bytes per launch of the render kernel on this workload, from the committed rocprofv3 --pmc passes of this
+    same command (profiles/profile.sh -> profiles/round1/traffic.json); PMC counters cannot be read from inside this run."""
+    try:
+        return json.loads((ROOT / "profiles" / "round1" / "traffic.json").read_text())[fmt]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,7 +62,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--format", choices=["esvo", "csvo"], default="csvo", help="node format; csvo is the reference's default build feature")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock target for the cpu_baseline sample (all host cores)")
     args = ap.parse_args()
 
     import numpy as np
@@ -180,7 +189,7 @@ def main():
     kernel_avg_ms = kernel_ms / max(launches, 1)
     achieved = my_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": None, "kernel": "render_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4), "launches": launches,
+                "traffic": measured_traffic(args.format) if (W, H, args.depth, world_size) == (1920, 1080, 12, 1) else None, "kernel": "render_persistent", "kernel_avg_ms": round(kernel_avg_ms, 4), "launches": launches,
                 "algorithmic_bytes_per_launch": int(my_bytes), "bytes_per_ray": round(my_bytes / max(my_rays, 1), 2)}
 
     cpu = None
@@ -200,11 +209,12 @@ def main():
         rows_budget = int(len(probe_rows) * 2 * args.cpu_seconds / max(probe_s, 1e-6))
         cc = orc.Counters()
         if rows_budget >= H:
-            # the whole frame fits the budget: repeat it until about cpu_seconds of CPU work have been timed
-            reps = max(1, min(200, rows_budget // H))
+            # the whole frame fits the budget: repeat it until about cpu_seconds of wall time on all host cores have been timed
+            reps = 0
             t0 = time.perf_counter()
-            for _ in range(reps):
+            while reps < 400 and (reps == 0 or time.perf_counter() - t0 < args.cpu_seconds):
                 scene.render(ou, W, H, want_hits=False, counters=cc, threads=cores)
+                reps += 1
             cpu_s = time.perf_counter() - t0
             sample = f"{reps} x the whole {W}x{H} frame"
         else:
