@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B sweeps of render-kernel variants in ONE process (interleaved rounds, median and min of the HIP-event kernel time).
 
-    python profiles/sweep.py --format esvo --configs "k=1" "k=2,r=16,s=12" "k=2,r=8,s=8" --rounds 3 --steps 10
+    python profiles/sweep.py --format esvo --configs "k=1" "k=2" "k=2,r=8,s=20" --rounds 3 --steps 10
 """
 import argparse
 import os
@@ -16,7 +16,7 @@ from _pkg import load_package  # noqa: E402
 vra = load_package()
 from voxel_rs_amd import hip, scenes  # noqa: E402
 
-KEYS = {"k": "VX_RENDER_KERNEL", "r": "VX_REFILL_MIN", "s": "VX_SERVICE_MIN", "m": "VX_MIN_WAVES", "i": "VX_IMAGE", "w": "VX_WAVES_PER_CU"}
+KEYS = {"k": "VX_RENDER_KERNEL", "r": "VX_REFILL_MIN", "s": "VX_SERVICE_MIN", "m": "VX_MIN_WAVES", "w": "VX_WAVES_PER_CU"}
 
 
 def main():
