@@ -13,6 +13,7 @@
 #include "csvo.hpp"
 #include "esvo.hpp"
 #include "octree.hpp"
+#include "physics.hpp"
 #include "range_buffer.hpp"
 #include "worldsvo.hpp"
 
@@ -637,6 +638,116 @@ static void shift_chunks_x_out_of_range() {  // worldsvo.rs:357-385
 
 // ---------------------------------------------------------------------------------------------------------
 
+
+// ---------------------------------------------------------------------------------------------------------
+// physics  (src/systems/physics.rs:216-494)
+// ---------------------------------------------------------------------------------------------------------
+
+namespace {
+using vx::Vec3;
+using vx::systems::AABBDef;
+using vx::systems::Entity;
+using vx::systems::EntityCapabilities;
+
+// MockRaycaster (physics.rs:226-250): asserts the batch it is handed and answers with canned AABB results
+struct MockRaycaster final : vx::systems::Raycaster {
+    std::vector<vx::Aabb> expected;
+    std::vector<vx::AabbResult> answer;
+    mutable int calls = 0;
+    void raycast(vx::PickerBatch& batch, vx::PickerBatchResult& result) const override {
+        ++calls;
+        CHECK(batch.rays.empty());
+        CHECK(batch.aabbs.size() == expected.size());
+        for (size_t i = 0; i < expected.size() && i < batch.aabbs.size(); ++i) {
+            CHECK(batch.aabbs[i].pos == expected[i].pos);
+            CHECK(batch.aabbs[i].offset == expected[i].offset);
+            CHECK(batch.aabbs[i].extents == expected[i].extents);
+        }
+        result.rays.clear();
+        result.aabbs = answer;
+    }
+};
+
+const EntityCapabilities kTestCaps{false, false, 0.008f, 3.0f};
+const AABBDef kUnitBox{Vec3{0, 0, 0}, Vec3{1, 1, 1}};
+}  // namespace
+
+static void physics_step() {  // physics.rs:254-290
+    Entity e(Vec3{0, 0, 0}, kUnitBox);
+    e.caps = kTestCaps;
+    MockRaycaster mock;
+    mock.expected = {vx::Aabb{e.position, e.aabb_def.offset, e.aabb_def.extents}};
+    mock.answer = {vx::AabbResult{}};
+    vx::systems::Physics physics;
+    physics.step(1.0f, mock, e);
+    CHECK(mock.calls == 1);
+    CHECK((e.position == Vec3{0.0f, -0.008f, 0.0f}));
+    CHECK((e.velocity == Vec3{0.0f, -0.008f, 0.0f}));
+    CHECK(e.state.is_grounded == false);
+}
+
+static void physics_step_many() {  // physics.rs:294-493
+    struct Case {
+        const char* name;
+        Vec3 position, velocity;
+        EntityCapabilities caps;
+        vx::AabbResult aabb_result;
+        Vec3 expected_position, expected_velocity;
+        bool expected_grounded;
+    };
+    const EntityCapabilities clip{true, false, 0.008f, 3.0f}, fly{false, true, 0.008f, 3.0f};
+    const Vec3 none{-1, -1, -1};
+    const std::vector<Case> cases = {
+        {"falling - first time", {0, 0, 0}, {0, 0, 0}, kTestCaps, {{-1, 1, -1}, none}, {0, -0.008f, 0}, {0, -0.008f, 0}, false},
+        {"falling - second time", {0, -0.008f, 0}, {0, -0.008f, 0}, kTestCaps, {{-1, 1, -1}, none}, {0, -0.024f, 0}, {0, -0.016f, 0}, false},
+        {"falling - hitting floor", {0, -0.024f, 0}, {0, -0.016f, 0}, kTestCaps, {{-1, 0.01f, -1}, none}, {0, -0.0335f, 0}, {0, 0, 0}, true},
+        {"falling - hitting floor with wall clip enabled", {0, -0.024f, 0}, {0, -0.016f, 0}, clip, {{-1, 0.01f, -1}, none}, {0, -0.0335f, 0}, {0, 0, 0}, true},
+        {"falling - max velocity", {0, 0, 0}, {0, -4, 0}, kTestCaps, {{-1, 10, -1}, none}, {0, -3, 0}, {0, -3, 0}, false},
+        {"jumping - no velocity limit", {0, 0, 0}, {0, 5, 0}, kTestCaps, {none, none}, {0, 4.992f, 0}, {0, 4.992f, 0}, false},
+        {"jumping - with collision", {0, 0, 0}, {0, 5, 0}, kTestCaps, {none, {-1, 2, -1}}, {0, 1.9995f, 0}, {0, 4.992f, 0}, false},
+        {"jumping - after collision for velocity reset", {0, 1.9995f, 0}, {0, 1.9995f, 0}, kTestCaps, {none, {-1, 0.0005f, -1}}, {0, 1.9995f, 0}, {0, 1.9915f, 0}, false},
+        {"jumping - with collision and wall clip enabled", {0, 0, 0}, {0, 5, 0}, clip, {none, {-1, 2, -1}}, {0, 1.9995f, 0}, {0, 4.992f, 0}, false},
+        {"flying - ground state not set", {0, 5, 0}, {3, -5, 3}, fly, {{-1, 5, -1}, {2, -1, 2}}, {3, 0, 3}, {3, -5, 3}, false},
+        {"horizontal positive collision", {0, 0, 0}, {2, 0, 2}, kTestCaps, {{-1, 0, -1}, {1, -1, 1}}, {0.9995f, 0, 0.9995f}, {2, 0, 2}, true},
+        {"horizontal negative collision", {0, 0, 0}, {-2, 0, -2}, kTestCaps, {{1, 0, 1}, none}, {-0.9995f, 0, -0.9995f}, {-2, 0, -2}, true},
+        {"horizontal positive collision - with wall clip enabled", {0, 0, 0}, {2, 0, 2}, clip, {{-1, 0, -1}, {1, -1, 1}}, {2, 0, 2}, {2, 0, 2}, true},
+    };
+    std::vector<Entity> entities;
+    MockRaycaster mock;
+    for (const Case& c : cases) {
+        Entity e(c.position, kUnitBox);
+        e.velocity = c.velocity;
+        e.caps = c.caps;
+        mock.expected.push_back(vx::Aabb{c.position, kUnitBox.offset, kUnitBox.extents});
+        mock.answer.push_back(c.aabb_result);
+        entities.push_back(e);
+    }
+    vx::systems::Physics physics;
+    physics.step_many(1.0f, mock, entities);
+    CHECK(mock.calls == 1);
+    for (size_t i = 0; i < cases.size(); ++i) {
+        const bool ok = entities[i].position == cases[i].expected_position && entities[i].velocity == cases[i].expected_velocity &&
+                        entities[i].state.is_grounded == cases[i].expected_grounded;
+        if (!ok) {
+            std::printf("  entity case '%s': pos (%.9g %.9g %.9g) vel (%.9g %.9g %.9g) grounded %d\n", cases[i].name, entities[i].position.x,
+                        entities[i].position.y, entities[i].position.z, entities[i].velocity.x, entities[i].velocity.y, entities[i].velocity.z,
+                        int(entities[i].state.is_grounded));
+            ++g_failures;
+        }
+    }
+}
+
+static void physics_apply_axial() {  // physics.rs:173-185, the branches one by one
+    using vx::systems::Physics;
+    CHECK(Physics::apply_axial_physics(0.5f, -1.0f, 3.0f) == 0.5f);       // no obstacle in the direction of travel
+    CHECK(Physics::apply_axial_physics(-0.5f, 3.0f, -1.0f) == -0.5f);
+    CHECK(Physics::apply_axial_physics(0.5f, 0.0009f, -1.0f) == 0.0f);    // closer than 2 epsilon: stop
+    CHECK(Physics::apply_axial_physics(0.5f, 0.25f, -1.0f) == 0.25f - 0.0005f);
+    CHECK(Physics::apply_axial_physics(-0.5f, -1.0f, 0.25f) == -(0.25f - 0.0005f));
+    CHECK(Physics::apply_axial_physics(0.125f, 0.25f, -1.0f) == 0.125f);  // slower than the distance: unchanged
+    CHECK(Physics::apply_axial_physics(0.0f, 5.0f, 0.0001f) == 0.0f);     // speed 0 looks at the negative side
+}
+
 int main(int argc, char** argv) {
     const std::map<std::string, std::function<void()>> cases = {
         {"octree_add_leaf_single", octree_add_leaf_single},
@@ -666,6 +777,9 @@ int main(int argc, char** argv) {
         {"shift_chunks_x_positive", shift_chunks_x_positive},
         {"shift_chunks_x_negative", shift_chunks_x_negative},
         {"shift_chunks_x_out_of_range", shift_chunks_x_out_of_range},
+        {"physics_step", physics_step},
+        {"physics_step_many", physics_step_many},
+        {"physics_apply_axial", physics_apply_axial},
     };
     if (argc >= 2 && std::string(argv[1]) == "--list") {
         for (auto& c : cases) std::printf("%s\n", c.first.c_str());

@@ -14,6 +14,7 @@
 #include "csvo.hpp"
 #include "esvo.hpp"
 #include "graphics_svo.hpp"
+#include "physics.hpp"
 #include "scene.hpp"
 #include "svo_picker.hpp"
 #include "svo_registry.hpp"
@@ -180,6 +181,68 @@ void vxh_picker_deserialize(const float* rays, uint32_t n_rays, const float* aab
         const AabbResult& a = res.aabbs[i];
         const float v[6] = {a.neg.x, a.neg.y, a.neg.z, a.pos.x, a.pos.y, a.pos.z};
         std::memcpy(out_aabbs + 6 * i, v, sizeof v);
+    }
+}
+
+// ---- physics (src/systems/physics.rs) -----------------------------------------------------------------------------------
+// entity record = 17 floats: position[3], velocity[3], aabb offset[3], aabb extents[3], wall_clip, flying, gravity,
+// max_fall_velocity, is_grounded (in: ignored, out: state after the step)
+
+namespace {
+constexpr uint32_t kEntityFloats = 17;
+systems::Entity entity_from(const float* e) {
+    systems::Entity out(Vec3{e[0], e[1], e[2]}, systems::AABBDef{Vec3{e[6], e[7], e[8]}, Vec3{e[9], e[10], e[11]}});
+    out.velocity = Vec3{e[3], e[4], e[5]};
+    out.caps = systems::EntityCapabilities{e[12] != 0.0f, e[13] != 0.0f, e[14], e[15]};
+    return out;
+}
+void entity_to(const systems::Entity& in, float* e) {
+    e[0] = in.position.x; e[1] = in.position.y; e[2] = in.position.z;
+    e[3] = in.velocity.x; e[4] = in.velocity.y; e[5] = in.velocity.z;
+    e[16] = in.state.is_grounded ? 1.0f : 0.0f;
+}
+
+// Raycaster over a raw vx_context: what graphics::Svo::raycast does (svo.rs:233-255)
+struct ContextRaycaster final : systems::Raycaster {
+    vx_context* ctx;
+    mutable std::vector<vx_picker_task> tasks;
+    mutable std::vector<vx_picker_result> results;
+    mutable uint64_t total_tasks = 0;
+    explicit ContextRaycaster(vx_context* c) : ctx(c) {}
+    void raycast(PickerBatch& batch, PickerBatchResult& result) const override {
+        const size_t n = batch.serialize_tasks(tasks);
+        results.resize(n);
+        total_tasks += n;
+        if (n && vx_raycast(ctx, tasks.data(), uint32_t(n), results.data()) != VX_OK) throw std::runtime_error(vx_last_error());
+        batch.deserialize_results(results.data(), result);
+    }
+};
+}  // namespace
+
+// Physics::step_many `steps` times through vx_raycast on `ctx` (one picker launch per step for all entities).
+// Returns the number of picker tasks cast in total, or -1 (see vx_last_error()).
+int64_t vxh_physics_step_many(void* ctx, float delta_time, uint32_t steps, float* entities, uint32_t n) {
+    try {
+        std::vector<systems::Entity> es;
+        for (uint32_t i = 0; i < n; ++i) es.push_back(entity_from(entities + kEntityFloats * i));
+        systems::Physics physics;
+        ContextRaycaster rc(static_cast<vx_context*>(ctx));
+        for (uint32_t s = 0; s < steps; ++s) physics.step_many(delta_time, rc, es);
+        for (uint32_t i = 0; i < n; ++i) entity_to(es[i], entities + kEntityFloats * i);
+        return int64_t(rc.total_tasks);
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+// Physics::update_entity with externally supplied AabbResults (6 floats each: neg[3], pos[3]) -- lets a test stand an
+// oracle in for the raycaster
+void vxh_physics_update(float delta_time, float* entities, const float* aabb_results, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) {
+        systems::Entity e = entity_from(entities + kEntityFloats * i);
+        const float* r = aabb_results + 6 * i;
+        systems::Physics::update_entity(e, AabbResult{Vec3{r[0], r[1], r[2]}, Vec3{r[3], r[4], r[5]}}, delta_time);
+        entity_to(e, entities + kEntityFloats * i);
     }
 }
 

@@ -47,6 +47,8 @@ def lib():
             "vxh_scene_build_heightfield": (u64, [vp, u32, u32, u32, vp, vp]),
             "vxh_picker_serialize": (u32, [vp, u32, vp, u32, vp, u32]),
             "vxh_picker_deserialize": (None, [vp, u32, vp, u32, vp, vp, vp]),
+            "vxh_physics_step_many": (C.c_int64, [vp, C.c_float, u32, vp, u32]),
+            "vxh_physics_update": (None, [C.c_float, vp, vp, u32]),
             "vxh_reference_render_test": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, sz]),
             "vxh_mapper_raycast_test": (C.c_int, [C.c_int, u32, vp, vp, u32, vp, vp, u32, C.c_float, vp, vp, C.c_char_p, sz]),
             "vxh_scene_height": (u32, [u32, u32, u32, u32]),
@@ -202,6 +204,39 @@ def picker_deserialize(rays, aabbs, results):
     lib().vxh_picker_deserialize(r.ctypes.data_as(C.c_void_p), len(rays), a.ctypes.data_as(C.c_void_p), len(aabbs), res.ctypes.data_as(C.c_void_p),
                                  out_r.ctypes.data_as(C.c_void_p), out_a.ctypes.data_as(C.c_void_p))
     return out_r, out_a
+
+
+ENTITY_FLOATS = 17  # position, velocity, aabb offset, aabb extents, wall_clip, flying, gravity, max_fall_velocity, is_grounded
+
+
+def make_entities(positions, extents=(0.8, 1.8, 0.8), offset=(-0.4, 0.0, -0.4), gravity=60.0, max_fall_velocity=100.0):
+    """Entity records for physics_step_many (src/systems/physics.rs:10-75)."""
+    e = np.zeros((len(positions), ENTITY_FLOATS), dtype=np.float32)
+    e[:, 0:3] = positions
+    e[:, 6:9] = offset
+    e[:, 9:12] = extents
+    e[:, 14] = gravity
+    e[:, 15] = max_fall_velocity
+    return e
+
+
+def physics_step_many(svo_handle, delta_time, steps, entities):
+    """Physics::step_many (physics.rs:122-136) `steps` times over vx_raycast of the given context (needs a GPU).
+    Updates `entities` in place; returns the number of picker tasks cast."""
+    e = np.ascontiguousarray(entities, dtype=np.float32)
+    n = lib().vxh_physics_step_many(svo_handle, delta_time, steps, e.ctypes.data_as(C.c_void_p), len(e))
+    if n < 0:
+        raise RuntimeError("vxh_physics_step_many failed")
+    entities[...] = e
+    return int(n)
+
+
+def physics_update(delta_time, entities, aabb_results):
+    """Physics::update_entity (physics.rs:139-170) with given AabbResults (n x 6: neg, pos)."""
+    e = np.ascontiguousarray(entities, dtype=np.float32)
+    r = np.ascontiguousarray(aabb_results, dtype=np.float32)
+    lib().vxh_physics_update(delta_time, e.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), len(e))
+    entities[...] = e
 
 
 def reference_render_test(svo_type, texture_dir, expected_png, actual_png_out=""):
