@@ -1,6 +1,7 @@
 // Known-answer tests for the host-side mirror (octree, RangeBuffer, ESVO/CSVO serializers, coordinate types).
 // Each case restates the expected values of one of the reference's own #[test]s; the case name carries the
 // reference location. Run by tests/test_host_kats.py (one pytest case per KAT).
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -10,6 +11,7 @@
 #include <vector>
 
 #include "chunk.hpp"
+#include "chunkloader.hpp"
 #include "csvo.hpp"
 #include "esvo.hpp"
 #include "octree.hpp"
@@ -748,6 +750,67 @@ static void physics_apply_axial() {  // physics.rs:173-185, the branches one by 
     CHECK(Physics::apply_axial_physics(0.0f, 5.0f, 0.0001f) == 0.0f);     // speed 0 looks at the negative side
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// chunk loader  (src/systems/chunkloader.rs:146-267)
+// ---------------------------------------------------------------------------------------------------------
+
+namespace {
+using vx::systems::ChunkEvent;
+ChunkEvent ev_load(int x, int y, int z, uint8_t lod) { return ChunkEvent{ChunkEvent::Load, vx::ChunkPos{x, y, z}, lod}; }
+ChunkEvent ev_unload(int x, int y, int z) { return ChunkEvent{ChunkEvent::Unload, vx::ChunkPos{x, y, z}, 0}; }
+void check_events(std::vector<ChunkEvent> got, const std::vector<ChunkEvent>& want, int line) {
+    std::sort(got.begin(), got.end());  // the reference's tests sort by the derived Ord before comparing
+    bool ok = got.size() == want.size();
+    for (size_t i = 0; ok && i < got.size(); ++i) ok = got[i] == want[i];
+    if (!ok) {
+        std::printf("  event list mismatch at line %d (%zu events, expected %zu)\n", line, got.size(), want.size());
+        ++g_failures;
+    }
+}
+// chunkloader.rs:243-266
+std::vector<int> lod_scale_on_x_axis(const std::vector<ChunkEvent>& events, int z) {
+    std::map<int, int> columns;
+    for (const ChunkEvent& e : events)
+        if (e.kind != ChunkEvent::Unload && e.pos.z == z) columns[e.pos.x] = e.lod;
+    std::vector<int> scale;
+    for (auto& kv : columns) scale.push_back(kv.second);
+    return scale;
+}
+}  // namespace
+
+static void chunkloader_load_and_unload() {  // chunkloader.rs:150-213
+    vx::systems::ChunkLoader cl(1, 0, 1);
+    check_events(cl.update(0, 0, 0), {ev_load(-1, 0, 0, 5), ev_load(0, 0, -1, 5), ev_load(0, 0, 0, 5), ev_load(0, 0, 1, 5), ev_load(1, 0, 0, 5)}, __LINE__);
+    CHECK(cl.update(16, 16, 16).empty());  // same chunk
+    check_events(cl.update(32, 0, 0), {ev_load(1, 0, -1, 5), ev_load(1, 0, 1, 5), ev_load(2, 0, 0, 5), ev_unload(-1, 0, 0), ev_unload(0, 0, -1), ev_unload(0, 0, 1)},
+                 __LINE__);
+    check_events(cl.update(128, 0, 0), {ev_load(3, 0, 0, 5), ev_load(4, 0, -1, 5), ev_load(4, 0, 0, 5), ev_load(4, 0, 1, 5), ev_load(5, 0, 0, 5), ev_unload(0, 0, 0),
+                                        ev_unload(1, 0, -1), ev_unload(1, 0, 0), ev_unload(1, 0, 1), ev_unload(2, 0, 0)}, __LINE__);
+    check_events(cl.update(128, 64, 0), {ev_unload(3, 0, 0), ev_unload(4, 0, -1), ev_unload(4, 0, 0), ev_unload(4, 0, 1), ev_unload(5, 0, 0)}, __LINE__);
+    CHECK(cl.update(0, 64, 0).empty());  // y still out of range: nothing to do anywhere
+    CHECK(cl.loaded_count() == 0);
+}
+
+static void chunkloader_changing_lod() {  // chunkloader.rs:217-241
+    vx::systems::ChunkLoader cl(25, 0, 1);
+    const std::vector<ChunkEvent> first = cl.update(0, 0, 0);
+    const std::vector<int> z0 = {2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 4, 4, 4, 4, 4, 4, 3, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2};
+    const std::vector<int> z1 = {2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 4, 4, 4, 4, 4, 4, 3, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2};
+    CHECK_SEQ(lod_scale_on_x_axis(first, -1), z1);
+    CHECK_SEQ(lod_scale_on_x_axis(first, 0), z0);
+    CHECK_SEQ(lod_scale_on_x_axis(first, 1), z1);
+    // nearest first: the list is ordered by distance to the target chunk
+    for (size_t i = 1; i < first.size(); ++i) CHECK(first[i - 1].pos.dst_sq(vx::ChunkPos{0, 0, 0}) <= first[i].pos.dst_sq(vx::ChunkPos{0, 0, 0}));
+    CHECK(first.front().pos == (vx::ChunkPos{0, 0, 0}));
+    // one chunk further in +x: one chunk per LOD ring changes on each row, plus one new chunk on z = 0
+    const std::vector<ChunkEvent> second = cl.update(32, 0, 0);
+    const std::vector<int> change = {2, 3, 4, 5, 4, 3, 2};
+    CHECK_SEQ(lod_scale_on_x_axis(second, -1), change);
+    CHECK_SEQ(lod_scale_on_x_axis(second, 0), change);
+    CHECK_SEQ(lod_scale_on_x_axis(second, 1), change);
+}
+
 int main(int argc, char** argv) {
     const std::map<std::string, std::function<void()>> cases = {
         {"octree_add_leaf_single", octree_add_leaf_single},
@@ -777,6 +840,8 @@ int main(int argc, char** argv) {
         {"shift_chunks_x_positive", shift_chunks_x_positive},
         {"shift_chunks_x_negative", shift_chunks_x_negative},
         {"shift_chunks_x_out_of_range", shift_chunks_x_out_of_range},
+        {"chunkloader_load_and_unload", chunkloader_load_and_unload},
+        {"chunkloader_changing_lod", chunkloader_changing_lod},
         {"physics_step", physics_step},
         {"physics_step_many", physics_step_many},
         {"physics_apply_axial", physics_apply_axial},
