@@ -16,6 +16,7 @@
 #include "graphics_svo.hpp"
 #include "physics.hpp"
 #include "scene.hpp"
+#include "stream.hpp"
 #include "svo_picker.hpp"
 #include "svo_registry.hpp"
 #include "worldsvo.hpp"
@@ -244,6 +245,69 @@ void vxh_physics_update(float delta_time, float* entities, const float* aabb_res
         systems::Physics::update_entity(e, AabbResult{Vec3{r[0], r[1], r[2]}, Vec3{r[3], r[4], r[5]}}, delta_time);
         entity_to(e, entities + kEntityFloats * i);
     }
+}
+
+// ---- world streaming (chunk loader -> generated chunks -> dirty ranges -> vx_commit) --------------------------------------
+
+namespace {
+struct Streamer {
+    int svo_type;
+    systems::WorldStreamer<Esvo<EsvoSerializedChunk>, EsvoSerializedChunk> esvo;
+    systems::WorldStreamer<Csvo, CsvoSerializedChunk> csvo;
+    Streamer(int t, uint32_t depth, uint32_t seed, uint32_t radius, int32_t y0, int32_t y1)
+        : svo_type(t), esvo(depth, seed, radius, y0, y1), csvo(depth, seed, radius, y0, y1) {}
+};
+}  // namespace
+
+void* vxh_stream_new(int svo_type, uint32_t scene_depth, uint32_t seed, uint32_t radius, int32_t start_y, int32_t end_y) {
+    if ((svo_type != 1 && svo_type != 2) || !(start_y < end_y)) return nullptr;
+    return new (std::nothrow) Streamer(svo_type, scene_depth, seed, radius, start_y, end_y);
+}
+void vxh_stream_free(void* s) { delete static_cast<Streamer*>(s); }
+
+uint64_t vxh_stream_move_to(void* sp, float x, float y, float z) {
+    Streamer* s = static_cast<Streamer*>(sp);
+    return s->svo_type == 1 ? s->esvo.move_to(x, y, z) : s->csvo.move_to(x, y, z);
+}
+
+// out[8] = events, loads, unloads, lod_changes, ranges, bytes, arena_bytes, pending; returns 0 or -1 (capacity / HIP error)
+int vxh_stream_pump(void* sp, void* ctx, uint32_t max_events, uint64_t* out) {
+    Streamer* s = static_cast<Streamer*>(sp);
+    try {
+        const systems::PumpStats st = s->svo_type == 1 ? s->esvo.pump(static_cast<vx_context*>(ctx), max_events) : s->csvo.pump(static_cast<vx_context*>(ctx), max_events);
+        const uint64_t v[8] = {st.events, st.loads, st.unloads, st.lod_changes, st.ranges, st.bytes, st.arena_bytes, st.pending};
+        std::memcpy(out, v, sizeof v);
+        return 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+// the streamer's whole world as one frame [f32 2^-depth][header][arena] (what a full upload would send), for the oracle
+size_t vxh_stream_frame(void* sp, uint8_t* dst, size_t cap) {
+    Streamer* s = static_cast<Streamer*>(sp);
+    auto emit = [&](auto& w, size_t header) -> size_t {
+        const size_t need = 4 + header + w.size_in_bytes();
+        if (!dst || cap < need) return need;
+        const float scale = std::ldexp(1.0f, -int(w.depth()));
+        std::memcpy(dst, &scale, 4);
+        w.write_to(dst + 4);
+        return need;
+    };
+    return s->svo_type == 1 ? emit(s->esvo.world(), 20) : emit(s->csvo.world(), 4);
+}
+
+// world block position -> SVO position of the streamer's current coordinate space
+void vxh_stream_to_svo(void* sp, const float* world_pos, float* svo_pos) {
+    Streamer* s = static_cast<Streamer*>(sp);
+    const systems::SvoCoordSpace& cs = s->svo_type == 1 ? s->esvo.coord_space() : s->csvo.coord_space();
+    const Vec3 p = cs.cnv_block_pos(Vec3{world_pos[0], world_pos[1], world_pos[2]});
+    svo_pos[0] = p.x; svo_pos[1] = p.y; svo_pos[2] = p.z;
+}
+
+uint64_t vxh_stream_resident_chunks(void* sp) {
+    Streamer* s = static_cast<Streamer*>(sp);
+    return s->svo_type == 1 ? s->esvo.resident_chunks() : s->csvo.resident_chunks();
 }
 
 // ---- graphics::Svo end to end (src/graphics/svo.rs:342-449), needs a GPU -----------------------------------------------

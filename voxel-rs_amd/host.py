@@ -47,6 +47,13 @@ def lib():
             "vxh_scene_build_heightfield": (u64, [vp, u32, u32, u32, vp, vp]),
             "vxh_picker_serialize": (u32, [vp, u32, vp, u32, vp, u32]),
             "vxh_picker_deserialize": (None, [vp, u32, vp, u32, vp, vp, vp]),
+            "vxh_stream_new": (vp, [C.c_int, u32, u32, u32, C.c_int32, C.c_int32]),
+            "vxh_stream_free": (None, [vp]),
+            "vxh_stream_move_to": (u64, [vp, C.c_float, C.c_float, C.c_float]),
+            "vxh_stream_pump": (C.c_int, [vp, vp, u32, vp]),
+            "vxh_stream_frame": (sz, [vp, vp, sz]),
+            "vxh_stream_to_svo": (None, [vp, vp, vp]),
+            "vxh_stream_resident_chunks": (u64, [vp]),
             "vxh_physics_step_many": (C.c_int64, [vp, C.c_float, u32, vp, u32]),
             "vxh_physics_update": (None, [C.c_float, vp, vp, u32]),
             "vxh_reference_render_test": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, sz]),
@@ -204,6 +211,51 @@ def picker_deserialize(rays, aabbs, results):
     lib().vxh_picker_deserialize(r.ctypes.data_as(C.c_void_p), len(rays), a.ctypes.data_as(C.c_void_p), len(aabbs), res.ctypes.data_as(C.c_void_p),
                                  out_r.ctypes.data_as(C.c_void_p), out_a.ctypes.data_as(C.c_void_p))
     return out_r, out_a
+
+
+class WorldStreamer:
+    """Chunk loader -> generated heightfield chunks at their LOD -> SVO leaves -> dirty ranges -> vx_commit
+    (csrc/host/stream.hpp; src/systems/chunkloader.rs + src/systems/worldsvo.rs:133-196)."""
+
+    PUMP_FIELDS = ("events", "loads", "unloads", "lod_changes", "ranges", "bytes", "arena_bytes", "pending")
+
+    def __init__(self, svo_type, scene_depth, radius, start_y, end_y, seed=0x5EED0001):
+        self._h = lib().vxh_stream_new(svo_type, scene_depth, seed, radius, start_y, end_y)
+        if not self._h:
+            raise ValueError("bad streamer parameters")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vxh_stream_free(self._h)
+            self._h = None
+
+    def move_to(self, x, y, z):
+        """Queues the chunk events of the target moving to this world position; returns how many."""
+        return int(lib().vxh_stream_move_to(self._h, x, y, z))
+
+    def pump(self, svo_handle, max_events=400):
+        """Applies up to max_events queued events and commits the dirty ranges to the vx context (needs a GPU)."""
+        out = (C.c_uint64 * 8)()
+        if lib().vxh_stream_pump(self._h, svo_handle, max_events, out) != 0:
+            raise RuntimeError("stream pump failed (capacity exceeded or HIP error)")
+        return dict(zip(self.PUMP_FIELDS, (int(v) for v in out)))
+
+    def frame(self, pad_words=4):
+        """The whole current world as one frame (what a full upload would send), uint32 words."""
+        need = lib().vxh_stream_frame(self._h, None, 0)
+        buf = np.zeros((need + 3) // 4 + pad_words, dtype=np.uint32)
+        lib().vxh_stream_frame(self._h, buf.ctypes.data_as(C.c_void_p), buf.size * 4)
+        return buf
+
+    def to_svo(self, world_pos):
+        w = (C.c_float * 3)(*world_pos)
+        s = (C.c_float * 3)()
+        lib().vxh_stream_to_svo(self._h, w, s)
+        return tuple(s)
+
+    @property
+    def resident_chunks(self):
+        return int(lib().vxh_stream_resident_chunks(self._h))
 
 
 ENTITY_FLOATS = 17  # position, velocity, aabb offset, aabb extents, wall_clip, flying, gravity, max_fall_velocity, is_grounded
