@@ -270,12 +270,14 @@ uint64_t vxh_stream_move_to(void* sp, float x, float y, float z) {
     return s->svo_type == 1 ? s->esvo.move_to(x, y, z) : s->csvo.move_to(x, y, z);
 }
 
-// out[8] = events, loads, unloads, lod_changes, ranges, bytes, arena_bytes, pending; returns 0 or -1 (capacity / HIP error)
+// out[11] = events, loads, unloads, lod_changes, ranges, bytes, arena_bytes, pending, build_us, apply_us, commit_us;
+// returns 0 or -1 (capacity / HIP error)
 int vxh_stream_pump(void* sp, void* ctx, uint32_t max_events, uint64_t* out) {
     Streamer* s = static_cast<Streamer*>(sp);
     try {
         const systems::PumpStats st = s->svo_type == 1 ? s->esvo.pump(static_cast<vx_context*>(ctx), max_events) : s->csvo.pump(static_cast<vx_context*>(ctx), max_events);
-        const uint64_t v[8] = {st.events, st.loads, st.unloads, st.lod_changes, st.ranges, st.bytes, st.arena_bytes, st.pending};
+        const uint64_t v[11] = {st.events, st.loads, st.unloads, st.lod_changes, st.ranges, st.bytes, st.arena_bytes, st.pending,
+                                uint64_t(st.build_ms * 1000.0), uint64_t(st.apply_ms * 1000.0), uint64_t(st.commit_ms * 1000.0)};
         std::memcpy(out, v, sizeof v);
         return 0;
     } catch (const std::exception&) {

@@ -9,9 +9,12 @@
 // Terrain is the build's integer value-noise heightfield (scene.hpp), evaluated per chunk in world coordinates.
 #pragma once
 
+#include <atomic>
+#include <chrono>
 #include <deque>
 #include <optional>
 #include <stdexcept>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -61,14 +64,16 @@ struct PumpStats {
     uint64_t arena_bytes = 0;   // size_in_bytes() after the commit
     uint32_t depth = 0;
     uint32_t pending = 0;       // events still queued
+    double build_ms = 0, apply_ms = 0, commit_ms = 0;  // host time: chunk generation + serialization (workers), set_leaf / root, staging write + vx_commit
 };
 
 template <class WorldT, class SerializedT>
 class WorldStreamer {
 public:
-    WorldStreamer(uint32_t scene_depth, uint32_t seed, uint32_t radius, int32_t start_y, int32_t end_y)
+    WorldStreamer(uint32_t scene_depth, uint32_t seed, uint32_t radius, int32_t start_y, int32_t end_y, uint32_t threads = 0)
         : scene_depth_(scene_depth), seed_(seed), loader_(radius, start_y, end_y) {
         cs_.dst = radius;
+        threads_ = threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     }
 
     // returns the number of events the move produced
@@ -87,9 +92,38 @@ public:
 
     PumpStats pump(vx_context* ctx, uint32_t max_events) {
         PumpStats st;
-        while (!queue_.empty() && st.events < max_events) {
-            const ChunkEvent e = queue_.front();
+        using clock = std::chrono::steady_clock;
+        auto ms_since = [](clock::time_point t0) { return std::chrono::duration<double, std::milli>(clock::now() - t0).count(); };
+        clock::time_point t0 = clock::now();
+        // take the batch, build its chunks on worker threads (the reference serializes chunks on its job system,
+        // worldsvo.rs:90-99), then apply the results in event order on this thread
+        std::vector<ChunkEvent> batch;
+        while (!queue_.empty() && batch.size() < max_events) {
+            batch.push_back(queue_.front());
             queue_.pop_front();
+        }
+        std::vector<std::optional<Position>> where(batch.size());
+        std::vector<std::optional<SerializedT>> built(batch.size());
+        for (size_t i = 0; i < batch.size(); ++i)
+            if (batch[i].kind != ChunkEvent::Unload) where[i] = cs_.cnv_chunk_pos(batch[i].pos);  // none: outside the cylinder by now
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < batch.size();) {
+                if (!where[i]) continue;
+                std::optional<Chunk> chunk = generate_heightfield_chunk(scene_depth_, seed_, batch[i].pos, batch[i].lod);
+                if (chunk) built[i].emplace(*chunk);
+            }
+        };
+        const uint32_t n_workers = std::min<uint32_t>(threads_, uint32_t(batch.size() / 8 + 1));
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < n_workers; ++t) pool.emplace_back(worker);
+        worker();
+        for (std::thread& t : pool) t.join();
+        st.build_ms = ms_since(t0);
+        t0 = clock::now();
+
+        for (size_t i = 0; i < batch.size(); ++i) {
+            const ChunkEvent& e = batch[i];
             ++st.events;
             if (e.kind == ChunkEvent::Unload) {
                 ++st.unloads;
@@ -97,14 +131,12 @@ public:
                 continue;
             }
             if (e.kind == ChunkEvent::Load) ++st.loads; else ++st.lod_changes;
-            const std::optional<Position> p = cs_.cnv_chunk_pos(e.pos);
-            if (!p) continue;  // outside the SVO's cylinder by now (the centre moved on): the loader will unload it
-            std::optional<Chunk> chunk = generate_heightfield_chunk(scene_depth_, seed_, e.pos, e.lod);
-            if (!chunk) {
+            if (!where[i]) continue;
+            if (!built[i]) {
                 remove(e.pos);  // an LOD change of a chunk that has nothing to show
                 continue;
             }
-            auto r = world_.set_leaf(*p, SerializedT(*chunk), true);
+            auto r = world_.set_leaf(*where[i], std::move(*built[i]), true);
             leaf_ids_[e.pos] = r.first;
             dirty_ = true;
         }
@@ -112,6 +144,8 @@ public:
         if (dirty_) {
             dirty_ = false;
             world_.serialize();
+            st.apply_ms = ms_since(t0);
+            t0 = clock::now();
             std::vector<vx_range> ranges;
             for (const Range& r : world_.buffer.updated_ranges) {
                 ranges.push_back(vx_range{r.start, r.length});  // RangeBuffer counts bytes for both formats here
@@ -125,6 +159,7 @@ public:
             } else {
                 world_.buffer.updated_ranges.clear();  // dry run (host-only tests): the world is updated, nothing is uploaded
             }
+            st.commit_ms = ms_since(t0);
         }
         st.arena_bytes = world_.size_in_bytes();
         st.depth = world_.depth();
@@ -145,7 +180,7 @@ private:
         dirty_ = true;
     }
 
-    uint32_t scene_depth_, seed_;
+    uint32_t scene_depth_, seed_, threads_ = 1;
     ChunkLoader loader_;
     SvoCoordSpace cs_;
     bool has_centre_ = false, dirty_ = false;

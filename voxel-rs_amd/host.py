@@ -217,7 +217,7 @@ class WorldStreamer:
     """Chunk loader -> generated heightfield chunks at their LOD -> SVO leaves -> dirty ranges -> vx_commit
     (csrc/host/stream.hpp; src/systems/chunkloader.rs + src/systems/worldsvo.rs:133-196)."""
 
-    PUMP_FIELDS = ("events", "loads", "unloads", "lod_changes", "ranges", "bytes", "arena_bytes", "pending")
+    PUMP_FIELDS = ("events", "loads", "unloads", "lod_changes", "ranges", "bytes", "arena_bytes", "pending", "build_us", "apply_us", "commit_us")
 
     def __init__(self, svo_type, scene_depth, radius, start_y, end_y, seed=0x5EED0001):
         self._h = lib().vxh_stream_new(svo_type, scene_depth, seed, radius, start_y, end_y)
@@ -235,7 +235,7 @@ class WorldStreamer:
 
     def pump(self, svo_handle, max_events=400):
         """Applies up to max_events queued events and commits the dirty ranges to the vx context (needs a GPU)."""
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 11)()
         if lib().vxh_stream_pump(self._h, svo_handle, max_events, out) != 0:
             raise RuntimeError("stream pump failed (capacity exceeded or HIP error)")
         return dict(zip(self.PUMP_FIELDS, (int(v) for v in out)))
