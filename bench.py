@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--format", choices=["esvo", "csvo"], default="csvo", help="node format; csvo is the reference's default build feature")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N > 1 code path (tile lists, RCCL gather, assembly) even with one rank; needs a torch.distributed.run launch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock target for the cpu_baseline sample (all host cores)")
     args = ap.parse_args()
 
@@ -82,7 +84,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world_size > 1:
+    sharded = world_size > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
@@ -111,7 +114,7 @@ def main():
     my_rays = counters["rays"]
     my_bytes = algorithmic_bytes(args.format, counters)
 
-    if world_size > 1:
+    if sharded:
         from voxel_rs_amd.sharding import FrameSharder
 
         vx_stream = torch.cuda.ExternalStream(svo.stream)
@@ -120,16 +123,18 @@ def main():
             svo.render_device(uniforms, W, H, tiles.data_ptr(), tile_rank=rank, tile_count=world_size)
 
         def assemble(gathered, image):
-            svo.assemble_tiles(gathered.data_ptr(), gathered.shape[1] * 32 * 32 * 4, world_size, W, H, image.data_ptr())
+            # on the collective's stream: ordered after the gather by construction, and the render stream stays free for the
+            # next frame's tiles
+            svo.assemble_tiles(gathered.data_ptr(), gathered.shape[1] * 32 * 32 * 4, world_size, W, H, image.data_ptr(),
+                               stream=torch.cuda.current_stream().cuda_stream)
 
-        # The renderer has its own stream and the collective runs on torch's. With two tile buffers, render k+1 may start
-        # once collective k-1 (the previous user of its buffer) is done; waiting for ALL prior collectives is a superset.
-        # An event per buffer would be tighter; stream-level waits keep this simple and are correct.
+        # The renderer has its own stream; the gather and the assembly run on torch's. Two tile buffers: render k+1 only has
+        # to wait for the collective that last read its buffer (k-1), so it overlaps gather + assembly of frame k.
         gather_done = [torch.cuda.Event(), torch.cuda.Event()]
         state = {"i": 0}
 
         def before_render():
-            gather_done[state["i"] % 2].wait(vx_stream)  # the collective that last read this tile buffer (no-op until recorded)
+            gather_done[state["i"] % 2].wait(vx_stream)  # no-op until the event has been recorded once
 
         def before_gather():
             torch.cuda.current_stream().wait_stream(vx_stream)
@@ -139,7 +144,7 @@ def main():
             state["i"] += 1
 
         sharder = FrameSharder(W, H, rank, world_size, dist, "cuda", render_tiles, assemble, before_render=before_render,
-                               before_gather=before_gather, after_gather=lambda: vx_stream.wait_stream(torch.cuda.current_stream()))
+                               before_gather=before_gather)
         _step = sharder.step
 
         def step():

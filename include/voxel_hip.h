@@ -206,6 +206,10 @@ int vx_sync(vx_context* ctx);
  * width*height RGBA32F image; all pointers are device memory on this context's device. */
 int vx_assemble_tiles(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
                       float* out_rgba32f);
+/* The same on a caller-supplied hipStream_t (e.g. the stream the gather ran on, so that the context's own stream is free to
+ * render the next frame meanwhile); NULL = the legacy default stream. */
+int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
+                         float* out_rgba32f, void* stream);
 /* Number of tiles (32x32) rank `tile_rank` of `tile_count` owns for a width x height image. */
 uint32_t vx_local_tile_count(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count);
 

@@ -909,11 +909,16 @@ int vx_sync(vx_context* ctx) {
 
 int vx_assemble_tiles(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
                       float* out_rgba32f) {
+    return vx_assemble_tiles_on(ctx, tiles, stride_floats, tile_count, width, height, out_rgba32f, ctx ? ctx->stream : nullptr);
+}
+
+int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
+                         float* out_rgba32f, void* stream) {
     if (!ctx || !tiles || !out_rgba32f || !tile_count || !width || !height || (stride_floats & 3))
         return fail(VX_ERR_INVALID_ARGUMENT, "assemble_tiles: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
     const dim3 grid((width + 15) / 16, (height + 15) / 16), block(256);
-    hipLaunchKernelGGL(assemble_kernel, grid, block, 0, ctx->stream, reinterpret_cast<const float4*>(tiles), stride_floats / 4, tile_count, width, height,
+    hipLaunchKernelGGL(assemble_kernel, grid, block, 0, static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(tiles), stride_floats / 4, tile_count, width, height,
                        (width + kTile - 1) / kTile, reinterpret_cast<float4*>(out_rgba32f));
     HIP_TRY(hipGetLastError());
     return VX_OK;

@@ -76,6 +76,7 @@ SYMBOLS = {
     "vx_debug_trace": (_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.c_float, _int, C.POINTER(Result), _vp, _u32, C.POINTER(_u32)]),
     "vx_sync": (_int, [_vp]),
     "vx_assemble_tiles": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
+    "vx_assemble_tiles_on": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp]),
     "vx_local_tile_count": (_u32, [_u32, _u32, _u32, _u32]),
     "vx_render_counters": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, _u32, _u32, C.POINTER(Counters)]),
     "vx_profile_enable": (_int, [_vp, _int]),
@@ -227,8 +228,12 @@ class Svo:
                                     max_frames, C.byref(n)))
         return res, frames[:min(n.value, max_frames)], n.value
 
-    def assemble_tiles(self, tiles_ptr, stride_floats, tile_count, width, height, out_ptr):
-        _check(lib().vx_assemble_tiles(self._h, tiles_ptr, stride_floats, tile_count, width, height, out_ptr))
+    def assemble_tiles(self, tiles_ptr, stride_floats, tile_count, width, height, out_ptr, stream=None):
+        """stream = a raw hipStream_t to launch on (default: the context's own stream)."""
+        if stream is None:
+            _check(lib().vx_assemble_tiles(self._h, tiles_ptr, stride_floats, tile_count, width, height, out_ptr))
+        else:
+            _check(lib().vx_assemble_tiles_on(self._h, tiles_ptr, stride_floats, tile_count, width, height, out_ptr, _vp(stream)))
 
     def sync(self):
         _check(lib().vx_sync(self._h))
