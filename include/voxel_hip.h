@@ -199,6 +199,15 @@ int vx_debug_trace(vx_context* ctx, const float pos[3], const float dir[3], floa
                    vx_frame* frames, uint32_t max_frames, uint32_t* n_frames);
 /* Fence::wait for everything enqueued on this context (src/graphics/fence.rs:8-42). */
 int vx_sync(vx_context* ctx);
+/* Frames in flight. vx_render of an image (no hit records) into DEVICE memory returns after enqueueing and consecutive
+ * frames alternate between two internal streams, so that frame k+1 starts on the compute units frame k's last rays leave
+ * idle. Two calls order such a render against the caller's own streams:
+ *   vx_wait_event(ctx, e)           the NEXT vx_render waits for the hipEvent_t `e` (e.g. "the buffer I am about to
+ *                                   render into has been consumed"); one-shot
+ *   vx_stream_wait_render(ctx, s)   the caller's hipStream_t `s` waits for the most recently issued vx_render
+ * vx_sync waits for everything; vx_commit orders uploads after every frame in flight (Svo::update's fence, svo.rs:178). */
+int vx_wait_event(vx_context* ctx, void* hip_event);
+int vx_stream_wait_render(vx_context* ctx, void* stream);
 
 /* ---- multi-GPU image assembly ----------------------------------------------------------------------------- */
 

@@ -6,6 +6,7 @@
 import argparse
 import os
 import statistics
+import time
 import sys
 from pathlib import Path
 
@@ -16,7 +17,7 @@ from _pkg import load_package  # noqa: E402
 vra = load_package()
 from voxel_rs_amd import hip, scenes  # noqa: E402
 
-KEYS = {"k": "VX_RENDER_KERNEL", "r": "VX_REFILL_MIN", "s": "VX_SERVICE_MIN", "m": "VX_MIN_WAVES", "w": "VX_WAVES_PER_CU"}
+KEYS = {"k": "VX_RENDER_KERNEL", "r": "VX_REFILL_MIN", "s": "VX_SERVICE_MIN", "m": "VX_MIN_WAVES", "w": "VX_WAVES_PER_CU", "f": "VX_FRAMES_IN_FLIGHT"}
 
 
 def main():
@@ -28,6 +29,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--configs", nargs="+", required=True)
+    ap.add_argument("--tiles", type=int, default=1, help="render only rank 0's share of an N-way tile sharding (what one of N GPUs does)")
     args = ap.parse_args()
     import torch
 
@@ -50,23 +52,27 @@ def main():
         svo.set_textures(tex, 6)
         svo.update_full(world)
         for _ in range(3):
-            svo.render_device(u, W, H, image.data_ptr())
+            svo.render_device(u, W, H, image.data_ptr(), tile_rank=0, tile_count=args.tiles)
         svo.sync()
-        ctxs.append((cfg, svo, []))
-    counters = ctxs[0][1].render_counters(u, W, H)
+        ctxs.append((cfg, svo, [], []))
+    counters = ctxs[0][1].render_counters(u, W, H, 0, args.tiles)
     rays = counters["rays"]
     print("counters:", {k: int(v) for k, v in counters.items()})
     for _ in range(args.rounds):
-        for cfg, svo, times in ctxs:
+        for cfg, svo, times, walls in ctxs:
             svo.profile_enable(True)
+            svo.sync()
+            t0 = time.perf_counter()
             for _ in range(args.steps):
-                svo.render_device(u, W, H, image.data_ptr())
+                svo.render_device(u, W, H, image.data_ptr(), tile_rank=0, tile_count=args.tiles)
+            svo.sync()
+            walls.append((time.perf_counter() - t0) * 1e3 / args.steps)
             ms, n = svo.profile_read()
             svo.profile_enable(False)
             times.append(ms / n)
-    for cfg, svo, times in ctxs:
-        med, mn = statistics.median(times), min(times)
-        print(f"{args.format} {cfg:28s} kernel ms median {med:.4f} min {mn:.4f}  -> {rays / med / 1e3:.1f} Mrays/s")
+    for cfg, svo, times, walls in ctxs:
+        med, mn, wall = statistics.median(times), min(times), statistics.median(walls)
+        print(f"{args.format} {cfg:24s} kernel span ms median {med:.4f} min {mn:.4f} | wall ms/frame {wall:.4f} -> {rays / wall / 1e3:.1f} Mrays/s")
 
 
 if __name__ == "__main__":

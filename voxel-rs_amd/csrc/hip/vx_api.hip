@@ -430,6 +430,18 @@ struct vx_context {
     hipStream_t upload_stream = nullptr;  // range uploads
     hipEvent_t upload_done = nullptr, render_done = nullptr;
     bool committed = false, render_recorded = false;
+    // Frames in flight: image-only renders into device memory alternate between two streams, so that the first waves of
+    // frame k+1 fill the CUs the last long rays of frame k leave idle (each frame is one persistent kernel whose tail runs at
+    // low occupancy). Everything else (picker, hit records, host targets, counters) stays on `stream`.
+    static constexpr int kFrameStreams = 2;
+    hipStream_t frame_stream[kFrameStreams] = {};
+    hipEvent_t frame_done[kFrameStreams] = {};
+    bool frame_recorded[kFrameStreams] = {};
+    uint32_t* d_frame_counter[kFrameStreams] = {};
+    hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
+    int frames_in_flight = 2;           // VX_FRAMES_IN_FLIGHT=1 serialises frames on `stream` again
+    unsigned frame_index = 0;
+    int last_frame_slot = -1;           // slot of the most recent pipelined render, -1 = it ran on `stream`
     vx_stats stats = {};
 
     vx_material* d_materials = nullptr;
@@ -495,13 +507,15 @@ int check_ready(vx_context* ctx) {
 }
 
 template <bool HITS, bool STATS>
-int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hits, unsigned long long* counters) {
+int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hits, unsigned long long* counters, int slot = -1) {
+    const hipStream_t stream = slot >= 0 ? ctx->frame_stream[slot] : ctx->stream;
+    uint32_t* const work_counter = slot >= 0 ? ctx->d_frame_counter[slot] : ctx->d_work_counter;
     const size_t lds = Stack<kBlockThreads>::kBytes;
     const dim3 grid(p.n_local_tiles * 4), block(kBlockThreads);
     if (grid.x == 0) return VX_OK;
     const SceneArgs sc = scene_of(ctx);
 
-    if (ctx->kernel_version != 1) HIP_TRY(hipMemsetAsync(ctx->d_work_counter, 0, sizeof(uint32_t), ctx->stream));  // sub-tile queue head
+    if (ctx->kernel_version != 1) HIP_TRY(hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream));  // sub-tile queue head
     ProfiledLaunch ev{};
     if (ctx->profile) {
         if (!ctx->event_pool.empty()) {
@@ -511,13 +525,13 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             HIP_TRY(hipEventCreate(&ev.start));
             HIP_TRY(hipEventCreate(&ev.stop));
         }
-        HIP_TRY(hipEventRecord(ev.start, ctx->stream));
+        HIP_TRY(hipEventRecord(ev.start, stream));
     }
     if (ctx->kernel_version == 1) {
         if (ctx->svo_type == VX_SVO_ESVO)
-            hipLaunchKernelGGL((render_kernel<VX_SVO_ESVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters);
+            hipLaunchKernelGGL((render_kernel<VX_SVO_ESVO, HITS, STATS>), grid, block, lds, stream, sc, p, reinterpret_cast<float4*>(out), hits, counters);
         else
-            hipLaunchKernelGGL((render_kernel<VX_SVO_CSVO, HITS, STATS>), grid, block, lds, ctx->stream, sc, p, reinterpret_cast<float4*>(out), hits, counters);
+            hipLaunchKernelGGL((render_kernel<VX_SVO_CSVO, HITS, STATS>), grid, block, lds, stream, sc, p, reinterpret_cast<float4*>(out), hits, counters);
     } else {
         // persistent waves: as many 64-thread workgroups as the device keeps resident, fed from the sub-tile queue
         const size_t wave_lds = Stack<64>::kBytes;
@@ -534,22 +548,28 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             per_cu = n;
         }
         PersistentArgs a;
-        a.work_counter = ctx->d_work_counter;
+        a.work_counter = work_counter;
         a.total_subtiles = p.n_local_tiles * 16;
         a.refill_min = ctx->refill_min;
         a.service_min = ctx->service_min;
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters};
-        HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, ctx->stream));
+        HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
     }
     HIP_TRY(hipGetLastError());
     if (ctx->profile) {
-        HIP_TRY(hipEventRecord(ev.stop, ctx->stream));
+        HIP_TRY(hipEventRecord(ev.stop, stream));
         ctx->launches.push_back(ev);
     }
-    HIP_TRY(hipEventRecord(ctx->render_done, ctx->stream));
-    ctx->render_recorded = true;
+    if (slot >= 0) {
+        HIP_TRY(hipEventRecord(ctx->frame_done[slot], stream));
+        ctx->frame_recorded[slot] = true;
+    } else {
+        HIP_TRY(hipEventRecord(ctx->render_done, stream));
+        ctx->render_recorded = true;
+    }
+    ctx->last_frame_slot = slot;
     return VX_OK;
 }
 
@@ -626,6 +646,17 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     CREATE_TRY(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&c->render_done, hipEventDisableTiming));
+    // The two frame streams must sit on different hardware queues or their kernels serialise; the runtime shares a small
+    // pool of queues between streams of equal priority (GPU_MAX_HW_QUEUES) with no way to ask which one a stream got, but a
+    // stream of another priority never shares a queue with them. Odd frames therefore run at the next priority level.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    for (int i = 0; i < vx_context::kFrameStreams; ++i) {
+        const int prio = (i == 1 && prio_greatest < prio_least) ? prio_least - 1 : prio_least;
+        CREATE_TRY(hipStreamCreateWithPriority(&c->frame_stream[i], hipStreamNonBlocking, prio));
+        CREATE_TRY(hipEventCreateWithFlags(&c->frame_done[i], hipEventDisableTiming));
+        CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_frame_counter[i]), sizeof(uint32_t)));
+    }
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
     {
@@ -634,6 +665,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("VX_MIN_WAVES")) c->min_waves = std::atoi(e);
+        if (const char* e = std::getenv("VX_FRAMES_IN_FLIGHT")) c->frames_in_flight = std::atoi(e) >= 2 ? 2 : 1;
         if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
@@ -664,6 +696,12 @@ void vx_destroy(vx_context* c) {
                    c->d_trace_count, c->d_counters, c->d_work_counter};
     for (void* p : dev)
         if (p) (void)hipFree(p);
+    for (int i = 0; i < vx_context::kFrameStreams; ++i) {
+        if (c->frame_stream[i]) (void)hipStreamSynchronize(c->frame_stream[i]);
+        if (c->d_frame_counter[i]) (void)hipFree(c->d_frame_counter[i]);
+        if (c->frame_done[i]) (void)hipEventDestroy(c->frame_done[i]);
+        if (c->frame_stream[i]) (void)hipStreamDestroy(c->frame_stream[i]);
+    }
     if (c->upload_done) (void)hipEventDestroy(c->upload_done);
     if (c->render_done) (void)hipEventDestroy(c->render_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -749,6 +787,8 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
 
     // render_fence.wait() (svo.rs:178): do not overwrite nodes a frame in flight is still traversing
     if (ctx->render_recorded) HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, ctx->render_done, 0));
+    for (int i = 0; i < vx_context::kFrameStreams; ++i)
+        if (ctx->frame_recorded[i]) HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, ctx->frame_done[i], 0));
     HIP_TRY(hipMemcpyAsync(ctx->d_world, ctx->staging, head, hipMemcpyHostToDevice, ctx->upload_stream));
     for (uint32_t i = 0; i < count; ++i) {
         if (!ranges[i].length) continue;
@@ -757,6 +797,7 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
     }
     HIP_TRY(hipEventRecord(ctx->upload_done, ctx->upload_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_done, 0));
+    for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamWaitEvent(ctx->frame_stream[i], ctx->upload_done, 0));
     // the caller may rewrite the staging mirror as soon as we return: wait for the copies to have read it
     HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
 
@@ -794,7 +835,17 @@ int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint
             hits = ctx->d_hits;
         }
     }
-    const int rc = hits ? launch_render<true, false>(ctx, p, out, hits, nullptr) : launch_render<false, false>(ctx, p, out, nullptr, nullptr);
+    int slot = -1;
+    if (!hits && target->memory == VX_MEM_DEVICE && ctx->frames_in_flight > 1 && ctx->kernel_version != 1) {
+        slot = int(ctx->frame_index++ % vx_context::kFrameStreams);
+        // ordered after whatever the caller put on `stream` before the PREVIOUS frame on this slot was issued is implied by
+        // stream order; explicit cross-stream dependencies come in through vx_wait_event
+        if (ctx->pending_wait) HIP_TRY(hipStreamWaitEvent(ctx->frame_stream[slot], ctx->pending_wait, 0));
+    } else if (ctx->pending_wait) {
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->pending_wait, 0));
+    }
+    ctx->pending_wait = nullptr;
+    const int rc = hits ? launch_render<true, false>(ctx, p, out, hits, nullptr) : launch_render<false, false>(ctx, p, out, nullptr, nullptr, slot);
     if (rc) return rc;
     if (target->memory == VX_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(target->rgba32f, ctx->d_frame, pixels * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -904,12 +955,35 @@ int vx_sync(vx_context* ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
+    return VX_OK;
+}
+
+int vx_wait_event(vx_context* ctx, void* hip_event) {
+    if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    ctx->pending_wait = static_cast<hipEvent_t>(hip_event);
+    return VX_OK;
+}
+
+int vx_stream_wait_render(vx_context* ctx, void* stream) {
+    if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int slot = ctx->last_frame_slot;
+    if (slot >= 0) {
+        if (ctx->frame_recorded[slot]) HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), ctx->frame_done[slot], 0));
+    } else if (ctx->render_recorded) {
+        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), ctx->render_done, 0));
+    }
     return VX_OK;
 }
 
 int vx_assemble_tiles(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
                       float* out_rgba32f) {
-    return vx_assemble_tiles_on(ctx, tiles, stride_floats, tile_count, width, height, out_rgba32f, ctx ? ctx->stream : nullptr);
+    if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    // on the context's own stream the tile lists may come from frames still in flight on the frame streams: order after them
+    for (int i = 0; i < vx_context::kFrameStreams; ++i)
+        if (ctx->frame_recorded[i]) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->frame_done[i], 0));
+    return vx_assemble_tiles_on(ctx, tiles, stride_floats, tile_count, width, height, out_rgba32f, ctx->stream);
 }
 
 int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
@@ -934,6 +1008,7 @@ int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches) 
     if (!ctx || !kernel_ms_sum || !launches) return fail(VX_ERR_INVALID_ARGUMENT, "profile_read: null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
     double sum = 0.0;
     for (auto& l : ctx->launches) {
         float ms = 0.0f;

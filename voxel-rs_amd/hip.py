@@ -75,6 +75,8 @@ SYMBOLS = {
     "vx_raycast": (_int, [_vp, _vp, _u32, _vp]),
     "vx_debug_trace": (_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.c_float, _int, C.POINTER(Result), _vp, _u32, C.POINTER(_u32)]),
     "vx_sync": (_int, [_vp]),
+    "vx_wait_event": (_int, [_vp, _vp]),
+    "vx_stream_wait_render": (_int, [_vp, _vp]),
     "vx_assemble_tiles": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "vx_assemble_tiles_on": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp]),
     "vx_local_tile_count": (_u32, [_u32, _u32, _u32, _u32]),
@@ -237,6 +239,14 @@ class Svo:
 
     def sync(self):
         _check(lib().vx_sync(self._h))
+
+    def wait_event(self, hip_event):
+        """The next render waits for this raw hipEvent_t (e.g. torch.cuda.Event.cuda_event)."""
+        _check(lib().vx_wait_event(self._h, _vp(hip_event)))
+
+    def stream_wait_render(self, stream):
+        """Makes the raw hipStream_t `stream` wait for the most recently issued render."""
+        _check(lib().vx_stream_wait_render(self._h, _vp(stream)))
 
     def profile_enable(self, on=True):
         _check(lib().vx_profile_enable(self._h, int(on)))
