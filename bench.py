@@ -126,24 +126,26 @@ def main():
             svo.assemble_tiles(gathered.data_ptr(), gathered.shape[1] * 32 * 32 * 4, world_size, W, H, image.data_ptr(),
                                stream=torch.cuda.current_stream().cuda_stream)
 
-        # The renderer runs frames on its own streams; the gather and the assembly run on torch's. Two tile buffers: render
-        # k+1 only has to wait for the collective that last read its buffer (k-1), so it overlaps gather + assembly of frame k.
-        gather_done = [torch.cuda.Event(), torch.cuda.Event()]
+        # The renderer runs frames on its own streams; the gather and the assembly run on torch's. One tile buffer per frame
+        # in flight: a render only has to wait for the collective that last read its buffer.
+        FRAMES = 3  # frames in flight: a rank's share of the frame is small, its tail relatively long
+        svo.set_frames_in_flight(FRAMES)
+        gather_done = [torch.cuda.Event() for _ in range(FRAMES)]
         state = {"i": 0}
 
         def before_render():
-            if state["i"] >= 2:  # recorded at least once
-                svo.wait_event(gather_done[state["i"] % 2].cuda_event)
+            if state["i"] >= FRAMES:  # recorded at least once
+                svo.wait_event(gather_done[state["i"] % FRAMES].cuda_event)
 
         def before_gather():
             svo.stream_wait_render(torch.cuda.current_stream().cuda_stream)
 
         def after_gather_all():
-            gather_done[state["i"] % 2].record(torch.cuda.current_stream())
+            gather_done[state["i"] % FRAMES].record(torch.cuda.current_stream())
             state["i"] += 1
 
         sharder = FrameSharder(W, H, rank, world_size, dist, "cuda", render_tiles, assemble, before_render=before_render,
-                               before_gather=before_gather)
+                               before_gather=before_gather, buffers=FRAMES)
         _step = sharder.step
 
         def step():
@@ -200,7 +202,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(my_bytes), "bytes_per_ray": round(my_bytes / max(my_rays, 1), 2),
                 # two frames are in flight: the per-launch spans above overlap (span x launches > elapsed). What the
                 # device sustains over the timed region is bytes x launches / elapsed:
-                "frames_in_flight": 2, "sustained_GBps": round(my_bytes * launches / max(elapsed, 1e-9) / 1e9, 3)}
+                "frames_in_flight": 3 if sharded else 2, "sustained_GBps": round(my_bytes * launches / max(elapsed, 1e-9) / 1e9, 3)}
 
     cpu = None
     if not args.no_cpu_baseline:

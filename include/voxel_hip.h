@@ -206,6 +206,9 @@ int vx_sync(vx_context* ctx);
  *                                   render into has been consumed"); one-shot
  *   vx_stream_wait_render(ctx, s)   the caller's hipStream_t `s` waits for the most recently issued vx_render
  * vx_sync waits for everything; vx_commit orders uploads after every frame in flight (Svo::update's fence, svo.rs:178). */
+/* 1 = every render on the context's stream again; 2 (default) or 3 = that many frame streams in rotation. More frames in
+ * flight hide more of each frame's tail, which matters when a context renders only a share of the tiles (multi-GPU). */
+int vx_set_frames_in_flight(vx_context* ctx, int frames);
 int vx_wait_event(vx_context* ctx, void* hip_event);
 int vx_stream_wait_render(vx_context* ctx, void* stream);
 

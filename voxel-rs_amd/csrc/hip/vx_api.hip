@@ -433,13 +433,13 @@ struct vx_context {
     // Frames in flight: image-only renders into device memory alternate between two streams, so that the first waves of
     // frame k+1 fill the CUs the last long rays of frame k leave idle (each frame is one persistent kernel whose tail runs at
     // low occupancy). Everything else (picker, hit records, host targets, counters) stays on `stream`.
-    static constexpr int kFrameStreams = 2;
+    static constexpr int kFrameStreams = 3;
     hipStream_t frame_stream[kFrameStreams] = {};
     hipEvent_t frame_done[kFrameStreams] = {};
     bool frame_recorded[kFrameStreams] = {};
     uint32_t* d_frame_counter[kFrameStreams] = {};
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
-    int frames_in_flight = 2;           // VX_FRAMES_IN_FLIGHT=1 serialises frames on `stream` again
+    int frames_in_flight = 2;           // 1 serialises frames on `stream` again (vx_set_frames_in_flight / VX_FRAMES_IN_FLIGHT)
     unsigned frame_index = 0;
     int last_frame_slot = -1;           // slot of the most recent pipelined render, -1 = it ran on `stream`
     vx_stats stats = {};
@@ -652,7 +652,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
-        const int prio = (i == 1 && prio_greatest < prio_least) ? prio_least - 1 : prio_least;
+        const int prio = prio_least - i >= prio_greatest ? prio_least - i : prio_greatest;
         CREATE_TRY(hipStreamCreateWithPriority(&c->frame_stream[i], hipStreamNonBlocking, prio));
         CREATE_TRY(hipEventCreateWithFlags(&c->frame_done[i], hipEventDisableTiming));
         CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_frame_counter[i]), sizeof(uint32_t)));
@@ -665,7 +665,9 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("VX_MIN_WAVES")) c->min_waves = std::atoi(e);
-        if (const char* e = std::getenv("VX_FRAMES_IN_FLIGHT")) c->frames_in_flight = std::atoi(e) >= 2 ? 2 : 1;
+        if (const char* e = std::getenv("VX_FRAMES_IN_FLIGHT")) c->frames_in_flight = std::atoi(e);
+        if (c->frames_in_flight < 1) c->frames_in_flight = 1;
+        if (c->frames_in_flight > vx_context::kFrameStreams) c->frames_in_flight = vx_context::kFrameStreams;
         if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
@@ -837,7 +839,7 @@ int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint
     }
     int slot = -1;
     if (!hits && target->memory == VX_MEM_DEVICE && ctx->frames_in_flight > 1 && ctx->kernel_version != 1) {
-        slot = int(ctx->frame_index++ % vx_context::kFrameStreams);
+        slot = int(ctx->frame_index++ % unsigned(ctx->frames_in_flight));
         // ordered after whatever the caller put on `stream` before the PREVIOUS frame on this slot was issued is implied by
         // stream order; explicit cross-stream dependencies come in through vx_wait_event
         if (ctx->pending_wait) HIP_TRY(hipStreamWaitEvent(ctx->frame_stream[slot], ctx->pending_wait, 0));
@@ -956,6 +958,15 @@ int vx_sync(vx_context* ctx) {
     HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
+    return VX_OK;
+}
+
+int vx_set_frames_in_flight(vx_context* ctx, int frames) {
+    if (!ctx || frames < 1 || frames > vx_context::kFrameStreams) return fail(VX_ERR_INVALID_ARGUMENT, "frames in flight: 1..3");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
+    ctx->frames_in_flight = frames;
+    ctx->frame_index = 0;
     return VX_OK;
 }
 

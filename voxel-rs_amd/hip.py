@@ -75,6 +75,7 @@ SYMBOLS = {
     "vx_raycast": (_int, [_vp, _vp, _u32, _vp]),
     "vx_debug_trace": (_int, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.c_float, _int, C.POINTER(Result), _vp, _u32, C.POINTER(_u32)]),
     "vx_sync": (_int, [_vp]),
+    "vx_set_frames_in_flight": (_int, [_vp, _int]),
     "vx_wait_event": (_int, [_vp, _vp]),
     "vx_stream_wait_render": (_int, [_vp, _vp]),
     "vx_assemble_tiles": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
@@ -239,6 +240,9 @@ class Svo:
 
     def sync(self):
         _check(lib().vx_sync(self._h))
+
+    def set_frames_in_flight(self, frames):
+        _check(lib().vx_set_frames_in_flight(self._h, frames))
 
     def wait_event(self, hip_event):
         """The next render waits for this raw hipEvent_t (e.g. torch.cuda.Event.cuda_event)."""
