@@ -1,0 +1,106 @@
+"""BASELINE.json's configurations at their full sizes, HIP path against the oracle:
+C1 256x256 rays against one 32^3 chunk through the picker path; C2 1920x1080 primary rays only on a depth-10 SVO;
+C3 1920x1080 primary + shadow, textured and normal-mapped, on the depth-12 SVO the benchmark uses. Every hit record is
+compared exactly (t, position, uv, value, face, flags, shadow distance, step count); colours to 2e-6."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import orc, vra
+from voxel_rs_amd import scenes
+
+pytestmark = pytest.mark.gpu
+FMTS = {"esvo": vra.SVO_ESVO, "csvo": vra.SVO_CSVO}
+SEED = 0x5EED0001
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from voxel_rs_amd import hip as h
+
+    return h
+
+
+def hash32(seed, o, i, j):
+    from voxel_rs_amd import host
+
+    return int(host.lib().vxh_scene_hash32(seed, o, i, j))
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_c1_picker_rays_against_one_chunk(hip, fmt):
+    """One chunk at SVO position (0,0,0); voxel (x,y,z) solid iff y <= 8 + (hash32(seed,x,z) & 7); 256x256 perspective rays
+    from eye (16,24,-24) towards (16,8,16), each a PickerTask with max_dst 100, cast_translucent = false (picker.glsl)."""
+    chunk = vra.Chunk(0, 0, 0, 5)
+    for x in range(32):
+        for z in range(32):
+            top = 8 + (hash32(SEED, 0, x, z) & 7)
+            for y in range(top + 1):
+                chunk.set_block(x, y, z, 1 if y == top else (2 if y + 3 >= top else 3))
+    chunk.compact()
+    world = vra.World(FMTS[fmt])
+    world.set_chunk((0, 0, 0), chunk)
+    world.serialize()
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    scene = orc.OracleScene(FMTS[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    svo = hip.Svo(FMTS[fmt], 4 << 20)
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+
+    n = 256
+    eye = np.float32([16, 24, -24])
+    fwd = np.float32([16, 8, 16]) - eye
+    u = scenes.render_params_to_uniforms(tuple(eye), tuple(fwd), (0.0, 1.0, 0.0), math.radians(72.0), 1.0, 0.3, (-1.0, -1.0, -1.0), False, 500.0)
+    ou = orc.Uniforms.from_buffer_copy(bytes(u))
+    tasks = np.zeros(n * n, dtype=orc.PICKER_TASK_DTYPE)
+    import ctypes as C
+
+    ro, rd = (C.c_float * 3)(), (C.c_float * 3)()
+    for y in range(n):
+        for x in range(n):
+            orc.lib().or_primary_ray(C.byref(ou), n, n, x, y, C.byref(ro), C.byref(rd))
+            t = tasks[y * n + x]
+            t["max_dst"], t["pos"], t["dir"] = 100.0, list(ro), list(rd)
+    got = svo.raycast(tasks)  # one call: vx_raycast has no 100-task cap (svo_picker.rs:5)
+    exp = scene.picker(tasks, threads=8)
+    assert got.tobytes() == exp.tobytes()
+    assert (exp["dst"] > 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("config", ["C2", "C3"])
+def test_full_size_frames(hip, fmt, config):
+    depth, shadows = (10, False) if config == "C2" else (12, True)
+    world = vra.World(FMTS[fmt])
+    st = world.build_heightfield(depth)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    scene = orc.OracleScene(FMTS[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    svo = hip.Svo(FMTS[fmt], world.size_in_bytes + (16 << 20))
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+    w, h = 1920, 1080
+    u = scenes.bench_camera(depth, st["h_max"], w, h, shadow_distance=3.0e38, render_shadows=shadows)
+    img, hits = svo.render(u, w, h, want_hits=True)
+    cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
+    assert hits.tobytes() == chits.tobytes()
+    assert np.array_equal(np.isnan(img), np.isnan(cimg))
+    assert np.nanmax(np.abs(img - cimg)) <= 2e-6
+    primary_hits = int((chits["flags"] & 1).sum())
+    shadow_rays = int(((chits["flags"] >> 1) & 1).sum())
+    assert primary_hits > 0.4 * w * h
+    assert shadow_rays == (primary_hits if shadows else 0)
+    # the image-only kernel (no hit records; what the benchmark times) and two frames in flight write the same pixels
+    import torch
+
+    a = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    b = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        svo.render_device(u, w, h, a.data_ptr())
+        svo.render_device(u, w, h, b.data_ptr())
+    svo.sync()
+    for t in (a, b):
+        got = t.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(img)) and np.nanmax(np.abs(got - img)) == 0.0

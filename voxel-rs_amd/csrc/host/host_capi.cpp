@@ -142,6 +142,7 @@ uint64_t vxh_scene_build_heightfield(void* wp, uint32_t depth, uint32_t seed, ui
 }
 
 uint32_t vxh_scene_height(uint32_t depth, uint32_t seed, uint32_t x, uint32_t z) { return heightfield_height(depth, seed, x, z); }
+uint32_t vxh_scene_hash32(uint32_t seed, uint32_t o, uint32_t i, uint32_t j) { return scene_hash32(seed, o, i, j); }
 
 // ---- picker batches (src/graphics/svo_picker.rs) --------------------------------------------------------------------
 

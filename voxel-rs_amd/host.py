@@ -59,6 +59,7 @@ def lib():
             "vxh_reference_render_test": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, sz]),
             "vxh_mapper_raycast_test": (C.c_int, [C.c_int, u32, vp, vp, u32, vp, vp, u32, C.c_float, vp, vp, C.c_char_p, sz]),
             "vxh_scene_height": (u32, [u32, u32, u32, u32]),
+            "vxh_scene_hash32": (u32, [u32, u32, u32, u32]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
