@@ -499,10 +499,11 @@ struct Trav {
         if (tc_max >= tcrz) { step_mask ^= 4; pz -= scale_exp2; }
 
         t_min = tc_max;
-        idx ^= step_mask;
+        const int stepped_idx = idx ^ step_mask;
+        if (!ST::kFast) idx = stepped_idx;  // (a fast-stack step derives idx from the position bits instead, see step())
 
         bool inside = true;
-        if ((idx & step_mask) != 0) {
+        if ((stepped_idx & step_mask) != 0) {
             // svo.esvo.glsl:345-349: per stepped axis, bits(pos) ^ bits(pos + scale_exp2). While scale >= 0 every coordinate is a
             // multiple of scale_exp2 >= 2^-23 in [1, 2), the subtraction above was exact and pos + scale_exp2 is the old
             // coordinate again (unstepped axes contribute 0 on their own); below that (a ray that started inside a voxel and
@@ -538,7 +539,7 @@ struct Trav {
                 px = __uint_as_float(bx & keep);
                 py = __uint_as_float(by & keep);
                 pz = __uint_as_float(bz & keep);
-                idx = int(((bx >> scale) & 1u) | (((by >> scale) & 1u) << 1) | (((bz >> scale) & 1u) << 2));
+                if (!ST::kFast) idx = int(((bx >> scale) & 1u) | (((by >> scale) & 1u) << 1) | (((bz >> scale) & 1u) << 2));
                 h = 0.0f;
             }
         }
@@ -555,6 +556,11 @@ struct Trav {
         if (!live) return kTravFinished;
         ++iter;
         if (STATS) ctr->iterations++;
+        // While scale >= 0 the child index is the position's mantissa bit at `scale` on each axis (the corner is a multiple
+        // of scale_exp2; PUSH adds half a cell = sets the bit, ADVANCE subtracts a cell = flips it, POP masks below it), so
+        // the loop that only ever sees LDS-resident scales reads it off the position instead of maintaining it in three places.
+        if (ST::kFast)
+            idx = int(((__float_as_uint(px) >> scale) & 1u) | (((__float_as_uint(py) >> scale) & 1u) << 1) | (((__float_as_uint(pz) >> scale) & 1u) << 2));
 
         const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
         const float tc_max = gmin3(tcrx, tcry, tcrz);
@@ -640,10 +646,11 @@ struct Trav {
             h = tc_max;
             --scale;
             scale_exp2 = half_scale;
-            idx = 0;
-            if (t_min < tcenx) { idx ^= 1; px += scale_exp2; }
-            if (t_min < tceny) { idx ^= 2; py += scale_exp2; }
-            if (t_min < tcenz) { idx ^= 4; pz += scale_exp2; }
+            const bool upper_x = t_min < tcenx, upper_y = t_min < tceny, upper_z = t_min < tcenz;
+            if (upper_x) px += scale_exp2;
+            if (upper_y) py += scale_exp2;
+            if (upper_z) pz += scale_exp2;
+            if (!ST::kFast) idx = int(upper_x) | (int(upper_y) << 1) | (int(upper_z) << 2);
             t_max = tv_max;
             sched_fence();
             if (!CSVO) {
