@@ -154,6 +154,7 @@ def main():
     else:
         # two frames in flight (the library alternates two streams): one image per frame in flight
         images = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        torch.cuda.synchronize()  # zero fills run on torch's stream, the renderer on its own
         state = {"i": 0}
 
         def step():

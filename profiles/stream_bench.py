@@ -46,6 +46,7 @@ def main():
     svo.set_textures(scenes.synthetic_textures(), 6)
     W, H = args.width, args.height
     image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     eye = [0.3 * n, n / 4 + 0.02 * n, 0.5 * n]
     # phase 1: initial fill around the start position (large commits, no frames in between)
     t0 = time.perf_counter()

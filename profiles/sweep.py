@@ -40,6 +40,7 @@ def main():
     W, H = args.width, args.height
     u = scenes.bench_camera(args.depth, st["h_max"], W, H, shadow_distance=3.0e38)
     image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     ctxs = []
     for cfg in args.configs:
         for k in KEYS.values():

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 FMTS = ["esvo", "csvo"]
 EPS = 1e-5
-COLOR_TOL = 2e-6  # absolute, on colours in [0,1]: powf/acosf differ by a few ulp between glibc and ocml
+COLOR_TOL = 5e-6  # absolute, on colours in [0,1]: powf/acosf differ by a few ulp between glibc and ocml, texel blending order
 
 
 def f32(x):
@@ -360,9 +360,10 @@ def test_tile_sharded_render_matches_full(hip, fmt):
     count = 3
     per = max(hip.local_tile_count(w, h, r, count) for r in range(count))
     gathered = torch.zeros((count, per, 32, 32, 4), dtype=torch.float32, device="cuda")
+    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # torch zero-fills on ITS stream; the renderer's streams do not wait for it
     for r in range(count):
         svo.render_device(u, w, h, gathered[r].data_ptr(), tile_rank=r, tile_count=count)
-    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     svo.assemble_tiles(gathered.data_ptr(), per * 32 * 32 * 4, count, w, h, out.data_ptr())
     svo.sync()
     got = out.cpu().numpy()

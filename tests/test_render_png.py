@@ -102,4 +102,4 @@ def test_hip_matches_reference_png(fmt):
     scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
     cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(uniforms())), W, H)
     assert hits.tobytes() == chits.tobytes()
-    assert np.nanmax(np.abs(img - cimg)) <= 2e-6
+    assert np.nanmax(np.abs(img - cimg)) <= 5e-6

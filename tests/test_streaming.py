@@ -77,7 +77,7 @@ def test_incremental_commits_render_like_a_full_upload(svo_type):
             scene = orc.OracleScene(svo_type, s.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
             cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
             assert hits.tobytes() == chits.tobytes(), f"hit records differ at {eye} with {st['pending']} events pending"
-            assert np.nanmax(np.abs(img - cimg)) <= 2e-6
+            assert np.nanmax(np.abs(img - cimg)) <= 5e-6
             seen["frames"] += 1
             if st["pending"] == 0:
                 break

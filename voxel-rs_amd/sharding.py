@@ -74,6 +74,8 @@ class FrameSharder:
         self.gathered = [torch.zeros((world, self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) if rank == 0 else None
                          for _ in range(buffers)]
         self.image = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if rank == 0 else None
+        if str(device).startswith("cuda"):
+            torch.cuda.synchronize()  # the zero fills ran on torch's stream; a renderer with its own streams must not race them
         self.frame = 0
 
     def step(self):
