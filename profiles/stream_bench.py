@@ -47,7 +47,12 @@ def main():
     W, H = args.width, args.height
     image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    eye = [0.3 * n, n / 4 + 0.02 * n, 0.5 * n]
+    def ground(x, z):
+        return float(host.lib().vxh_scene_height(args.scene_depth, 0x5EED0001, int(x), int(z)))
+
+    # fly 90 blocks above the highest ground along the path, so that the terrain is inside the loader's vertical radius
+    path_x = [0.3 * n + args.speed * i for i in range(args.frames + 1)]
+    eye = [0.3 * n, max(ground(x, 0.5 * n) for x in path_x) + 90.0, 0.5 * n]
     # phase 1: initial fill around the start position (large commits, no frames in between)
     t0 = time.perf_counter()
     s.move_to(*eye)
