@@ -128,7 +128,9 @@ def main():
 
         # The renderer runs frames on its own streams; the gather and the assembly run on torch's. One tile buffer per frame
         # in flight: a render only has to wait for the collective that last read its buffer.
-        FRAMES = 3  # frames in flight: a rank's share of the frame is small, its tail relatively long
+        # frames in flight: the smaller a rank's share of the frame, the longer its tail relative to its body (a frame cannot
+        # finish before its longest ray) and the more frames it takes to keep the device full
+        FRAMES = min(8, max(3, world_size))
         svo.set_frames_in_flight(FRAMES)
         gather_done = [torch.cuda.Event() for _ in range(FRAMES)]
         state = {"i": 0}
@@ -175,6 +177,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    enqueue_s = time.perf_counter() - t0  # host time to issue the steps (a lower bound of the step time: the loop is asynchronous)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = svo.profile_read()
@@ -203,7 +206,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(my_bytes), "bytes_per_ray": round(my_bytes / max(my_rays, 1), 2),
                 # two frames are in flight: the per-launch spans above overlap (span x launches > elapsed). What the
                 # device sustains over the timed region is bytes x launches / elapsed:
-                "frames_in_flight": 3 if sharded else 2, "sustained_GBps": round(my_bytes * launches / max(elapsed, 1e-9) / 1e9, 3)}
+                "frames_in_flight": min(8, max(3, world_size)) if sharded else 2, "sustained_GBps": round(my_bytes * launches / max(elapsed, 1e-9) / 1e9, 3)}
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -251,7 +254,8 @@ def main():
                                f"({args.format.upper()} nodes), 1 frame per step", "svo_format": args.format, "svo_bytes": world.size_in_bytes,
                    "leaves": st["leaves"], "chunks": st["chunks"], "rays_per_frame": int(total_rays), "primary_rays": W * H,
                    "parallelism": f"screen tiles (32x32, interleaved) over {world_size} GPU(s), SVO replicated, RCCL gather to rank 0",
-                   "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 3)},
+                   "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 3),
+                   "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

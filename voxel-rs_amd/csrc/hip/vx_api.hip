@@ -430,10 +430,10 @@ struct vx_context {
     hipStream_t upload_stream = nullptr;  // range uploads
     hipEvent_t upload_done = nullptr, render_done = nullptr;
     bool committed = false, render_recorded = false;
-    // Frames in flight: image-only renders into device memory alternate between two streams, so that the first waves of
-    // frame k+1 fill the CUs the last long rays of frame k leave idle (each frame is one persistent kernel whose tail runs at
+    // Frames in flight: image-only renders into device memory rotate over `frames_in_flight` streams, so that the first waves
+    // of the next frames fill the CUs the last long rays of frame k leave idle (each frame is one persistent kernel whose tail runs at
     // low occupancy). Everything else (picker, hit records, host targets, counters) stays on `stream`.
-    static constexpr int kFrameStreams = 3;
+    static constexpr int kFrameStreams = 8;
     hipStream_t frame_stream[kFrameStreams] = {};
     hipEvent_t frame_done[kFrameStreams] = {};
     bool frame_recorded[kFrameStreams] = {};
@@ -646,13 +646,14 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     CREATE_TRY(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&c->render_done, hipEventDisableTiming));
-    // The two frame streams must sit on different hardware queues or their kernels serialise; the runtime shares a small
-    // pool of queues between streams of equal priority (GPU_MAX_HW_QUEUES) with no way to ask which one a stream got, but a
-    // stream of another priority never shares a queue with them. Odd frames therefore run at the next priority level.
+    // Frame streams must sit on different hardware queues or their kernels serialise. The runtime hands out queues from a
+    // small pool per priority level (GPU_MAX_HW_QUEUES, 4 by default), least used first, with no way to ask which one a
+    // stream got; the default-priority pool is already shared with this context's other streams and the caller's. The frame
+    // streams therefore alternate between the lowest and the highest priority level, whose pools nothing else uses.
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
-        const int prio = prio_least - i >= prio_greatest ? prio_least - i : prio_greatest;
+        const int prio = (i & 1) ? prio_greatest : prio_least;
         CREATE_TRY(hipStreamCreateWithPriority(&c->frame_stream[i], hipStreamNonBlocking, prio));
         CREATE_TRY(hipEventCreateWithFlags(&c->frame_done[i], hipEventDisableTiming));
         CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_frame_counter[i]), sizeof(uint32_t)));
@@ -962,7 +963,7 @@ int vx_sync(vx_context* ctx) {
 }
 
 int vx_set_frames_in_flight(vx_context* ctx, int frames) {
-    if (!ctx || frames < 1 || frames > vx_context::kFrameStreams) return fail(VX_ERR_INVALID_ARGUMENT, "frames in flight: 1..3");
+    if (!ctx || frames < 1 || frames > vx_context::kFrameStreams) return fail(VX_ERR_INVALID_ARGUMENT, "frames in flight: 1..8");
     HIP_TRY(hipSetDevice(ctx->device));
     for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
     ctx->frames_in_flight = frames;
