@@ -109,7 +109,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
 enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4, kDeep = 5 };
 
 struct PersistentArgs {
-    uint32_t* work_counter;   // next sub-tile; zeroed before every launch
+    uint32_t* work_counter;   // ticket dispenser, never reset: this launch's sub-tile t is ticket ticket_base + t
+    uint32_t ticket_base;
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
 };
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
                 if (cursor >= 64) {
                     uint32_t t = 0;
-                    if (lane == 0) t = atomicAdd(a.work_counter, 1u);
+                    if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base;  // unsigned: survives the counter wrapping
                     t = __builtin_amdgcn_readfirstlane(t);
                     if (t >= a.total_subtiles) {
                         queue_empty = true;
@@ -438,6 +439,10 @@ struct vx_context {
     hipEvent_t frame_done[kFrameStreams] = {};
     bool frame_recorded[kFrameStreams] = {};
     uint32_t* d_frame_counter[kFrameStreams] = {};
+    // Tickets drawn from each dispenser so far. A launch draws exactly total_subtiles + waves tickets (every wave draws one
+    // ticket past the end before it stops), so the next launch on the same stream starts there and no reset is needed.
+    uint32_t frame_tickets[kFrameStreams] = {};
+    uint32_t main_tickets = 0;
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
     int frames_in_flight = 2;           // 1 serialises frames on `stream` again (vx_set_frames_in_flight / VX_FRAMES_IN_FLIGHT)
     unsigned frame_index = 0;
@@ -515,7 +520,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
     if (grid.x == 0) return VX_OK;
     const SceneArgs sc = scene_of(ctx);
 
-    if (ctx->kernel_version != 1) HIP_TRY(hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream));  // sub-tile queue head
+    uint32_t& tickets = slot >= 0 ? ctx->frame_tickets[slot] : ctx->main_tickets;
     ProfiledLaunch ev{};
     if (ctx->profile) {
         if (!ctx->event_pool.empty()) {
@@ -549,6 +554,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         }
         PersistentArgs a;
         a.work_counter = work_counter;
+        a.ticket_base = tickets;
         a.total_subtiles = p.n_local_tiles * 16;
         a.refill_min = ctx->refill_min;
         a.service_min = ctx->service_min;
@@ -556,6 +562,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         if (waves > a.total_subtiles) waves = a.total_subtiles;
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
+        tickets += a.total_subtiles + waves;
     }
     HIP_TRY(hipGetLastError());
     if (ctx->profile) {
@@ -657,9 +664,11 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         CREATE_TRY(hipStreamCreateWithPriority(&c->frame_stream[i], hipStreamNonBlocking, prio));
         CREATE_TRY(hipEventCreateWithFlags(&c->frame_done[i], hipEventDisableTiming));
         CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_frame_counter[i]), sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(c->d_frame_counter[i], 0, sizeof(uint32_t)));
     }
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(c->d_work_counter, 0, sizeof(uint32_t)));
     {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
