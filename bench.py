@@ -215,17 +215,15 @@ def main():
         scene = orc.OracleScene(fmt, world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
         ou = orc.Uniforms.from_buffer_copy(bytes(uniforms))
         cores = orc.lib().or_max_threads()
-        # probe a few rows spread over the image to size the sample for ~cpu_seconds of work
-        probe_rows = [int(H * f) for f in (0.1, 0.3, 0.5, 0.7, 0.9)]
-        pc = orc.Counters()
+        # warm up the thread pool and the page cache on a thin band, then time one band of a tenth of the frame to decide
+        # between whole frames and bands (a frame this size takes well under a second on a server CPU)
+        scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 8), want_hits=False, counters=orc.Counters(), threads=cores)
         t0 = time.perf_counter()
-        for y in probe_rows:
-            scene.render(ou, W, H, rect=(0, y, W, y + 2), want_hits=False, counters=pc, threads=cores)
-        probe_s = time.perf_counter() - t0
-        rows_budget = int(len(probe_rows) * 2 * args.cpu_seconds / max(probe_s, 1e-6))
+        scene.render(ou, W, H, rect=(0, H // 2 - H // 20, W, H // 2 + H // 20), want_hits=False, counters=orc.Counters(), threads=cores)
+        frame_estimate_s = 10.0 * (time.perf_counter() - t0)
         cc = orc.Counters()
-        if rows_budget >= H:
-            # the whole frame fits the budget: repeat it until about cpu_seconds of wall time on all host cores have been timed
+        if frame_estimate_s <= args.cpu_seconds:
+            # repeat the whole frame until about cpu_seconds of wall time on all host cores have been timed
             reps = 0
             t0 = time.perf_counter()
             while reps < 400 and (reps == 0 or time.perf_counter() - t0 < args.cpu_seconds):
@@ -235,7 +233,7 @@ def main():
             sample = f"{reps} x the whole {W}x{H} frame"
         else:
             bands = 8
-            band_h = max(rows_budget // bands, 1)
+            band_h = max(int(H * args.cpu_seconds / frame_estimate_s) // bands, 1)
             t0 = time.perf_counter()
             for b in range(bands):
                 y0 = int((b + 0.5) * H / bands) - band_h // 2
