@@ -223,6 +223,10 @@ int vx_assemble_tiles(vx_context* ctx, const float* tiles, uint64_t stride_float
  * render the next frame meanwhile); NULL = the legacy default stream. */
 int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
                          float* out_rgba32f, void* stream);
+/* 2x2 ordered-grid supersampling (BASELINE.json C5): box-filters a (2*width) x (2*height) RGBA32F render down to
+ * width x height, both in device memory, on the caller's hipStream_t (NULL = legacy default stream). Render the large
+ * image with vx_render first (order it with vx_stream_wait_render). */
+int vx_resolve_2x2(vx_context* ctx, const float* src_rgba32f, uint32_t width, uint32_t height, float* dst_rgba32f, void* stream);
 /* Number of tiles (32x32) rank `tile_rank` of `tile_count` owns for a width x height image. */
 uint32_t vx_local_tile_count(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count);
 

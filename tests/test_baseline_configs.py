@@ -105,3 +105,39 @@ def test_full_size_frames(hip, fmt, config):
     for t in (a, b):
         got = t.cpu().numpy()
         assert np.array_equal(np.isnan(got), np.isnan(img)) and np.nanmax(np.abs(got - img)) == 0.0
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_c5_supersampled_frame(hip, fmt):
+    """2x2 ordered-grid supersampling: a (2w x 2h) render box-filtered down, against the oracle's (2w x 2h) frame filtered
+    the same way in numpy (same association order: (a + b) + (c + d), then * 0.25)."""
+    import torch
+
+    depth = 9
+    world = vra.World(FMTS[fmt])
+    st = world.build_heightfield(depth, threads=4)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    scene = orc.OracleScene(FMTS[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    svo = hip.Svo(FMTS[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+    w, h = 480, 270
+    u = scenes.bench_camera(depth, st["h_max"], 2 * w, 2 * h, shadow_distance=3.0e38, render_shadows=True)
+    big = torch.zeros((2 * h, 2 * w, 4), dtype=torch.float32, device="cuda")
+    small = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    svo.render_device(u, 2 * w, 2 * h, big.data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream
+    svo.stream_wait_render(stream)
+    svo.resolve_2x2(big.data_ptr(), w, h, small.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    cimg, _ = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), 2 * w, 2 * h, want_hits=False)
+    ref = ((cimg[0::2, 0::2] + cimg[0::2, 1::2]) + (cimg[1::2, 0::2] + cimg[1::2, 1::2])) * np.float32(0.25)
+    got = small.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.nanmax(np.abs(got - ref)) <= 5e-6
+    # the filter itself is exact: the GPU's own large frame filtered in numpy gives the GPU's small frame bit for bit
+    gbig = big.cpu().numpy()
+    mine = ((gbig[0::2, 0::2] + gbig[0::2, 1::2]) + (gbig[1::2, 0::2] + gbig[1::2, 1::2])) * np.float32(0.25)
+    assert got.tobytes() == mine.tobytes()

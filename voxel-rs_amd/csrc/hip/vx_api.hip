@@ -326,6 +326,18 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     }
 }
 
+// 2x2 ordered-grid supersampling (BASELINE.json C5): box filter of a (2w x 2h) render down to (w x h); one thread per
+// output pixel, float4 loads and stores
+__global__ __launch_bounds__(256) void resolve_2x2_kernel(const float4* __restrict__ src, uint32_t w, uint32_t h, float4* __restrict__ dst) {
+    const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15u), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= w || y >= h) return;
+    const size_t sw = size_t(w) * 2;
+    const float4 a = src[size_t(2 * y) * sw + 2 * x], b = src[size_t(2 * y) * sw + 2 * x + 1];
+    const float4 c = src[size_t(2 * y + 1) * sw + 2 * x], d = src[size_t(2 * y + 1) * sw + 2 * x + 1];
+    dst[size_t(y) * w + x] = make_float4(((a.x + b.x) + (c.x + d.x)) * 0.25f, ((a.y + b.y) + (c.y + d.y)) * 0.25f, ((a.z + b.z) + (c.z + d.z)) * 0.25f,
+                                         ((a.w + b.w) + (c.w + d.w)) * 0.25f);
+}
+
 template <int SVO>
 __global__ __launch_bounds__(64) void picker_kernel(SceneArgs sa, const vx_picker_task* __restrict__ tasks, uint32_t n,
                                                     vx_picker_result* __restrict__ results) {
@@ -1015,6 +1027,16 @@ int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_fl
     const dim3 grid((width + 15) / 16, (height + 15) / 16), block(256);
     hipLaunchKernelGGL(assemble_kernel, grid, block, 0, static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(tiles), stride_floats / 4, tile_count, width, height,
                        (width + kTile - 1) / kTile, reinterpret_cast<float4*>(out_rgba32f));
+    HIP_TRY(hipGetLastError());
+    return VX_OK;
+}
+
+int vx_resolve_2x2(vx_context* ctx, const float* src_rgba32f, uint32_t width, uint32_t height, float* dst_rgba32f, void* stream) {
+    if (!ctx || !src_rgba32f || !dst_rgba32f || !width || !height) return fail(VX_ERR_INVALID_ARGUMENT, "resolve_2x2: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const dim3 grid((width + 15) / 16, (height + 15) / 16), block(256);
+    hipLaunchKernelGGL(resolve_2x2_kernel, grid, block, 0, static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(src_rgba32f), width, height,
+                       reinterpret_cast<float4*>(dst_rgba32f));
     HIP_TRY(hipGetLastError());
     return VX_OK;
 }

@@ -78,6 +78,7 @@ SYMBOLS = {
     "vx_set_frames_in_flight": (_int, [_vp, _int]),
     "vx_wait_event": (_int, [_vp, _vp]),
     "vx_stream_wait_render": (_int, [_vp, _vp]),
+    "vx_resolve_2x2": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "vx_assemble_tiles": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "vx_assemble_tiles_on": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp]),
     "vx_local_tile_count": (_u32, [_u32, _u32, _u32, _u32]),
@@ -237,6 +238,10 @@ class Svo:
             _check(lib().vx_assemble_tiles(self._h, tiles_ptr, stride_floats, tile_count, width, height, out_ptr))
         else:
             _check(lib().vx_assemble_tiles_on(self._h, tiles_ptr, stride_floats, tile_count, width, height, out_ptr, _vp(stream)))
+
+    def resolve_2x2(self, src_ptr, width, height, dst_ptr, stream=None):
+        """Box-filters a (2*width x 2*height) device image down to width x height on the raw hipStream_t `stream`."""
+        _check(lib().vx_resolve_2x2(self._h, src_ptr, width, height, dst_ptr, _vp(stream or 0)))
 
     def sync(self):
         _check(lib().vx_sync(self._h))
