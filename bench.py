@@ -209,7 +209,7 @@ def main():
                 "frames_in_flight": min(8, max(3, world_size)) if sharded else 2, "sustained_GBps": round(my_bytes * launches / max(elapsed, 1e-9) / 1e9, 3)}
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world_size == 1:  # rank 0 at N = 1 only: a baseline of the workload, not of the scaling run
         from oracle import oracle as orc  # the checker, timed here as the CPU baseline ("port": the reference has no CPU raycast)
 
         scene = orc.OracleScene(fmt, world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
