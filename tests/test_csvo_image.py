@@ -1,0 +1,100 @@
+"""The traversal image of a CSVO world (voxel-rs_amd/csrc/hip/csvo_image.hpp, exported as vx_csvo_to_image): the oracle's ESVO
+traversal on the image against the oracle's CSVO traversal on the original bytes. Every ray that does not start inside a
+voxel must give the same result bit for bit in the same number of iterations (rays that do are handed to the CSVO traversal
+by the kernel, see test_hip_parity / test_baseline_configs on the GPU)."""
+import numpy as np
+import pytest
+
+from helpers import orc, vra
+from voxel_rs_amd import hip, host, scenes
+
+
+def scenes_pair(world):
+    frame = world.frame()
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    image = hip.csvo_to_image(frame, world.size_in_bytes)
+    csvo = orc.OracleScene(vra.SVO_CSVO, frame, mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    esvo = orc.OracleScene(vra.SVO_ESVO, np.concatenate([image, np.zeros(4, dtype=np.uint32)]), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    return csvo, esvo
+
+
+def compare_rays(csvo, esvo, origins, dirs, min_hits):
+    hits = inside = 0
+    for o, d in zip(origins, dirs):
+        for translucent in (False, True):
+            a, fa, na = csvo.intersect(o, d, -1.0, translucent, max_frames=1)
+            if a.inside_voxel:
+                inside += 1
+                continue
+            b, fb, nb = esvo.intersect(o, d, -1.0, translucent, max_frames=1)
+            assert na == nb, (o, d, na, nb)  # iterations
+            for k in ("t", "value", "face_id", "inside_voxel", "lod"):
+                assert getattr(a, k) == getattr(b, k), (k, o, d)
+            assert list(a.pos) == list(b.pos) and list(a.uv) == list(b.uv) and list(a.color) == list(b.color)
+            hits += a.t > 0
+    assert hits >= min_hits
+    return inside
+
+
+@pytest.mark.parametrize("seed,svo_pos,n_blocks", [(2, (1, 0, 1), 600), (3, (3, 2, 1), 6000), (5, (0, 0, 0), 1), (7, (200, 3, 201), 3000)])
+def test_random_chunk_worlds(seed, svo_pos, n_blocks):
+    rng = np.random.default_rng(seed)
+    chunk = vra.Chunk(0, 0, 0, 5)
+    for x, y, z in rng.integers(0, 32, size=(n_blocks, 3)):
+        chunk.set_block(int(x), int(y), int(z), int(rng.choice([1, 2, 3, 5, 10])))
+    chunk.compact()
+    world = vra.World(vra.SVO_CSVO)
+    world.set_chunk(svo_pos, chunk)
+    world.serialize()
+    csvo, esvo = scenes_pair(world)
+    base = np.float32(svo_pos) * 32
+    n = 400
+    origins = (base + rng.uniform(-20, 52, size=(n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d[::9] = np.eye(3)[rng.integers(0, 3, size=len(d[::9]))] * rng.choice([-1, 1], size=(len(d[::9]), 1))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    compare_rays(csvo, esvo, origins, d.astype(np.float32), 10 if n_blocks > 1 else 0)
+
+
+def test_heightfield_world_frames_agree():
+    world = vra.World(vra.SVO_CSVO)
+    st = world.build_heightfield(8, threads=4)
+    csvo, esvo = scenes_pair(world)
+    w, h = 160, 96
+    u = scenes.bench_camera(8, st["h_max"], w, h, shadow_distance=3.0e38)
+    ou = orc.Uniforms.from_buffer_copy(bytes(u))
+    ia, ha = csvo.render(ou, w, h)
+    ib, hb = esvo.render(ou, w, h)
+    # primary rays start in the air: identical records; a shadow ray may start inside a neighbouring voxel, where the two
+    # formats lead it through different bytes -- those pixels may differ in shadow_t / steps and are left to the GPU tests
+    same = ha["shadow_t"] == hb["shadow_t"]
+    for k in ("t", "value", "face_id", "lod"):
+        assert np.array_equal(ha[k], hb[k]), k
+    assert np.array_equal(ha["pos"], hb["pos"]) and np.array_equal(ha["uv"], hb["uv"])
+    assert same.mean() > 0.995
+    assert np.array_equal(ha["steps"][same], hb["steps"][same])
+    assert np.array_equal(ia[same], ib[same])
+
+
+def test_streamed_world_with_lod_chunks_agrees():
+    s = host.WorldStreamer(vra.SVO_CSVO, 9, 9, 0, 8)  # LOD 5 near the centre, LOD 4 beyond 6 chunks
+    eye = (200.5, 70.0, 230.5)
+    s.move_to(*eye)
+    while s.pump(None, 4000)["pending"]:
+        pass
+    frame = s.frame()
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    used = frame.size * 4 - 8 - 16  # arena bytes: the frame minus scale, root_ptr and the zero padding
+    image = hip.csvo_to_image(frame, used)
+    csvo = orc.OracleScene(vra.SVO_CSVO, frame, mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    esvo = orc.OracleScene(vra.SVO_ESVO, np.concatenate([image, np.zeros(4, dtype=np.uint32)]), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    cam = s.to_svo(eye)
+    w, h = 128, 80
+    import math
+
+    u = scenes.render_params_to_uniforms(cam, (0.6, -0.4, 0.7), (0.0, 1.0, 0.0), math.radians(72.0), w / h, 0.3, (-1.0, -1.0, -1.0), False, 500.0)
+    ou = orc.Uniforms.from_buffer_copy(bytes(u))
+    ia, ha = csvo.render(ou, w, h)
+    ib, hb = esvo.render(ou, w, h)
+    assert ha.tobytes() == hb.tobytes() and np.array_equal(ia, ib)  # no shadow rays here: every record identical
+    assert (ha["flags"] & 1).mean() > 0.2

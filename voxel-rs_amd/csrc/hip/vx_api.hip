@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "csvo_image.hpp"
 #include "voxel_hip.h"
 #include "vx_device.hpp"
 
@@ -1029,6 +1030,15 @@ int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_fl
                        (width + kTile - 1) / kTile, reinterpret_cast<float4*>(out_rgba32f));
     HIP_TRY(hipGetLastError());
     return VX_OK;
+}
+
+uint64_t vx_csvo_to_image(const uint8_t* world_frame, uint64_t used_bytes, uint32_t* out_words, uint64_t capacity_words) {
+    if (!world_frame) return 0;
+    vximg::WorldImage img;
+    if (!img.update(world_frame, used_bytes, nullptr, 0, true, std::max(1u, std::min(16u, std::thread::hardware_concurrency())))) return 0;
+    const std::vector<uint32_t>& f = img.frame();
+    if (out_words && capacity_words >= f.size()) std::memcpy(out_words, f.data(), f.size() * 4);
+    return f.size();
 }
 
 int vx_resolve_2x2(vx_context* ctx, const float* src_rgba32f, uint32_t width, uint32_t height, float* dst_rgba32f, void* stream) {

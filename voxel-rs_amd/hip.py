@@ -78,6 +78,7 @@ SYMBOLS = {
     "vx_set_frames_in_flight": (_int, [_vp, _int]),
     "vx_wait_event": (_int, [_vp, _vp]),
     "vx_stream_wait_render": (_int, [_vp, _vp]),
+    "vx_csvo_to_image": (_u64, [_vp, _u64, _vp, _u64]),
     "vx_resolve_2x2": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "vx_assemble_tiles": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "vx_assemble_tiles_on": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp]),
@@ -131,6 +132,17 @@ def make_uniforms(view, fovy, aspect, ambient, light_dir, cam_pos, render_shadow
 
 def local_tile_count(width, height, rank, count):
     return lib().vx_local_tile_count(width, height, rank, count)
+
+
+def csvo_to_image(world_frame_words, used_bytes):
+    """vx_csvo_to_image: CSVO frame (uint32 words: scale, root_ptr, bytes...) -> ESVO-layout traversal image (uint32 words)."""
+    f = np.ascontiguousarray(world_frame_words, dtype=np.uint32)
+    n = lib().vx_csvo_to_image(f.ctypes.data_as(_vp), used_bytes, None, 0)
+    if n == 0:
+        raise ValueError("this CSVO frame cannot be imaged")
+    out = np.zeros(n, dtype=np.uint32)
+    lib().vx_csvo_to_image(f.ctypes.data_as(_vp), used_bytes, out.ctypes.data_as(_vp), n)
+    return out
 
 
 class Svo:
