@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
 // shows that `service_min` lanes are waiting (or nobody is left traversing); idle lanes are re-filled with new pixels
 // when `refill_min` of them are free. The common descend/advance/pop step therefore runs with most lanes active
 // instead of the ~30 % the one-thread-per-pixel kernel reached (profiles/round1/v1_*).
-enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4, kDeep = 5 };
+enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4, kDeep = 5, kForeign = 6 };
 
 struct PersistentArgs {
     uint32_t* work_counter;   // ticket dispenser, never reset: this launch's sub-tile t is ticket ticket_base + t
@@ -116,10 +116,37 @@ struct PersistentArgs {
     uint32_t refill_min, service_min;
 };
 
-template <int SVO, bool HITS, bool STATS, int MINW = 1>
+// Pixels whose rays a traversal image cannot serve, handed from the image kernel to the kernel that re-renders them on the
+// world's own bytes.
+struct PixelList {
+    uint32_t* pixels;    // ring of out_index values, `mask` + 1 entries (a power of two, at least the pixels of a frame)
+    uint32_t* counters;  // [0] appended, [1] claimed: both only ever grow; entries [claimed, appended) wait for a taker
+    uint32_t mask;
+};
+
+// compact / row-major output index -> pixel coordinates (the inverse of the index computation in the refill)
+__device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t out_index, uint32_t& x, uint32_t& y) {
+    if (p.tile_count > 1) {
+        const uint32_t local_tile = out_index >> 10, in_y = (out_index >> 5) & 31u, in_x = out_index & 31u;
+        const uint32_t tile = local_tile * p.tile_count + p.tile_rank;
+        x = (tile % p.tiles_x) * kTile + in_x;
+        y = (tile / p.tiles_x) * kTile + in_y;
+    } else {
+        x = out_index % p.width;
+        y = out_index / p.width;
+    }
+}
+
+// FOREIGN (CSVO contexts): SVO = VX_SVO_ESVO and the rays walk the traversal image of the world (csvo_image.hpp). A ray that
+// is about to be led into the voxel it started in cannot be continued on the image: its pixel is dropped and appended to
+// `todo`, and every wave, once the tile queue is empty and its own rays are done, renders listed pixels from scratch on the
+// compressed bytes -- exactly what the reference does for them -- until none is waiting. (A second phase of the same waves,
+// not a second kernel: its registers overlay the first phase's instead of adding to them, and a frame stays one command.)
+template <int SVO, bool HITS, bool STATS, int MINW = 1, bool FOREIGN = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
-                                                        vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters) {
-    const DevScene sc = make_scene(sa);
+                                                        vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
+    static_assert(!FOREIGN || (SVO == VX_SVO_ESVO && !STATS), "the traversal image is ESVO-layout; the instrumented kernel counts the reference's own fetches");
+    const DevScene sc = FOREIGN ? make_image_scene(sa) : make_scene(sa);
     const uint32_t lane = threadIdx.x;
     StackSpill spill;
     Stack<64, false> st;       // all 23 levels: LDS, then the per-lane spill array
@@ -153,9 +180,9 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle)));  // idle lanes are not waiting for anything
         for (;;) {
             if (tr.iter < uint32_t(kMaxSteps)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
-                const TravStatus s = tr.template step<false, STATS, false, Stack<64, true>, false>(sc, fast_st, nullptr, STATS ? &ctr : nullptr);
+                const TravStatus s = tr.template step<false, STATS, false, Stack<64, true>, false, FOREIGN>(sc, fast_st, nullptr, STATS ? &ctr : nullptr);
                 if (s != kTravContinue) {
-                    state = s == kTravAtLeaf ? kLeaf : (s == kTravDeep ? kDeep : kMissed);
+                    state = s == kTravAtLeaf ? kLeaf : (s == kTravDeep ? kDeep : (s == kTravForeign ? kForeign : kMissed));
                     tr.iter |= kParked;
                 }
             }
@@ -176,12 +203,34 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if (state == kDeep) {
             tr.iter &= ~kParked;
             for (;;) {
-                const TravStatus s = tr.template step<false, STATS, false>(sc, st, nullptr, STATS ? &ctr : nullptr);
+                const TravStatus s = tr.template step<false, STATS, false, Stack<64, false>, true, FOREIGN>(sc, st, nullptr, STATS ? &ctr : nullptr);
                 if (s == kTravContinue && tr.scale < kFastFloor) continue;
-                state = s == kTravContinue ? kTrav : (s == kTravAtLeaf ? kLeaf : kMissed);
+                state = s == kTravContinue ? kTrav : (s == kTravAtLeaf ? kLeaf : (s == kTravForeign ? kForeign : kMissed));
                 break;
             }
             if (state != kTrav) tr.iter |= kParked;
+        }
+
+        // ---- rays that started inside a voxel (FOREIGN): their pixels go to the kernel that renders them on the CSVO bytes ----
+        if (FOREIGN) {
+            const unsigned long long fm = __ballot(state == kForeign);
+            if (fm) {
+                uint32_t base = 0;
+                // entries first, then the count that publishes them
+                if (lane == 0) base = atomicAdd(&todo.counters[2], uint32_t(__popcll(fm)));  // [2]: slots reserved
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (state == kForeign) {
+                    const uint32_t e = base + __builtin_amdgcn_mbcnt_hi(uint32_t(fm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(fm), 0u));
+                    __hip_atomic_store(&todo.pixels[e & todo.mask], out_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    state = kIdle;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) {
+                    // publish in reservation order: wait until every earlier reservation has been published
+                    while (__hip_atomic_load(&todo.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != base) __builtin_amdgcn_s_sleep(1);
+                    __hip_atomic_store(&todo.counters[0], base + uint32_t(__popcll(fm)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
 
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
@@ -306,6 +355,42 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             state = kTrav;
         }
         if (__ballot(state != kIdle) == 0 && queue_empty) break;
+    }
+
+    // ---- second phase (FOREIGN): pixels whose rays started inside a voxel, whole, on the compressed bytes ----
+    // Entries [claimed, published) wait for a taker. A wave leaves when none is waiting; whatever a wave still in its first
+    // phase appends after that, that wave itself finds when it gets here.
+    if (FOREIGN) {
+        const DevScene sc_orig = make_scene(sa);
+        for (;;) {
+            uint32_t first = 0, n = 0;
+            if (lane == 0) {
+                for (;;) {
+                    const uint32_t claimed = __hip_atomic_load(&todo.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t waiting = __hip_atomic_load(&todo.counters[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - claimed;
+                    if (waiting == 0) break;
+                    const uint32_t take = waiting < 64u ? waiting : 64u;
+                    if (atomicCAS(&todo.counters[1], claimed, claimed + take) == claimed) {
+                        first = claimed;
+                        n = take;
+                        break;
+                    }
+                }
+            }
+            first = __builtin_amdgcn_readfirstlane(first);
+            n = __builtin_amdgcn_readfirstlane(n);
+            if (n == 0) break;
+            if (lane < n) {
+                const uint32_t index = __hip_atomic_load(&todo.pixels[(first + lane) & todo.mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t x, y;
+                out_index_to_xy(p, index, x, y);
+                float color[4];
+                vx_hit r;
+                shade_pixel<VX_SVO_CSVO, false>(sc_orig, p, x, y, st, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
+                if (out) out[index] = make_float4(color[0], color[1], color[2], color[3]);
+                if (HITS) hits[index] = r;
+            }
+        }
     }
 
     if (STATS) {
@@ -455,6 +540,11 @@ struct vx_context {
     // Tickets drawn from each dispenser so far. A launch draws exactly total_subtiles + waves tickets (every wave draws one
     // ticket past the end before it stops), so the next launch on the same stream starts there and no reset is needed.
     uint32_t frame_tickets[kFrameStreams] = {};
+    uint32_t* d_frame_todo[kFrameStreams] = {};  // CSVO image contexts: [3 counters][-][ring of pixel indices] per stream
+    size_t frame_todo_pixels[kFrameStreams] = {};
+    uint32_t* d_main_todo = nullptr;
+    size_t main_todo_pixels = 0;
+
     uint32_t main_tickets = 0;
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
     int frames_in_flight = 2;           // 1 serialises frames on `stream` again (vx_set_frames_in_flight / VX_FRAMES_IN_FLIGHT)
@@ -476,12 +566,18 @@ struct vx_context {
     unsigned long long* d_counters = nullptr;
 
     uint32_t* d_work_counter = nullptr;
+    // CSVO contexts: the traversal image of the world (csvo_image.hpp), rebuilt for the changed chunks by every commit
+    vximg::WorldImage image;
+    uint8_t* d_image = nullptr;
+    size_t d_image_capacity = 0;
+    bool image_enabled = true;  // VX_CSVO_IMAGE=0: traverse the compressed bytes directly
+    bool image_ok = false;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
     uint32_t refill_min = 4, service_min = 28;
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int cu_count = 256;
-    int persistent_blocks[2][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
+    int persistent_blocks[3][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
 
     bool profile = false;
     std::vector<ProfiledLaunch> launches;
@@ -504,6 +600,8 @@ SceneArgs scene_of(const vx_context* c) {
     s.tex_bytes = c->tex_bytes;
     s.width = c->tex.width; s.height = c->tex.height; s.layers = c->tex.layers; s.levels = c->tex.levels;
     for (int l = 0; l < 16; ++l) s.level_offset[l] = c->tex.level_offset[l];
+    s.image = c->image_ok ? c->d_image : nullptr;
+    s.image_bytes = c->image_ok ? uint32_t(c->image.frame_bytes() + kWorldPad) : 0u;
     return s;
 }
 
@@ -559,7 +657,13 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         if (!HITS && !STATS && ctx->min_waves == 4)
             fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 4>)
                       : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 4>);
-        int& per_cu = ctx->persistent_blocks[esvo ? 0 : 1][HITS][STATS];
+        // CSVO worlds are rendered from their traversal image; the instrumented variant stays on the compressed bytes so that
+        // its counters are the reference's own fetches
+        const bool imaged = !esvo && !STATS && ctx->image_ok;
+        if (imaged)
+            fn = (!HITS && ctx->min_waves == 4) ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, false, 4, true>)
+                                                : reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, false, 1, true>);
+        int& per_cu = ctx->persistent_blocks[esvo ? 0 : (imaged ? 2 : 1)][HITS][STATS];
         if (per_cu == 0) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, wave_lds) != hipSuccess || n <= 0) n = 8;
@@ -573,7 +677,30 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.service_min = ctx->service_min;
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
-        void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters};
+        PixelList todo = {nullptr, nullptr, 0};
+        if (imaged) {
+            // per stream: a ring of pixel indices (a power of two, at least the pixels of this launch) behind three counters that
+            // only ever grow -- nothing to reset between frames
+            uint32_t*& ring = slot >= 0 ? ctx->d_frame_todo[slot] : ctx->d_main_todo;
+            size_t& have = slot >= 0 ? ctx->frame_todo_pixels[slot] : ctx->main_todo_pixels;
+            const size_t pixels = size_t(p.n_local_tiles) * kTile * kTile;
+            if (have < pixels) {
+                if (ring) {
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    (void)hipFree(ring);
+                    ring = nullptr;
+                }
+                size_t cap = 1024;
+                while (cap < pixels) cap <<= 1;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ring), (cap + 4) * sizeof(uint32_t)));  // [published][claimed][reserved][-][ring...]
+                HIP_TRY(hipMemsetAsync(ring, 0, 4 * sizeof(uint32_t), stream));
+                have = cap;
+            }
+            todo.counters = ring;
+            todo.pixels = ring + 4;
+            todo.mask = uint32_t(have - 1);
+        }
+        void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, &todo};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
         tickets += a.total_subtiles + waves;
     }
@@ -691,6 +818,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_FRAMES_IN_FLIGHT")) c->frames_in_flight = std::atoi(e);
         if (c->frames_in_flight < 1) c->frames_in_flight = 1;
         if (c->frames_in_flight > vx_context::kFrameStreams) c->frames_in_flight = vx_context::kFrameStreams;
+        if (const char* e = std::getenv("VX_CSVO_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
@@ -718,12 +846,13 @@ void vx_destroy(vx_context* c) {
     for (auto& l : c->event_pool) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     if (c->staging) (void)hipHostFree(c->staging);
     void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_frame, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
-                   c->d_trace_count, c->d_counters, c->d_work_counter};
+                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_main_todo};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
         if (c->frame_stream[i]) (void)hipStreamSynchronize(c->frame_stream[i]);
         if (c->d_frame_counter[i]) (void)hipFree(c->d_frame_counter[i]);
+        if (c->d_frame_todo[i]) (void)hipFree(c->d_frame_todo[i]);
         if (c->frame_done[i]) (void)hipEventDestroy(c->frame_done[i]);
         if (c->frame_stream[i]) (void)hipStreamDestroy(c->frame_stream[i]);
     }
@@ -819,6 +948,38 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
         if (!ranges[i].length) continue;
         const uint64_t off = head + ranges[i].start;
         HIP_TRY(hipMemcpyAsync(ctx->d_world + off, ctx->staging + off, ranges[i].length, hipMemcpyHostToDevice, ctx->upload_stream));
+    }
+    if (ctx->svo_type == VX_SVO_CSVO && ctx->image_enabled && ctx->kernel_version != 1) {
+        // re-lay the changed chunks (and the root octree, which every commit rewrites) out as octants and upload those
+        std::vector<vximg::Range> changed(count);
+        for (uint32_t i = 0; i < count; ++i) changed[i] = vximg::Range{ranges[i].start, ranges[i].length};
+        const unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        ctx->image_ok = ctx->image.update(ctx->staging, used_bytes, changed.data(), changed.size(), false, threads);
+        if (ctx->image_ok) {
+            const size_t need = ctx->image.frame_bytes() + kWorldPad;
+            bool whole = false;
+            if (need > ctx->d_image_capacity) {
+                if (ctx->d_image) {  // frames in flight still read the old image
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
+                    HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
+                    (void)hipFree(ctx->d_image);
+                    ctx->d_image = nullptr;
+                }
+                const size_t cap = need + need / 2 + (1 << 20);
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_image), cap));
+                HIP_TRY(hipMemsetAsync(ctx->d_image, 0, cap, ctx->upload_stream));
+                ctx->d_image_capacity = cap;
+                whole = true;
+            }
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(ctx->image.frame().data());
+            if (whole) {
+                HIP_TRY(hipMemcpyAsync(ctx->d_image, src, ctx->image.frame_bytes(), hipMemcpyHostToDevice, ctx->upload_stream));
+            } else {
+                for (const vximg::Range& r : ctx->image.dirty_bytes())
+                    HIP_TRY(hipMemcpyAsync(ctx->d_image + r.start, src + r.start, r.length, hipMemcpyHostToDevice, ctx->upload_stream));
+            }
+        }
     }
     HIP_TRY(hipEventRecord(ctx->upload_done, ctx->upload_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_done, 0));

@@ -76,6 +76,8 @@ struct SceneArgs {
     uint32_t tex_bytes;
     uint32_t width, height, layers, levels;
     uint32_t level_offset[16];
+    const uint8_t* image;   // CSVO contexts: the ESVO-layout traversal image of the world (csvo_image.hpp), else null
+    uint32_t image_bytes;
 };
 
 __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
@@ -87,6 +89,16 @@ __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
     sc.tex.level_offset = a.level_offset;
     sc.octree_scale = __uint_as_float(buf_u32(sc.world, 0));
     sc.root_ptr = buf_u32(sc.world, 4);
+    return sc;
+}
+
+// the same scene with the traversal image in place of the world buffer
+__device__ __forceinline__ DevScene make_image_scene(const SceneArgs& a) {
+    SceneArgs b = a;
+    b.world = a.image;
+    b.world_bytes = a.image_bytes;
+    DevScene sc = make_scene(b);
+    sc.tex.level_offset = a.level_offset;  // (make_scene took the address of the copy's array)
     return sc;
 }
 
@@ -388,7 +400,10 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
 //         (and on the stack); the pointer-table entry is only read by the iteration that descends through it.
 // kTravDeep (fast stacks only): the next PUSH would leave the LDS-resident levels; the cursor is untouched and the caller
 // continues this ray with a full stack.
-enum TravStatus : int { kTravContinue = 0, kTravAtLeaf = 1, kTravFinished = 2, kTravDeep = 3 };
+// kTravForeign (FOREIGN steps only, i.e. a traversal image): the ray is about to be led INTO a leaf (it started inside that
+// voxel, svo.esvo.glsl:183-185); what follows depends on the bytes behind the leaf in the world's own format, so the caller
+// restarts this ray on the original buffer.
+enum TravStatus : int { kTravContinue = 0, kTravAtLeaf = 1, kTravFinished = 2, kTravDeep = 3, kTravForeign = 4 };
 enum LeafOutcome : int { kLeafHit = 0, kLeafPassed = 1, kLeafPassedAndFinished = 2 };
 
 // Debug-trace state (trace kernel only): the output frames, and the reference's (ptr, parent_octant_idx) view of the
@@ -552,8 +567,8 @@ struct Trav {
 
     // One iteration of the reference's loop (svo.esvo.glsl:152-391 / svo.csvo.glsl:261-508) minus the leaf test.
     // LIMIT = the ray has a maximum distance (picker); render rays are unlimited and skip the test.
-    // CAPPED = test the iteration cap here (a caller that already did passes false).
-    template <bool TRACE, bool STATS, bool LIMIT, class ST, bool CAPPED = true>
+    // CAPPED = test the iteration cap here (a caller that already did passes false). FOREIGN: see kTravForeign.
+    template <bool TRACE, bool STATS, bool LIMIT, class ST, bool CAPPED = true, bool FOREIGN = false>
     __device__ __forceinline__ TravStatus step(const DevScene& sc, const ST& st, TracePtr tk, Counters* ctr) {
         bool live = !CAPPED || iter < uint32_t(kMaxSteps);
         if (LIMIT) live = live && !(max_dst >= 0.0f && t_min > max_dst);
@@ -607,6 +622,7 @@ struct Trav {
         if (!descend) flags &= ~kHasAdjacentLeaf;
         if (descend && is_leaf) {
             if (t_min > 0.0f) return kTravAtLeaf;  // leaf_test() decides; the cursor is left untouched
+            if (FOREIGN) return kTravForeign;
             if (t_min == 0.0f) flags |= kInsideVoxel;
         }
         const float tv_max = gmin(t_max, tc_max);
