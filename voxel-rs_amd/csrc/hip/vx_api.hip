@@ -119,10 +119,14 @@ struct PersistentArgs {
 // Pixels whose rays a traversal image cannot serve, handed from the image kernel to the kernel that re-renders them on the
 // world's own bytes.
 struct PixelList {
-    uint32_t* pixels;    // ring of out_index values, `mask` + 1 entries (a power of two, at least the pixels of a frame)
-    uint32_t* counters;  // [0] appended, [1] claimed: both only ever grow; entries [claimed, appended) wait for a taker
+    // Pixels a wave has to re-render, in chunks of 128 dwords that the wave chains together: [0] previous chunk + 1 (0 = none),
+    // [1] entries, [2..127] out_index values. Chunks come from a ring (`mask` + 1 of them, a power of two) through one counter
+    // that only ever grows; a wave touches nothing but its own chunks, so no wave ever waits for another.
+    uint32_t* chunks;
+    uint32_t* next_chunk;
     uint32_t mask;
 };
+constexpr uint32_t kChunkDwords = 128, kChunkEntries = 126;
 
 // compact / row-major output index -> pixel coordinates (the inverse of the index computation in the refill)
 __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t out_index, uint32_t& x, uint32_t& y) {
@@ -138,10 +142,10 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
 }
 
 // FOREIGN (CSVO contexts): SVO = VX_SVO_ESVO and the rays walk the traversal image of the world (csvo_image.hpp). A ray that
-// is about to be led into the voxel it started in cannot be continued on the image: its pixel is dropped and appended to
-// `todo`, and every wave, once the tile queue is empty and its own rays are done, renders listed pixels from scratch on the
-// compressed bytes -- exactly what the reference does for them -- until none is waiting. (A second phase of the same waves,
-// not a second kernel: its registers overlay the first phase's instead of adding to them, and a frame stays one command.)
+// is about to be led into the voxel it started in cannot be continued on the image: its pixel is dropped and noted in the
+// wave's own list (`todo`), and every wave, once the tile queue is empty and its rays are done, renders the pixels it noted
+// from scratch on the compressed bytes -- exactly what the reference does for them. (A second phase of the same waves, not a
+// second kernel: its registers overlay the first phase's instead of adding to them, and a frame stays one command.)
 template <int SVO, bool HITS, bool STATS, int MINW = 1, bool FOREIGN = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
     bool queue_empty = false;
+    uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
 
     for (;;) {
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
@@ -215,21 +220,22 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if (FOREIGN) {
             const unsigned long long fm = __ballot(state == kForeign);
             if (fm) {
-                uint32_t base = 0;
-                // entries first, then the count that publishes them
-                if (lane == 0) base = atomicAdd(&todo.counters[2], uint32_t(__popcll(fm)));  // [2]: slots reserved
-                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t k = uint32_t(__popcll(fm));
+                if (my_chunk == 0 || my_fill + k > kChunkEntries) {  // a fresh chunk always has room for a whole wave
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(todo.next_chunk, 1u);
+                    c = __builtin_amdgcn_readfirstlane(c) & todo.mask;
+                    if (lane == 0) todo.chunks[size_t(c) * kChunkDwords] = my_chunk;
+                    my_chunk = c + 1;
+                    my_fill = 0;
+                }
+                uint32_t* chunk = todo.chunks + size_t(my_chunk - 1) * kChunkDwords;
                 if (state == kForeign) {
-                    const uint32_t e = base + __builtin_amdgcn_mbcnt_hi(uint32_t(fm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(fm), 0u));
-                    __hip_atomic_store(&todo.pixels[e & todo.mask], out_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    chunk[2 + my_fill + __builtin_amdgcn_mbcnt_hi(uint32_t(fm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(fm), 0u))] = out_index;
                     state = kIdle;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (lane == 0) {
-                    // publish in reservation order: wait until every earlier reservation has been published
-                    while (__hip_atomic_load(&todo.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != base) __builtin_amdgcn_s_sleep(1);
-                    __hip_atomic_store(&todo.counters[0], base + uint32_t(__popcll(fm)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                my_fill += k;
+                if (lane == 0) chunk[1] = my_fill;
             }
         }
 
@@ -357,38 +363,24 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if (__ballot(state != kIdle) == 0 && queue_empty) break;
     }
 
-    // ---- second phase (FOREIGN): pixels whose rays started inside a voxel, whole, on the compressed bytes ----
-    // Entries [claimed, published) wait for a taker. A wave leaves when none is waiting; whatever a wave still in its first
-    // phase appends after that, that wave itself finds when it gets here.
+    // ---- second phase (FOREIGN): the pixels this wave noted, whole, on the compressed bytes ----
     if (FOREIGN) {
         const DevScene sc_orig = make_scene(sa);
-        for (;;) {
-            uint32_t first = 0, n = 0;
-            if (lane == 0) {
-                for (;;) {
-                    const uint32_t claimed = __hip_atomic_load(&todo.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t waiting = __hip_atomic_load(&todo.counters[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - claimed;
-                    if (waiting == 0) break;
-                    const uint32_t take = waiting < 64u ? waiting : 64u;
-                    if (atomicCAS(&todo.counters[1], claimed, claimed + take) == claimed) {
-                        first = claimed;
-                        n = take;
-                        break;
-                    }
+        for (uint32_t c = my_chunk; c != 0;) {
+            const uint32_t* chunk = todo.chunks + size_t(c - 1) * kChunkDwords;
+            const uint32_t n = __builtin_amdgcn_readfirstlane(chunk[1]);
+            c = __builtin_amdgcn_readfirstlane(chunk[0]);
+            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                if (i0 + lane < n) {
+                    const uint32_t index = chunk[2 + i0 + lane];
+                    uint32_t x, y;
+                    out_index_to_xy(p, index, x, y);
+                    float color[4];
+                    vx_hit r;
+                    shade_pixel<VX_SVO_CSVO, false>(sc_orig, p, x, y, st, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
+                    if (out) out[index] = make_float4(color[0], color[1], color[2], color[3]);
+                    if (HITS) hits[index] = r;
                 }
-            }
-            first = __builtin_amdgcn_readfirstlane(first);
-            n = __builtin_amdgcn_readfirstlane(n);
-            if (n == 0) break;
-            if (lane < n) {
-                const uint32_t index = __hip_atomic_load(&todo.pixels[(first + lane) & todo.mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t x, y;
-                out_index_to_xy(p, index, x, y);
-                float color[4];
-                vx_hit r;
-                shade_pixel<VX_SVO_CSVO, false>(sc_orig, p, x, y, st, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
-                if (out) out[index] = make_float4(color[0], color[1], color[2], color[3]);
-                if (HITS) hits[index] = r;
             }
         }
     }
@@ -540,7 +532,7 @@ struct vx_context {
     // Tickets drawn from each dispenser so far. A launch draws exactly total_subtiles + waves tickets (every wave draws one
     // ticket past the end before it stops), so the next launch on the same stream starts there and no reset is needed.
     uint32_t frame_tickets[kFrameStreams] = {};
-    uint32_t* d_frame_todo[kFrameStreams] = {};  // CSVO image contexts: [3 counters][-][ring of pixel indices] per stream
+    uint32_t* d_frame_todo[kFrameStreams] = {};  // CSVO image contexts: [chunk counter][ring of 128-dword chunks] per stream
     size_t frame_todo_pixels[kFrameStreams] = {};
     uint32_t* d_main_todo = nullptr;
     size_t main_todo_pixels = 0;
@@ -679,25 +671,25 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         if (waves > a.total_subtiles) waves = a.total_subtiles;
         PixelList todo = {nullptr, nullptr, 0};
         if (imaged) {
-            // per stream: a ring of pixel indices (a power of two, at least the pixels of this launch) behind three counters that
-            // only ever grow -- nothing to reset between frames
+            // per stream: a ring of chunks behind a counter that only ever grows -- nothing to reset between frames. A finished
+            // chunk holds at least 63 pixels, every wave can have one unfinished one: pixels / 63 + waves chunks per launch at most.
             uint32_t*& ring = slot >= 0 ? ctx->d_frame_todo[slot] : ctx->d_main_todo;
             size_t& have = slot >= 0 ? ctx->frame_todo_pixels[slot] : ctx->main_todo_pixels;
-            const size_t pixels = size_t(p.n_local_tiles) * kTile * kTile;
-            if (have < pixels) {
+            const size_t need = size_t(p.n_local_tiles) * kTile * kTile / 63 + waves + 1;
+            if (have < need) {
                 if (ring) {
                     HIP_TRY(hipStreamSynchronize(stream));
                     (void)hipFree(ring);
                     ring = nullptr;
                 }
-                size_t cap = 1024;
-                while (cap < pixels) cap <<= 1;
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ring), (cap + 4) * sizeof(uint32_t)));  // [published][claimed][reserved][-][ring...]
-                HIP_TRY(hipMemsetAsync(ring, 0, 4 * sizeof(uint32_t), stream));
+                size_t cap = 64;
+                while (cap < need) cap <<= 1;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ring), (cap * kChunkDwords + 32) * sizeof(uint32_t)));  // [counter, pad][chunks...]
+                HIP_TRY(hipMemsetAsync(ring, 0, 32 * sizeof(uint32_t), stream));
                 have = cap;
             }
-            todo.counters = ring;
-            todo.pixels = ring + 4;
+            todo.next_chunk = ring;
+            todo.chunks = ring + 32;
             todo.mask = uint32_t(have - 1);
         }
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, &todo};
