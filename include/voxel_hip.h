@@ -177,7 +177,11 @@ size_t vx_capacity(const vx_context* ctx);
 /* Svo::update (svo.rs:171-189): stores f32 2^-depth at byte 0 (:173-175), waits for in-flight renders like
  * render_fence.wait() (:178), then copies the writer's header and the given dirty arena ranges to the device
  * (asynchronously; later renders/raycasts are ordered after it). used_bytes = WorldSvo::size_in_bytes() for
- * vx_get_stats (:183-187). */
+ * vx_get_stats (:183-187).
+ * CSVO contexts also keep a traversal image of the world (vx_csvo_to_image): the chunks inside the given ranges and the root
+ * octree are re-laid out as 48-byte octants on host worker threads and the changed parts uploaded; vx_render walks the image
+ * (device memory: about 4.7x the CSVO bytes on top of them). The staging mirror must hold the whole current world, i.e. every
+ * change has to go through vx_staging_ptr (it does when write_changes_to is the only writer). */
 int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes);
 /* Same, treating [0, used_bytes) of the arena as dirty (what the first write_changes_to after write_to does). */
 int vx_commit_all(vx_context* ctx, uint32_t depth, uint64_t used_bytes);
