@@ -227,11 +227,13 @@ int vx_assemble_tiles(vx_context* ctx, const float* tiles, uint64_t stride_float
  * render the next frame meanwhile); NULL = the legacy default stream. */
 int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
                          float* out_rgba32f, void* stream);
-/* The traversal image of a CSVO world: the ESVO-layout frame ([f32 2^-depth][5-word preamble][12-word octants]) that a CSVO
- * context traverses instead of the compressed bytes. `world_frame` = [f32 scale][u32 root_ptr][bytes] as
- * committed, `used_bytes` = arena bytes in use. Returns the image size in 32-bit words (0 = cannot be imaged) and fills
- * `out_words` when it is large enough. Pure host function (no device needed): vx_commit does this itself. */
-uint64_t vx_csvo_to_image(const uint8_t* world_frame, uint64_t used_bytes, uint32_t* out_words, uint64_t capacity_words);
+/* The traversal image of a CSVO world: the octant tree a CSVO context traverses instead of the compressed
+ * bytes. `world_frame` = [f32 scale][u32 root_ptr][bytes] as committed, `used_bytes` = arena bytes in use. layout 1 = what the
+ * renderer walks ([64-byte header][64-byte octants of eight {pointer | value, masks} entries]); layout 0 = the same tree as an
+ * ESVO frame ([f32 2^-depth][5-word preamble][12-word octants], esvo.rs:74-101), which any ESVO traversal can walk (the tests
+ * do, with the oracle). Returns the image size in 32-bit words (0 = cannot be imaged) and fills `out_words` when it is large
+ * enough. Pure host function (no device needed): vx_commit does this itself. */
+uint64_t vx_csvo_to_image(const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words);
 /* 2x2 ordered-grid supersampling (BASELINE.json C5): box-filters a (2*width) x (2*height) RGBA32F render down to
  * width x height, both in device memory, on the caller's hipStream_t (NULL = legacy default stream). Render the large
  * image with vx_render first (order it with vx_stream_wait_render). */

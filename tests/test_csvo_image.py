@@ -98,3 +98,54 @@ def test_streamed_world_with_lod_chunks_agrees():
     ib, hb = esvo.render(ou, w, h)
     assert ha.tobytes() == hb.tobytes() and np.array_equal(ia, ib)  # no shadow rays here: every record identical
     assert (ha["flags"] & 1).mean() > 0.2
+
+
+def _walk_esvo_image(img):
+    """(path, masks | leaf value) records of the ESVO-layout image, depth-first in child order."""
+    d = img[1:]  # descriptors[]
+    out = []
+    stack = [((), int(d[4]), int(d[0]) & 0xFFFF)]
+    while stack:
+        path, octant, masks = stack.pop()
+        out.append((path, "node", masks))
+        for c in range(8):
+            if not (masks >> 8) & (1 << c):
+                continue
+            w = int(d[octant + 4 + c])
+            if masks & (1 << c):
+                out.append((path + (c,), "leaf", w))
+                continue
+            child_masks = (int(d[octant + (c >> 1)]) >> ((c & 1) * 16)) & 0xFFFF
+            target = octant + 4 + c + (w & 0x7FFFFFFF) if w & 0x80000000 else w
+            stack.append((path + (c,), target, child_masks))
+    return sorted(out)
+
+
+def _walk_oct64_image(img):
+    out = []
+    stack = [((), int(img[2]), int(img[1]))]
+    while stack:
+        path, octant, masks = stack.pop()
+        assert octant % 64 == 0 and masks >> 16 == 0
+        out.append((path, "node", masks))
+        for c in range(8):
+            lo, hi = int(img[octant // 4 + 2 * c]), int(img[octant // 4 + 2 * c + 1])
+            if not (masks >> 8) & (1 << c):
+                assert lo == 0 and hi == 0
+            elif masks & (1 << c):
+                out.append((path + (c,), "leaf", lo))
+            else:
+                stack.append((path + (c,), lo, hi))
+    return sorted(out)
+
+
+def test_renderer_layout_holds_the_same_tree():
+    """Layout 1 (64-byte octants, what the kernel walks) against layout 0 (validated above with the oracle's traversal)."""
+    world = vra.World(vra.SVO_CSVO)
+    world.build_heightfield(7, threads=4)
+    frame = world.frame()
+    a = _walk_esvo_image(hip.csvo_to_image(frame, world.size_in_bytes, 0))
+    b_img = hip.csvo_to_image(frame, world.size_in_bytes, 1)
+    assert b_img[0] == frame[0] and b_img.size % 16 == 0
+    b = _walk_oct64_image(b_img)
+    assert len(a) > 10000 and a == b

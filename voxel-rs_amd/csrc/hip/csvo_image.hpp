@@ -1,16 +1,20 @@
 // CSVO -> traversal image. The reference's compressed node format (src/world/hds/csvo.rs:434-546) costs the traversal a
-// bit-field decode, two popcount sums and a dependent table read per descent; its 48-byte-octant sibling (esvo.rs:74-101)
-// costs two independent loads. A CSVO world is therefore re-laid out, on the host at commit time, as octants of that second
-// kind -- the "traversal image" -- and rays walk the image. Structure is preserved node for node (including the empty
-// octants the reference's never-compacted root octree carries), so every ray that starts outside a voxel takes the same
-// iterations to the same leaf with the same floats. A ray that starts INSIDE a voxel makes the reference wander through
-// leaf bytes as if they were nodes, which is format specific: the kernel hands exactly those rays to the CSVO traversal on
-// the original bytes (render_persistent, kForeign).
+// bit-field decode, two popcount sums and a dependent table read per descent. A CSVO world is therefore re-laid out, on the
+// host at commit time, as fixed-size octants -- the "traversal image" -- and rays walk the image. Structure is preserved node
+// for node (including the empty octants the reference's never-compacted root octree carries), so every ray that starts
+// outside a voxel takes the same iterations to the same leaf with the same floats. A ray that starts INSIDE a voxel makes the
+// reference wander through leaf bytes as if they were nodes, which is format specific: the kernel re-renders exactly those
+// pixels on the original bytes (render_persistent, kForeign).
 //
-// Host-only, no HIP calls: vx_api.hip owns the device side. Image layout = the ESVO frame Trav<VX_SVO_ESVO> reads:
-//   [f32 2^-depth][5-word preamble: root masks, 0, 0, 0, absolute index of the root octant][arena of 12-word octants]
-// Octant of node N: words 0..3 = masks of N's children, two per word (child_mask << 8 | leaf_mask); words 4..11 = per child
-// the relative pointer (bit 31) to its octant, or the absolute index of a chunk's root octant, or the leaf value.
+// Two encodings of the same octant tree:
+//   kOct64   what the renderer walks. Frame = 64-byte header [f32 2^-depth][u32 root masks][u32 byte offset of the root
+//            octant][0...] followed by 64-byte octants of eight {lo, hi} entries, one per child: lo = byte offset (from the
+//            frame start) of the child's own octant, or the leaf's value; hi = the child's masks (child_mask << 8 | leaf_mask).
+//            A descent is ONE aligned 8-byte load that yields the new pointer and the new masks; every pointer in the image
+//            is valid by construction, so the loads need no clamping.
+//   kEsvo48  the reference's other format (esvo.rs:74-101): [f32][5-word preamble][12-word octants], relative pointers.
+//            Kept because any ESVO traversal can walk it: tests/test_csvo_image.py checks the tree walk with the oracle.
+// Host-only, no HIP calls: vx_api.hip owns the device side.
 #pragma once
 
 #include <algorithm>
@@ -23,6 +27,8 @@
 #include <vector>
 
 namespace vximg {
+
+enum Layout : int { kEsvo48 = 0, kOct64 = 1 };
 
 struct Range {
     uint64_t start, length;
@@ -51,32 +57,39 @@ struct NodeMasks {
     uint32_t packed() const { return (child_mask << 8) | leaf_mask; }
 };
 
-// One chunk frame [lod:u8][material_bytes:u32][materials][nodes] (csvo.rs:217-227) -> position-independent octants.
-struct ChunkImage {
-    std::vector<uint32_t> words;  // octant 0 = the chunk's root node
-    NodeMasks root;
-    uint64_t csvo_end = 0;        // one past the last byte the chunk's nodes and materials occupy
+// One node of the walked tree, layout independent. Per child: nothing, a leaf (value), a node (index of its octant in the
+// same tree) or -- root octree only -- a chunk (its frame offset in the CSVO bytes).
+struct Octant {
+    uint32_t lo[8] = {};
+    uint16_t masks[8] = {};  // the child's own masks (nodes), filled in for chunks at placement
+    uint8_t node_mask = 0, leaf_mask = 0, chunk_mask = 0;
 };
 
-class ChunkTranscoder {
+struct Tree {
+    std::vector<Octant> octants;  // octant 0 = the root of this tree
+    NodeMasks root;
+    uint64_t csvo_end = 0;        // chunks: one past the last byte the chunk's materials and nodes occupy
+};
+
+// One chunk frame [lod:u8][material_bytes:u32][materials][nodes] (csvo.rs:217-227).
+class ChunkWalker {
 public:
-    ChunkTranscoder(Bytes b, ChunkImage& out) : b_(b), out_(out) {}
+    ChunkWalker(Bytes b, Tree& out) : b_(b), out_(out) {}
 
     void run(uint64_t frame) {
         const uint32_t lod = b_.u8(frame);
         const uint32_t material_bytes = b_.u32(frame + 1);
         materials_ = frame + 5;
         end_ = materials_ + material_bytes;
-        out_.words.clear();
+        out_.octants.clear();
         out_.root = node(materials_ + material_bytes, lod, 0);
         out_.csvo_end = end_;
     }
 
 private:
-    // emits the octant of the node at `ptr` (appended to out_.words, children after it) and returns the node's masks
     NodeMasks node(uint64_t ptr, uint32_t depth, uint64_t pre_leaf) {
-        const size_t at = out_.words.size();
-        out_.words.resize(at + 12, 0u);
+        const size_t at = out_.octants.size();
+        out_.octants.emplace_back();
         NodeMasks m;
         if (depth == 0 || depth > 32) return m;  // malformed: an octant without children
         if (depth == 1) {
@@ -85,13 +98,14 @@ private:
             end_ = std::max(end_, ptr + 1);
             const uint32_t material_offset = b_.u16(pre_leaf + 1);
             const uint64_t leaf_index = ptr - (pre_leaf + 3);
+            uint32_t preceding = 0;  // leaves before this byte under the depth-2 node
+            for (uint64_t k = 0; k < leaf_index; ++k) preceding += uint32_t(__builtin_popcount(b_.u8(pre_leaf + 3 + k)));
             for (uint32_t c = 0; c < 8; ++c) {
                 if (!((mask >> c) & 1u)) continue;
-                const uint64_t bit_mark = leaf_index * 8 + c;  // leaves preceding this one under the depth-2 node
-                uint32_t preceding = 0;
-                for (uint64_t k = 0; k < bit_mark; ++k) preceding += (b_.u8(pre_leaf + 3 + k / 8) >> (k % 8)) & 1u;
-                out_.words[at + 4 + c] = b_.u32(materials_ + uint64_t(material_offset) * 4 + uint64_t(preceding) * 4);
+                const uint32_t before = preceding + uint32_t(__builtin_popcount(mask & ((1u << c) - 1u)));
+                out_.octants[at].lo[c] = b_.u32(materials_ + uint64_t(material_offset) * 4 + uint64_t(before) * 4);
             }
+            out_.octants[at].leaf_mask = uint8_t(mask);
             m.child_mask = m.leaf_mask = mask;
             return m;
         }
@@ -106,7 +120,7 @@ private:
                 uint32_t e = 0;
                 for (uint32_t k = 0; k < width; ++k) e |= b_.u8(ptr + 2 + offset + k) << (8 * k);
                 end_ = std::max(end_, ptr + 2 + table);
-                child = ptr + 2 + table + e;  // (an absolute pointer, bit 31, only exists in the root octree: see RootTranscoder)
+                child = ptr + 2 + table + e;  // (an absolute pointer, bit 31, only exists in the root octree: RootWalker)
             } else if (depth == 3) {  // pre-leaf node: u8 mask, u8 offsets (svo.csvo.glsl:107-112)
                 const uint32_t header = b_.u8(ptr);
                 if (!((header >> c) & 1u)) continue;
@@ -119,19 +133,52 @@ private:
                 child = ptr + 3 + uint32_t(__builtin_popcount(header & ((1u << c) - 1u)));
                 end_ = std::max(end_, ptr + 3 + uint32_t(__builtin_popcount(header)));
             }
-            const size_t child_at = out_.words.size();
+            const size_t child_at = out_.octants.size();
             const NodeMasks cm = node(child, depth - 1, depth == 2 ? ptr : pre_leaf);
             m.child_mask |= 1u << c;
-            out_.words[at + (c >> 1)] |= cm.packed() << ((c & 1u) * 16);
-            out_.words[at + 4 + c] = 0x80000000u | uint32_t(child_at - (at + 4 + c));  // relative to this body word (esvo.rs:501-504)
+            Octant& o = out_.octants[at];
+            o.node_mask |= uint8_t(1u << c);
+            o.lo[c] = uint32_t(child_at);
+            o.masks[c] = uint16_t(cm.packed());
         }
         return m;
     }
 
     Bytes b_;
-    ChunkImage& out_;
+    Tree& out_;
     uint64_t materials_ = 0, end_ = 0;
 };
+
+// Root octree: internal nodes only (their depth is always above a chunk's); a 4-byte entry with bit 31 is the frame offset of
+// a chunk (csvo.rs:76-86,100-105).
+inline NodeMasks walk_root(const Bytes& b, uint64_t ptr, uint32_t depth, Tree& out) {
+    const size_t at = out.octants.size();
+    out.octants.emplace_back();
+    NodeMasks m;
+    if (depth <= 3 || depth > 32) return m;
+    const uint32_t header = b.u16(ptr);
+    const uint32_t table = tag_bytes(header);
+    for (uint32_t c = 0; c < 8; ++c) {
+        const uint32_t tag = (header >> (2 * c)) & 3u;
+        if (!tag) continue;
+        const uint32_t offset = tag_bytes(header & ((1u << (2 * c)) - 1u)), width = tag == 3 ? 4u : tag;
+        uint32_t e = 0;
+        for (uint32_t k = 0; k < width; ++k) e |= b.u8(ptr + 2 + offset + k) << (8 * k);
+        m.child_mask |= 1u << c;
+        if (e & 0x80000000u) {
+            out.octants[at].chunk_mask |= uint8_t(1u << c);
+            out.octants[at].lo[c] = e ^ 0x80000000u;
+        } else {
+            const size_t child_at = out.octants.size();
+            const NodeMasks cm = walk_root(b, ptr + 2 + table + e, depth - 1, out);
+            Octant& o = out.octants[at];
+            o.node_mask |= uint8_t(1u << c);
+            o.lo[c] = uint32_t(child_at);
+            o.masks[c] = uint16_t(cm.packed());
+        }
+    }
+    return m;
+}
 
 // first-fit word allocator over the image arena (the reference's RangeBuffer idea, internal.rs:163-277)
 class WordAllocator {
@@ -173,10 +220,10 @@ private:
 // The image of a whole CSVO world, kept up to date commit by commit.
 class WorldImage {
 public:
-    static constexpr uint64_t kPreambleWords = 5;
+    explicit WorldImage(Layout layout = kOct64) : layout_(layout) {}
 
-    // host mirror of the image frame: byte 0 = f32 scale, then descriptors[] words
-    const std::vector<uint32_t>& frame() const { return frame_; }  // frame_[0] = scale bits, frame_[1 + i] = descriptors[i]
+    // host mirror of the image frame, as 32-bit words
+    const std::vector<uint32_t>& frame() const { return frame_; }
     uint64_t frame_bytes() const { return frame_.size() * 4; }
     // byte ranges of frame() changed by the last update(), sorted and merged
     std::vector<Range> dirty_bytes() const {
@@ -195,9 +242,9 @@ public:
     size_t chunk_count() const { return chunks_.size(); }
 
     // `world` = the CSVO frame as committed: [f32 scale][u32 root_ptr][descriptor bytes]; `used` = bytes of the arena in use;
-    // `changed` = byte ranges (relative to the arena, like vx_commit's) rewritten since the last call, or empty + `all` = true.
+    // `changed` = byte ranges (relative to the arena, like vx_commit's) rewritten since the last call.
     // Returns false when the world cannot be imaged (malformed or image beyond 4 GiB): the caller then traverses the CSVO bytes.
-    bool update(const uint8_t* world, uint64_t used, const Range* changed, size_t n_changed, bool all, unsigned threads) {
+    bool update(const uint8_t* world, uint64_t used, const Range* changed, size_t n_changed, unsigned threads) {
         dirty_.clear();
         if (used < 2) return false;
         const Bytes b{world + 8, size_t(used)};
@@ -207,23 +254,19 @@ public:
         const uint32_t depth = 127u - ((scale_bits >> 23) & 0xffu);  // svo.csvo.glsl:254
         if (depth < 1 || depth > 23) return false;
         if (frame_.empty()) {
-            frame_.assign(1 + kPreambleWords, 0u);
-            alloc_.reset(kPreambleWords);
-            all = true;
-        }
-        if (all) {
-            for (auto& kv : chunks_) alloc_.release(kv.second.at, kv.second.words);
-            chunks_.clear();
+            frame_.assign(header_words(), 0u);
+            alloc_.reset(header_words());
         }
 
-        // 1. walk the root octree: which chunk frames does it reference, and where
-        std::vector<uint32_t> root_words;
-        std::vector<std::pair<size_t, uint32_t>> chunk_refs;  // (index of the body word in root_words, chunk frame offset)
-        const NodeMasks root_masks = root_node(b, root_ptr, depth, root_words, chunk_refs);
+        // 1. walk the root octree: which chunk frames does it reference
+        Tree root;
+        root.root = walk_root(b, root_ptr, depth, root);
+        std::unordered_set<uint32_t> referenced;
+        for (const Octant& o : root.octants)
+            for (uint32_t c = 0; c < 8; ++c)
+                if ((o.chunk_mask >> c) & 1u) referenced.insert(o.lo[c]);
 
         // 2. drop images of chunks that are gone or whose bytes were rewritten
-        std::unordered_set<uint32_t> referenced;
-        for (auto& r : chunk_refs) referenced.insert(r.second);
         for (auto it = chunks_.begin(); it != chunks_.end();) {
             bool stale = !referenced.count(it->first);
             for (size_t i = 0; i < n_changed && !stale; ++i)
@@ -236,95 +279,117 @@ public:
             }
         }
 
-        // 3. transcode what is missing (worker threads), then place it
+        // 3. walk what is missing (worker threads), place it (this thread), encode it in place (worker threads)
         std::vector<uint32_t> todo;
         for (uint32_t off : referenced)
             if (!chunks_.count(off)) todo.push_back(off);
         std::sort(todo.begin(), todo.end());
-        std::vector<ChunkImage> built(todo.size());
-        std::atomic<size_t> next{0};
-        auto worker = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < todo.size();) ChunkTranscoder(b, built[i]).run(todo[i]);
-        };
-        const unsigned n_workers = std::max(1u, std::min<unsigned>(threads, unsigned(todo.size() / 16 + 1)));
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < n_workers; ++t) pool.emplace_back(worker);
-        worker();
-        for (auto& t : pool) t.join();
+        std::vector<Tree> built(todo.size());
+        parallel(todo.size(), threads, [&](size_t i) { ChunkWalker(b, built[i]).run(todo[i]); });
+        std::vector<Placed> placed(todo.size());
+        uint64_t top = frame_.size();
         for (size_t i = 0; i < todo.size(); ++i) {
-            Placed pl;
-            pl.words = built[i].words.size();
+            Placed& pl = placed[i];
+            pl.words = built[i].octants.size() * octant_words();
             pl.at = alloc_.alloc(pl.words);
             pl.masks = built[i].root.packed();
             pl.csvo_end = built[i].csvo_end;
-            write(pl.at, built[i].words.data(), pl.words);
+            top = std::max(top, pl.at + pl.words);
+            dirty_.push_back(Range{pl.at * 4, pl.words * 4});
             chunks_[todo[i]] = pl;
         }
+        if (frame_.size() < top) frame_.resize(top, 0u);
+        parallel(todo.size(), threads, [&](size_t i) { encode(built[i], placed[i].at); });
 
         // 4. the root octree is rewritten by every commit (csvo.rs:68-139 re-serializes it): so is its image
         alloc_.release(root_at_, root_words_);
-        for (auto& r : chunk_refs) {
-            const Placed& pl = chunks_.at(r.second);
-            const size_t body = r.first;
-            root_words[body] = uint32_t(pl.at);  // absolute index of the chunk's root octant (bit 31 clear, esvo.rs:164-171)
-            // the chunk's masks go into the header half-word of the same child slot of the same octant
-            const size_t oct = (body / 12) * 12, c = body - oct - 4;
-            root_words[oct + (c >> 1)] |= pl.masks << ((c & 1u) * 16);
-        }
-        root_words_ = root_words.size();
+        root_words_ = root.octants.size() * octant_words();
         root_at_ = alloc_.alloc(root_words_);
-        write(root_at_, root_words.data(), root_words_);
-        const uint32_t preamble[5] = {root_masks.packed(), 0, 0, 0, uint32_t(root_at_)};
-        write(0, preamble, 5);
-        if (frame_[0] != scale_bits) {
-            frame_[0] = scale_bits;
-            dirty_.push_back(Range{0, 4});
+        if (frame_.size() < root_at_ + root_words_) frame_.resize(root_at_ + root_words_, 0u);
+        for (Octant& o : root.octants)
+            for (uint32_t c = 0; c < 8; ++c)
+                if ((o.chunk_mask >> c) & 1u) {
+                    const Placed& pl = chunks_.at(o.lo[c]);
+                    o.lo[c] = uint32_t(pl.at);  // word index of the chunk's root octant
+                    o.masks[c] = uint16_t(pl.masks);
+                }
+        encode(root, root_at_);
+        dirty_.push_back(Range{root_at_ * 4, root_words_ * 4});
+
+        // 5. header
+        frame_[0] = scale_bits;
+        if (layout_ == kOct64) {
+            frame_[1] = root.root.packed();
+            frame_[2] = uint32_t(root_at_ * 4);
+        } else {
+            frame_[1] = root.root.packed();  // preamble: a fake octant whose child 0 is the root (esvo.rs:179-188)
+            frame_[2] = frame_[3] = frame_[4] = 0;
+            frame_[5] = uint32_t(root_at_ - 1);  // descriptors[] index = frame word index - 1
         }
-        return (alloc_.end() + 1) * 4 < (uint64_t(1) << 32) - 64;
+        dirty_.push_back(Range{0, header_words() * 4});
+        return alloc_.end() * 4 < (uint64_t(1) << 31);  // kOct64 pointers are byte offsets that must stay clear of the sign games of 32-bit offsets
     }
 
 private:
     struct Placed {
-        uint64_t at = 0, words = 0, csvo_end = 0;
+        uint64_t at = 0, words = 0, csvo_end = 0;  // `at` in frame words
         uint32_t masks = 0;
     };
 
-    // Root octree nodes are internal nodes (their depth is always above a chunk's); a 4-byte entry with bit 31 is the frame
-    // offset of a chunk (csvo.rs:76-86,100-105). Octants are appended to `out` with relative pointers; chunk slots are
-    // recorded and patched by the caller once the chunks have been placed.
-    NodeMasks root_node(const Bytes& b, uint64_t ptr, uint32_t depth, std::vector<uint32_t>& out, std::vector<std::pair<size_t, uint32_t>>& refs) {
-        const size_t at = out.size();
-        out.resize(at + 12, 0u);
-        NodeMasks m;
-        if (depth <= 3 || depth > 32) return m;
-        const uint32_t header = b.u16(ptr);
-        const uint32_t table = tag_bytes(header);
-        for (uint32_t c = 0; c < 8; ++c) {
-            const uint32_t tag = (header >> (2 * c)) & 3u;
-            if (!tag) continue;
-            const uint32_t offset = tag_bytes(header & ((1u << (2 * c)) - 1u)), width = tag == 3 ? 4u : tag;
-            uint32_t e = 0;
-            for (uint32_t k = 0; k < width; ++k) e |= b.u8(ptr + 2 + offset + k) << (8 * k);
-            m.child_mask |= 1u << c;
-            if (e & 0x80000000u) {
-                refs.emplace_back(at + 4 + c, e ^ 0x80000000u);
+    uint64_t header_words() const { return layout_ == kOct64 ? 16 : 6; }
+    uint64_t octant_words() const { return layout_ == kOct64 ? 16 : 12; }
+
+    template <class F>
+    static void parallel(size_t n, unsigned threads, F f) {
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
+        };
+        const unsigned n_workers = std::max(1u, std::min<unsigned>(threads, unsigned(n / 16 + 1)));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_workers; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+    }
+
+    // writes the tree's octants at frame word `at` (octant i at at + i * octant_words()); chunk children hold the frame word
+    // index of the chunk's root octant by now
+    void encode(const Tree& t, uint64_t at) {
+        uint32_t* dst = frame_.data() + at;
+        for (size_t i = 0; i < t.octants.size(); ++i) {
+            const Octant& o = t.octants[i];
+            if (layout_ == kOct64) {
+                uint32_t* w = dst + i * 16;
+                for (uint32_t c = 0; c < 8; ++c) {
+                    const uint32_t bit = 1u << c;
+                    uint32_t lo = 0, hi = 0;
+                    if (o.node_mask & bit) { lo = uint32_t((at + uint64_t(o.lo[c]) * 16) * 4); hi = o.masks[c]; }
+                    else if (o.chunk_mask & bit) { lo = o.lo[c] * 4u; hi = o.masks[c]; }
+                    else if (o.leaf_mask & bit) { lo = o.lo[c]; }
+                    w[2 * c] = lo;
+                    w[2 * c + 1] = hi;
+                }
             } else {
-                const size_t child_at = out.size();
-                const NodeMasks cm = root_node(b, ptr + 2 + table + e, depth - 1, out, refs);
-                out[at + (c >> 1)] |= cm.packed() << ((c & 1u) * 16);
-                out[at + 4 + c] = 0x80000000u | uint32_t(child_at - (at + 4 + c));
+                uint32_t* w = dst + i * 12;
+                for (int k = 0; k < 12; ++k) w[k] = 0;
+                for (uint32_t c = 0; c < 8; ++c) {
+                    const uint32_t bit = 1u << c;
+                    if (o.node_mask & bit) {
+                        const uint64_t target = at + uint64_t(o.lo[c]) * 12, body = at + i * 12 + 4 + c;
+                        w[4 + c] = 0x80000000u | uint32_t(target - body);  // relative to this body word (esvo.rs:501-504)
+                        w[c >> 1] |= uint32_t(o.masks[c]) << ((c & 1u) * 16);
+                    } else if (o.chunk_mask & bit) {
+                        w[4 + c] = o.lo[c] - 1u;  // absolute descriptors[] index of the chunk's root octant (esvo.rs:164-171)
+                        w[c >> 1] |= uint32_t(o.masks[c]) << ((c & 1u) * 16);
+                    } else if (o.leaf_mask & bit) {
+                        w[4 + c] = o.lo[c];
+                    }
+                }
             }
         }
-        return m;
     }
 
-    void write(uint64_t at, const uint32_t* src, uint64_t n) {
-        if (!n) return;
-        if (frame_.size() < 1 + at + n) frame_.resize(1 + at + n, 0u);
-        std::memcpy(frame_.data() + 1 + at, src, n * 4);
-        dirty_.push_back(Range{(1 + at) * 4, n * 4});
-    }
-
+    Layout layout_;
     std::vector<uint32_t> frame_;
     std::vector<Range> dirty_;
     WordAllocator alloc_;

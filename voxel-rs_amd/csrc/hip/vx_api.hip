@@ -141,7 +141,7 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
     }
 }
 
-// FOREIGN (CSVO contexts): SVO = VX_SVO_ESVO and the rays walk the traversal image of the world (csvo_image.hpp). A ray that
+// FOREIGN (CSVO contexts): SVO = VX_SVO_IMAGE and the rays walk the traversal image of the world (csvo_image.hpp). A ray that
 // is about to be led into the voxel it started in cannot be continued on the image: its pixel is dropped and noted in the
 // wave's own list (`todo`), and every wave, once the tile queue is empty and its rays are done, renders the pixels it noted
 // from scratch on the compressed bytes -- exactly what the reference does for them. (A second phase of the same waves, not a
@@ -149,7 +149,7 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
 template <int SVO, bool HITS, bool STATS, int MINW = 1, bool FOREIGN = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
-    static_assert(!FOREIGN || (SVO == VX_SVO_ESVO && !STATS), "the traversal image is ESVO-layout; the instrumented kernel counts the reference's own fetches");
+    static_assert(FOREIGN == (SVO == VX_SVO_IMAGE) && !(FOREIGN && STATS), "image traversal <=> foreign handling; the instrumented kernel counts the reference's own fetches");
     const DevScene sc = FOREIGN ? make_image_scene(sa) : make_scene(sa);
     const uint32_t lane = threadIdx.x;
     StackSpill spill;
@@ -653,8 +653,8 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // its counters are the reference's own fetches
         const bool imaged = !esvo && !STATS && ctx->image_ok;
         if (imaged)
-            fn = (!HITS && ctx->min_waves == 4) ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, false, 4, true>)
-                                                : reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, false, 1, true>);
+            fn = (!HITS && ctx->min_waves == 4) ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 4, true>)
+                                                : reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 1, true>);
         int& per_cu = ctx->persistent_blocks[esvo ? 0 : (imaged ? 2 : 1)][HITS][STATS];
         if (per_cu == 0) {
             int n = 0;
@@ -946,7 +946,7 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
         std::vector<vximg::Range> changed(count);
         for (uint32_t i = 0; i < count; ++i) changed[i] = vximg::Range{ranges[i].start, ranges[i].length};
         const unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        ctx->image_ok = ctx->image.update(ctx->staging, used_bytes, changed.data(), changed.size(), false, threads);
+        ctx->image_ok = ctx->image.update(ctx->staging, used_bytes, changed.data(), changed.size(), threads);
         if (ctx->image_ok) {
             const size_t need = ctx->image.frame_bytes() + kWorldPad;
             bool whole = false;
@@ -1185,10 +1185,10 @@ int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_fl
     return VX_OK;
 }
 
-uint64_t vx_csvo_to_image(const uint8_t* world_frame, uint64_t used_bytes, uint32_t* out_words, uint64_t capacity_words) {
-    if (!world_frame) return 0;
-    vximg::WorldImage img;
-    if (!img.update(world_frame, used_bytes, nullptr, 0, true, std::max(1u, std::min(16u, std::thread::hardware_concurrency())))) return 0;
+uint64_t vx_csvo_to_image(const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words) {
+    if (!world_frame || (layout != 0 && layout != 1)) return 0;
+    vximg::WorldImage img(layout == 0 ? vximg::kEsvo48 : vximg::kOct64);
+    if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(16u, std::thread::hardware_concurrency())))) return 0;
     const std::vector<uint32_t>& f = img.frame();
     if (out_words && capacity_words >= f.size()) std::memcpy(out_words, f.data(), f.size() * 4);
     return f.size();

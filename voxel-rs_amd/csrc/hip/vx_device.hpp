@@ -418,16 +418,20 @@ struct TraceSink {
 
 typedef VX_AS_PRIVATE TraceSink* TracePtr;
 
+// third node format, internal to the library: the 64-byte-octant traversal image of a CSVO world (csvo_image.hpp, kOct64)
+#define VX_SVO_IMAGE 3
+
 template <int SVO>
 struct Trav {
     static constexpr bool CSVO = SVO == VX_SVO_CSVO;
+    static constexpr bool IMG = SVO == VX_SVO_IMAGE;
 
     float rox, roy, roz, rdx, rdy, rdz;   // origin in [1,2) space, epsilon-clamped direction
     float tcx, tcy, tcz, tbx, tby, tbz;   // t(x) = x * t_coef - t_bias per axis
     float px, py, pz;                     // current octant corner
     float t_min, t_max, h, scale_exp2;
     float max_dst;                        // already scaled to [0,1]; < 0 = unlimited
-    uint32_t ptr;                         // ESVO: word index of the examined node's own octant; CSVO: its byte pointer
+    uint32_t ptr;                         // ESVO: word index of the examined node's own octant; CSVO: its byte pointer; image: byte offset of its octant
     uint32_t node;                        // ESVO: child_mask << 8 | leaf_mask of the examined node; CSVO: its header
     uint32_t depth;                       // CSVO only (svo.csvo.glsl:254); wraps below 0 exactly like the reference's uint
     uint32_t material_section_ptr, pre_leaf_pointer;  // CSVO only
@@ -497,6 +501,10 @@ struct Trav {
             depth = 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu);  // svo.csvo.glsl:254
             node = csvo_header(sc);
             if (depth == 2) pre_leaf_pointer = ptr;
+        } else if (IMG) {
+            depth = 0;
+            node = buf_u32(sc.world, 4);  // header of the image: root masks, byte offset of the root octant
+            ptr = buf_u32(sc.world, 8);
         } else {
             // the reference starts at (ptr 0, parent_octant_idx 0): the preamble is an octant whose only child is the root
             depth = 0;
@@ -599,6 +607,7 @@ struct Trav {
             if (STATS) ctr->csvo_header_bytes += depth > 3 ? 2u : 1u;
         }
 
+        static_assert(!(TRACE && IMG), "the debug trace reports the reference's own pointers: it runs on the world's own bytes");
         if (TRACE) {
             if (tk->n_frames < tk->max_frames) {
                 const float octree_scale = sc.octree_scale;
@@ -641,7 +650,12 @@ struct Trav {
             // depend on it -- new scale, child centre distances, first child index and corner -- while the request is in
             // flight, (3) the dependent part. The scheduling fences keep the compiler from pulling (3) up to the loads.
             uint32_t w0 = 0, w1 = 0, table = 0, offset = 0;
-            if (!CSVO) {
+            if (IMG) {
+                // one aligned 8-byte entry: the child's octant and the child's masks (no clamp: image pointers are valid by construction)
+                const uint2 e = buf_u64(sc.world, ptr + octant_idx * 8u);
+                w0 = e.x;
+                w1 = e.y;
+            } else if (!CSVO) {
                 // the child's pointer word and the header word with its masks, both in the octant at `ptr`
                 w0 = esvo_word(sc, ptr + 4 + octant_idx);
                 w1 = esvo_word(sc, ptr + (octant_idx >> 1));
@@ -673,7 +687,10 @@ struct Trav {
             if (!ST::kFast) idx = int(upper_x) | (int(upper_y) << 1) | (int(upper_z) << 2);
             t_max = tv_max;
             sched_fence();
-            if (!CSVO) {
+            if (IMG) {
+                ptr = w0;
+                node = w1;
+            } else if (!CSVO) {
                 if (TRACE) { tk->ref_ptr = ptr; tk->ref_aux = octant_idx; }
                 ptr = (w0 & 0x80000000u) ? ptr + 4 + octant_idx + (w0 & 0x7fffffffu) : w0;
                 node = (octant_idx & 1u) ? w1 >> 16 : w1;
@@ -714,7 +731,9 @@ struct Trav {
         const float octree_scale = sc.octree_scale;
         const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 2^depth, exact
         const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
-        const uint32_t value = CSVO ? csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx) : esvo_word(sc, ptr + 4 + octant_idx);
+        const uint32_t value = CSVO  ? csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx)
+                               : IMG ? buf_u32(sc.world, ptr + octant_idx * 8u)
+                                     : esvo_word(sc, ptr + 4 + octant_idx);
 
         const float ex = __builtin_fmaf(px + scale_exp2, tcx, -tbx);
         const float ey = __builtin_fmaf(py + scale_exp2, tcy, -tby);
