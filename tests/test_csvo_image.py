@@ -121,12 +121,19 @@ def _walk_esvo_image(img):
     return sorted(out)
 
 
+def _oct64_masks(m):
+    """child c: 'exists' at bit 31 - c, 'is a leaf' at bit 23 - c  ->  child_mask << 8 | leaf_mask"""
+    assert m & 0xFFFF == 0
+    rev = lambda b: int(f"{b:08b}"[::-1], 2)
+    return (rev(m >> 24) << 8) | rev((m >> 16) & 0xFF)
+
+
 def _walk_oct64_image(img):
     out = []
-    stack = [((), int(img[2]), int(img[1]))]
+    stack = [((), int(img[2]), _oct64_masks(int(img[1])))]
     while stack:
         path, octant, masks = stack.pop()
-        assert octant % 64 == 0 and masks >> 16 == 0
+        assert octant % 64 == 0
         out.append((path, "node", masks))
         for c in range(8):
             lo, hi = int(img[octant // 4 + 2 * c]), int(img[octant // 4 + 2 * c + 1])
@@ -135,7 +142,7 @@ def _walk_oct64_image(img):
             elif masks & (1 << c):
                 out.append((path + (c,), "leaf", lo))
             else:
-                stack.append((path + (c,), lo, hi))
+                stack.append((path + (c,), lo, _oct64_masks(hi)))
     return sorted(out)
 
 

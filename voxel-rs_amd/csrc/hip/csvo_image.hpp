@@ -9,7 +9,7 @@
 // Two encodings of the same octant tree:
 //   kOct64   what the renderer walks. Frame = 64-byte header [f32 2^-depth][u32 root masks][u32 byte offset of the root
 //            octant][0...] followed by 64-byte octants of eight {lo, hi} entries, one per child: lo = byte offset (from the
-//            frame start) of the child's own octant, or the leaf's value; hi = the child's masks (child_mask << 8 | leaf_mask).
+//            frame start) of the child's own octant, or the leaf's value; hi = the child's masks (oct64_masks()).
 //            A descent is ONE aligned 8-byte load that yields the new pointer and the new masks; every pointer in the image
 //            is valid by construction, so the loads need no clamping.
 //   kEsvo48  the reference's other format (esvo.rs:74-101): [f32][5-word preamble][12-word octants], relative pointers.
@@ -56,6 +56,17 @@ struct NodeMasks {
     uint32_t child_mask = 0, leaf_mask = 0;
     uint32_t packed() const { return (child_mask << 8) | leaf_mask; }
 };
+
+// kOct64's form of packed masks: child c's "exists" bit at 31 - c and its "is a leaf" bit at 23 - c (the traversal shifts the
+// word left by the child index and finds "exists" in the sign bit and "leaf" in bit 23, vx_device.hpp Trav::step_with)
+inline uint32_t oct64_masks(uint32_t packed) {
+    uint32_t out = 0;
+    for (uint32_t c = 0; c < 8; ++c) {
+        if ((packed >> (8 + c)) & 1u) out |= 0x80000000u >> c;
+        if ((packed >> c) & 1u) out |= 0x00800000u >> c;
+    }
+    return out;
+}
 
 // One node of the walked tree, layout independent. Per child: nothing, a leaf (value), a node (index of its octant in the
 // same tree) or -- root octree only -- a chunk (its frame offset in the CSVO bytes).
@@ -319,7 +330,7 @@ public:
         // 5. header
         frame_[0] = scale_bits;
         if (layout_ == kOct64) {
-            frame_[1] = root.root.packed();
+            frame_[1] = oct64_masks(root.root.packed());
             frame_[2] = uint32_t(root_at_ * 4);
         } else {
             frame_[1] = root.root.packed();  // preamble: a fake octant whose child 0 is the root (esvo.rs:179-188)
@@ -363,8 +374,8 @@ private:
                 for (uint32_t c = 0; c < 8; ++c) {
                     const uint32_t bit = 1u << c;
                     uint32_t lo = 0, hi = 0;
-                    if (o.node_mask & bit) { lo = uint32_t((at + uint64_t(o.lo[c]) * 16) * 4); hi = o.masks[c]; }
-                    else if (o.chunk_mask & bit) { lo = o.lo[c] * 4u; hi = o.masks[c]; }
+                    if (o.node_mask & bit) { lo = uint32_t((at + uint64_t(o.lo[c]) * 16) * 4); hi = oct64_masks(o.masks[c]); }
+                    else if (o.chunk_mask & bit) { lo = o.lo[c] * 4u; hi = oct64_masks(o.masks[c]); }
                     else if (o.leaf_mask & bit) { lo = o.lo[c]; }
                     w[2 * c] = lo;
                     w[2 * c + 1] = hi;

@@ -108,6 +108,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
 // when `refill_min` of them are free. The common descend/advance/pop step therefore runs with most lanes active
 // instead of the ~30 % the one-thread-per-pixel kernel reached (profiles/round1/v1_*).
 enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4, kDeep = 5, kForeign = 6 };
+static_assert(int(kTrav) == int(vxd::kTravContinue) && int(kLeaf) == int(vxd::kTravAtLeaf) && int(kMissed) == int(vxd::kTravFinished) &&
+                  int(kDeep) == int(vxd::kTravDeep) && int(kForeign) == int(vxd::kTravForeign),
+              "a TravStatus is stored as the lane's state");
 
 struct PersistentArgs {
     uint32_t* work_counter;   // ticket dispenser, never reset: this launch's sub-tile t is ticket ticket_base + t
@@ -185,11 +188,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle)));  // idle lanes are not waiting for anything
         for (;;) {
             if (tr.iter < uint32_t(kMaxSteps)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
-                const TravStatus s = tr.template step<false, STATS, false, Stack<64, true>, false, FOREIGN>(sc, fast_st, nullptr, STATS ? &ctr : nullptr);
-                if (s != kTravContinue) {
-                    state = s == kTravAtLeaf ? kLeaf : (s == kTravDeep ? kDeep : (s == kTravForeign ? kForeign : kMissed));
-                    tr.iter |= kParked;
-                }
+                tr.template step_with<false, STATS, false, Stack<64, true>, false, FOREIGN>(sc, fast_st, nullptr, STATS ? &ctr : nullptr, [&](TravStatus s) {
+                    state = LaneState(s);
+                    tr.iter = (s == kTravDeep ? tr.iter - 1 : tr.iter) | kParked;  // a handed-over iteration is counted by the step that repeats it
+                });
             }
             const unsigned long long trav = __ballot(tr.iter < uint32_t(kMaxSteps));
             if (STATS) {
@@ -207,10 +209,11 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // ---- rays below the LDS-resident levels (they started inside a voxel and were led on by leaf data): full stack ----
         if (state == kDeep) {
             tr.iter &= ~kParked;
+            tr.sync_idx();
             for (;;) {
                 const TravStatus s = tr.template step<false, STATS, false, Stack<64, false>, true, FOREIGN>(sc, st, nullptr, STATS ? &ctr : nullptr);
                 if (s == kTravContinue && tr.scale < kFastFloor) continue;
-                state = s == kTravContinue ? kTrav : (s == kTravAtLeaf ? kLeaf : (s == kTravForeign ? kForeign : kMissed));
+                state = LaneState(s);
                 break;
             }
             if (state != kTrav) tr.iter |= kParked;
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
         if (state == kLeaf) {
             tr.iter &= ~kParked;
+            tr.sync_idx();
             const LeafOutcome o = tr.template leaf_test<false, STATS>(sc, st, true, res, nullptr, STATS ? &ctr : nullptr);
             state = o == kLeafHit ? kDone : (o == kLeafPassed ? (tr.scale >= kFastFloor ? kTrav : kDeep) : kMissed);
             if (state != kTrav) tr.iter |= kParked;

@@ -183,6 +183,13 @@ struct Stack {
     }
 };
 
+// bit `pos` of `v` (one v_bfe_u32)
+#ifndef VX_DEVICE_ON_HOST
+__device__ __forceinline__ uint32_t bit_at(uint32_t v, int pos) { return __builtin_amdgcn_ubfe(v, uint32_t(pos), 1u); }
+#else
+inline uint32_t bit_at(uint32_t v, int pos) { return (v >> pos) & 1u; }
+#endif
+
 // instruction-scheduling fence: nothing is moved across it (orders memory requests against the arithmetic that hides them)
 #ifndef VX_DEVICE_ON_HOST
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
@@ -403,7 +410,8 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
 // kTravForeign (FOREIGN steps only, i.e. a traversal image): the ray is about to be led INTO a leaf (it started inside that
 // voxel, svo.esvo.glsl:183-185); what follows depends on the bytes behind the leaf in the world's own format, so the caller
 // restarts this ray on the original buffer.
-enum TravStatus : int { kTravContinue = 0, kTravAtLeaf = 1, kTravFinished = 2, kTravDeep = 3, kTravForeign = 4 };
+// (the values are the render kernel's lane states -- kTrav, kLeaf, kMissed, kDeep, kForeign -- so that it can store a status as is)
+enum TravStatus : int { kTravContinue = 1, kTravAtLeaf = 2, kTravFinished = 4, kTravDeep = 5, kTravForeign = 6 };
 enum LeafOutcome : int { kLeafHit = 0, kLeafPassed = 1, kLeafPassedAndFinished = 2 };
 
 // Debug-trace state (trace kernel only): the output frames, and the reference's (ptr, parent_octant_idx) view of the
@@ -520,32 +528,45 @@ struct Trav {
     __device__ __forceinline__ bool advance(const DevScene& sc, const ST& st, float tcrx, float tcry, float tcrz, float tc_max, TracePtr tk) {
         (void)sc;
         const uint32_t ox = __float_as_uint(px), oy = __float_as_uint(py), oz = __float_as_uint(pz);
-        int step_mask = 0;
-        if (tc_max >= tcrx) { step_mask ^= 1; px -= scale_exp2; }
-        if (tc_max >= tcry) { step_mask ^= 2; py -= scale_exp2; }
-        if (tc_max >= tcrz) { step_mask ^= 4; pz -= scale_exp2; }
-
         t_min = tc_max;
-        const int stepped_idx = idx ^ step_mask;
-        if (!ST::kFast) idx = stepped_idx;  // (a fast-stack step derives idx from the position bits instead, see step())
+        bool pop;
+        uint32_t differing_bits;
+        if (ST::kFast) {
+            // scale >= 0 and the child index IS the position bit at `scale` (see step()): stepping an axis whose bit is set clears
+            // just that bit, stepping one whose bit is clear borrows from above it. So "idx & step_mask after the flip"
+            // (svo.esvo.glsl:337-343) == "the old and new corners differ above bit `scale`", and the differing bits are the POP's own
+            // (svo.esvo.glsl:345-349: per stepped axis bits(pos) ^ bits(pos + scale_exp2), the subtraction being exact).
+            if (tc_max >= tcrx) px -= scale_exp2;
+            if (tc_max >= tcry) py -= scale_exp2;
+            if (tc_max >= tcrz) pz -= scale_exp2;
+            differing_bits = (ox ^ __float_as_uint(px)) | (oy ^ __float_as_uint(py)) | (oz ^ __float_as_uint(pz));
+            pop = differing_bits >= (2u << scale);
+        } else {
+            int step_mask = 0;
+            if (tc_max >= tcrx) { step_mask ^= 1; px -= scale_exp2; }
+            if (tc_max >= tcry) { step_mask ^= 2; py -= scale_exp2; }
+            if (tc_max >= tcrz) { step_mask ^= 4; pz -= scale_exp2; }
+            idx ^= step_mask;
+            pop = (idx & step_mask) != 0;
+            differing_bits = 0;
+            if (pop) {
+                // While scale >= 0 every coordinate is a multiple of scale_exp2 >= 2^-23 in [1, 2), the subtraction above was exact
+                // and pos + scale_exp2 is the old coordinate again (unstepped axes contribute 0 on their own); below that (a ray
+                // that started inside a voxel and was taken more than `depth` levels further down) the sums round and are formed
+                // as written.
+                if (scale >= 0) {
+                    differing_bits = (ox ^ __float_as_uint(px)) | (oy ^ __float_as_uint(py)) | (oz ^ __float_as_uint(pz));
+                } else {
+                    if (step_mask & 1) differing_bits |= __float_as_uint(px) ^ __float_as_uint(px + scale_exp2);
+                    if (step_mask & 2) differing_bits |= __float_as_uint(py) ^ __float_as_uint(py + scale_exp2);
+                    if (step_mask & 4) differing_bits |= __float_as_uint(pz) ^ __float_as_uint(pz + scale_exp2);
+                }
+            }
+        }
 
         bool inside = true;
-        if ((stepped_idx & step_mask) != 0) {
-            // svo.esvo.glsl:345-349: per stepped axis, bits(pos) ^ bits(pos + scale_exp2). While scale >= 0 every coordinate is a
-            // multiple of scale_exp2 >= 2^-23 in [1, 2), the subtraction above was exact and pos + scale_exp2 is the old
-            // coordinate again (unstepped axes contribute 0 on their own); below that (a ray that started inside a voxel and
-            // was taken more than `depth` levels further down) the sums round and are formed as written.
-            uint32_t differing_bits;
-            if (ST::kFast || scale >= 0) {
-                differing_bits = (ox ^ __float_as_uint(px)) | (oy ^ __float_as_uint(py)) | (oz ^ __float_as_uint(pz));
-            } else {
-                differing_bits = 0;
-                if (step_mask & 1) differing_bits |= __float_as_uint(px) ^ __float_as_uint(px + scale_exp2);
-                if (step_mask & 2) differing_bits |= __float_as_uint(py) ^ __float_as_uint(py + scale_exp2);
-                if (step_mask & 4) differing_bits |= __float_as_uint(pz) ^ __float_as_uint(pz + scale_exp2);
-            }
-
-            scale = differing_bits ? 31 - __clz(differing_bits) : -1;
+        if (pop) {
+            scale = (ST::kFast || differing_bits) ? 31 - __builtin_clz(differing_bits) : -1;  // (fast: pop implies bits above `scale`)
             inside = uint32_t(scale) < uint32_t(kMaxScale);
             if (inside) {
                 scale_exp2 = pow2i(scale - kMaxScale);
@@ -578,24 +599,40 @@ struct Trav {
     // CAPPED = test the iteration cap here (a caller that already did passes false). FOREIGN: see kTravForeign.
     template <bool TRACE, bool STATS, bool LIMIT, class ST, bool CAPPED = true, bool FOREIGN = false>
     __device__ __forceinline__ TravStatus step(const DevScene& sc, const ST& st, TracePtr tk, Counters* ctr) {
+        TravStatus status = kTravContinue;
+        step_with<TRACE, STATS, LIMIT, ST, CAPPED, FOREIGN>(sc, st, tk, ctr, [&](TravStatus s) { status = s; });
+        return status;
+    }
+
+    // The same with the outcome delivered to `on_exit(status)` -- called only when the ray stops being a plain traversal
+    // (never with kTravContinue), from the spot where that is found out. The render kernel's loop records its lane state
+    // there, which keeps the common paths free of a status value to merge.
+    template <bool TRACE, bool STATS, bool LIMIT, class ST, bool CAPPED, bool FOREIGN, class EXIT>
+    __device__ __forceinline__ void step_with(const DevScene& sc, const ST& st, TracePtr tk, Counters* ctr, EXIT&& on_exit) {
         bool live = !CAPPED || iter < uint32_t(kMaxSteps);
         if (LIMIT) live = live && !(max_dst >= 0.0f && t_min > max_dst);
-        if (!live) return kTravFinished;
+        if (!live) return on_exit(kTravFinished);
         ++iter;
         if (STATS) ctr->iterations++;
         // While scale >= 0 the child index is the position's mantissa bit at `scale` on each axis (the corner is a multiple
         // of scale_exp2; PUSH adds half a cell = sets the bit, ADVANCE subtracts a cell = flips it, POP masks below it), so
         // the loop that only ever sees LDS-resident scales reads it off the position instead of maintaining it in three places.
-        if (ST::kFast)
-            idx = int(((__float_as_uint(px) >> scale) & 1u) | (((__float_as_uint(py) >> scale) & 1u) << 1) | (((__float_as_uint(pz) >> scale) & 1u) << 2));
+        // (The member `idx` is not kept up to date by fast steps: sync_idx() before handing the ray to anything else.)
+        const int cur_idx = ST::kFast ? idx_from_position() : idx;
 
         const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
         const float tc_max = gmin3(tcrx, tcry, tcrz);
-        const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
+        const uint32_t octant_idx = uint32_t(cur_idx ^ octant_mask);
 
         bool is_child, is_leaf;
         uint32_t tag = 0;  // CSVO: the child's 2-bit pointer-width tag (01 for every present child of the 1-bit levels)
-        if (!CSVO) {
+        if (IMG) {
+            // image masks (csvo_image.hpp, oct64_masks): child c's "exists" bit at 31 - c, its "is a leaf" bit at 23 - c, so
+            // that one shift brings both to fixed places and "exists" into the sign
+            const uint32_t m = node << octant_idx;
+            is_child = int32_t(m) < 0;
+            is_leaf = (m & 0x00800000u) != 0;
+        } else if (!CSVO) {
             is_child = (node & (0x100u << octant_idx)) != 0;
             is_leaf = (node & (1u << octant_idx)) != 0;
         } else {
@@ -630,20 +667,22 @@ struct Trav {
         const bool descend = is_child && t_min <= t_max;
         if (!descend) flags &= ~kHasAdjacentLeaf;
         if (descend && is_leaf) {
-            if (t_min > 0.0f) return kTravAtLeaf;  // leaf_test() decides; the cursor is left untouched
-            if (FOREIGN) return kTravForeign;
+            if (t_min > 0.0f) return on_exit(kTravAtLeaf);  // leaf_test() decides; the cursor is left untouched
+            if (FOREIGN) return on_exit(kTravForeign);
             if (t_min == 0.0f) flags |= kInsideVoxel;
         }
         const float tv_max = gmin(t_max, tc_max);
         if (descend && t_min <= tv_max) {
             // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
-            if (ST::kFast && scale < kLdsBaseScale) {  // this PUSH would write a slot below the resident ones: undo and hand over
-                --iter;
+            if (ST::kFast && scale < kLdsBaseScale) {
+                // this PUSH would write a slot below the resident ones: hand over. The iteration is repeated by the caller's
+                // full-stack step, so the CALLER takes `iter` back by one (undoing it here would make the counter's update
+                // path dependent, which costs every iteration a register copy).
                 if (STATS) {
                     ctr->iterations--;
                     if (CSVO) ctr->csvo_header_bytes -= depth > 3 ? 2u : 1u;
                 }
-                return kTravDeep;
+                return on_exit(kTravDeep);
             }
             if (STATS) ctr->pushes++;
             // Order of the block: (1) request what the descent reads, (2) the stack write and all arithmetic that does not
@@ -717,10 +756,16 @@ struct Trav {
                 node = csvo_header(sc);
                 if (depth == 2) pre_leaf_pointer = ptr;
             }
-            return kTravContinue;
+            return;
         }
-        return advance<TRACE>(sc, st, tcrx, tcry, tcrz, tc_max, tk) ? kTravContinue : kTravFinished;
+        if (!advance<TRACE>(sc, st, tcrx, tcry, tcrz, tc_max, tk)) on_exit(kTravFinished);
     }
+
+    // child index from the corner's mantissa bits (scale >= 0)
+    __device__ __forceinline__ int idx_from_position() const {
+        return int(bit_at(__float_as_uint(px), scale) | (bit_at(__float_as_uint(py), scale) << 1) | (bit_at(__float_as_uint(pz), scale) << 2));
+    }
+    __device__ __forceinline__ void sync_idx() { idx = idx_from_position(); }
 
     // HIT phase (svo.esvo.glsl:185-265) for a ray whose step() returned kTravAtLeaf. kLeafHit: the leaf is the result
     // (res filled in). Otherwise the translucent leaf is recorded and the ADVANCE half of the iteration is run.
