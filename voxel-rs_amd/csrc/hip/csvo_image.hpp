@@ -79,6 +79,7 @@ struct Octant {
 struct Tree {
     std::vector<Octant> octants;  // octant 0 = the root of this tree
     NodeMasks root;
+    bool too_deep = false;        // root octree: a chunk has more levels than the slot it hangs in
     uint64_t csvo_end = 0;        // chunks: one past the last byte the chunk's materials and nodes occupy
 };
 
@@ -179,6 +180,8 @@ inline NodeMasks walk_root(const Bytes& b, uint64_t ptr, uint32_t depth, Tree& o
         if (e & 0x80000000u) {
             out.octants[at].chunk_mask |= uint8_t(1u << c);
             out.octants[at].lo[c] = e ^ 0x80000000u;
+            // a child of a node at `depth` has depth - 1 levels to itself: the chunk's lod byte says how many it uses
+            if (b.u8(e ^ 0x80000000u) > depth - 1) out.too_deep = true;
         } else {
             const size_t child_at = out.octants.size();
             const NodeMasks cm = walk_root(b, ptr + 2 + table + e, depth - 1, out);
@@ -251,6 +254,8 @@ public:
         return out;
     }
     size_t chunk_count() const { return chunks_.size(); }
+    // levels of the imaged octree (the world's depth); no path of the image is longer
+    uint32_t depth() const { return depth_; }
 
     // `world` = the CSVO frame as committed: [f32 scale][u32 root_ptr][descriptor bytes]; `used` = bytes of the arena in use;
     // `changed` = byte ranges (relative to the arena, like vx_commit's) rewritten since the last call.
@@ -272,6 +277,8 @@ public:
         // 1. walk the root octree: which chunk frames does it reference
         Tree root;
         root.root = walk_root(b, root_ptr, depth, root);
+        if (root.too_deep) return false;  // (what follows relies on the image having at most `depth` levels, like the world says)
+        depth_ = depth;
         std::unordered_set<uint32_t> referenced;
         for (const Octant& o : root.octants)
             for (uint32_t c = 0; c < 8; ++c)
@@ -406,6 +413,7 @@ private:
     WordAllocator alloc_;
     std::unordered_map<uint32_t, Placed> chunks_;
     uint64_t root_at_ = 0, root_words_ = 0;
+    uint32_t depth_ = 0;
 };
 
 }  // namespace vximg

@@ -149,15 +149,19 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
 // wave's own list (`todo`), and every wave, once the tile queue is empty and its rays are done, renders the pixels it noted
 // from scratch on the compressed bytes -- exactly what the reference does for them. (A second phase of the same waves, not a
 // second kernel: its registers overlay the first phase's instead of adding to them, and a frame stays one command.)
-template <int SVO, bool HITS, bool STATS, int MINW = 1, bool FOREIGN = false>
+template <int SVO, bool HITS, bool STATS, int MINW = 1, bool FOREIGN = false, bool SHALLOW = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
     static_assert(FOREIGN == (SVO == VX_SVO_IMAGE) && !(FOREIGN && STATS), "image traversal <=> foreign handling; the instrumented kernel counts the reference's own fetches");
+    static_assert(!SHALLOW || FOREIGN, "only a traversal image bounds how deep a ray can get");
     const DevScene sc = FOREIGN ? make_image_scene(sa) : make_scene(sa);
     const uint32_t lane = threadIdx.x;
     StackSpill spill;
     Stack<64, false> st;       // all 23 levels: LDS, then the per-lane spill array
-    Stack<64, true> fast_st;   // the same LDS slots, no range checks: what the traversal loop uses
+    // the same LDS slots, no range checks: what the traversal loop uses. SHALLOW (an image of at most kLdsLevels levels): no ray
+    // ever needs anything else
+    typedef Stack<64, true, SHALLOW> FastStack;
+    FastStack fast_st;
     st.init(lane, &spill);
     fast_st.init(lane, &spill);
     // a ray may use fast_st while every level it can pop to is LDS resident
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle)));  // idle lanes are not waiting for anything
         for (;;) {
             if (tr.iter < uint32_t(kMaxSteps)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
-                tr.template step_with<false, STATS, false, Stack<64, true>, false, FOREIGN>(sc, fast_st, nullptr, STATS ? &ctr : nullptr, [&](TravStatus s) {
+                tr.template step_with<false, STATS, false, FastStack, false, FOREIGN>(sc, fast_st, nullptr, STATS ? &ctr : nullptr, [&](TravStatus s) {
                     state = LaneState(s);
                     tr.iter = (s == kTravDeep ? tr.iter - 1 : tr.iter) | kParked;  // a handed-over iteration is counted by the step that repeats it
                 });
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         }
 
         // ---- rays below the LDS-resident levels (they started inside a voxel and were led on by leaf data): full stack ----
-        if (state == kDeep) {
+        if (!SHALLOW && state == kDeep) {
             tr.iter &= ~kParked;
             tr.sync_idx();
             for (;;) {
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             tr.iter &= ~kParked;
             tr.sync_idx();
             const LeafOutcome o = tr.template leaf_test<false, STATS>(sc, st, true, res, nullptr, STATS ? &ctr : nullptr);
-            state = o == kLeafHit ? kDone : (o == kLeafPassed ? (tr.scale >= kFastFloor ? kTrav : kDeep) : kMissed);
+            state = o == kLeafHit ? kDone : (o == kLeafPassed ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep) : kMissed);
             if (state != kTrav) tr.iter |= kParked;
         }
         if (state == kMissed) {
@@ -573,7 +577,7 @@ struct vx_context {
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int cu_count = 256;
-    int persistent_blocks[3][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
+    int persistent_blocks[4][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
 
     bool profile = false;
     std::vector<ProfiledLaunch> launches;
@@ -656,10 +660,15 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // CSVO worlds are rendered from their traversal image; the instrumented variant stays on the compressed bytes so that
         // its counters are the reference's own fetches
         const bool imaged = !esvo && !STATS && ctx->image_ok;
-        if (imaged)
+        // (the image holds at most `depth` levels, csvo_image.hpp: up to kLdsLevels of them no ray can outgrow the LDS-resident stack)
+        const bool shallow = imaged && ctx->image.depth() <= uint32_t(kLdsLevels);
+        if (imaged && shallow)
+            fn = (!HITS && ctx->min_waves == 4) ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 4, true, true>)
+                                                : reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 1, true, true>);
+        else if (imaged)
             fn = (!HITS && ctx->min_waves == 4) ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 4, true>)
                                                 : reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 1, true>);
-        int& per_cu = ctx->persistent_blocks[esvo ? 0 : (imaged ? 2 : 1)][HITS][STATS];
+        int& per_cu = ctx->persistent_blocks[esvo ? 0 : (imaged ? (shallow ? 3 : 2) : 1)][HITS][STATS];
         if (per_cu == 0) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, wave_lds) != hipSuccess || n <= 0) n = 8;

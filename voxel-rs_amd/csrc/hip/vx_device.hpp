@@ -150,9 +150,12 @@ struct StackSpill {
 // What a slot holds -- ESVO: {own-octant pointer, t_max, child masks}; CSVO: {node byte pointer, t_max, depth << 16 | header}.
 // FAST = the caller guarantees LDS-resident scales only (see Trav::step: a ray that is about to leave them reports
 // kTravDeep instead), so push/pop are the bare LDS accesses.
-template <int THREADS, bool FAST = false>
+// BOUNDED (fast stacks): the caller also guarantees that no PUSH goes below them -- an octree of at most kLdsLevels levels whose
+// rays cannot be led beyond its leaves (a validated traversal image) -- so step() does not even look.
+template <int THREADS, bool FAST = false, bool BOUNDED = false>
 struct Stack {
     static constexpr bool kFast = FAST;
+    static constexpr bool kCanOverflow = FAST && !BOUNDED;
     static constexpr uint32_t kPlane = uint32_t(kLdsLevels) * THREADS * 4;  // bytes between planes
     static constexpr uint32_t kBytes = 3 * kPlane;                          // dynamic LDS a block of THREADS threads needs
     uint32_t slot0;  // byte offset of this thread's slot for scale 0 of a (virtual) full-height plane; may be "negative"
@@ -674,7 +677,7 @@ struct Trav {
         const float tv_max = gmin(t_max, tc_max);
         if (descend && t_min <= tv_max) {
             // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
-            if (ST::kFast && scale < kLdsBaseScale) {
+            if (ST::kCanOverflow && scale < kLdsBaseScale) {
                 // this PUSH would write a slot below the resident ones: hand over. The iteration is repeated by the caller's
                 // full-stack step, so the CALLER takes `iter` back by one (undoing it here would make the counter's update
                 // path dependent, which costs every iteration a register copy).
