@@ -218,18 +218,19 @@ def test_heightfield_frame(hip, fmt, depth, size):
         assert gc["pixels"] == w * h
 
 
+@pytest.mark.parametrize("base,depth", [((200, 3, 201), 13), ((400, 3, 401), 14)])
 @pytest.mark.parametrize("fmt", FMTS)
-def test_rays_from_inside_voxels_in_a_deep_world(hip, fmt):
+def test_rays_from_inside_voxels_in_a_deep_world(hip, fmt, base, depth):
     """Depth 13 (a few chunks far from the origin): the leaves sit on the last LDS-resident stack level, so a ray that
     starts inside a voxel (every primary ray of a camera buried in a block, and shadow rays that start inside a
     neighbour) is led below them by leaf data (svo.esvo.glsl:183-185 only accepts a leaf when t_min > 0) and has to be
-    carried through the full, spill-backed stack."""
+    carried through the full, spill-backed stack. Depth 14: ordinary descents leave the LDS-resident levels too (and a CSVO
+    world's traversal image is walked by the kernel variant that checks for it)."""
     import math
     from voxel_rs_amd import scenes
 
     rng = np.random.default_rng(11)
     world = vra.World(SVO_TYPES[fmt])
-    base = (200, 3, 201)
     for dx in range(2):
         for dz in range(2):
             chunk = vra.Chunk(base[0] + dx, base[1], base[2] + dz, 5)
@@ -250,7 +251,7 @@ def test_rays_from_inside_voxels_in_a_deep_world(hip, fmt):
     svo.set_materials(mats)
     svo.set_textures(tex, 6)
     svo.update(world)
-    assert svo.get_stats()["depth"] == 13
+    assert svo.get_stats()["depth"] == depth
     w, h = 96, 64
     ox, oy, oz = (32.0 * c for c in base)
     wandering = 0
