@@ -179,9 +179,10 @@ size_t vx_capacity(const vx_context* ctx);
  * (asynchronously; later renders/raycasts are ordered after it). used_bytes = WorldSvo::size_in_bytes() for
  * vx_get_stats (:183-187).
  * CSVO contexts also keep a traversal image of the world (vx_csvo_to_image): the chunks inside the given ranges and the root
- * octree are re-laid out as 48-byte octants on host worker threads and the changed parts uploaded; vx_render walks the image
- * (device memory: about 4.7x the CSVO bytes on top of them). The staging mirror must hold the whole current world, i.e. every
- * change has to go through vx_staging_ptr (it does when write_changes_to is the only writer). */
+ * octree are re-laid out as 64-byte octants on host worker threads and the changed parts uploaded; vx_render walks the image
+ * (device memory: about 6.3x the CSVO bytes on top of them; VX_CSVO_IMAGE=0 in the environment turns it off). The staging
+ * mirror must hold the whole current world, i.e. every change has to go through vx_staging_ptr (it does when
+ * write_changes_to is the only writer). */
 int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes);
 /* Same, treating [0, used_bytes) of the arena as dirty (what the first write_changes_to after write_to does). */
 int vx_commit_all(vx_context* ctx, uint32_t depth, uint64_t used_bytes);
