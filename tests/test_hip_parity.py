@@ -218,14 +218,14 @@ def test_heightfield_frame(hip, fmt, depth, size):
         assert gc["pixels"] == w * h
 
 
-@pytest.mark.parametrize("base,depth", [((200, 3, 201), 13), ((400, 3, 401), 14)])
+@pytest.mark.parametrize("base,depth", [((200, 3, 201), 13), ((400, 3, 401), 14), ((800, 3, 801), 15)])
 @pytest.mark.parametrize("fmt", FMTS)
 def test_rays_from_inside_voxels_in_a_deep_world(hip, fmt, base, depth):
     """Depth 13 (a few chunks far from the origin): the leaves sit on the last LDS-resident stack level, so a ray that
     starts inside a voxel (every primary ray of a camera buried in a block, and shadow rays that start inside a
     neighbour) is led below them by leaf data (svo.esvo.glsl:183-185 only accepts a leaf when t_min > 0) and has to be
-    carried through the full, spill-backed stack. Depth 14: ordinary descents leave the LDS-resident levels too (and a CSVO
-    world's traversal image is walked by the kernel variant that checks for it)."""
+    carried through the full, spill-backed stack. Depth 14: ordinary descents of the world's own bytes leave the LDS-resident
+    levels too; depth 15: so do descents of a CSVO world's traversal image (the kernel variant with the hand-over test)."""
     import math
     from voxel_rs_amd import scenes
 

@@ -660,8 +660,10 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // CSVO worlds are rendered from their traversal image; the instrumented variant stays on the compressed bytes so that
         // its counters are the reference's own fetches
         const bool imaged = !esvo && !STATS && ctx->image_ok;
-        // (the image holds at most `depth` levels, csvo_image.hpp: up to kLdsLevels of them no ray can outgrow the LDS-resident stack)
-        const bool shallow = imaged && ctx->image.depth() <= uint32_t(kLdsLevels);
+        // The image holds at most `depth` levels (csvo_image.hpp) and its rays never descend into a leaf (kTravForeign), so the
+        // deepest PUSH is into a node one level above the voxels, at scale 24 - depth: up to kLdsLevels + 1 levels every stack slot
+        // a ray can touch is LDS resident.
+        const bool shallow = imaged && ctx->image.depth() <= uint32_t(kLdsLevels) + 1u;
         if (imaged && shallow)
             fn = (!HITS && ctx->min_waves == 4) ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 4, true, true>)
                                                 : reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 1, true, true>);
