@@ -178,11 +178,11 @@ size_t vx_capacity(const vx_context* ctx);
  * render_fence.wait() (:178), then copies the writer's header and the given dirty arena ranges to the device
  * (asynchronously; later renders/raycasts are ordered after it). used_bytes = WorldSvo::size_in_bytes() for
  * vx_get_stats (:183-187).
- * CSVO contexts also keep a traversal image of the world (vx_csvo_to_image): the chunks inside the given ranges and the root
+ * A context also keeps a traversal image of the world (vx_traversal_image): the chunks inside the given ranges and the root
  * octree are re-laid out as 64-byte octants on host worker threads and the changed parts uploaded; vx_render walks the image
- * (device memory: about 6.3x the CSVO bytes on top of them; VX_CSVO_IMAGE=0 in the environment turns it off). The staging
- * mirror must hold the whole current world, i.e. every change has to go through vx_staging_ptr (it does when
- * write_changes_to is the only writer). */
+ * (device memory on top of the world's own bytes: 1.33x them for ESVO, about 6.3x for CSVO; VX_TRAVERSAL_IMAGE=0 in the
+ * environment turns it off). The staging mirror must hold the whole current world, i.e. every change has to go through
+ * vx_staging_ptr (it does when write_changes_to is the only writer). */
 int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes);
 /* Same, treating [0, used_bytes) of the arena as dirty (what the first write_changes_to after write_to does). */
 int vx_commit_all(vx_context* ctx, uint32_t depth, uint64_t used_bytes);
@@ -228,13 +228,13 @@ int vx_assemble_tiles(vx_context* ctx, const float* tiles, uint64_t stride_float
  * render the next frame meanwhile); NULL = the legacy default stream. */
 int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
                          float* out_rgba32f, void* stream);
-/* The traversal image of a CSVO world: the octant tree a CSVO context traverses instead of the compressed
- * bytes. `world_frame` = [f32 scale][u32 root_ptr][bytes] as committed, `used_bytes` = arena bytes in use. layout 1 = what the
- * renderer walks ([64-byte header][64-byte octants of eight {pointer | value, masks} entries]); layout 0 = the same tree as an
- * ESVO frame ([f32 2^-depth][5-word preamble][12-word octants], esvo.rs:74-101), which any ESVO traversal can walk (the tests
- * do, with the oracle). Returns the image size in 32-bit words (0 = cannot be imaged) and fills `out_words` when it is large
- * enough. Pure host function (no device needed): vx_commit does this itself. */
-uint64_t vx_csvo_to_image(const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words);
+/* The traversal image of a world: the octant tree a context traverses instead of the world's own bytes.
+ * `world_frame` = the world as committed ([f32 scale][ESVO: 5-word preamble | CSVO: u32 root_ptr][arena]), `used_bytes` = arena
+ * bytes in use. layout 1 = what the renderer walks ([64-byte header][64-byte octants of eight {pointer | value, masks}
+ * entries]); layout 0 = the same tree as an ESVO frame ([f32 2^-depth][5-word preamble][12-word octants], esvo.rs:74-101),
+ * which any ESVO traversal can walk (the tests do, with the oracle). Returns the image size in 32-bit words (0 = cannot be
+ * imaged) and fills `out_words` when it is large enough. Pure host function (no device needed): vx_commit does this itself. */
+uint64_t vx_traversal_image(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words);
 /* 2x2 ordered-grid supersampling (BASELINE.json C5): box-filters a (2*width) x (2*height) RGBA32F render down to
  * width x height, both in device memory, on the caller's hipStream_t (NULL = legacy default stream). Render the large
  * image with vx_render first (order it with vx_stream_wait_render). */

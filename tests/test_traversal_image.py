@@ -1,21 +1,24 @@
-"""The traversal image of a CSVO world (voxel-rs_amd/csrc/hip/csvo_image.hpp, exported as vx_csvo_to_image): the oracle's ESVO
-traversal on the image against the oracle's CSVO traversal on the original bytes. Every ray that does not start inside a
-voxel must give the same result bit for bit in the same number of iterations (rays that do are handed to the CSVO traversal
-by the kernel, see test_hip_parity / test_baseline_configs on the GPU)."""
+"""The traversal image of a world (voxel-rs_amd/csrc/hip/traversal_image.hpp, exported as vx_traversal_image): the oracle's
+ESVO traversal on the image (emitted as an ESVO frame, layout 0) against the oracle's traversal of the world's own bytes. Every
+ray that does not start inside a voxel must give the same result bit for bit in the same number of iterations (rays that do are
+handed to the world's own traversal by the kernel, see test_hip_parity / test_baseline_configs on the GPU). The layout the
+renderer walks (1) is checked to hold the same tree."""
 import numpy as np
 import pytest
 
 from helpers import orc, vra
 from voxel_rs_amd import hip, host, scenes
 
+FMTS = {"esvo": vra.SVO_ESVO, "csvo": vra.SVO_CSVO}
 
-def scenes_pair(world):
+
+def scenes_pair(world, fmt):
     frame = world.frame()
     tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
-    image = hip.csvo_to_image(frame, world.size_in_bytes)
-    csvo = orc.OracleScene(vra.SVO_CSVO, frame, mats.view(orc.MATERIAL_DTYPE), tex, 6)
-    esvo = orc.OracleScene(vra.SVO_ESVO, np.concatenate([image, np.zeros(4, dtype=np.uint32)]), mats.view(orc.MATERIAL_DTYPE), tex, 6)
-    return csvo, esvo
+    image = hip.traversal_image(fmt, frame, world.size_in_bytes)
+    own = orc.OracleScene(fmt, frame, mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    imaged = orc.OracleScene(vra.SVO_ESVO, np.concatenate([image, np.zeros(4, dtype=np.uint32)]), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    return own, imaged
 
 
 def compare_rays(csvo, esvo, origins, dirs, min_hits):
@@ -36,17 +39,18 @@ def compare_rays(csvo, esvo, origins, dirs, min_hits):
     return inside
 
 
+@pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("seed,svo_pos,n_blocks", [(2, (1, 0, 1), 600), (3, (3, 2, 1), 6000), (5, (0, 0, 0), 1), (7, (200, 3, 201), 3000)])
-def test_random_chunk_worlds(seed, svo_pos, n_blocks):
+def test_random_chunk_worlds(seed, svo_pos, n_blocks, fmt):
     rng = np.random.default_rng(seed)
     chunk = vra.Chunk(0, 0, 0, 5)
     for x, y, z in rng.integers(0, 32, size=(n_blocks, 3)):
         chunk.set_block(int(x), int(y), int(z), int(rng.choice([1, 2, 3, 5, 10])))
     chunk.compact()
-    world = vra.World(vra.SVO_CSVO)
+    world = vra.World(FMTS[fmt])
     world.set_chunk(svo_pos, chunk)
     world.serialize()
-    csvo, esvo = scenes_pair(world)
+    csvo, esvo = scenes_pair(world, FMTS[fmt])
     base = np.float32(svo_pos) * 32
     n = 400
     origins = (base + rng.uniform(-20, 52, size=(n, 3))).astype(np.float32)
@@ -56,10 +60,11 @@ def test_random_chunk_worlds(seed, svo_pos, n_blocks):
     compare_rays(csvo, esvo, origins, d.astype(np.float32), 10 if n_blocks > 1 else 0)
 
 
-def test_heightfield_world_frames_agree():
-    world = vra.World(vra.SVO_CSVO)
+@pytest.mark.parametrize("fmt", FMTS)
+def test_heightfield_world_frames_agree(fmt):
+    world = vra.World(FMTS[fmt])
     st = world.build_heightfield(8, threads=4)
-    csvo, esvo = scenes_pair(world)
+    csvo, esvo = scenes_pair(world, FMTS[fmt])
     w, h = 160, 96
     u = scenes.bench_camera(8, st["h_max"], w, h, shadow_distance=3.0e38)
     ou = orc.Uniforms.from_buffer_copy(bytes(u))
@@ -76,17 +81,18 @@ def test_heightfield_world_frames_agree():
     assert np.array_equal(ia[same], ib[same])
 
 
-def test_streamed_world_with_lod_chunks_agrees():
-    s = host.WorldStreamer(vra.SVO_CSVO, 9, 9, 0, 8)  # LOD 5 near the centre, LOD 4 beyond 6 chunks
+@pytest.mark.parametrize("fmt", FMTS)
+def test_streamed_world_with_lod_chunks_agrees(fmt):
+    s = host.WorldStreamer(FMTS[fmt], 9, 9, 0, 8)  # LOD 5 near the centre, LOD 4 beyond 6 chunks
     eye = (200.5, 70.0, 230.5)
     s.move_to(*eye)
     while s.pump(None, 4000)["pending"]:
         pass
     frame = s.frame()
     tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
-    used = frame.size * 4 - 8 - 16  # arena bytes: the frame minus scale, root_ptr and the zero padding
-    image = hip.csvo_to_image(frame, used)
-    csvo = orc.OracleScene(vra.SVO_CSVO, frame, mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    used = frame.size * 4 - (8 if fmt == "csvo" else 24) - 16  # arena bytes: the frame minus scale, root_ptr / preamble and the zero padding
+    image = hip.traversal_image(FMTS[fmt], frame, used)
+    csvo = orc.OracleScene(FMTS[fmt], frame, mats.view(orc.MATERIAL_DTYPE), tex, 6)
     esvo = orc.OracleScene(vra.SVO_ESVO, np.concatenate([image, np.zeros(4, dtype=np.uint32)]), mats.view(orc.MATERIAL_DTYPE), tex, 6)
     cam = s.to_svo(eye)
     w, h = 128, 80
@@ -146,13 +152,37 @@ def _walk_oct64_image(img):
     return sorted(out)
 
 
-def test_renderer_layout_holds_the_same_tree():
+@pytest.mark.parametrize("fmt", FMTS)
+def test_renderer_layout_holds_the_same_tree(fmt):
     """Layout 1 (64-byte octants, what the kernel walks) against layout 0 (validated above with the oracle's traversal)."""
-    world = vra.World(vra.SVO_CSVO)
+    world = vra.World(FMTS[fmt])
     world.build_heightfield(7, threads=4)
     frame = world.frame()
-    a = _walk_esvo_image(hip.csvo_to_image(frame, world.size_in_bytes, 0))
-    b_img = hip.csvo_to_image(frame, world.size_in_bytes, 1)
+    a = _walk_esvo_image(hip.traversal_image(FMTS[fmt], frame, world.size_in_bytes, 0))
+    b_img = hip.traversal_image(FMTS[fmt], frame, world.size_in_bytes, 1)
     assert b_img[0] == frame[0] and b_img.size % 16 == 0
     b = _walk_oct64_image(b_img)
     assert len(a) > 10000 and a == b
+
+
+def test_an_esvo_world_and_its_image_hold_the_same_tree():
+    """The ESVO-frame form of an ESVO world's image is the world again, octant for octant (placed elsewhere)."""
+    world = vra.World(vra.SVO_ESVO)
+    world.build_heightfield(7, threads=4)
+    frame = world.frame()
+    assert _walk_esvo_image(frame) == _walk_esvo_image(hip.traversal_image(vra.SVO_ESVO, frame, world.size_in_bytes, 0))
+
+
+def test_malformed_worlds_are_not_imaged():
+    world = vra.World(vra.SVO_ESVO)
+    world.build_heightfield(6, threads=2)
+    frame = world.frame().copy()
+    frame[0] = np.float32(2.0 ** -3).view(np.uint32)  # claims 3 levels, has 6: deeper than the stack the kernel plans for
+    with pytest.raises(ValueError):
+        hip.traversal_image(vra.SVO_ESVO, frame, world.size_in_bytes, 1)
+    cw = vra.World(vra.SVO_CSVO)
+    cw.build_heightfield(6, threads=2)
+    cframe = cw.frame().copy()
+    cframe[0] = np.float32(2.0 ** -4).view(np.uint32)
+    with pytest.raises(ValueError):
+        hip.traversal_image(vra.SVO_CSVO, cframe, cw.size_in_bytes, 1)

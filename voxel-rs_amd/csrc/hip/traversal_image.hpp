@@ -1,10 +1,11 @@
-// CSVO -> traversal image. The reference's compressed node format (src/world/hds/csvo.rs:434-546) costs the traversal a
-// bit-field decode, two popcount sums and a dependent table read per descent. A CSVO world is therefore re-laid out, on the
-// host at commit time, as fixed-size octants -- the "traversal image" -- and rays walk the image. Structure is preserved node
-// for node (including the empty octants the reference's never-compacted root octree carries), so every ray that starts
-// outside a voxel takes the same iterations to the same leaf with the same floats. A ray that starts INSIDE a voxel makes the
-// reference wander through leaf bytes as if they were nodes, which is format specific: the kernel re-renders exactly those
-// pixels on the original bytes (render_persistent, kForeign).
+// World -> traversal image. The reference's node formats make a descent expensive: CSVO (src/world/hds/csvo.rs:434-546) costs
+// a bit-field decode, two popcount sums and a dependent table read, ESVO (esvo.rs:74-101) two loads, a relative/absolute
+// pointer resolve and a half-word select. A world is therefore re-laid out, on the host at commit time, as fixed-size octants
+// -- the "traversal image" -- and rays walk the image. Structure is preserved node for node (including the empty octants the
+// reference's never-compacted root octree carries), so every ray that starts outside a voxel takes the same iterations to the
+// same leaf with the same floats. A ray that starts INSIDE a voxel makes the reference wander through leaf data as if they
+// were nodes, which is format specific: the kernel re-renders exactly those pixels on the original bytes (render_persistent,
+// kForeign).
 //
 // Two encodings of the same octant tree:
 //   kOct64   what the renderer walks. Frame = 64-byte header [f32 2^-depth][u32 root masks][u32 byte offset of the root
@@ -12,8 +13,9 @@
 //            frame start) of the child's own octant, or the leaf's value; hi = the child's masks (oct64_masks()).
 //            A descent is ONE aligned 8-byte load that yields the new pointer and the new masks; every pointer in the image
 //            is valid by construction, so the loads need no clamping.
-//   kEsvo48  the reference's other format (esvo.rs:74-101): [f32][5-word preamble][12-word octants], relative pointers.
-//            Kept because any ESVO traversal can walk it: tests/test_csvo_image.py checks the tree walk with the oracle.
+//   kEsvo48  the reference's ESVO format: [f32][5-word preamble][12-word octants], relative pointers. Kept because any ESVO
+//            traversal can walk it: tests/test_traversal_image.py checks the tree walk with the oracle.
+// The image never has more levels than the world's depth says (a world that breaks this is not imaged): the kernel relies on it.
 // Host-only, no HIP calls: vx_api.hip owns the device side.
 #pragma once
 
@@ -79,8 +81,14 @@ struct Octant {
 struct Tree {
     std::vector<Octant> octants;  // octant 0 = the root of this tree
     NodeMasks root;
-    bool too_deep = false;        // root octree: a chunk has more levels than the slot it hangs in
-    uint64_t csvo_end = 0;        // chunks: one past the last byte the chunk's materials and nodes occupy
+    bool too_deep = false;        // more levels than the slot the tree hangs in leaves it (or a runaway walk)
+    uint64_t src_begin = 0, src_end = 0;  // chunks: the arena bytes the chunk was read from
+};
+
+// A chunk hanging in the root octree: `key` identifies its bytes (CSVO: arena offset of its frame; ESVO: descriptors[] index of
+// its root octant), `levels` is what the slot leaves it, `masks` its root's masks where the format keeps them outside the chunk.
+struct ChunkRef {
+    uint32_t key, masks, levels;
 };
 
 // One chunk frame [lod:u8][material_bytes:u32][materials][nodes] (csvo.rs:217-227).
@@ -95,7 +103,8 @@ public:
         end_ = materials_ + material_bytes;
         out_.octants.clear();
         out_.root = node(materials_ + material_bytes, lod, 0);
-        out_.csvo_end = end_;
+        out_.src_begin = frame;
+        out_.src_end = end_;
     }
 
 private:
@@ -163,7 +172,7 @@ private:
 
 // Root octree: internal nodes only (their depth is always above a chunk's); a 4-byte entry with bit 31 is the frame offset of
 // a chunk (csvo.rs:76-86,100-105).
-inline NodeMasks walk_root(const Bytes& b, uint64_t ptr, uint32_t depth, Tree& out) {
+inline NodeMasks walk_root(const Bytes& b, uint64_t ptr, uint32_t depth, Tree& out, std::vector<ChunkRef>& refs) {
     const size_t at = out.octants.size();
     out.octants.emplace_back();
     NodeMasks m;
@@ -182,9 +191,10 @@ inline NodeMasks walk_root(const Bytes& b, uint64_t ptr, uint32_t depth, Tree& o
             out.octants[at].lo[c] = e ^ 0x80000000u;
             // a child of a node at `depth` has depth - 1 levels to itself: the chunk's lod byte says how many it uses
             if (b.u8(e ^ 0x80000000u) > depth - 1) out.too_deep = true;
+            refs.push_back(ChunkRef{e ^ 0x80000000u, 0u, depth - 1});
         } else {
             const size_t child_at = out.octants.size();
-            const NodeMasks cm = walk_root(b, ptr + 2 + table + e, depth - 1, out);
+            const NodeMasks cm = walk_root(b, ptr + 2 + table + e, depth - 1, out, refs);
             Octant& o = out.octants[at];
             o.node_mask |= uint8_t(1u << c);
             o.lo[c] = uint32_t(child_at);
@@ -193,6 +203,80 @@ inline NodeMasks walk_root(const Bytes& b, uint64_t ptr, uint32_t depth, Tree& o
     }
     return m;
 }
+
+// ---- ESVO source (esvo.rs:74-101): descriptors[] = [5-word preamble][arena of 12-word octants] ----
+struct Words {
+    const uint32_t* p;
+    size_t n;
+    uint32_t at(uint64_t i) const { return i < n ? p[i] : 0u; }  // reads beyond the end return 0 like the traversal's
+};
+
+// Walks the subtree of the octant at descriptors[] index `octant`; its masks (child_mask << 8 | leaf_mask) live in its parent's
+// header (esvo.rs:74-86) and are handed in. `levels` = levels below this node (1 = its children can only be voxels). With
+// `refs`, absolute pointers end the tree (the root octree: they are the chunks, esvo.rs:164-171); without, they are followed.
+class EsvoWalker {
+public:
+    EsvoWalker(Words w, Tree& out, std::vector<ChunkRef>* refs) : w_(w), out_(out), refs_(refs) {}
+
+    void run(uint64_t octant, uint32_t masks, uint32_t levels) {
+        out_.octants.clear();
+        lo_ = ~uint64_t(0);
+        hi_ = 0;
+        out_.root.child_mask = (masks >> 8) & 0xffu;
+        out_.root.leaf_mask = masks & 0xffu;
+        node(octant, masks, levels);
+        // descriptors[] index -> arena byte (the preamble's 5 words come first)
+        out_.src_begin = lo_ == ~uint64_t(0) ? 0 : (lo_ < 5 ? 0 : (lo_ - 5) * 4);
+        out_.src_end = hi_ < 5 ? 0 : (hi_ - 5) * 4;
+    }
+
+private:
+    void node(uint64_t octant, uint32_t masks, uint32_t levels) {
+        const size_t at = out_.octants.size();
+        out_.octants.emplace_back();
+        if (at > kMaxOctants) {  // shared or cyclic subtrees would never end: not a world the serializer wrote
+            out_.too_deep = true;
+            return;
+        }
+        lo_ = std::min(lo_, octant);
+        hi_ = std::max(hi_, octant + 12);
+        const uint32_t child_mask = (masks >> 8) & 0xffu, leaf_mask = masks & 0xffu;
+        for (uint32_t c = 0; c < 8 && !out_.too_deep; ++c) {
+            if (!((child_mask >> c) & 1u)) continue;
+            const uint32_t body = w_.at(octant + 4 + c);
+            if ((leaf_mask >> c) & 1u) {
+                out_.octants[at].leaf_mask |= uint8_t(1u << c);
+                out_.octants[at].lo[c] = body;
+                continue;
+            }
+            if (levels <= 1) {  // a node where only voxels fit
+                out_.too_deep = true;
+                return;
+            }
+            const uint32_t cm = (w_.at(octant + (c >> 1)) >> ((c & 1u) * 16)) & 0xffffu;
+            const bool relative = (body & 0x80000000u) != 0;
+            const uint64_t target = relative ? octant + 4 + c + (body & 0x7fffffffu) : body;  // svo.esvo.glsl:283-290
+            if (!relative && refs_) {
+                out_.octants[at].chunk_mask |= uint8_t(1u << c);
+                out_.octants[at].lo[c] = uint32_t(target);
+                refs_->push_back(ChunkRef{uint32_t(target), cm, levels - 1});
+                continue;
+            }
+            const size_t child_at = out_.octants.size();
+            node(target, cm, levels - 1);
+            Octant& o = out_.octants[at];
+            o.node_mask |= uint8_t(1u << c);
+            o.lo[c] = uint32_t(child_at);
+            o.masks[c] = uint16_t(cm);
+        }
+    }
+
+    static constexpr size_t kMaxOctants = size_t(1) << 25;  // 2 GiB of 64-byte octants
+    Words w_;
+    Tree& out_;
+    std::vector<ChunkRef>* refs_;
+    uint64_t lo_ = 0, hi_ = 0;
+};
 
 // first-fit word allocator over the image arena (the reference's RangeBuffer idea, internal.rs:163-277)
 class WordAllocator {
@@ -231,10 +315,11 @@ private:
     uint64_t end_ = 0;
 };
 
-// The image of a whole CSVO world, kept up to date commit by commit.
+// The image of a whole world, kept up to date commit by commit.
 class WorldImage {
 public:
-    explicit WorldImage(Layout layout = kOct64) : layout_(layout) {}
+    // svo_type: VX_SVO_ESVO (1) or VX_SVO_CSVO (2), the format of the worlds handed to update()
+    explicit WorldImage(int svo_type = 2, Layout layout = kOct64) : esvo_(svo_type == 1), layout_(layout) {}
 
     // host mirror of the image frame, as 32-bit words
     const std::vector<uint32_t>& frame() const { return frame_; }
@@ -257,16 +342,16 @@ public:
     // levels of the imaged octree (the world's depth); no path of the image is longer
     uint32_t depth() const { return depth_; }
 
-    // `world` = the CSVO frame as committed: [f32 scale][u32 root_ptr][descriptor bytes]; `used` = bytes of the arena in use;
-    // `changed` = byte ranges (relative to the arena, like vx_commit's) rewritten since the last call.
-    // Returns false when the world cannot be imaged (malformed or image beyond 4 GiB): the caller then traverses the CSVO bytes.
+    // `world` = the frame as committed: [f32 scale][CSVO: u32 root_ptr | ESVO: 5-word preamble][arena]; `used` = bytes of the
+    // arena in use; `changed` = byte ranges (relative to the arena, like vx_commit's) rewritten since the last call.
+    // Returns false when the world cannot be imaged (malformed or image beyond 2 GiB): the caller then traverses the world's bytes.
     bool update(const uint8_t* world, uint64_t used, const Range* changed, size_t n_changed, unsigned threads) {
         dirty_.clear();
         if (used < 2) return false;
-        const Bytes b{world + 8, size_t(used)};
-        uint32_t scale_bits, root_ptr;
+        const Bytes b{world + 8, size_t(used)};                                                        // CSVO arena
+        const Words w{reinterpret_cast<const uint32_t*>(world + 4), size_t(used / 4 + 5)};             // ESVO descriptors[]
+        uint32_t scale_bits;
         std::memcpy(&scale_bits, world, 4);
-        std::memcpy(&root_ptr, world + 4, 4);
         const uint32_t depth = 127u - ((scale_bits >> 23) & 0xffu);  // svo.csvo.glsl:254
         if (depth < 1 || depth > 23) return false;
         if (frame_.empty()) {
@@ -274,21 +359,32 @@ public:
             alloc_.reset(header_words());
         }
 
-        // 1. walk the root octree: which chunk frames does it reference
+        // 1. walk the root octree: which chunks does it reference
         Tree root;
-        root.root = walk_root(b, root_ptr, depth, root);
-        if (root.too_deep) return false;  // (what follows relies on the image having at most `depth` levels, like the world says)
+        std::vector<ChunkRef> refs;
+        if (esvo_) {
+            // the preamble is an octant whose child 0 is the root (esvo.rs:179-188, svo.esvo.glsl:139-141)
+            const uint32_t p = w.at(4);
+            EsvoWalker(w, root, &refs).run((p & 0x80000000u) ? 4u + (p & 0x7fffffffu) : p, w.at(0) & 0xffffu, depth);
+        } else {
+            uint32_t root_ptr;
+            std::memcpy(&root_ptr, world + 4, 4);
+            root.root = walk_root(b, root_ptr, depth, root, refs);
+        }
+        if (root.too_deep) return fail();  // (what follows relies on the image having at most `depth` levels, like the world says)
         depth_ = depth;
-        std::unordered_set<uint32_t> referenced;
-        for (const Octant& o : root.octants)
-            for (uint32_t c = 0; c < 8; ++c)
-                if ((o.chunk_mask >> c) & 1u) referenced.insert(o.lo[c]);
+        std::unordered_map<uint32_t, ChunkRef> referenced;
+        for (const ChunkRef& r : refs) {
+            const auto it = referenced.emplace(r.key, r).first;
+            if (it->second.masks != r.masks || it->second.levels != r.levels) return fail();  // one chunk, two different slots
+        }
 
-        // 2. drop images of chunks that are gone or whose bytes were rewritten
+        // 2. drop images of chunks that are gone, whose bytes were rewritten or that now hang in a different slot
         for (auto it = chunks_.begin(); it != chunks_.end();) {
-            bool stale = !referenced.count(it->first);
+            const auto ref = referenced.find(it->first);
+            bool stale = ref == referenced.end() || (esvo_ && (ref->second.masks != it->second.masks || ref->second.levels != it->second.levels));
             for (size_t i = 0; i < n_changed && !stale; ++i)
-                stale = changed[i].start < it->second.csvo_end && it->first < changed[i].start + changed[i].length;
+                stale = changed[i].start < it->second.src_end && it->second.src_begin < changed[i].start + changed[i].length;
             if (stale) {
                 alloc_.release(it->second.at, it->second.words);
                 it = chunks_.erase(it);
@@ -298,23 +394,29 @@ public:
         }
 
         // 3. walk what is missing (worker threads), place it (this thread), encode it in place (worker threads)
-        std::vector<uint32_t> todo;
-        for (uint32_t off : referenced)
-            if (!chunks_.count(off)) todo.push_back(off);
-        std::sort(todo.begin(), todo.end());
+        std::vector<ChunkRef> todo;
+        for (const auto& kv : referenced)
+            if (!chunks_.count(kv.first)) todo.push_back(kv.second);
+        std::sort(todo.begin(), todo.end(), [](const ChunkRef& x, const ChunkRef& y) { return x.key < y.key; });
         std::vector<Tree> built(todo.size());
-        parallel(todo.size(), threads, [&](size_t i) { ChunkWalker(b, built[i]).run(todo[i]); });
+        parallel(todo.size(), threads, [&](size_t i) {
+            if (esvo_) EsvoWalker(w, built[i], nullptr).run(todo[i].key, todo[i].masks, todo[i].levels);
+            else ChunkWalker(b, built[i]).run(todo[i].key);
+        });
         std::vector<Placed> placed(todo.size());
         uint64_t top = frame_.size();
         for (size_t i = 0; i < todo.size(); ++i) {
+            if (built[i].too_deep) return fail();
             Placed& pl = placed[i];
             pl.words = built[i].octants.size() * octant_words();
             pl.at = alloc_.alloc(pl.words);
             pl.masks = built[i].root.packed();
-            pl.csvo_end = built[i].csvo_end;
+            pl.levels = todo[i].levels;
+            pl.src_begin = built[i].src_begin;
+            pl.src_end = built[i].src_end;
             top = std::max(top, pl.at + pl.words);
             dirty_.push_back(Range{pl.at * 4, pl.words * 4});
-            chunks_[todo[i]] = pl;
+            chunks_[todo[i].key] = pl;
         }
         if (frame_.size() < top) frame_.resize(top, 0u);
         parallel(todo.size(), threads, [&](size_t i) { encode(built[i], placed[i].at); });
@@ -350,9 +452,19 @@ public:
 
 private:
     struct Placed {
-        uint64_t at = 0, words = 0, csvo_end = 0;  // `at` in frame words
-        uint32_t masks = 0;
+        uint64_t at = 0, words = 0;             // in frame words
+        uint64_t src_begin = 0, src_end = 0;    // arena bytes it was read from
+        uint32_t masks = 0, levels = 0;
     };
+
+    // nothing of a half-made update may survive: the next one starts from an empty image
+    bool fail() {
+        chunks_.clear();
+        frame_.clear();
+        dirty_.clear();
+        root_at_ = root_words_ = 0;
+        return false;
+    }
 
     uint64_t header_words() const { return layout_ == kOct64 ? 16 : 6; }
     uint64_t octant_words() const { return layout_ == kOct64 ? 16 : 12; }
@@ -407,6 +519,7 @@ private:
         }
     }
 
+    bool esvo_;
     Layout layout_;
     std::vector<uint32_t> frame_;
     std::vector<Range> dirty_;

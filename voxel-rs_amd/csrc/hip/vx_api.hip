@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "csvo_image.hpp"
+#include "traversal_image.hpp"
 #include "voxel_hip.h"
 #include "vx_device.hpp"
 
@@ -144,15 +144,16 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
     }
 }
 
-// FOREIGN (CSVO contexts): SVO = VX_SVO_IMAGE and the rays walk the traversal image of the world (csvo_image.hpp). A ray that
+// FOREIGN (= the world's own format): SVO = VX_SVO_IMAGE and the rays walk the traversal image of the world (traversal_image.hpp). A ray that
 // is about to be led into the voxel it started in cannot be continued on the image: its pixel is dropped and noted in the
 // wave's own list (`todo`), and every wave, once the tile queue is empty and its rays are done, renders the pixels it noted
 // from scratch on the compressed bytes -- exactly what the reference does for them. (A second phase of the same waves, not a
 // second kernel: its registers overlay the first phase's instead of adding to them, and a frame stays one command.)
-template <int SVO, bool HITS, bool STATS, int MINW = 1, bool FOREIGN = false, bool SHALLOW = false>
+template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
-    static_assert(FOREIGN == (SVO == VX_SVO_IMAGE) && !(FOREIGN && STATS), "image traversal <=> foreign handling; the instrumented kernel counts the reference's own fetches");
+    static_assert((FOREIGN != 0) == (SVO == VX_SVO_IMAGE) && !(FOREIGN && STATS), "image traversal <=> foreign handling; the instrumented kernel counts the reference's own fetches");
+    static_assert(FOREIGN == 0 || FOREIGN == VX_SVO_ESVO || FOREIGN == VX_SVO_CSVO, "FOREIGN names the world's own format");
     static_assert(!SHALLOW || FOREIGN, "only a traversal image bounds how deep a ray can get");
     const DevScene sc = FOREIGN ? make_image_scene(sa) : make_scene(sa);
     const uint32_t lane = threadIdx.x;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle)));  // idle lanes are not waiting for anything
         for (;;) {
             if (tr.iter < uint32_t(kMaxSteps)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
-                tr.template step_with<false, STATS, false, FastStack, false, FOREIGN>(sc, fast_st, nullptr, STATS ? &ctr : nullptr, [&](TravStatus s) {
+                tr.template step_with<false, STATS, false, FastStack, false, FOREIGN != 0>(sc, fast_st, nullptr, STATS ? &ctr : nullptr, [&](TravStatus s) {
                     state = LaneState(s);
                     tr.iter = (s == kTravDeep ? tr.iter - 1 : tr.iter) | kParked;  // a handed-over iteration is counted by the step that repeats it
                 });
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             tr.iter &= ~kParked;
             tr.sync_idx();
             for (;;) {
-                const TravStatus s = tr.template step<false, STATS, false, Stack<64, false>, true, FOREIGN>(sc, st, nullptr, STATS ? &ctr : nullptr);
+                const TravStatus s = tr.template step<false, STATS, false, Stack<64, false>, true, FOREIGN != 0>(sc, st, nullptr, STATS ? &ctr : nullptr);
                 if (s == kTravContinue && tr.scale < kFastFloor) continue;
                 state = LaneState(s);
                 break;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     out_index_to_xy(p, index, x, y);
                     float color[4];
                     vx_hit r;
-                    shade_pixel<VX_SVO_CSVO, false>(sc_orig, p, x, y, st, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
+                    shade_pixel<FOREIGN ? FOREIGN : VX_SVO_ESVO, false>(sc_orig, p, x, y, st, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
                     if (out) out[index] = make_float4(color[0], color[1], color[2], color[3]);
                     if (HITS) hits[index] = r;
                 }
@@ -566,18 +567,18 @@ struct vx_context {
     unsigned long long* d_counters = nullptr;
 
     uint32_t* d_work_counter = nullptr;
-    // CSVO contexts: the traversal image of the world (csvo_image.hpp), rebuilt for the changed chunks by every commit
+    // the traversal image of the world (traversal_image.hpp), rebuilt for the changed chunks by every commit
     vximg::WorldImage image;
     uint8_t* d_image = nullptr;
     size_t d_image_capacity = 0;
-    bool image_enabled = true;  // VX_CSVO_IMAGE=0: traverse the compressed bytes directly
+    bool image_enabled = true;  // VX_TRAVERSAL_IMAGE=0: traverse the world's own bytes
     bool image_ok = false;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
     uint32_t refill_min = 4, service_min = 28;
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int cu_count = 256;
-    int persistent_blocks[4][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
+    int persistent_blocks[6][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
 
     bool profile = false;
     std::vector<ProfiledLaunch> launches;
@@ -657,20 +658,23 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         if (!HITS && !STATS && ctx->min_waves == 4)
             fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 4>)
                       : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 4>);
-        // CSVO worlds are rendered from their traversal image; the instrumented variant stays on the compressed bytes so that
-        // its counters are the reference's own fetches
-        const bool imaged = !esvo && !STATS && ctx->image_ok;
-        // The image holds at most `depth` levels (csvo_image.hpp) and its rays never descend into a leaf (kTravForeign), so the
+        // Worlds are rendered from their traversal image; the instrumented variant stays on the world's own bytes so that its
+        // counters are the reference's own fetches
+        const bool imaged = !STATS && ctx->image_ok;
+        // The image holds at most `depth` levels (traversal_image.hpp) and its rays never descend into a leaf (kTravForeign), so the
         // deepest PUSH is into a node one level above the voxels, at scale 24 - depth: up to kLdsLevels + 1 levels every stack slot
         // a ray can touch is LDS resident.
         const bool shallow = imaged && ctx->image.depth() <= uint32_t(kLdsLevels) + 1u;
-        if (imaged && shallow)
-            fn = (!HITS && ctx->min_waves == 4) ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 4, true, true>)
-                                                : reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 1, true, true>);
-        else if (imaged)
-            fn = (!HITS && ctx->min_waves == 4) ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 4, true>)
-                                                : reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, 1, true>);
-        int& per_cu = ctx->persistent_blocks[esvo ? 0 : (imaged ? (shallow ? 3 : 2) : 1)][HITS][STATS];
+        if (imaged) {
+            const bool w4 = !HITS && ctx->min_waves == 4;
+#define VX_IMAGE_KERNEL(ORIG, MINW, SHALLOW) reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, MINW, ORIG, SHALLOW>)
+            if (esvo) fn = shallow ? (w4 ? VX_IMAGE_KERNEL(VX_SVO_ESVO, 4, true) : VX_IMAGE_KERNEL(VX_SVO_ESVO, 1, true))
+                                   : (w4 ? VX_IMAGE_KERNEL(VX_SVO_ESVO, 4, false) : VX_IMAGE_KERNEL(VX_SVO_ESVO, 1, false));
+            else fn = shallow ? (w4 ? VX_IMAGE_KERNEL(VX_SVO_CSVO, 4, true) : VX_IMAGE_KERNEL(VX_SVO_CSVO, 1, true))
+                              : (w4 ? VX_IMAGE_KERNEL(VX_SVO_CSVO, 4, false) : VX_IMAGE_KERNEL(VX_SVO_CSVO, 1, false));
+#undef VX_IMAGE_KERNEL
+        }
+        int& per_cu = ctx->persistent_blocks[(imaged ? (shallow ? 4 : 2) : 0) + (esvo ? 0 : 1)][HITS][STATS];
         if (per_cu == 0) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, wave_lds) != hipSuccess || n <= 0) n = 8;
@@ -825,7 +829,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_FRAMES_IN_FLIGHT")) c->frames_in_flight = std::atoi(e);
         if (c->frames_in_flight < 1) c->frames_in_flight = 1;
         if (c->frames_in_flight > vx_context::kFrameStreams) c->frames_in_flight = vx_context::kFrameStreams;
-        if (const char* e = std::getenv("VX_CSVO_IMAGE")) c->image_enabled = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
+        c->image = vximg::WorldImage(svo_type);
         if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
@@ -956,7 +961,7 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
         const uint64_t off = head + ranges[i].start;
         HIP_TRY(hipMemcpyAsync(ctx->d_world + off, ctx->staging + off, ranges[i].length, hipMemcpyHostToDevice, ctx->upload_stream));
     }
-    if (ctx->svo_type == VX_SVO_CSVO && ctx->image_enabled && ctx->kernel_version != 1) {
+    if (ctx->image_enabled && ctx->kernel_version != 1) {
         // re-lay the changed chunks (and the root octree, which every commit rewrites) out as octants and upload those
         std::vector<vximg::Range> changed(count);
         for (uint32_t i = 0; i < count; ++i) changed[i] = vximg::Range{ranges[i].start, ranges[i].length};
@@ -1200,9 +1205,9 @@ int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_fl
     return VX_OK;
 }
 
-uint64_t vx_csvo_to_image(const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words) {
-    if (!world_frame || (layout != 0 && layout != 1)) return 0;
-    vximg::WorldImage img(layout == 0 ? vximg::kEsvo48 : vximg::kOct64);
+uint64_t vx_traversal_image(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words) {
+    if (!world_frame || (layout != 0 && layout != 1) || (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO)) return 0;
+    vximg::WorldImage img(svo_type, layout == 0 ? vximg::kEsvo48 : vximg::kOct64);
     if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(16u, std::thread::hardware_concurrency())))) return 0;
     const std::vector<uint32_t>& f = img.frame();
     if (out_words && capacity_words >= f.size()) std::memcpy(out_words, f.data(), f.size() * 4);

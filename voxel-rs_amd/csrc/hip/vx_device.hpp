@@ -76,7 +76,7 @@ struct SceneArgs {
     uint32_t tex_bytes;
     uint32_t width, height, layers, levels;
     uint32_t level_offset[16];
-    const uint8_t* image;   // CSVO contexts: the ESVO-layout traversal image of the world (csvo_image.hpp), else null
+    const uint8_t* image;   // CSVO contexts: the ESVO-layout traversal image of the world (traversal_image.hpp), else null
     uint32_t image_bytes;
 };
 
@@ -429,7 +429,7 @@ struct TraceSink {
 
 typedef VX_AS_PRIVATE TraceSink* TracePtr;
 
-// third node format, internal to the library: the 64-byte-octant traversal image of a CSVO world (csvo_image.hpp, kOct64)
+// third node format, internal to the library: the 64-byte-octant traversal image of a CSVO world (traversal_image.hpp, kOct64)
 #define VX_SVO_IMAGE 3
 
 template <int SVO>
@@ -630,7 +630,7 @@ struct Trav {
         bool is_child, is_leaf;
         uint32_t tag = 0;  // CSVO: the child's 2-bit pointer-width tag (01 for every present child of the 1-bit levels)
         if (IMG) {
-            // image masks (csvo_image.hpp, oct64_masks): child c's "exists" bit at 31 - c, its "is a leaf" bit at 23 - c, so
+            // image masks (traversal_image.hpp, oct64_masks): child c's "exists" bit at 31 - c, its "is a leaf" bit at 23 - c, so
             // that one shift brings both to fixed places and "exists" into the sign
             const uint32_t m = node << octant_idx;
             is_child = int32_t(m) < 0;

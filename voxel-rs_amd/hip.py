@@ -78,7 +78,7 @@ SYMBOLS = {
     "vx_set_frames_in_flight": (_int, [_vp, _int]),
     "vx_wait_event": (_int, [_vp, _vp]),
     "vx_stream_wait_render": (_int, [_vp, _vp]),
-    "vx_csvo_to_image": (_u64, [_vp, _u64, _int, _vp, _u64]),
+    "vx_traversal_image": (_u64, [_int, _vp, _u64, _int, _vp, _u64]),
     "vx_resolve_2x2": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "vx_assemble_tiles": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "vx_assemble_tiles_on": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp]),
@@ -134,15 +134,15 @@ def local_tile_count(width, height, rank, count):
     return lib().vx_local_tile_count(width, height, rank, count)
 
 
-def csvo_to_image(world_frame_words, used_bytes, layout=0):
-    """vx_csvo_to_image: CSVO frame (uint32 words: scale, root_ptr, bytes...) -> traversal image (uint32 words);
+def traversal_image(svo_type, world_frame_words, used_bytes, layout=0):
+    """vx_traversal_image: world frame (uint32 words: scale, header, arena...) -> traversal image (uint32 words);
     layout 0 = ESVO frame (walkable by any ESVO traversal), 1 = the 64-byte-octant layout the renderer walks."""
     f = np.ascontiguousarray(world_frame_words, dtype=np.uint32)
-    n = lib().vx_csvo_to_image(f.ctypes.data_as(_vp), used_bytes, layout, None, 0)
+    n = lib().vx_traversal_image(svo_type, f.ctypes.data_as(_vp), used_bytes, layout, None, 0)
     if n == 0:
-        raise ValueError("this CSVO frame cannot be imaged")
+        raise ValueError("this world frame cannot be imaged")
     out = np.zeros(n, dtype=np.uint32)
-    lib().vx_csvo_to_image(f.ctypes.data_as(_vp), used_bytes, layout, out.ctypes.data_as(_vp), n)
+    lib().vx_traversal_image(svo_type, f.ctypes.data_as(_vp), used_bytes, layout, out.ctypes.data_as(_vp), n)
     return out
 
 
