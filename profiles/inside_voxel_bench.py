@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Worst case of the CSVO traversal image: the camera sits INSIDE a voxel, so every primary ray is one the image cannot
 serve and every pixel goes through the second phase (whole pixel on the compressed bytes). Compared with the image switched
-off (VX_CSVO_IMAGE=0, set by the caller) and with a camera just above the same spot."""
+off (VX_TRAVERSAL_IMAGE=0, set by the caller) and with a camera just above the same spot."""
 import json
 import math
 import sys

@@ -541,7 +541,7 @@ struct vx_context {
     // Tickets drawn from each dispenser so far. A launch draws exactly total_subtiles + waves tickets (every wave draws one
     // ticket past the end before it stops), so the next launch on the same stream starts there and no reset is needed.
     uint32_t frame_tickets[kFrameStreams] = {};
-    uint32_t* d_frame_todo[kFrameStreams] = {};  // CSVO image contexts: [chunk counter][ring of 128-dword chunks] per stream
+    uint32_t* d_frame_todo[kFrameStreams] = {};  // imaged contexts: [chunk counter][ring of 128-dword chunks] per stream
     size_t frame_todo_pixels[kFrameStreams] = {};
     uint32_t* d_main_todo = nullptr;
     size_t main_todo_pixels = 0;

@@ -76,7 +76,7 @@ struct SceneArgs {
     uint32_t tex_bytes;
     uint32_t width, height, layers, levels;
     uint32_t level_offset[16];
-    const uint8_t* image;   // CSVO contexts: the ESVO-layout traversal image of the world (traversal_image.hpp), else null
+    const uint8_t* image;   // the traversal image of the world (traversal_image.hpp), or null
     uint32_t image_bytes;
 };
 
