@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--format", choices=["esvo", "csvo"], default="csvo", help="node format; csvo is the reference's default build feature")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames the renderer keeps in flight (1..8); default: the library's own (2) on one GPU, max(3, N) when the frame is sharded over N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (tile lists, RCCL gather, assembly) even with one rank; needs a torch.distributed.run launch")
@@ -88,6 +90,13 @@ def main():
     if sharded:
         import torch.distributed as dist
 
+        if "RANK" not in os.environ:  # --force-sharded started as a plain script: a one-rank group of its own
+            import socket
+
+            with socket.socket() as probe:
+                probe.bind(("127.0.0.1", 0))
+                port = probe.getsockname()[1]
+            os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
     fmt = vra.SVO_ESVO if args.format == "esvo" else vra.SVO_CSVO
@@ -130,7 +139,7 @@ def main():
         # in flight: a render only has to wait for the collective that last read its buffer.
         # frames in flight: the smaller a rank's share of the frame, the longer its tail relative to its body (a frame cannot
         # finish before its longest ray) and the more frames it takes to keep the device full
-        FRAMES = min(8, max(3, world_size))
+        FRAMES = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else min(8, max(3, world_size))
         svo.set_frames_in_flight(FRAMES)
         gather_done = [torch.cuda.Event() for _ in range(FRAMES)]
         state = {"i": 0}
@@ -154,13 +163,15 @@ def main():
             _step()
             after_gather_all()
     else:
-        # two frames in flight (the library alternates two streams): one image per frame in flight
-        images = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        # frames in flight (the library rotates over that many streams; its default is 2): one image per frame in flight
+        FRAMES = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else 2
+        svo.set_frames_in_flight(FRAMES)
+        images = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(FRAMES)]
         torch.cuda.synchronize()  # zero fills run on torch's stream, the renderer on its own
         state = {"i": 0}
 
         def step():
-            svo.render_device(uniforms, W, H, images[state["i"] % 2].data_ptr())
+            svo.render_device(uniforms, W, H, images[state["i"] % FRAMES].data_ptr())
             state["i"] += 1
 
     def barrier():
@@ -206,7 +217,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(my_bytes), "bytes_per_ray": round(my_bytes / max(my_rays, 1), 2),
                 # two frames are in flight: the per-launch spans above overlap (span x launches > elapsed). What the
                 # device sustains over the timed region is bytes x launches / elapsed:
-                "frames_in_flight": min(8, max(3, world_size)) if sharded else 2, "sustained_GBps": round(my_bytes * launches / max(elapsed, 1e-9) / 1e9, 3)}
+                "frames_in_flight": FRAMES, "sustained_GBps": round(my_bytes * launches / max(elapsed, 1e-9) / 1e9, 3)}
 
     cpu = None
     if not args.no_cpu_baseline and world_size == 1:  # rank 0 at N = 1 only: a baseline of the workload, not of the scaling run
