@@ -271,7 +271,7 @@ private:
         }
     }
 
-    static constexpr size_t kMaxOctants = size_t(1) << 25;  // 2 GiB of 64-byte octants
+    static constexpr size_t kMaxOctants = size_t(1) << 26;  // 4 GiB of 64-byte octants
     Words w_;
     Tree& out_;
     std::vector<ChunkRef>* refs_;
@@ -344,7 +344,7 @@ public:
 
     // `world` = the frame as committed: [f32 scale][CSVO: u32 root_ptr | ESVO: 5-word preamble][arena]; `used` = bytes of the
     // arena in use; `changed` = byte ranges (relative to the arena, like vx_commit's) rewritten since the last call.
-    // Returns false when the world cannot be imaged (malformed or image beyond 2 GiB): the caller then traverses the world's bytes.
+    // Returns false when the world cannot be imaged (malformed or image beyond 4 GiB): the caller then traverses the world's bytes.
     bool update(const uint8_t* world, uint64_t used, const Range* changed, size_t n_changed, unsigned threads) {
         dirty_.clear();
         if (used < 2) return false;
@@ -447,7 +447,7 @@ public:
             frame_[5] = uint32_t(root_at_ - 1);  // descriptors[] index = frame word index - 1
         }
         dirty_.push_back(Range{0, header_words() * 4});
-        return alloc_.end() * 4 < (uint64_t(1) << 31);  // kOct64 pointers are byte offsets that must stay clear of the sign games of 32-bit offsets
+        return alloc_.end() * 4 + 4096 < (uint64_t(1) << 32);  // pointers are 32-bit byte offsets (and so are the buffer resource's)
     }
 
 private:
