@@ -19,6 +19,7 @@
 #include "stream.hpp"
 #include "svo_picker.hpp"
 #include "svo_registry.hpp"
+#include "traversal_image.hpp"  // (csrc/hip: host-only header)
 #include "worldsvo.hpp"
 
 using namespace vx;
@@ -257,7 +258,25 @@ struct Streamer {
     systems::WorldStreamer<Csvo, CsvoSerializedChunk> csvo;
     Streamer(int t, uint32_t depth, uint32_t seed, uint32_t radius, int32_t y0, int32_t y1)
         : svo_type(t), esvo(depth, seed, radius, y0, y1), csvo(depth, seed, radius, y0, y1) {}
+    // tests: a host-side stand-in for the device world buffer and the traversal image vx_commit keeps next to it
+    std::vector<uint8_t> mirror;
+    std::unique_ptr<vximg::WorldImage> image;
+    bool image_ok = false;
 };
+
+extern "C++" {
+template <class S>
+void mirror_commits(Streamer* s, S& streamer) {
+    streamer.on_dry_commit = [s](auto& world, const std::vector<vx_range>& ranges) {
+        const float scale = std::ldexp(1.0f, -int(world.depth()));
+        std::memcpy(s->mirror.data(), &scale, 4);
+        if (!world.write_changes_to(s->mirror.data() + 4, s->mirror.size() - 5, true)) throw std::runtime_error("mirror too small");
+        std::vector<vximg::Range> changed;
+        for (const vx_range& r : ranges) changed.push_back(vximg::Range{r.start, r.length});
+        s->image_ok = s->image->update(s->mirror.data(), world.size_in_bytes(), changed.data(), changed.size(), 2);
+    };
+}
+}  // extern "C++"
 }  // namespace
 
 void* vxh_stream_new(int svo_type, uint32_t scene_depth, uint32_t seed, uint32_t radius, int32_t start_y, int32_t end_y) {
@@ -298,6 +317,52 @@ size_t vxh_stream_frame(void* sp, uint8_t* dst, size_t cap) {
         return need;
     };
     return s->svo_type == 1 ? emit(s->esvo.world(), 20) : emit(s->csvo.world(), 4);
+}
+
+// Tests: from now on pump(ctx = NULL) applies its dirty ranges to a host mirror of `capacity` bytes exactly like vx_commit
+// applies them to the staging mirror, and keeps a traversal image (layout as vx_traversal_image) up to date incrementally.
+int vxh_stream_mirror_image(void* sp, uint64_t capacity, int layout) {
+    Streamer* s = static_cast<Streamer*>(sp);
+    if (capacity < 64 || (layout != 0 && layout != 1)) return -1;
+    s->mirror.assign(capacity, 0);
+    s->image.reset(new vximg::WorldImage(s->svo_type, layout == 0 ? vximg::kEsvo48 : vximg::kOct64));
+    s->image_ok = false;
+    if (s->svo_type == 1) mirror_commits(s, s->esvo); else mirror_commits(s, s->csvo);
+    return 0;
+}
+// the incrementally maintained image, in 32-bit words (0 = none / the world could not be imaged)
+uint64_t vxh_stream_image(void* sp, uint32_t* dst, uint64_t cap_words) {
+    Streamer* s = static_cast<Streamer*>(sp);
+    if (!s->image || !s->image_ok) return 0;
+    const std::vector<uint32_t>& f = s->image->frame();
+    if (dst && cap_words >= f.size()) std::memcpy(dst, f.data(), f.size() * 4);
+    return f.size();
+}
+
+// Tests: do two images of layout 1 ([64-byte header][64-byte octants of eight {lo, hi}], traversal_image.hpp) hold the same
+// tree -- same masks, same leaf values, same shape -- wherever their octants were placed? 1 / 0; -1 = a pointer out of range.
+int vxh_oct64_same_tree(const uint32_t* a, uint64_t na, const uint32_t* b, uint64_t nb) {
+    if (na < 16 || nb < 16 || a[0] != b[0] || a[1] != b[1]) return 0;
+    struct Pair { uint32_t pa, pb, masks; };
+    std::vector<Pair> todo{{a[2], b[2], a[1]}};
+    while (!todo.empty()) {
+        const Pair p = todo.back();
+        todo.pop_back();
+        if (p.pa % 64 || p.pb % 64 || uint64_t(p.pa) / 4 + 16 > na || uint64_t(p.pb) / 4 + 16 > nb) return -1;
+        const uint32_t *oa = a + p.pa / 4, *ob = b + p.pb / 4;
+        for (uint32_t c = 0; c < 8; ++c) {
+            const bool exists = (p.masks >> (31 - c)) & 1u, leaf = (p.masks >> (23 - c)) & 1u;
+            if (!exists) {
+                if (oa[2 * c] | oa[2 * c + 1] | ob[2 * c] | ob[2 * c + 1]) return 0;
+            } else if (leaf) {
+                if (oa[2 * c] != ob[2 * c]) return 0;
+            } else {
+                if (oa[2 * c + 1] != ob[2 * c + 1]) return 0;
+                todo.push_back(Pair{oa[2 * c], ob[2 * c], oa[2 * c + 1]});
+            }
+        }
+    }
+    return 1;
 }
 
 // world block position -> SVO position of the streamer's current coordinate space

@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <deque>
+#include <functional>
 #include <optional>
 #include <stdexcept>
 #include <thread>
@@ -75,6 +76,9 @@ public:
         cs_.dst = radius;
         threads_ = threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     }
+
+    // pump(nullptr, ..) hands the dirty ranges here instead of to vx_commit (tests)
+    std::function<void(WorldT&, const std::vector<vx_range>&)> on_dry_commit;
 
     // returns the number of events the move produced
     size_t move_to(float x, float y, float z) {
@@ -156,6 +160,9 @@ public:
                 const size_t cap = vx_capacity(ctx);
                 if (!world_.write_changes_to(vx_staging_ptr(ctx) + 4, cap - 1, true)) throw std::runtime_error("world buffer capacity exceeded");
                 if (vx_commit(ctx, world_.depth(), ranges.data(), uint32_t(ranges.size()), world_.size_in_bytes()) != VX_OK) throw std::runtime_error(vx_last_error());
+            } else if (on_dry_commit) {
+                on_dry_commit(world_, ranges);  // host-only tests: someone else plays the device (must consume the ranges)
+                world_.buffer.updated_ranges.clear();
             } else {
                 world_.buffer.updated_ranges.clear();  // dry run (host-only tests): the world is updated, nothing is uploaded
             }

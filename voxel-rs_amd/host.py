@@ -52,6 +52,9 @@ def lib():
             "vxh_stream_move_to": (u64, [vp, C.c_float, C.c_float, C.c_float]),
             "vxh_stream_pump": (C.c_int, [vp, vp, u32, vp]),
             "vxh_stream_frame": (sz, [vp, vp, sz]),
+            "vxh_stream_mirror_image": (C.c_int, [vp, C.c_uint64, C.c_int]),
+            "vxh_stream_image": (C.c_uint64, [vp, vp, C.c_uint64]),
+            "vxh_oct64_same_tree": (C.c_int, [vp, C.c_uint64, vp, C.c_uint64]),
             "vxh_stream_to_svo": (None, [vp, vp, vp]),
             "vxh_stream_resident_chunks": (u64, [vp]),
             "vxh_physics_step_many": (C.c_int64, [vp, C.c_float, u32, vp, u32]),
@@ -248,6 +251,21 @@ class WorldStreamer:
         lib().vxh_stream_frame(self._h, buf.ctypes.data_as(C.c_void_p), buf.size * 4)
         return buf
 
+    def mirror_image(self, capacity_bytes, layout=1):
+        """Tests: pump(None) from now on applies its dirty ranges to a host mirror like vx_commit does to the staging buffer
+        and keeps a traversal image of it up to date incrementally (what a context does next to its device world buffer)."""
+        if lib().vxh_stream_mirror_image(self._h, capacity_bytes, layout) != 0:
+            raise ValueError("bad mirror parameters")
+
+    def image(self):
+        """The incrementally maintained traversal image (uint32 words)."""
+        n = lib().vxh_stream_image(self._h, None, 0)
+        if n == 0:
+            raise ValueError("no image (mirror_image() not called, nothing committed yet, or the world cannot be imaged)")
+        out = np.zeros(n, dtype=np.uint32)
+        lib().vxh_stream_image(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
     def to_svo(self, world_pos):
         w = (C.c_float * 3)(*world_pos)
         s = (C.c_float * 3)()
@@ -257,6 +275,15 @@ class WorldStreamer:
     @property
     def resident_chunks(self):
         return int(lib().vxh_stream_resident_chunks(self._h))
+
+
+def oct64_same_tree(a, b):
+    """Do two layout-1 traversal images hold the same tree (wherever their octants are placed)?"""
+    a, b = np.ascontiguousarray(a, dtype=np.uint32), np.ascontiguousarray(b, dtype=np.uint32)
+    r = lib().vxh_oct64_same_tree(a.ctypes.data_as(C.c_void_p), a.size, b.ctypes.data_as(C.c_void_p), b.size)
+    if r < 0:
+        raise ValueError("an image pointer is out of range")
+    return bool(r)
 
 
 ENTITY_FLOATS = 17  # position, velocity, aabb offset, aabb extents, wall_clip, flying, gravity, max_fall_velocity, is_grounded
