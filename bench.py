@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--format", choices=["esvo", "csvo"], default="csvo", help="node format; csvo is the reference's default build feature")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames the renderer keeps in flight (1..8); default: the library's own (2) on one GPU, max(3, N) when the frame is sharded over N")
+    ap.add_argument("--gather-group", type=int, default=0, help="sharded: frames per gather (default 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (tile lists, RCCL gather, assembly) even with one rank; needs a torch.distributed.run launch")
@@ -131,8 +132,8 @@ def main():
 
         def assemble(gathered, image):
             # on the collective's stream: ordered after the gather by construction, and the render streams stay free for the
-            # next frame's tiles
-            svo.assemble_tiles(gathered.data_ptr(), gathered.shape[1] * 32 * 32 * 4, world_size, W, H, image.data_ptr(),
+            # next frame's tiles. `gathered` is [rank][tile]... with the ranks a whole group of frames apart.
+            svo.assemble_tiles(gathered.data_ptr(), gathered.stride(0), world_size, W, H, image.data_ptr(),
                                stream=torch.cuda.current_stream().cuda_stream)
 
         # The renderer runs frames on its own streams; the gather and the assembly run on torch's. One tile buffer per frame
@@ -140,28 +141,29 @@ def main():
         # frames in flight: the smaller a rank's share of the frame, the longer its tail relative to its body (a frame cannot
         # finish before its longest ray) and the more frames it takes to keep the device full
         FRAMES = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else min(8, max(3, world_size))
+        # frames per collective (1: every frame is gathered as soon as it is rendered; more: fewer, larger messages)
+        GROUP = args.gather_group if args.gather_group else 1
+        GROUP = max(1, min(GROUP, FRAMES))
+        FRAMES -= FRAMES % GROUP
         svo.set_frames_in_flight(FRAMES)
-        gather_done = [torch.cuda.Event() for _ in range(FRAMES)]
-        state = {"i": 0}
+        exchange_done = [torch.cuda.Event() for _ in range(FRAMES // GROUP)]
+        recorded = [False] * (FRAMES // GROUP)
 
-        def before_render():
-            if state["i"] >= FRAMES:  # recorded at least once
-                svo.wait_event(gather_done[state["i"] % FRAMES].cuda_event)
+        def before_render(g):
+            if recorded[g]:
+                svo.wait_event(exchange_done[g].cuda_event)
 
-        def before_gather():
+        def after_render():
             svo.stream_wait_render(torch.cuda.current_stream().cuda_stream)
 
-        def after_gather_all():
-            gather_done[state["i"] % FRAMES].record(torch.cuda.current_stream())
-            state["i"] += 1
+        def after_exchange(g):
+            exchange_done[g].record(torch.cuda.current_stream())
+            recorded[g] = True
 
         sharder = FrameSharder(W, H, rank, world_size, dist, "cuda", render_tiles, assemble, before_render=before_render,
-                               before_gather=before_gather, buffers=FRAMES)
-        _step = sharder.step
-
-        def step():
-            _step()
-            after_gather_all()
+                               after_render=after_render, after_exchange=after_exchange, buffers=FRAMES, group=GROUP)
+        step = sharder.step
+        flush = sharder.flush
     else:
         # frames in flight (the library rotates over that many streams; its default is 2): one image per frame in flight
         FRAMES = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else 2
@@ -174,7 +176,11 @@ def main():
             svo.render_device(uniforms, W, H, images[state["i"] % FRAMES].data_ptr())
             state["i"] += 1
 
+        def flush():
+            pass
+
     def barrier():
+        flush()  # (sharded: a group of frames that has not been exchanged yet)
         svo.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -208,6 +214,22 @@ def main():
             dist.destroy_process_group()
         return
 
+    # sharded: the frame rank 0 assembled last against the same frame rendered whole on this GPU (outside the timed region)
+    sharded_frame_identical = None
+    if sharded:
+        whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        svo.render_device(uniforms, W, H, whole.data_ptr())
+        svo.sync()
+        if world_size > 1:
+            got = sharder.image
+        else:
+            # one rank (--force-sharded): tile_count 1 means "the whole frame, row-major" to vx_render, so this rank's "tile
+            # list" is the frame itself and the assembly kernel (which runs for its cost) scatters something that is no tile
+            # list -- the check is on what the gather delivered
+            got = sharder.last_gathered[0].reshape(-1)[:H * W * 4].view(H, W, 4)
+        sharded_frame_identical = bool(torch.equal(whole.view(torch.int32), got.contiguous().view(torch.int32)))
+
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (ms_per_step * 1e-3) / 1e6  # Mrays/s, whole job
     kernel_avg_ms = kernel_ms / max(launches, 1)
@@ -217,7 +239,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(my_bytes), "bytes_per_ray": round(my_bytes / max(my_rays, 1), 2),
                 # two frames are in flight: the per-launch spans above overlap (span x launches > elapsed). What the
                 # device sustains over the timed region is bytes x launches / elapsed:
-                "frames_in_flight": FRAMES, "sustained_GBps": round(my_bytes * launches / max(elapsed, 1e-9) / 1e9, 3)}
+                "frames_in_flight": FRAMES, **({"frames_per_gather": GROUP} if sharded else {}), "sustained_GBps": round(my_bytes * launches / max(elapsed, 1e-9) / 1e9, 3)}
 
     cpu = None
     if not args.no_cpu_baseline and world_size == 1:  # rank 0 at N = 1 only: a baseline of the workload, not of the scaling run
@@ -263,6 +285,7 @@ def main():
                                f"({args.format.upper()} nodes), 1 frame per step", "svo_format": args.format, "svo_bytes": world.size_in_bytes,
                    "leaves": st["leaves"], "chunks": st["chunks"], "rays_per_frame": int(total_rays), "primary_rays": W * H,
                    "parallelism": f"screen tiles (32x32, interleaved) over {world_size} GPU(s), SVO replicated, RCCL gather to rank 0",
+                   **({"sharded_frame_identical_to_whole_render": sharded_frame_identical} if sharded else {}),
                    "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 3),
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4)},
         "roofline": roofline, "cpu_baseline": cpu,

@@ -37,12 +37,33 @@ def main():
     def assemble(gathered, image):
         image.copy_(torch.from_numpy(sharding.assemble_tiles(gathered.numpy(), w, h)))
 
-    fs = sharding.FrameSharder(w, h, rank, world, dist, "cpu", render_tiles, assemble)
-    image = fs.step()
+    # argv[4] = frames per gather, argv[5] = frames to run (every frame has its own ambient light, so that a frame delivered
+    # in another frame's place is noticed)
+    group = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    n_frames = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    calls = {"before": [], "exchange": []}
+    fs = sharding.FrameSharder(w, h, rank, world, dist, "cpu", render_tiles, assemble, buffers=2 * group, group=group,
+                               before_render=lambda g: calls["before"].append(g), after_exchange=lambda g: calls["exchange"].append(g))
+    delivered = []
+    for f in range(n_frames):
+        u.ambient = 0.3 + 0.05 * f
+        image = fs.step()
+        if rank == 0 and image is not None:
+            # a full group came back: its frames are in fs.images[0..group)
+            delivered += [im.numpy().copy() for im in fs.images]
+    image = fs.flush()
+    if rank == 0 and n_frames % group:
+        delivered += [im.numpy().copy() for im in fs.images[:n_frames % group]]
     dist.barrier()
+    assert calls["exchange"] == [k % 2 for k in range(-(-n_frames // group))], calls
+    assert calls["before"] == [(f // group) % 2 for f in range(n_frames)], calls
     if rank == 0:
-        full, _ = scene.render(u, w, h, want_hits=False, threads=2)
-        same = np.array_equal(np.nan_to_num(image.numpy(), nan=-7.0), np.nan_to_num(full, nan=-7.0))
+        same = len(delivered) == n_frames
+        for f in range(n_frames):
+            u.ambient = 0.3 + 0.05 * f
+            full, _ = scene.render(u, w, h, want_hits=False, threads=2)
+            same = same and np.array_equal(np.nan_to_num(delivered[f], nan=-7.0), np.nan_to_num(full, nan=-7.0))
+        same = same and np.array_equal(np.nan_to_num(image.numpy(), nan=-7.0), np.nan_to_num(delivered[-1], nan=-7.0))
         Path(out_path).write_text(f"{int(same)} {world} {fs.n_max} {int(np.isfinite(full).all())}\n")
     dist.destroy_process_group()
 

@@ -53,41 +53,80 @@ class FrameSharder:
     """One frame = render own tiles -> gather to rank 0 -> assemble.
 
     render_tiles(tiles_tensor): fills this rank's compact tile list (asynchronously on the renderer's stream is fine).
-    assemble(gathered_tensor, image_tensor): rank 0 only.
-    Stream-ordering hooks (GPU: the renderer has its own stream, the collective runs on torch's; no-ops on CPU):
-      before_render -- the renderer must not overwrite a tile list the previous collective using it is still sending;
-      before_gather -- the collective waits for the render;  after_gather -- the assembly waits for the collective.
-    Tile lists and gather buffers are double-buffered so that frame k+1's render overlaps frame k's gather/assembly.
+    assemble(gathered_view, image_tensor): rank 0 only; gathered_view is [world][n_max][32][32][4], possibly strided over ranks.
+
+    `buffers` frames are in flight (one tile list each), so that frame k+1's render overlaps frame k's gather/assembly.
+    `group` consecutive frames share ONE collective (their tile lists are adjacent in memory): the gather's fixed cost -- launch,
+    rendezvous, one message per peer -- is paid once per group, which is what matters when a rank's share of a frame takes
+    about as long as a small collective does (8 GPUs at 1080p). step() then returns None for the frames that only rendered,
+    and flush() exchanges a group that is not full yet (call it before waiting for the last frames).
+
+    Stream-ordering hooks (GPU: the renderer has its own streams, the collective runs on torch's; no-ops on CPU):
+      before_render(g)  -- the renderer must not overwrite group g's tile lists while the collective that last used them is
+                           still sending;
+      after_render()    -- the collective's stream has to wait for the render just issued;
+      after_exchange(g) -- group g's gather (and, on rank 0, assembly) has been issued.
     """
 
-    def __init__(self, width, height, rank, world, dist, device, render_tiles, assemble, before_render=None, before_gather=None,
-                 after_gather=None, buffers=2):
+    def __init__(self, width, height, rank, world, dist, device, render_tiles, assemble, before_render=None, after_render=None,
+                 after_exchange=None, buffers=2, group=1):
         import torch
 
+        if group < 1 or buffers < group or buffers % group:
+            raise ValueError("buffers must be a multiple of group")
         self.width, self.height, self.rank, self.world, self.dist = width, height, rank, world, dist
         self.render_tiles, self.assemble = render_tiles, assemble
-        noop = lambda: None  # noqa: E731
-        self.before_render, self.before_gather, self.after_gather = before_render or noop, before_gather or noop, after_gather or noop
+        self.before_render = before_render or (lambda g: None)
+        self.after_render = after_render or (lambda: None)
+        self.after_exchange = after_exchange or (lambda g: None)
+        self.group = group
         self.n_local = len(local_tile_ids(width, height, rank, world))
         self.n_max = max(len(local_tile_ids(width, height, r, world)) for r in range(world))
-        self.tiles = [torch.zeros((self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) for _ in range(buffers)]
-        self.gathered = [torch.zeros((world, self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) if rank == 0 else None
-                         for _ in range(buffers)]
-        self.image = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if rank == 0 else None
+        n_groups = buffers // group
+        # [group][frame in group][tile]...: the lists of one group are one contiguous message
+        self.tiles = [torch.zeros((group, self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) for _ in range(n_groups)]
+        self.gathered = [torch.zeros((world, group, self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) if rank == 0 else None
+                         for _ in range(n_groups)]
+        self.images = [torch.zeros((height, width, 4), dtype=torch.float32, device=device) for _ in range(group)] if rank == 0 else None
         if str(device).startswith("cuda"):
             torch.cuda.synchronize()  # the zero fills ran on torch's stream; a renderer with its own streams must not race them
-        self.frame = 0
+        self.frame = 0  # frames rendered
+        self._g = 0     # the group being filled ...
+        self._slot = 0  # ... and how many of its frames are rendered
+        self._last = None
+        self.last_gathered = None
+
+    @property
+    def image(self):
+        """rank 0: the most recently assembled frame"""
+        return self.images[self._last] if self.rank == 0 and self._last is not None else None
 
     def step(self):
-        b = self.frame % len(self.tiles)
+        g, j = self._g, self._slot
+        self.before_render(g)
+        self.render_tiles(self.tiles[g][j])
+        self.after_render()
         self.frame += 1
-        tiles, gathered = self.tiles[b], self.gathered[b]
-        self.before_render()
-        self.render_tiles(tiles)
-        self.before_gather()
+        self._slot += 1
+        if self._slot < self.group:
+            return None
+        return self._exchange()
+
+    def flush(self):
+        """Exchanges the frames of a group that is not full yet (same count on every rank: they step together); the next frame
+        starts a new group."""
+        return self._exchange() if self._slot else self.image
+
+    def _exchange(self):
+        g, count = self._g, self._slot
+        tiles, gathered = self.tiles[g][:count], self.gathered[g]
         # the one exchange step of the path: finished tiles -> rank 0
-        self.dist.gather(tiles, list(gathered.unbind(0)) if self.rank == 0 else None, dst=0)
+        self.dist.gather(tiles, [gathered[r, :count] for r in range(self.world)] if self.rank == 0 else None, dst=0)
         if self.rank == 0:
-            self.after_gather()
-            self.assemble(gathered, self.image)
+            for j in range(count):
+                self.assemble(gathered[:, j], self.images[j])
+            self._last = count - 1
+            self.last_gathered = gathered[:, count - 1]  # [world][n_max]...: the newest frame's tile lists as they arrived
+        self.after_exchange(g)
+        self._g, self._slot = (g + 1) % len(self.tiles), 0
         return self.image
