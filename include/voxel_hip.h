@@ -231,7 +231,8 @@ int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_fl
 /* The traversal image of a world: the octant tree a context traverses instead of the world's own bytes.
  * `world_frame` = the world as committed ([f32 scale][ESVO: 5-word preamble | CSVO: u32 root_ptr][arena]), `used_bytes` = arena
  * bytes in use. layout 1 = what the renderer walks ([64-byte header][64-byte octants of eight {pointer | value, masks}
- * entries]); layout 0 = the same tree as an ESVO frame ([f32 2^-depth][5-word preamble][12-word octants], esvo.rs:74-101),
+ * entries], pointers = byte offsets); layout 2 = the same with octant indices for pointers, what the renderer switches to when
+ * the image outgrows 4 GiB; layout 0 = the same tree as an ESVO frame ([f32 2^-depth][5-word preamble][12-word octants], esvo.rs:74-101),
  * which any ESVO traversal can walk (the tests do, with the oracle). Returns the image size in 32-bit words (0 = cannot be
  * imaged) and fills `out_words` when it is large enough. Pure host function (no device needed): vx_commit does this itself. */
 uint64_t vx_traversal_image(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words);

@@ -394,7 +394,8 @@ OCCUPANCY_COUNTERS = ("wave_steps", "services", "refills", "tail_wave_steps", "t
 @pytest.mark.parametrize("fmt", FMTS)
 def test_kernel_versions_agree(hip, fmt, monkeypatch):
     """The persistent wavefront kernel (default) and the one-thread-per-pixel kernel write identical images and hit
-    records, for several refill/service thresholds (they only reorder work between lanes)."""
+    records, for several refill/service thresholds (they only reorder work between lanes), from the traversal image (default),
+    from the world's own bytes, and from the image layout for more than 4 GiB (octant indices behind a 64-bit pointer)."""
     from voxel_rs_amd import scenes
 
     world = vra.World(SVO_TYPES[fmt])
@@ -404,8 +405,9 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     u = scenes.bench_camera(8, st["h_max"], w, h)
     results = []
     for env in ({"VX_RENDER_KERNEL": "1"}, {"VX_RENDER_KERNEL": "2"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"},
-                {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "64", "VX_SERVICE_MIN": "64"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"}):
-        for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN"):
+                {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "64", "VX_SERVICE_MIN": "64"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"},
+                {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_WIDE_IMAGE": "1", "VX_MIN_WAVES": "1"}):
+        for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_MIN_WAVES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -134,9 +134,11 @@ def _oct64_masks(m):
     return (rev(m >> 24) << 8) | rev((m >> 16) & 0xFF)
 
 
-def _walk_oct64_image(img):
+def _walk_oct64_image(img, wide=False):
+    """wide: pointers are octant indices (layout 2) instead of byte offsets (layout 1)"""
+    unit = 64 if wide else 1
     out = []
-    stack = [((), int(img[2]), _oct64_masks(int(img[1])))]
+    stack = [((), int(img[2]) * unit, _oct64_masks(int(img[1])))]
     while stack:
         path, octant, masks = stack.pop()
         assert octant % 64 == 0
@@ -148,7 +150,7 @@ def _walk_oct64_image(img):
             elif masks & (1 << c):
                 out.append((path + (c,), "leaf", lo))
             else:
-                stack.append((path + (c,), lo, _oct64_masks(hi)))
+                stack.append((path + (c,), lo * unit, _oct64_masks(hi)))
     return sorted(out)
 
 
@@ -163,6 +165,8 @@ def test_renderer_layout_holds_the_same_tree(fmt):
     assert b_img[0] == frame[0] and b_img.size % 16 == 0
     b = _walk_oct64_image(b_img)
     assert len(a) > 10000 and a == b
+    # ... and so does the layout for images beyond 4 GiB (octant indices for pointers)
+    assert _walk_oct64_image(hip.traversal_image(FMTS[fmt], frame, world.size_in_bytes, 2), wide=True) == a
     # the C++ comparison the incremental test relies on agrees, and notices a difference
     assert host.oct64_same_tree(b_img, b_img.copy())
     broken = b_img.copy()

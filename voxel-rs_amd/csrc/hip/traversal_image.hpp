@@ -13,6 +13,8 @@
 //            frame start) of the child's own octant, or the leaf's value; hi = the child's masks (oct64_masks()).
 //            A descent is ONE aligned 8-byte load that yields the new pointer and the new masks; every pointer in the image
 //            is valid by construction, so the loads need no clamping.
+//   kOct64Wide  kOct64 with octant INDICES (frame byte offset / 64) for pointers: images from 4 GiB up to 256 GiB, walked through
+//            a 64-bit pointer at two more instructions per descent. A context switches to it when kOct64 no longer fits.
 //   kEsvo48  the reference's ESVO format: [f32][5-word preamble][12-word octants], relative pointers. Kept because any ESVO
 //            traversal can walk it: tests/test_traversal_image.py checks the tree walk with the oracle.
 // The image never has more levels than the world's depth says (a world that breaks this is not imaged): the kernel relies on it.
@@ -30,7 +32,7 @@
 
 namespace vximg {
 
-enum Layout : int { kEsvo48 = 0, kOct64 = 1 };
+enum Layout : int { kEsvo48 = 0, kOct64 = 1, kOct64Wide = 2 };
 
 struct Range {
     uint64_t start, length;
@@ -319,7 +321,9 @@ private:
 class WorldImage {
 public:
     // svo_type: VX_SVO_ESVO (1) or VX_SVO_CSVO (2), the format of the worlds handed to update()
-    explicit WorldImage(int svo_type = 2, Layout layout = kOct64) : esvo_(svo_type == 1), layout_(layout) {}
+    // first_word: where the arena starts in the frame (tests start a wide image beyond 4 GiB to exercise its 64-bit addresses)
+    explicit WorldImage(int svo_type = 2, Layout layout = kOct64, uint64_t first_word = 0)
+        : esvo_(svo_type == 1), layout_(layout), first_word_(first_word) {}
 
     // host mirror of the image frame, as 32-bit words
     const std::vector<uint32_t>& frame() const { return frame_; }
@@ -341,12 +345,16 @@ public:
     size_t chunk_count() const { return chunks_.size(); }
     // levels of the imaged octree (the world's depth); no path of the image is longer
     uint32_t depth() const { return depth_; }
+    Layout layout() const { return layout_; }
+    // the last update() failed only because the image outgrew what this layout's pointers can reach
+    bool too_big() const { return too_big_; }
 
     // `world` = the frame as committed: [f32 scale][CSVO: u32 root_ptr | ESVO: 5-word preamble][arena]; `used` = bytes of the
     // arena in use; `changed` = byte ranges (relative to the arena, like vx_commit's) rewritten since the last call.
     // Returns false when the world cannot be imaged (malformed or image beyond 4 GiB): the caller then traverses the world's bytes.
     bool update(const uint8_t* world, uint64_t used, const Range* changed, size_t n_changed, unsigned threads) {
         dirty_.clear();
+        too_big_ = false;
         if (used < 2) return false;
         const Bytes b{world + 8, size_t(used)};                                                        // CSVO arena
         const Words w{reinterpret_cast<const uint32_t*>(world + 4), size_t(used / 4 + 5)};             // ESVO descriptors[]
@@ -356,7 +364,7 @@ public:
         if (depth < 1 || depth > 23) return false;
         if (frame_.empty()) {
             frame_.assign(header_words(), 0u);
-            alloc_.reset(header_words());
+            alloc_.reset(std::max(header_words(), first_word_ / octant_words() * octant_words()));
         }
 
         // 1. walk the root octree: which chunks does it reference
@@ -430,7 +438,7 @@ public:
             for (uint32_t c = 0; c < 8; ++c)
                 if ((o.chunk_mask >> c) & 1u) {
                     const Placed& pl = chunks_.at(o.lo[c]);
-                    o.lo[c] = uint32_t(pl.at);  // word index of the chunk's root octant
+                    o.lo[c] = uint32_t(layout_ == kEsvo48 ? pl.at : pl.at / 16);  // the chunk's root octant: frame word / octant index
                     o.masks[c] = uint16_t(pl.masks);
                 }
         encode(root, root_at_);
@@ -438,16 +446,19 @@ public:
 
         // 5. header
         frame_[0] = scale_bits;
-        if (layout_ == kOct64) {
+        if (layout_ != kEsvo48) {
             frame_[1] = oct64_masks(root.root.packed());
-            frame_[2] = uint32_t(root_at_ * 4);
+            frame_[2] = uint32_t(layout_ == kOct64 ? root_at_ * 4 : root_at_ / 16);
         } else {
             frame_[1] = root.root.packed();  // preamble: a fake octant whose child 0 is the root (esvo.rs:179-188)
             frame_[2] = frame_[3] = frame_[4] = 0;
             frame_[5] = uint32_t(root_at_ - 1);  // descriptors[] index = frame word index - 1
         }
         dirty_.push_back(Range{0, header_words() * 4});
-        return alloc_.end() * 4 + 4096 < (uint64_t(1) << 32);  // pointers are 32-bit byte offsets (and so are the buffer resource's)
+        // what the pointers can reach: 32-bit byte offsets (and the buffer resource's) / 32-bit octant indices / 31-bit word offsets
+        const uint64_t end = alloc_.end();
+        too_big_ = layout_ == kOct64 ? end * 4 + 4096 >= (uint64_t(1) << 32) : (layout_ == kOct64Wide ? end / 16 >= (uint64_t(1) << 32) : end >= (uint64_t(1) << 31));
+        return !too_big_;
     }
 
 private:
@@ -466,8 +477,8 @@ private:
         return false;
     }
 
-    uint64_t header_words() const { return layout_ == kOct64 ? 16 : 6; }
-    uint64_t octant_words() const { return layout_ == kOct64 ? 16 : 12; }
+    uint64_t header_words() const { return layout_ == kEsvo48 ? 6 : 16; }
+    uint64_t octant_words() const { return layout_ == kEsvo48 ? 12 : 16; }
 
     template <class F>
     static void parallel(size_t n, unsigned threads, F f) {
@@ -488,13 +499,14 @@ private:
         uint32_t* dst = frame_.data() + at;
         for (size_t i = 0; i < t.octants.size(); ++i) {
             const Octant& o = t.octants[i];
-            if (layout_ == kOct64) {
+            if (layout_ != kEsvo48) {
                 uint32_t* w = dst + i * 16;
+                const bool wide = layout_ == kOct64Wide;  // octant indices instead of byte offsets
                 for (uint32_t c = 0; c < 8; ++c) {
                     const uint32_t bit = 1u << c;
                     uint32_t lo = 0, hi = 0;
-                    if (o.node_mask & bit) { lo = uint32_t((at + uint64_t(o.lo[c]) * 16) * 4); hi = oct64_masks(o.masks[c]); }
-                    else if (o.chunk_mask & bit) { lo = o.lo[c] * 4u; hi = oct64_masks(o.masks[c]); }
+                    if (o.node_mask & bit) { lo = uint32_t(wide ? at / 16 + o.lo[c] : (at + uint64_t(o.lo[c]) * 16) * 4); hi = oct64_masks(o.masks[c]); }
+                    else if (o.chunk_mask & bit) { lo = wide ? o.lo[c] : o.lo[c] * 64u; hi = oct64_masks(o.masks[c]); }
                     else if (o.leaf_mask & bit) { lo = o.lo[c]; }
                     w[2 * c] = lo;
                     w[2 * c + 1] = hi;
@@ -521,12 +533,14 @@ private:
 
     bool esvo_;
     Layout layout_;
+    uint64_t first_word_;
     std::vector<uint32_t> frame_;
     std::vector<Range> dirty_;
     WordAllocator alloc_;
     std::unordered_map<uint32_t, Placed> chunks_;
     uint64_t root_at_ = 0, root_words_ = 0;
     uint32_t depth_ = 0;
+    bool too_big_ = false;
 };
 
 }  // namespace vximg

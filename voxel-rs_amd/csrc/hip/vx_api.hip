@@ -152,7 +152,8 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
 template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
-    static_assert((FOREIGN != 0) == (SVO == VX_SVO_IMAGE) && !(FOREIGN && STATS), "image traversal <=> foreign handling; the instrumented kernel counts the reference's own fetches");
+    static_assert((FOREIGN != 0) == (SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE) && !(FOREIGN && STATS),
+                  "image traversal <=> foreign handling; the instrumented kernel counts the reference's own fetches");
     static_assert(FOREIGN == 0 || FOREIGN == VX_SVO_ESVO || FOREIGN == VX_SVO_CSVO, "FOREIGN names the world's own format");
     static_assert(!SHALLOW || FOREIGN, "only a traversal image bounds how deep a ray can get");
     const DevScene sc = FOREIGN ? make_image_scene(sa) : make_scene(sa);
@@ -578,7 +579,7 @@ struct vx_context {
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int cu_count = 256;
-    int persistent_blocks[6][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
+    int persistent_blocks[10][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
 
     bool profile = false;
     std::vector<ProfiledLaunch> launches;
@@ -602,7 +603,7 @@ SceneArgs scene_of(const vx_context* c) {
     s.width = c->tex.width; s.height = c->tex.height; s.layers = c->tex.layers; s.levels = c->tex.levels;
     for (int l = 0; l < 16; ++l) s.level_offset[l] = c->tex.level_offset[l];
     s.image = c->image_ok ? c->d_image : nullptr;
-    s.image_bytes = c->image_ok ? uint32_t(c->image.frame_bytes() + kWorldPad) : 0u;
+    s.image_bytes = c->image_ok ? c->image.frame_bytes() + kWorldPad : 0u;
     return s;
 }
 
@@ -667,14 +668,16 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         const bool shallow = imaged && ctx->image.depth() <= uint32_t(kLdsLevels) + 1u;
         if (imaged) {
             const bool w4 = !HITS && ctx->min_waves == 4;
-#define VX_IMAGE_KERNEL(ORIG, MINW, SHALLOW) reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, HITS, false, MINW, ORIG, SHALLOW>)
-            if (esvo) fn = shallow ? (w4 ? VX_IMAGE_KERNEL(VX_SVO_ESVO, 4, true) : VX_IMAGE_KERNEL(VX_SVO_ESVO, 1, true))
-                                   : (w4 ? VX_IMAGE_KERNEL(VX_SVO_ESVO, 4, false) : VX_IMAGE_KERNEL(VX_SVO_ESVO, 1, false));
-            else fn = shallow ? (w4 ? VX_IMAGE_KERNEL(VX_SVO_CSVO, 4, true) : VX_IMAGE_KERNEL(VX_SVO_CSVO, 1, true))
-                              : (w4 ? VX_IMAGE_KERNEL(VX_SVO_CSVO, 4, false) : VX_IMAGE_KERNEL(VX_SVO_CSVO, 1, false));
+            const bool wide = ctx->image.layout() == vximg::kOct64Wide;  // an image beyond 4 GiB: octant indices, 64-bit addresses
+#define VX_IMAGE_KERNEL(IMAGE, ORIG, MINW, SHALLOW) reinterpret_cast<const void*>(&render_persistent<IMAGE, HITS, false, MINW, ORIG, SHALLOW>)
+#define VX_IMAGE_KERNELS(IMAGE, ORIG) (shallow ? (w4 ? VX_IMAGE_KERNEL(IMAGE, ORIG, 4, true) : VX_IMAGE_KERNEL(IMAGE, ORIG, 1, true)) \
+                                               : (w4 ? VX_IMAGE_KERNEL(IMAGE, ORIG, 4, false) : VX_IMAGE_KERNEL(IMAGE, ORIG, 1, false)))
+            if (wide) fn = esvo ? VX_IMAGE_KERNELS(VX_SVO_IMAGE_WIDE, VX_SVO_ESVO) : VX_IMAGE_KERNELS(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO);
+            else fn = esvo ? VX_IMAGE_KERNELS(VX_SVO_IMAGE, VX_SVO_ESVO) : VX_IMAGE_KERNELS(VX_SVO_IMAGE, VX_SVO_CSVO);
+#undef VX_IMAGE_KERNELS
 #undef VX_IMAGE_KERNEL
         }
-        int& per_cu = ctx->persistent_blocks[(imaged ? (shallow ? 4 : 2) : 0) + (esvo ? 0 : 1)][HITS][STATS];
+        int& per_cu = ctx->persistent_blocks[(imaged ? (shallow ? 4 : 2) + (ctx->image.layout() == vximg::kOct64Wide ? 4 : 0) : 0) + (esvo ? 0 : 1)][HITS][STATS];
         if (per_cu == 0) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, wave_lds) != hipSuccess || n <= 0) n = 8;
@@ -830,7 +833,11 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (c->frames_in_flight < 1) c->frames_in_flight = 1;
         if (c->frames_in_flight > vx_context::kFrameStreams) c->frames_in_flight = vx_context::kFrameStreams;
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
-        c->image = vximg::WorldImage(svo_type);
+        // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
+        // every pointer needs more than 32 bits of byte offset (tests)
+        int wide_image = 0;
+        if (const char* e = std::getenv("VX_WIDE_IMAGE")) wide_image = std::atoi(e);
+        c->image = vximg::WorldImage(svo_type, wide_image ? vximg::kOct64Wide : vximg::kOct64, wide_image == 2 ? (uint64_t(5) << 30) / 4 : 0);
         if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
@@ -967,6 +974,11 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
         for (uint32_t i = 0; i < count; ++i) changed[i] = vximg::Range{ranges[i].start, ranges[i].length};
         const unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         ctx->image_ok = ctx->image.update(ctx->staging, used_bytes, changed.data(), changed.size(), threads);
+        if (!ctx->image_ok && ctx->image.too_big() && ctx->image.layout() == vximg::kOct64) {
+            // past what 32-bit byte offsets reach: from here on octant indices (the image is rebuilt once, whole)
+            ctx->image = vximg::WorldImage(ctx->svo_type, vximg::kOct64Wide);
+            ctx->image_ok = ctx->image.update(ctx->staging, used_bytes, nullptr, 0, threads);
+        }
         if (ctx->image_ok) {
             const size_t need = ctx->image.frame_bytes() + kWorldPad;
             bool whole = false;
@@ -1206,8 +1218,8 @@ int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_fl
 }
 
 uint64_t vx_traversal_image(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words) {
-    if (!world_frame || (layout != 0 && layout != 1) || (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO)) return 0;
-    vximg::WorldImage img(svo_type, layout == 0 ? vximg::kEsvo48 : vximg::kOct64);
+    if (!world_frame || layout < 0 || layout > 2 || (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO)) return 0;
+    vximg::WorldImage img(svo_type, layout == 0 ? vximg::kEsvo48 : (layout == 1 ? vximg::kOct64 : vximg::kOct64Wide));
     if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(16u, std::thread::hardware_concurrency())))) return 0;
     const std::vector<uint32_t>& f = img.frame();
     if (out_words && capacity_words >= f.size()) std::memcpy(out_words, f.data(), f.size() * 4);

@@ -64,6 +64,7 @@ struct DevScene {
     float octree_scale;       // = world[0]
     uint32_t root_ptr;        // CSVO: world[1]
     DevTextures tex;
+    const uint8_t* wide;      // VX_SVO_IMAGE_WIDE: the traversal image behind a plain 64-bit pointer (it may exceed 4 GiB)
 };
 
 // what the host passes to a kernel; expanded into a DevScene (descriptors in SGPRs) at kernel entry
@@ -77,7 +78,7 @@ struct SceneArgs {
     uint32_t width, height, layers, levels;
     uint32_t level_offset[16];
     const uint8_t* image;   // the traversal image of the world (traversal_image.hpp), or null
-    uint32_t image_bytes;
+    uint64_t image_bytes;
 };
 
 __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
@@ -89,6 +90,7 @@ __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
     sc.tex.level_offset = a.level_offset;
     sc.octree_scale = __uint_as_float(buf_u32(sc.world, 0));
     sc.root_ptr = buf_u32(sc.world, 4);
+    sc.wide = nullptr;
     return sc;
 }
 
@@ -96,11 +98,25 @@ __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
 __device__ __forceinline__ DevScene make_image_scene(const SceneArgs& a) {
     SceneArgs b = a;
     b.world = a.image;
-    b.world_bytes = a.image_bytes;
+    b.world_bytes = a.image_bytes < 0xffffffffull ? uint32_t(a.image_bytes) : 0xffffffffu;  // (a wide image is not read through this)
     DevScene sc = make_scene(b);
     sc.tex.level_offset = a.level_offset;  // (make_scene took the address of the copy's array)
+    sc.wide = a.image;
     return sc;
 }
+
+// wide images: entry `child` of the octant with index `octant` (64 bytes each; the header is octant 0)
+#ifndef VX_DEVICE_ON_HOST
+__device__ __forceinline__ uint2 wide_entry(const DevScene& sc, uint32_t octant, uint32_t child) {
+    return *reinterpret_cast<const uint2*>(sc.wide + (uint64_t(octant) << 6) + child * 8u);
+}
+__device__ __forceinline__ uint32_t wide_u32(const DevScene& sc, uint32_t octant, uint32_t byte) {
+    return *reinterpret_cast<const uint32_t*>(sc.wide + (uint64_t(octant) << 6) + byte);
+}
+#else
+inline uint2 wide_entry(const DevScene& sc, uint32_t octant, uint32_t child) { uint2 v; std::memcpy(&v, sc.wide + (uint64_t(octant) << 6) + child * 8u, 8); return v; }
+inline uint32_t wide_u32(const DevScene& sc, uint32_t octant, uint32_t byte) { uint32_t v; std::memcpy(&v, sc.wide + (uint64_t(octant) << 6) + byte, 4); return v; }
+#endif
 
 struct Result {
     float t;
@@ -431,11 +447,14 @@ typedef VX_AS_PRIVATE TraceSink* TracePtr;
 
 // third node format, internal to the library: the 64-byte-octant traversal image of a CSVO world (traversal_image.hpp, kOct64)
 #define VX_SVO_IMAGE 3
+// the same with octant INDICES for pointers and 64-bit addressing: images beyond 4 GiB (traversal_image.hpp, kOct64Wide)
+#define VX_SVO_IMAGE_WIDE 4
 
 template <int SVO>
 struct Trav {
     static constexpr bool CSVO = SVO == VX_SVO_CSVO;
-    static constexpr bool IMG = SVO == VX_SVO_IMAGE;
+    static constexpr bool WIDE = SVO == VX_SVO_IMAGE_WIDE;
+    static constexpr bool IMG = SVO == VX_SVO_IMAGE || WIDE;
 
     float rox, roy, roz, rdx, rdy, rdz;   // origin in [1,2) space, epsilon-clamped direction
     float tcx, tcy, tcz, tbx, tby, tbz;   // t(x) = x * t_coef - t_bias per axis
@@ -514,8 +533,8 @@ struct Trav {
             if (depth == 2) pre_leaf_pointer = ptr;
         } else if (IMG) {
             depth = 0;
-            node = buf_u32(sc.world, 4);  // header of the image: root masks, byte offset of the root octant
-            ptr = buf_u32(sc.world, 8);
+            node = WIDE ? wide_u32(sc, 0, 4) : buf_u32(sc.world, 4);  // header of the image: root masks, root octant (byte offset / index)
+            ptr = WIDE ? wide_u32(sc, 0, 8) : buf_u32(sc.world, 8);
         } else {
             // the reference starts at (ptr 0, parent_octant_idx 0): the preamble is an octant whose only child is the root
             depth = 0;
@@ -694,7 +713,7 @@ struct Trav {
             uint32_t w0 = 0, w1 = 0, table = 0, offset = 0;
             if (IMG) {
                 // one aligned 8-byte entry: the child's octant and the child's masks (no clamp: image pointers are valid by construction)
-                const uint2 e = buf_u64(sc.world, ptr + octant_idx * 8u);
+                const uint2 e = WIDE ? wide_entry(sc, ptr, octant_idx) : buf_u64(sc.world, ptr + octant_idx * 8u);
                 w0 = e.x;
                 w1 = e.y;
             } else if (!CSVO) {
@@ -780,7 +799,8 @@ struct Trav {
         const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 2^depth, exact
         const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
         const uint32_t value = CSVO  ? csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx)
-                               : IMG ? buf_u32(sc.world, ptr + octant_idx * 8u)
+                               : WIDE ? wide_u32(sc, ptr, octant_idx * 8u)
+                               : IMG  ? buf_u32(sc.world, ptr + octant_idx * 8u)
                                      : esvo_word(sc, ptr + 4 + octant_idx);
 
         const float ex = __builtin_fmaf(px + scale_exp2, tcx, -tbx);
