@@ -180,7 +180,7 @@ size_t vx_capacity(const vx_context* ctx);
  * vx_get_stats (:183-187).
  * A context also keeps a traversal image of the world (vx_traversal_image): the chunks inside the given ranges and the root
  * octree are re-laid out as 64-byte octants on host worker threads and the changed parts uploaded; vx_render walks the image
- * (device memory on top of the world's own bytes: 1.33x them for ESVO, about 6.3x for CSVO; VX_TRAVERSAL_IMAGE=0 in the
+ * (device memory on top of the world's own bytes: 0.84x them for ESVO, about 3.9x for CSVO; VX_TRAVERSAL_IMAGE=0 in the
  * environment turns it off). The staging mirror must hold the whole current world, i.e. every change has to go through
  * vx_staging_ptr (it does when write_changes_to is the only writer). */
 int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes);
@@ -230,8 +230,8 @@ int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_fl
                          float* out_rgba32f, void* stream);
 /* The traversal image of a world: the octant tree a context traverses instead of the world's own bytes.
  * `world_frame` = the world as committed ([f32 scale][ESVO: 5-word preamble | CSVO: u32 root_ptr][arena]), `used_bytes` = arena
- * bytes in use. layout 1 = what the renderer walks ([64-byte header][64-byte octants of eight {pointer | value, masks}
- * entries], pointers = byte offsets); layout 2 = the same with octant indices for pointers, what the renderer switches to when
+ * bytes in use. layout 1 = what the renderer walks ([64-byte header][octants: eight {pointer | value, masks} entries, or
+ * just eight values when every child is a voxel], pointers = byte offsets); layout 2 = the same with 32-byte units for pointers, what the renderer switches to when
  * the image outgrows 4 GiB; layout 0 = the same tree as an ESVO frame ([f32 2^-depth][5-word preamble][12-word octants], esvo.rs:74-101),
  * which any ESVO traversal can walk (the tests do, with the oracle). Returns the image size in 32-bit words (0 = cannot be
  * imaged) and fills `out_words` when it is large enough. Pure host function (no device needed): vx_commit does this itself. */

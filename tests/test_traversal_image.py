@@ -135,19 +135,31 @@ def _oct64_masks(m):
 
 
 def _walk_oct64_image(img, wide=False):
-    """wide: pointers are octant indices (layout 2) instead of byte offsets (layout 1)"""
-    unit = 64 if wide else 1
+    """wide: pointers count 32-byte units (layout 2) instead of bytes (layout 1)"""
+    unit = 32 if wide else 1
     out = []
     stack = [((), int(img[2]) * unit, _oct64_masks(int(img[1])))]
     while stack:
         path, octant, masks = stack.pop()
-        assert octant % 64 == 0
         out.append((path, "node", masks))
+        children, leaves = masks >> 8, masks & 0xFF
+        assert leaves & ~children == 0
+        if not children:
+            continue  # an octant without children takes no room
+        assert octant % 32 == 0
+        if children == leaves:  # eight u32 values
+            for c in range(8):
+                v = int(img[octant // 4 + c])
+                if children & (1 << c):
+                    out.append((path + (c,), "leaf", v))
+                else:
+                    assert v == 0
+            continue
         for c in range(8):
             lo, hi = int(img[octant // 4 + 2 * c]), int(img[octant // 4 + 2 * c + 1])
-            if not (masks >> 8) & (1 << c):
+            if not children & (1 << c):
                 assert lo == 0 and hi == 0
-            elif masks & (1 << c):
+            elif leaves & (1 << c):
                 out.append((path + (c,), "leaf", lo))
             else:
                 stack.append((path + (c,), lo * unit, _oct64_masks(hi)))
@@ -162,7 +174,7 @@ def test_renderer_layout_holds_the_same_tree(fmt):
     frame = world.frame()
     a = _walk_esvo_image(hip.traversal_image(FMTS[fmt], frame, world.size_in_bytes, 0))
     b_img = hip.traversal_image(FMTS[fmt], frame, world.size_in_bytes, 1)
-    assert b_img[0] == frame[0] and b_img.size % 16 == 0
+    assert b_img[0] == frame[0] and b_img.size % 8 == 0
     b = _walk_oct64_image(b_img)
     assert len(a) > 10000 and a == b
     # ... and so does the layout for images beyond 4 GiB (octant indices for pointers)

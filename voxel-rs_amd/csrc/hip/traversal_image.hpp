@@ -12,8 +12,11 @@
 //            octant][0...] followed by 64-byte octants of eight {lo, hi} entries, one per child: lo = byte offset (from the
 //            frame start) of the child's own octant, or the leaf's value; hi = the child's masks (oct64_masks()).
 //            A descent is ONE aligned 8-byte load that yields the new pointer and the new masks; every pointer in the image
-//            is valid by construction, so the loads need no clamping.
-//   kOct64Wide  kOct64 with octant INDICES (frame byte offset / 64) for pointers: images from 4 GiB up to 256 GiB, walked through
+//            is valid by construction, so the loads need no clamping. An octant ALL of whose children are leaves -- the
+//            majority: every voxel's parent -- is stored as eight u32 values only (32 bytes; its masks, which live in its
+//            parent's entry, say so: child bits == leaf bits), and an octant without children (the reference's root octree
+//            keeps such) takes no room at all, nothing ever reads it.
+//   kOct64Wide  kOct64 with frame byte offset / 32 for pointers: images from 4 GiB up to 128 GiB, walked through
 //            a 64-bit pointer at two more instructions per descent. A context switches to it when kOct64 no longer fits.
 //   kEsvo48  the reference's ESVO format: [f32][5-word preamble][12-word octants], relative pointers. Kept because any ESVO
 //            traversal can walk it: tests/test_traversal_image.py checks the tree walk with the oracle.
@@ -63,10 +66,13 @@ struct NodeMasks {
 
 // kOct64's form of packed masks: child c's "exists" bit at 31 - c and its "is a leaf" bit at 23 - c (the traversal shifts the
 // word left by the child index and finds "exists" in the sign bit and "leaf" in bit 23, vx_device.hpp Trav::step_with)
+// A leaf bit without its child bit means nothing to the traversal (svo.esvo.glsl:168-173) and is dropped: "all children are
+// leaves" must read the same on the device (child bits == leaf bits) as here (oct64_words()).
 inline uint32_t oct64_masks(uint32_t packed) {
     uint32_t out = 0;
     for (uint32_t c = 0; c < 8; ++c) {
-        if ((packed >> (8 + c)) & 1u) out |= 0x80000000u >> c;
+        if (!((packed >> (8 + c)) & 1u)) continue;
+        out |= 0x80000000u >> c;
         if ((packed >> c) & 1u) out |= 0x00800000u >> c;
     }
     return out;
@@ -79,6 +85,12 @@ struct Octant {
     uint16_t masks[8] = {};  // the child's own masks (nodes), filled in for chunks at placement
     uint8_t node_mask = 0, leaf_mask = 0, chunk_mask = 0;
 };
+
+// frame words an octant takes in the kOct64 layouts: {pointer | value, masks} entries, values only, or nothing
+inline uint32_t oct64_words(const Octant& o) {
+    if (o.node_mask | o.chunk_mask) return 16;
+    return o.leaf_mask ? 8 : 0;
+}
 
 struct Tree {
     std::vector<Octant> octants;  // octant 0 = the root of this tree
@@ -364,7 +376,7 @@ public:
         if (depth < 1 || depth > 23) return false;
         if (frame_.empty()) {
             frame_.assign(header_words(), 0u);
-            alloc_.reset(std::max(header_words(), first_word_ / octant_words() * octant_words()));
+            alloc_.reset(std::max(header_words(), first_word_ / 16 * 16));
         }
 
         // 1. walk the root octree: which chunks does it reference
@@ -416,7 +428,7 @@ public:
         for (size_t i = 0; i < todo.size(); ++i) {
             if (built[i].too_deep) return fail();
             Placed& pl = placed[i];
-            pl.words = built[i].octants.size() * octant_words();
+            pl.words = tree_words(built[i]);
             pl.at = alloc_.alloc(pl.words);
             pl.masks = built[i].root.packed();
             pl.levels = todo[i].levels;
@@ -431,14 +443,14 @@ public:
 
         // 4. the root octree is rewritten by every commit (csvo.rs:68-139 re-serializes it): so is its image
         alloc_.release(root_at_, root_words_);
-        root_words_ = root.octants.size() * octant_words();
+        root_words_ = tree_words(root);
         root_at_ = alloc_.alloc(root_words_);
         if (frame_.size() < root_at_ + root_words_) frame_.resize(root_at_ + root_words_, 0u);
         for (Octant& o : root.octants)
             for (uint32_t c = 0; c < 8; ++c)
                 if ((o.chunk_mask >> c) & 1u) {
                     const Placed& pl = chunks_.at(o.lo[c]);
-                    o.lo[c] = uint32_t(layout_ == kEsvo48 ? pl.at : pl.at / 16);  // the chunk's root octant: frame word / octant index
+                    o.lo[c] = uint32_t(layout_ == kEsvo48 ? pl.at : pl.at / 8);  // the chunk's root octant: frame word / 32-byte unit
                     o.masks[c] = uint16_t(pl.masks);
                 }
         encode(root, root_at_);
@@ -448,7 +460,7 @@ public:
         frame_[0] = scale_bits;
         if (layout_ != kEsvo48) {
             frame_[1] = oct64_masks(root.root.packed());
-            frame_[2] = uint32_t(layout_ == kOct64 ? root_at_ * 4 : root_at_ / 16);
+            frame_[2] = uint32_t(layout_ == kOct64 ? root_at_ * 4 : root_at_ / 8);
         } else {
             frame_[1] = root.root.packed();  // preamble: a fake octant whose child 0 is the root (esvo.rs:179-188)
             frame_[2] = frame_[3] = frame_[4] = 0;
@@ -457,7 +469,7 @@ public:
         dirty_.push_back(Range{0, header_words() * 4});
         // what the pointers can reach: 32-bit byte offsets (and the buffer resource's) / 32-bit octant indices / 31-bit word offsets
         const uint64_t end = alloc_.end();
-        too_big_ = layout_ == kOct64 ? end * 4 + 4096 >= (uint64_t(1) << 32) : (layout_ == kOct64Wide ? end / 16 >= (uint64_t(1) << 32) : end >= (uint64_t(1) << 31));
+        too_big_ = layout_ == kOct64 ? end * 4 + 4096 >= (uint64_t(1) << 32) : (layout_ == kOct64Wide ? end / 8 >= (uint64_t(1) << 32) : end >= (uint64_t(1) << 31));
         return !too_big_;
     }
 
@@ -478,7 +490,12 @@ private:
     }
 
     uint64_t header_words() const { return layout_ == kEsvo48 ? 6 : 16; }
-    uint64_t octant_words() const { return layout_ == kEsvo48 ? 12 : 16; }
+    uint64_t tree_words(const Tree& t) const {
+        if (layout_ == kEsvo48) return t.octants.size() * 12;
+        uint64_t n = 0;
+        for (const Octant& o : t.octants) n += oct64_words(o);
+        return n;
+    }
 
     template <class F>
     static void parallel(size_t n, unsigned threads, F f) {
@@ -493,20 +510,38 @@ private:
         for (auto& t : pool) t.join();
     }
 
-    // writes the tree's octants at frame word `at` (octant i at at + i * octant_words()); chunk children hold the frame word
-    // index of the chunk's root octant by now
+    // writes the tree's octants at frame word `at` (in walk order, each as large as its layout makes it); chunk children hold
+    // the frame word index (kEsvo48) / 32-byte unit (kOct64*) of the chunk's root octant by now
     void encode(const Tree& t, uint64_t at) {
         uint32_t* dst = frame_.data() + at;
+        std::vector<uint64_t> where;  // kOct64*: word offset of octant i inside the tree
+        if (layout_ != kEsvo48) {
+            where.resize(t.octants.size());
+            uint64_t n = 0;
+            for (size_t i = 0; i < t.octants.size(); ++i) {
+                where[i] = n;
+                n += oct64_words(t.octants[i]);
+            }
+        }
         for (size_t i = 0; i < t.octants.size(); ++i) {
             const Octant& o = t.octants[i];
             if (layout_ != kEsvo48) {
-                uint32_t* w = dst + i * 16;
-                const bool wide = layout_ == kOct64Wide;  // octant indices instead of byte offsets
+                uint32_t* w = dst + where[i];
+                const bool wide = layout_ == kOct64Wide;  // 32-byte units instead of byte offsets
+                const uint32_t words = oct64_words(o);
+                if (words == 8) {
+                    for (uint32_t c = 0; c < 8; ++c) w[c] = ((o.leaf_mask >> c) & 1u) ? o.lo[c] : 0u;
+                    continue;
+                }
+                if (words == 0) continue;
                 for (uint32_t c = 0; c < 8; ++c) {
                     const uint32_t bit = 1u << c;
                     uint32_t lo = 0, hi = 0;
-                    if (o.node_mask & bit) { lo = uint32_t(wide ? at / 16 + o.lo[c] : (at + uint64_t(o.lo[c]) * 16) * 4); hi = oct64_masks(o.masks[c]); }
-                    else if (o.chunk_mask & bit) { lo = wide ? o.lo[c] : o.lo[c] * 64u; hi = oct64_masks(o.masks[c]); }
+                    if (o.node_mask & bit) {
+                        const uint64_t child = at + where[o.lo[c]];  // (an empty child octant takes no room: wherever the next octant starts)
+                        lo = uint32_t(wide ? child / 8 : child * 4);
+                        hi = oct64_masks(o.masks[c]);
+                    } else if (o.chunk_mask & bit) { lo = wide ? o.lo[c] : o.lo[c] * 32u; hi = oct64_masks(o.masks[c]); }
                     else if (o.leaf_mask & bit) { lo = o.lo[c]; }
                     w[2 * c] = lo;
                     w[2 * c + 1] = hi;

@@ -105,17 +105,17 @@ __device__ __forceinline__ DevScene make_image_scene(const SceneArgs& a) {
     return sc;
 }
 
-// wide images: entry `child` of the octant with index `octant` (64 bytes each; the header is octant 0)
+// wide images: pointers count 32-byte units from the start of the image (the header is unit 0)
 #ifndef VX_DEVICE_ON_HOST
 __device__ __forceinline__ uint2 wide_entry(const DevScene& sc, uint32_t octant, uint32_t child) {
-    return *reinterpret_cast<const uint2*>(sc.wide + (uint64_t(octant) << 6) + child * 8u);
+    return *reinterpret_cast<const uint2*>(sc.wide + (uint64_t(octant) << 5) + child * 8u);
 }
 __device__ __forceinline__ uint32_t wide_u32(const DevScene& sc, uint32_t octant, uint32_t byte) {
-    return *reinterpret_cast<const uint32_t*>(sc.wide + (uint64_t(octant) << 6) + byte);
+    return *reinterpret_cast<const uint32_t*>(sc.wide + (uint64_t(octant) << 5) + byte);
 }
 #else
-inline uint2 wide_entry(const DevScene& sc, uint32_t octant, uint32_t child) { uint2 v; std::memcpy(&v, sc.wide + (uint64_t(octant) << 6) + child * 8u, 8); return v; }
-inline uint32_t wide_u32(const DevScene& sc, uint32_t octant, uint32_t byte) { uint32_t v; std::memcpy(&v, sc.wide + (uint64_t(octant) << 6) + byte, 4); return v; }
+inline uint2 wide_entry(const DevScene& sc, uint32_t octant, uint32_t child) { uint2 v; std::memcpy(&v, sc.wide + (uint64_t(octant) << 5) + child * 8u, 8); return v; }
+inline uint32_t wide_u32(const DevScene& sc, uint32_t octant, uint32_t byte) { uint32_t v; std::memcpy(&v, sc.wide + (uint64_t(octant) << 5) + byte, 4); return v; }
 #endif
 
 struct Result {
@@ -783,6 +783,10 @@ struct Trav {
         if (!advance<TRACE>(sc, st, tcrx, tcry, tcrz, tc_max, tk)) on_exit(kTravFinished);
     }
 
+    // image octants: bytes between the children's values -- an octant all of whose children are leaves (child bits 31..24 == leaf
+    // bits 23..16 of its masks) holds eight u32 values, any other eight {value | pointer, masks} entries (traversal_image.hpp)
+    __device__ __forceinline__ uint32_t image_value_stride() const { return (((node >> 8) ^ node) & 0x00ff0000u) ? 8u : 4u; }
+
     // child index from the corner's mantissa bits (scale >= 0)
     __device__ __forceinline__ int idx_from_position() const {
         return int(bit_at(__float_as_uint(px), scale) | (bit_at(__float_as_uint(py), scale) << 1) | (bit_at(__float_as_uint(pz), scale) << 2));
@@ -799,8 +803,8 @@ struct Trav {
         const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 2^depth, exact
         const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
         const uint32_t value = CSVO  ? csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx)
-                               : WIDE ? wide_u32(sc, ptr, octant_idx * 8u)
-                               : IMG  ? buf_u32(sc.world, ptr + octant_idx * 8u)
+                               : WIDE ? wide_u32(sc, ptr, octant_idx * image_value_stride())
+                               : IMG  ? buf_u32(sc.world, ptr + octant_idx * image_value_stride())
                                      : esvo_word(sc, ptr + 4 + octant_idx);
 
         const float ex = __builtin_fmaf(px + scale_exp2, tcx, -tbx);

@@ -339,8 +339,8 @@ uint64_t vxh_stream_image(void* sp, uint32_t* dst, uint64_t cap_words) {
     return f.size();
 }
 
-// Tests: do two images of layout 1 ([64-byte header][64-byte octants of eight {lo, hi}], traversal_image.hpp) hold the same
-// tree -- same masks, same leaf values, same shape -- wherever their octants were placed? 1 / 0; -1 = a pointer out of range.
+// Tests: do two images of layout 1 ([64-byte header][octants], traversal_image.hpp) hold the same tree -- same masks, same leaf
+// values, same shape -- wherever their octants were placed? 1 / 0; -1 = a pointer out of range.
 int vxh_oct64_same_tree(const uint32_t* a, uint64_t na, const uint32_t* b, uint64_t nb) {
     if (na < 16 || nb < 16 || a[0] != b[0] || a[1] != b[1]) return 0;
     struct Pair { uint32_t pa, pb, masks; };
@@ -348,11 +348,16 @@ int vxh_oct64_same_tree(const uint32_t* a, uint64_t na, const uint32_t* b, uint6
     while (!todo.empty()) {
         const Pair p = todo.back();
         todo.pop_back();
-        if (p.pa % 64 || p.pb % 64 || uint64_t(p.pa) / 4 + 16 > na || uint64_t(p.pb) / 4 + 16 > nb) return -1;
+        const uint32_t children = p.masks >> 24, leaves = (p.masks >> 16) & 0xffu;
+        if (!children) continue;  // an octant without children takes no room
+        const uint32_t words = children == leaves ? 8u : 16u;  // values only / {pointer | value, masks} entries
+        if (p.pa % 32 || p.pb % 32 || uint64_t(p.pa) / 4 + words > na || uint64_t(p.pb) / 4 + words > nb) return -1;
         const uint32_t *oa = a + p.pa / 4, *ob = b + p.pb / 4;
         for (uint32_t c = 0; c < 8; ++c) {
-            const bool exists = (p.masks >> (31 - c)) & 1u, leaf = (p.masks >> (23 - c)) & 1u;
-            if (!exists) {
+            const bool exists = (children >> (7 - c)) & 1u, leaf = (leaves >> (7 - c)) & 1u;
+            if (words == 8) {
+                if (oa[c] != ob[c] || (!exists && oa[c])) return 0;
+            } else if (!exists) {
                 if (oa[2 * c] | oa[2 * c + 1] | ob[2 * c] | ob[2 * c + 1]) return 0;
             } else if (leaf) {
                 if (oa[2 * c] != ob[2 * c]) return 0;
