@@ -24,6 +24,7 @@ CONFIGS = {
     "C3": (12, 1920, 1080, True, 1),
     "C4": (13, 3840, 2160, True, 1),   # static stand-in at the deepest full-detail terrain that fits the 4 GiB world buffer
     "C5": (13, 3840, 2160, True, 2),
+    "C4-primary": (13, 3840, 2160, False, 1),   # (C4's stand-in without shadow rays: see DESIGN.md §9 on shadow rays far from the origin)
 }
 
 
