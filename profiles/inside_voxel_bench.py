@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Worst case of the CSVO traversal image: the camera sits INSIDE a voxel, so every primary ray is one the image cannot
-serve and every pixel goes through the second phase (whole pixel on the compressed bytes). Compared with the image switched
-off (VX_TRAVERSAL_IMAGE=0, set by the caller) and with a camera just above the same spot."""
+"""The camera sits INSIDE a voxel, so every primary ray is one the traversal image cannot serve. The renderer notices (a point
+query on the host mirror of the image) and sends such frames straight to the kernel that traverses the world's own bytes;
+with VX_EYE_CHECK=0 (set by the caller) they go through the image kernel instead, where every pixel ends up in the second
+phase. Compared with a camera just above the same spot."""
 import json
 import math
 import sys

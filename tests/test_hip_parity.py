@@ -220,7 +220,7 @@ def test_heightfield_frame(hip, fmt, depth, size):
 
 @pytest.mark.parametrize("base,depth", [((200, 3, 201), 13), ((400, 3, 401), 14), ((800, 3, 801), 15)])
 @pytest.mark.parametrize("fmt", FMTS)
-def test_rays_from_inside_voxels_in_a_deep_world(hip, fmt, base, depth):
+def test_rays_from_inside_voxels_in_a_deep_world(hip, fmt, base, depth, monkeypatch):
     """Depth 13 (a few chunks far from the origin): the leaves sit on the last LDS-resident stack level, so a ray that
     starts inside a voxel (every primary ray of a camera buried in a block, and shadow rays that start inside a
     neighbour) is led below them by leaf data (svo.esvo.glsl:183-185 only accepts a leaf when t_min > 0) and has to be
@@ -247,6 +247,9 @@ def test_rays_from_inside_voxels_in_a_deep_world(hip, fmt, base, depth):
     world.serialize()
     tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
     scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    # a frame whose eye is inside a voxel normally goes straight to the kernel that traverses the world's own bytes; at depth 13
+    # it is kept on the image kernel, whose inside-voxel hand-over then has every primary ray to deal with
+    monkeypatch.setenv("VX_EYE_CHECK", "0" if depth == 13 else "1")
     svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
     svo.set_materials(mats)
     svo.set_textures(tex, 6)

@@ -361,6 +361,29 @@ public:
     // the last update() failed only because the image outgrew what this layout's pointers can reach
     bool too_big() const { return too_big_; }
 
+    // Is the point (x, y, z), in the octree's [1, 2)^3 coordinates, inside a voxel of the imaged world? A walk down the host
+    // mirror, one child per level by the coordinates' mantissa bits. (The renderer asks this about the eye: every primary ray of
+    // an eye inside a voxel is an inside-voxel ray, which the image cannot serve.)
+    bool point_in_voxel(float x, float y, float z) const {
+        if (layout_ == kEsvo48 || frame_.size() < 16 || !(x >= 1.0f && x < 2.0f && y >= 1.0f && y < 2.0f && z >= 1.0f && z < 2.0f)) return false;
+        uint32_t bx, by, bz;
+        std::memcpy(&bx, &x, 4);
+        std::memcpy(&by, &y, 4);
+        std::memcpy(&bz, &z, 4);
+        uint32_t masks = frame_[1];
+        uint64_t at = layout_ == kOct64 ? frame_[2] / 4 : uint64_t(frame_[2]) * 8;  // frame word of the node's octant
+        for (int scale = 22; scale >= 0; --scale) {
+            const uint32_t c = ((bx >> scale) & 1u) | (((by >> scale) & 1u) << 1) | (((bz >> scale) & 1u) << 2);
+            const uint32_t m = masks << c;
+            if (!(m & 0x80000000u)) return false;
+            if (m & 0x00800000u) return true;
+            if (at + 2 * c + 1 >= frame_.size()) return false;
+            masks = frame_[at + 2 * c + 1];
+            at = layout_ == kOct64 ? frame_[at + 2 * c] / 4 : uint64_t(frame_[at + 2 * c]) * 8;
+        }
+        return false;
+    }
+
     // `world` = the frame as committed: [f32 scale][CSVO: u32 root_ptr | ESVO: 5-word preamble][arena]; `used` = bytes of the
     // arena in use; `changed` = byte ranges (relative to the arena, like vx_commit's) rewritten since the last call.
     // Returns false when the world cannot be imaged (malformed or image beyond 4 GiB): the caller then traverses the world's bytes.

@@ -574,6 +574,7 @@ struct vx_context {
     size_t d_image_capacity = 0;
     bool image_enabled = true;  // VX_TRAVERSAL_IMAGE=0: traverse the world's own bytes
     bool image_ok = false;
+    bool eye_check = true;      // VX_EYE_CHECK=0: frames whose eye is inside a voxel go through the image kernel too (tests)
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
     uint32_t refill_min = 4, service_min = 28;
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
@@ -661,7 +662,13 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
                       : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 4>);
         // Worlds are rendered from their traversal image; the instrumented variant stays on the world's own bytes so that its
         // counters are the reference's own fetches
-        const bool imaged = !STATS && ctx->image_ok;
+        bool imaged = !STATS && ctx->image_ok;
+        if (imaged) {
+            // an eye inside a voxel: every primary ray is an inside-voxel ray and would be re-rendered on the world's own bytes after
+            // a wasted start on the image (kTravForeign) -- such a frame goes to the kernel that traverses the bytes straight away
+            const float s = std::ldexp(1.0f, -int(ctx->image.depth()));
+            if (ctx->eye_check && ctx->image.point_in_voxel(p.ray_origin[0] * s + 1.0f, p.ray_origin[1] * s + 1.0f, p.ray_origin[2] * s + 1.0f)) imaged = false;
+        }
         // The image holds at most `depth` levels (traversal_image.hpp) and its rays never descend into a leaf (kTravForeign), so the
         // deepest PUSH is into a node one level above the voxels, at scale 24 - depth: up to kLdsLevels + 1 levels every stack slot
         // a ray can touch is LDS resident.
@@ -833,6 +840,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (c->frames_in_flight < 1) c->frames_in_flight = 1;
         if (c->frames_in_flight > vx_context::kFrameStreams) c->frames_in_flight = vx_context::kFrameStreams;
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_EYE_CHECK")) c->eye_check = std::atoi(e) != 0;
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)
         int wide_image = 0;
