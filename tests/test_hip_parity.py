@@ -271,6 +271,19 @@ def test_rays_from_inside_voxels_in_a_deep_world(hip, fmt, base, depth, monkeypa
             assert gc[k] == v, (k, gc[k], v)
         wandering += int((chits["steps"] > 3 * 13).sum())
     assert wandering > 100  # not vacuous: many rays go well past a plain root-to-leaf descent
+    # Frame after frame of the last view, a few in flight: with this many inside-voxel rays the renderer moves between the image
+    # kernel and the kernel on the world's own bytes as it goes (vx_api.hip, "steering"); every frame is the same frame.
+    import torch
+
+    targets = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    for i in range(70):
+        svo.render_device(u, w, h, targets[i % 3].data_ptr())
+        if i % 3 == 2:
+            svo.sync()
+            for t in targets:
+                got = t.cpu().numpy()
+                assert np.array_equal(np.isnan(got), np.isnan(img)) and np.nanmax(np.abs(got - img)) == 0.0
 
 
 @pytest.mark.parametrize("fmt", FMTS)

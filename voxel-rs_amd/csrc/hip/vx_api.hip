@@ -124,10 +124,12 @@ struct PersistentArgs {
 struct PixelList {
     // Pixels a wave has to re-render, in chunks of 128 dwords that the wave chains together: [0] previous chunk + 1 (0 = none),
     // [1] entries, [2..127] out_index values. Chunks come from a ring (`mask` + 1 of them, a power of two) through one counter
-    // that only ever grows; a wave touches nothing but its own chunks, so no wave ever waits for another.
+    // that only ever grows; a wave touches nothing but its own chunks, so no wave ever waits for another. `report` (host memory,
+    // one word per wave, or null): how many pixels the wave re-rendered.
     uint32_t* chunks;
     uint32_t* next_chunk;
     uint32_t mask;
+    uint32_t* report;
 };
 constexpr uint32_t kChunkDwords = 128, kChunkEntries = 126;
 
@@ -376,10 +378,12 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     // ---- second phase (FOREIGN): the pixels this wave noted, whole, on the compressed bytes ----
     if (FOREIGN) {
         const DevScene sc_orig = make_scene(sa);
+        uint32_t re_rendered = 0;
         for (uint32_t c = my_chunk; c != 0;) {
             const uint32_t* chunk = todo.chunks + size_t(c - 1) * kChunkDwords;
             const uint32_t n = __builtin_amdgcn_readfirstlane(chunk[1]);
             c = __builtin_amdgcn_readfirstlane(chunk[0]);
+            re_rendered += n;
             for (uint32_t i0 = 0; i0 < n; i0 += 64) {
                 if (i0 + lane < n) {
                     const uint32_t index = chunk[2 + i0 + lane];
@@ -393,6 +397,9 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 }
             }
         }
+        // how many pixels the image could not serve: the host steers by it (launch_render). A plain store per wave into pinned
+        // host memory: nothing for the stream to do after the kernel, nothing for the host to wait for.
+        if (todo.report && lane == 0) todo.report[blockIdx.x] = re_rendered;
     }
 
     if (STATS) {
@@ -574,6 +581,17 @@ struct vx_context {
     size_t d_image_capacity = 0;
     bool image_enabled = true;  // VX_TRAVERSAL_IMAGE=0: traverse the world's own bytes
     bool image_ok = false;
+    // Steering by the share of pixels the image could not serve (rays that start inside voxels: DESIGN.md §9): after a frame with
+    // more than an eighth (CSVO) / a sixteenth (ESVO) of them the next kFramesOnBytes frames traverse the world's own bytes, then the
+    // image is tried again.
+    static constexpr int kFramesOnBytes = 30;
+    static constexpr uint32_t kMaxReportWaves = 8192;
+    uint32_t* h_re_rendered = nullptr;                    // pinned, [kFrameStreams + 1][kMaxReportWaves]: per stream, what each wave of its last image frame re-rendered
+    uint32_t* d_re_rendered = nullptr;                    // the same memory as the device sees it
+    uint32_t report_waves[kFrameStreams + 1] = {};        // waves of the image frame that last ran on the stream (0 = nothing to look at)
+    uint64_t ring_pixels[kFrameStreams + 1] = {};         // ... and its pixels
+    int frames_on_bytes = 0;
+    bool steer = true;           // VX_IMAGE_STEERING=0: always the image (tests, measurements)
     bool eye_check = true;      // VX_EYE_CHECK=0: frames whose eye is inside a voxel go through the image kernel too (tests)
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
     uint32_t refill_min = 4, service_min = 28;
@@ -667,7 +685,23 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             // an eye inside a voxel: every primary ray is an inside-voxel ray and would be re-rendered on the world's own bytes after
             // a wasted start on the image (kTravForeign) -- such a frame goes to the kernel that traverses the bytes straight away
             const float s = std::ldexp(1.0f, -int(ctx->image.depth()));
-            if (ctx->eye_check && ctx->image.point_in_voxel(p.ray_origin[0] * s + 1.0f, p.ray_origin[1] * s + 1.0f, p.ray_origin[2] * s + 1.0f)) imaged = false;
+            if (ctx->steer) {
+                // what did the image frame that last ran on this stream report? (It has finished, or nearly: a heuristic may look early.)
+                uint32_t* report = ctx->h_re_rendered + size_t(slot + 1) * vx_context::kMaxReportWaves;
+                if (ctx->report_waves[slot + 1]) {
+                    uint64_t re_rendered = 0;
+                    for (uint32_t i = 0; i < ctx->report_waves[slot + 1]; ++i) re_rendered += report[i];
+                    // break-even: a re-rendered pixel costs about three ordinary ones, a frame on the world's own bytes 1.1 (ESVO) /
+                    // 1.4 (CSVO) frames on the image
+                    if (re_rendered * (esvo ? 16 : 8) > ctx->ring_pixels[slot + 1]) ctx->frames_on_bytes = vx_context::kFramesOnBytes;
+                    ctx->report_waves[slot + 1] = 0;  // looked at
+                }
+                if (ctx->frames_on_bytes > 0) {
+                    --ctx->frames_on_bytes;
+                    imaged = false;
+                }
+            }
+            if (imaged && ctx->eye_check && ctx->image.point_in_voxel(p.ray_origin[0] * s + 1.0f, p.ray_origin[1] * s + 1.0f, p.ray_origin[2] * s + 1.0f)) imaged = false;
         }
         // The image holds at most `depth` levels (traversal_image.hpp) and its rays never descend into a leaf (kTravForeign), so the
         // deepest PUSH is into a node one level above the voxels, at scale 24 - depth: up to kLdsLevels + 1 levels every stack slot
@@ -698,7 +732,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.service_min = ctx->service_min;
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
-        PixelList todo = {nullptr, nullptr, 0};
+        PixelList todo = {nullptr, nullptr, 0, nullptr};
         if (imaged) {
             // per stream: a ring of chunks behind a counter that only ever grows -- nothing to reset between frames. A finished
             // chunk holds at least 63 pixels, every wave can have one unfinished one: pixels / 63 + waves chunks per launch at most.
@@ -716,6 +750,11 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
                 HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ring), (cap * kChunkDwords + 32) * sizeof(uint32_t)));  // [counter, pad][chunks...]
                 HIP_TRY(hipMemsetAsync(ring, 0, 32 * sizeof(uint32_t), stream));
                 have = cap;
+            }
+            if (ctx->steer && waves <= vx_context::kMaxReportWaves) {
+                todo.report = ctx->d_re_rendered + size_t(slot + 1) * vx_context::kMaxReportWaves;
+                ctx->report_waves[slot + 1] = waves;
+                ctx->ring_pixels[slot + 1] = uint64_t(p.n_local_tiles) * kTile * kTile;
             }
             todo.next_chunk = ring;
             todo.chunks = ring + 32;
@@ -841,6 +880,11 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (c->frames_in_flight > vx_context::kFrameStreams) c->frames_in_flight = vx_context::kFrameStreams;
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_EYE_CHECK")) c->eye_check = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_IMAGE_STEERING")) c->steer = std::atoi(e) != 0;
+        const size_t report_bytes = size_t(vx_context::kFrameStreams + 1) * vx_context::kMaxReportWaves * sizeof(uint32_t);
+        CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_re_rendered), report_bytes, hipHostMallocMapped));
+        std::memset(c->h_re_rendered, 0, report_bytes);
+        CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_re_rendered), c->h_re_rendered, 0));
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)
         int wide_image = 0;
@@ -887,6 +931,7 @@ void vx_destroy(vx_context* c) {
     if (c->render_done) (void)hipEventDestroy(c->render_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
+    if (c->h_re_rendered) (void)hipHostFree(c->h_re_rendered);  // (the frame streams, which copy into it, are gone)
     delete c;
 }
 
