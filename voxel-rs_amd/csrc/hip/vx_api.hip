@@ -149,7 +149,7 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
 // FOREIGN (= the world's own format): SVO = VX_SVO_IMAGE and the rays walk the traversal image of the world (traversal_image.hpp). A ray that
 // is about to be led into the voxel it started in cannot be continued on the image: its pixel is dropped and noted in the
 // wave's own list (`todo`), and every wave, once the tile queue is empty and its rays are done, renders the pixels it noted
-// from scratch on the compressed bytes -- exactly what the reference does for them. (A second phase of the same waves, not a
+// from scratch on the world's own bytes -- exactly what the reference does for them. (A second phase of the same waves, not a
 // second kernel: its registers overlay the first phase's instead of adding to them, and a frame stays one command.)
 template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             if (state != kTrav) tr.iter |= kParked;
         }
 
-        // ---- rays that started inside a voxel (FOREIGN): their pixels go to the kernel that renders them on the CSVO bytes ----
+        // ---- rays that started inside a voxel (FOREIGN): their pixels are noted for the second phase, which renders them on the world's own bytes ----
         if (FOREIGN) {
             const unsigned long long fm = __ballot(state == kForeign);
             if (fm) {
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if (__ballot(state != kIdle) == 0 && queue_empty) break;
     }
 
-    // ---- second phase (FOREIGN): the pixels this wave noted, whole, on the compressed bytes ----
+    // ---- second phase (FOREIGN): the pixels this wave noted, whole, on the world's own bytes ----
     if (FOREIGN) {
         const DevScene sc_orig = make_scene(sa);
         uint32_t re_rendered = 0;
