@@ -46,17 +46,23 @@ struct Bytes {
     const uint8_t* p;
     size_t n;
     uint32_t u8(uint64_t o) const { return o < n ? p[o] : 0u; }
-    uint32_t u16(uint64_t o) const { return u8(o) | (u8(o + 1) << 8); }
-    uint32_t u32(uint64_t o) const { return u16(o) | (u16(o + 2) << 16); }
+    uint32_t u16(uint64_t o) const {
+        if (o + 2 <= n) return uint32_t(p[o]) | (uint32_t(p[o + 1]) << 8);
+        return u8(o) | (u8(o + 1) << 8);
+    }
+    uint32_t u32(uint64_t o) const {
+        if (o + 4 <= n) {
+            uint32_t v;
+            std::memcpy(&v, p + o, 4);  // (little-endian hosts, like the buffer itself)
+            return v;
+        }
+        return u16(o) | (u16(o + 2) << 16);
+    }
 };
 
 inline uint32_t tag_bytes(uint32_t m) {  // bytes of the table entries a 2-bit-per-child mask selects: tag 0,1,2,3 -> 0,1,2,4
-    uint32_t s = 0;
-    for (int c = 0; c < 8; ++c) {
-        const uint32_t t = (m >> (2 * c)) & 3u;
-        s += t == 3 ? 4u : t;
-    }
-    return s;
+    const uint32_t lo = m & 0x5555u, hi = (m >> 1) & 0x5555u;  // tag = hi:lo per child
+    return uint32_t(__builtin_popcount(lo & ~hi)) + 2u * uint32_t(__builtin_popcount(hi & ~lo)) + 4u * uint32_t(__builtin_popcount(lo & hi));
 }
 
 struct NodeMasks {
@@ -69,13 +75,13 @@ struct NodeMasks {
 // A leaf bit without its child bit means nothing to the traversal (svo.esvo.glsl:168-173) and is dropped: "all children are
 // leaves" must read the same on the device (child bits == leaf bits) as here (oct64_words()).
 inline uint32_t oct64_masks(uint32_t packed) {
-    uint32_t out = 0;
-    for (uint32_t c = 0; c < 8; ++c) {
-        if (!((packed >> (8 + c)) & 1u)) continue;
-        out |= 0x80000000u >> c;
-        if ((packed >> c) & 1u) out |= 0x00800000u >> c;
-    }
-    return out;
+    auto reversed = [](uint32_t b) {  // bit 0 <-> bit 7, ...
+        b = ((b & 0xf0u) >> 4) | ((b & 0x0fu) << 4);
+        b = ((b & 0xccu) >> 2) | ((b & 0x33u) << 2);
+        return ((b & 0xaau) >> 1) | ((b & 0x55u) << 1);
+    };
+    const uint32_t children = (packed >> 8) & 0xffu, leaves = packed & children;
+    return (reversed(children) << 24) | (reversed(leaves) << 16);
 }
 
 // One node of the walked tree, layout independent. Per child: nothing, a leaf (value), a node (index of its octant in the
@@ -405,6 +411,8 @@ public:
         // 1. walk the root octree: which chunks does it reference
         Tree root;
         std::vector<ChunkRef> refs;
+        root.octants.reserve(last_root_octants_ + 64);  // (every commit rebuilds the root: no growing in steps)
+        refs.reserve(chunks_.size() + 64);
         if (esvo_) {
             // the preamble is an octant whose child 0 is the root (esvo.rs:179-188, svo.esvo.glsl:139-141)
             const uint32_t p = w.at(4);
@@ -416,19 +424,38 @@ public:
         }
         if (root.too_deep) return fail();  // (what follows relies on the image having at most `depth` levels, like the world says)
         depth_ = depth;
-        std::unordered_map<uint32_t, ChunkRef> referenced;
-        for (const ChunkRef& r : refs) {
-            const auto it = referenced.emplace(r.key, r).first;
-            if (it->second.masks != r.masks || it->second.levels != r.levels) return fail();  // one chunk, two different slots
-        }
+        last_root_octants_ = root.octants.size();
 
-        // 2. drop images of chunks that are gone, whose bytes were rewritten or that now hang in a different slot
+        // 2. drop images of chunks whose bytes were rewritten, note which of the others are still referenced (and whether they
+        //    still hang in the same kind of slot), drop the rest; what is referenced and has no image is to be walked
+        for (auto it = chunks_.begin(); n_changed && it != chunks_.end();) {
+            bool rewritten = false;
+            for (size_t i = 0; i < n_changed && !rewritten; ++i)
+                rewritten = changed[i].start < it->second.src_end && it->second.src_begin < changed[i].start + changed[i].length;
+            if (rewritten) {
+                alloc_.release(it->second.at, it->second.words);
+                it = chunks_.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        ++epoch_;
+        std::vector<ChunkRef> todo;
+        for (const ChunkRef& r : refs) {
+            const auto it = chunks_.find(r.key);
+            if (it == chunks_.end()) {
+                todo.push_back(r);
+            } else if (esvo_ && (it->second.masks != r.masks || it->second.levels != r.levels)) {
+                if (it->second.seen == epoch_) return fail();  // one chunk, two different slots
+                alloc_.release(it->second.at, it->second.words);
+                chunks_.erase(it);
+                todo.push_back(r);
+            } else {
+                it->second.seen = epoch_;
+            }
+        }
         for (auto it = chunks_.begin(); it != chunks_.end();) {
-            const auto ref = referenced.find(it->first);
-            bool stale = ref == referenced.end() || (esvo_ && (ref->second.masks != it->second.masks || ref->second.levels != it->second.levels));
-            for (size_t i = 0; i < n_changed && !stale; ++i)
-                stale = changed[i].start < it->second.src_end && it->second.src_begin < changed[i].start + changed[i].length;
-            if (stale) {
+            if (it->second.seen != epoch_) {
                 alloc_.release(it->second.at, it->second.words);
                 it = chunks_.erase(it);
             } else {
@@ -437,10 +464,10 @@ public:
         }
 
         // 3. walk what is missing (worker threads), place it (this thread), encode it in place (worker threads)
-        std::vector<ChunkRef> todo;
-        for (const auto& kv : referenced)
-            if (!chunks_.count(kv.first)) todo.push_back(kv.second);
         std::sort(todo.begin(), todo.end(), [](const ChunkRef& x, const ChunkRef& y) { return x.key < y.key; });
+        for (size_t i = 1; i < todo.size(); ++i)
+            if (todo[i].key == todo[i - 1].key && (todo[i].masks != todo[i - 1].masks || todo[i].levels != todo[i - 1].levels)) return fail();
+        todo.erase(std::unique(todo.begin(), todo.end(), [](const ChunkRef& x, const ChunkRef& y) { return x.key == y.key; }), todo.end());
         std::vector<Tree> built(todo.size());
         parallel(todo.size(), threads, [&](size_t i) {
             if (esvo_) EsvoWalker(w, built[i], nullptr).run(todo[i].key, todo[i].masks, todo[i].levels);
@@ -455,6 +482,7 @@ public:
             pl.at = alloc_.alloc(pl.words);
             pl.masks = built[i].root.packed();
             pl.levels = todo[i].levels;
+            pl.seen = epoch_;
             pl.src_begin = built[i].src_begin;
             pl.src_end = built[i].src_end;
             top = std::max(top, pl.at + pl.words);
@@ -501,11 +529,13 @@ private:
         uint64_t at = 0, words = 0;             // in frame words
         uint64_t src_begin = 0, src_end = 0;    // arena bytes it was read from
         uint32_t masks = 0, levels = 0;
+        uint32_t seen = 0;  // the update() that last found it referenced
     };
 
     // nothing of a half-made update may survive: the next one starts from an empty image
     bool fail() {
         chunks_.clear();
+        alloc_.reset(0);
         frame_.clear();
         dirty_.clear();
         root_at_ = root_words_ = 0;
@@ -598,6 +628,8 @@ private:
     std::unordered_map<uint32_t, Placed> chunks_;
     uint64_t root_at_ = 0, root_words_ = 0;
     uint32_t depth_ = 0;
+    size_t last_root_octants_ = 0;
+    uint32_t epoch_ = 0;
     bool too_big_ = false;
 };
 
