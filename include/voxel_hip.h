@@ -170,10 +170,17 @@ int vx_set_textures(vx_context* ctx, const uint8_t* rgba8, uint32_t width, uint3
 /* ---- SVO upload ------------------------------------------------------------------------------------------ */
 
 /* MappedBuffer::cast / offset (svo.rs:175,181): host-pinned mirror of the world buffer, capacity_bytes long,
- * valid until vx_destroy. The caller's `WorldSvo::write_changes_to(ptr + 4, capacity - 1, reset)` writes here
+ * valid until vx_destroy. The caller's `WorldSvo::write_changes_to(ptr + 4, vx_arena_capacity(ctx), reset)` writes here
  * exactly as it writes into the mapped SSBO. */
 uint8_t* vx_staging_ptr(vx_context* ctx);
 size_t vx_capacity(const vx_context* ctx);
+/* Bytes the serialized arena may take: vx_capacity() minus the 4-byte scale and the writer's header (ESVO: 20-byte preamble,
+ * CSVO: 4-byte root pointer). This is the exact `dst_len` for write_changes_to(ptr + 4, dst_len, reset): its check
+ * `start + length < dst_len` (esvo.rs:328, csvo.rs:301) is relative to the first byte AFTER that header. (The reference itself
+ * passes `len - 1` (svo.rs:180), which lets a nearly full world run up to 22 bytes past the mapped buffer; the staging mirror
+ * is allocated 64 bytes larger than vx_capacity() so that this call pattern cannot write outside it, and vx_commit rejects
+ * any range or used_bytes beyond vx_arena_capacity() with VX_ERR_CAPACITY.) */
+size_t vx_arena_capacity(const vx_context* ctx);
 /* Svo::update (svo.rs:171-189): stores f32 2^-depth at byte 0 (:173-175), waits for in-flight renders like
  * render_fence.wait() (:178), then copies the writer's header and the given dirty arena ranges to the device
  * (asynchronously; later renders/raycasts are ordered after it). used_bytes = WorldSvo::size_in_bytes() for
@@ -236,6 +243,13 @@ int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_fl
  * which any ESVO traversal can walk (the tests do, with the oracle). Returns the image size in 32-bit words (0 = cannot be
  * imaged) and fills `out_words` when it is large enough. Pure host function (no device needed): vx_commit does this itself. */
 uint64_t vx_traversal_image(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words);
+/* The same, also returning the image's ORIGIN TABLE (layouts 1 and 2 of a CSVO world; empty otherwise): two words per 32-byte unit
+ * of the image -- image_words / 4 words in all -- which say, for the unit a voxel-parent octant starts at, where that node (a
+ * leaf-mask byte, svo.csvo.glsl:114-115) lies in the world's own bytes: [0] = its byte pointer, [1] = k << 29 | (pointer - the
+ * chunk's material section), k = its place among its depth-2 parent's leaf-mask bytes. The renderer consults it when a ray that
+ * started inside a voxel is led into it (svo.csvo.glsl:293-295): that walk is format specific and is made on the world's bytes. */
+uint64_t vx_traversal_image_with_origin(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words,
+                                        uint64_t capacity_words, uint32_t* out_origin_words, uint64_t origin_capacity_words);
 /* 2x2 ordered-grid supersampling (BASELINE.json C5): box-filters a (2*width) x (2*height) RGBA32F render down to
  * width x height, both in device memory, on the caller's hipStream_t (NULL = legacy default stream). Render the large
  * image with vx_render first (order it with vx_stream_wait_render). */

@@ -22,9 +22,11 @@ CONFIGS = {
     # name: (depth, width, height, shadows, supersample)
     "C2": (10, 1920, 1080, False, 1),
     "C3": (12, 1920, 1080, True, 1),
-    "C4": (13, 3840, 2160, True, 1),   # static stand-in at the deepest full-detail terrain that fits the 4 GiB world buffer
-    "C5": (13, 3840, 2160, True, 2),
-    "C4-primary": (13, 3840, 2160, False, 1),   # (C4's stand-in without shadow rays: see DESIGN.md §9 on shadow rays far from the origin)
+    "C4": (14, 3840, 2160, True, 1),   # the static full-detail depth-14 terrain (CSVO 1.4 GB, ESVO 5 GB: a world buffer beyond 4 GiB)
+    "C5": (14, 3840, 2160, True, 2),
+    "C4-primary": (14, 3840, 2160, False, 1),
+    "C4-d13": (13, 3840, 2160, True, 1),   # round 1's stand-in (then the deepest terrain a world buffer could hold)
+    "C5-d13": (13, 3840, 2160, True, 2),
 }
 
 
@@ -41,12 +43,18 @@ def main():
     for name in args.configs:
         depth, w, h, shadows, ss = CONFIGS[name]
         if depth not in worlds:
+            worlds.clear()  # (one world at a time: a depth-14 terrain takes gigabytes on both sides)
+            t0 = time.perf_counter()
             world = vra.World(fmt)
             st = world.build_heightfield(depth)
+            build_s = time.perf_counter() - t0
             svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20))
             svo.set_materials(scenes.synthetic_materials())
             svo.set_textures(scenes.synthetic_textures(), 6)
-            svo.update_full(world)
+            t0 = time.perf_counter()
+            svo.update(world)
+            print(json.dumps({"depth": depth, "format": args.format, "world_MB": round(world.size_in_bytes / 1e6, 1), "leaves": st["leaves"], "chunks": st["chunks"],
+                              "build_s": round(build_s, 2), "commit_s": round(time.perf_counter() - t0, 2)}), flush=True)
             worlds[depth] = (world, st, svo)
         world, st, svo = worlds[depth]
         W, H = w * ss, h * ss
@@ -75,7 +83,7 @@ def main():
         ms = (time.perf_counter() - t0) * 1e3 / args.steps
         print(json.dumps({"config": name, "format": args.format, "depth": depth, "width": w, "height": h, "supersample": ss, "shadows": shadows,
                           "world_MB": round(world.size_in_bytes / 1e6, 1), "rays_per_frame": int(rays), "ms_per_frame": round(ms, 4),
-                          "Mrays_per_s": round(rays / ms / 1e3, 1)}))
+                          "Mrays_per_s": round(rays / ms / 1e3, 1)}), flush=True)
 
 
 if __name__ == "__main__":

@@ -62,3 +62,92 @@ extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t worl
     }
 }
 
+
+// One ray on the traversal IMAGE of a world, driven the way a lane of render_persistent is driven (vx_api.hip): the fast stack in
+// the loop, the hand-over to the full stack below the LDS-resident levels, leaf tests, and -- for the image of a CSVO world --
+// the excursion onto the world's own bytes when the ray is led into a voxel. Returns the reference's OctreeResult and the
+// number of loop iterations.
+template <int IMG, int FOREIGN, bool SHALLOW>
+static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float pos[3], const float dir[3], float max_dst, bool cast_translucent,
+                       vx_result* out, uint32_t* steps) {
+    StackSpill spill;
+    Stack<1, false> st;
+    typedef Stack<1, true, SHALLOW> FastStack;
+    FastStack fast_st;
+    st.init(0, &spill);
+    fast_st.init(0, &spill);
+    constexpr int kFastFloor = kLdsBaseScale - 1;
+    Trav<IMG> tr;
+    tr.init(sc, pos, dir, max_dst);
+    Result res;
+    bool hit = false;
+    TravStatus s = kTravContinue;
+    for (;;) {
+        if (s == kTravContinue) {
+            if (SHALLOW || tr.scale >= kFastFloor) {
+                s = tr.template step<false, false, true, FastStack, true, FOREIGN != 0>(sc, fast_st, nullptr, nullptr);
+                if (s == kTravDeep || s == kTravForeign) --tr.iter;  // repeated by whoever takes over
+                if (s != kTravContinue) tr.sync_idx();
+            } else {
+                tr.sync_idx();
+                s = tr.template step<false, false, true, Stack<1, false>, true, FOREIGN != 0>(sc, st, nullptr, nullptr);
+                if (s == kTravForeign) --tr.iter;
+            }
+            continue;
+        }
+        if (s == kTravDeep) {
+            s = tr.template step<false, false, true, Stack<1, false>, true, FOREIGN != 0>(sc, st, nullptr, nullptr);
+            if (s == kTravForeign) --tr.iter;
+            continue;
+        }
+        if (s == kTravForeign) {
+            s = enter_voxel_on_bytes<IMG, Stack<1, false>, true>(sc, sc_bytes, tr, st, cast_translucent, res);
+            if (s == kTravAtLeaf) { hit = true; break; }
+            continue;
+        }
+        if (s == kTravAtLeaf) {
+            const LeafOutcome o = tr.template leaf_test<false, false>(sc, st, cast_translucent, res, nullptr, nullptr);
+            if (o == kLeafHit) { hit = true; break; }
+            s = o == kLeafPassed ? kTravContinue : kTravFinished;
+            continue;
+        }
+        break;  // kTravFinished
+    }
+    if (!hit) result_miss(res, tr.inside_voxel());
+    out->t = res.t; out->value = res.value; out->face_id = res.face_id;
+    std::memcpy(out->pos, res.pos, 12); std::memcpy(out->uv, res.uv, 8); std::memcpy(out->color, res.color, 16);
+    out->lod = res.lod; out->inside_voxel = res.inside_voxel ? 1 : 0;
+    *steps = tr.iter;
+}
+
+// layout: 1 = byte-offset image (VX_SVO_IMAGE), 2 = wide image (VX_SVO_IMAGE_WIDE); svo_type = the world's own format
+extern "C" void devhost_image_cast(int svo_type, int layout, int shallow, const uint8_t* world, uint64_t world_bytes, const uint8_t* image, uint64_t image_bytes,
+                                   const uint8_t* origin, const vx_material* mats, uint32_t n_mats, const uint8_t* tex, uint32_t tw, uint32_t th,
+                                   uint32_t layers, uint32_t levels, const uint32_t* level_offset, const vx_picker_task* tasks, uint32_t n,
+                                   int cast_translucent, vx_result* results, uint32_t* steps) {
+    SceneArgs sa = {};
+    sa.world = world; sa.world_bytes = world_bytes; sa.materials = mats; sa.n_materials = n_mats;
+    sa.tex = tex; sa.tex_bytes = 0;
+    sa.width = tw; sa.height = th; sa.layers = layers; sa.levels = levels;
+    for (uint32_t l = 0; l < levels && l < 16; ++l) {
+        sa.level_offset[l] = level_offset[l];
+        const uint32_t w = (tw >> l) ? (tw >> l) : 1, h = (th >> l) ? (th >> l) : 1;
+        sa.tex_bytes = level_offset[l] + layers * w * h * 4;
+    }
+    sa.image = image; sa.image_bytes = image_bytes; sa.origin = origin;
+    const DevScene sc = make_image_scene(sa), sc_bytes = make_scene(sa);
+    std::vector<unsigned char> lds(Stack<1>::kBytes + 64);
+    vx_smem = lds.data();
+    for (uint32_t i = 0; i < n; ++i) {
+        const bool ct = cast_translucent != 0;
+#define CAST(IMG, FOREIGN, SHALLOW) image_cast<IMG, FOREIGN, SHALLOW>(sc, sc_bytes, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, ct, &results[i], &steps[i])
+        if (svo_type == 1) {
+            if (layout == 1) { if (shallow) CAST(VX_SVO_IMAGE, 0, true); else CAST(VX_SVO_IMAGE, 0, false); }
+            else { if (shallow) CAST(VX_SVO_IMAGE_WIDE, 0, true); else CAST(VX_SVO_IMAGE_WIDE, 0, false); }
+        } else {
+            if (layout == 1) { if (shallow) CAST(VX_SVO_IMAGE, VX_SVO_CSVO, true); else CAST(VX_SVO_IMAGE, VX_SVO_CSVO, false); }
+            else { if (shallow) CAST(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO, true); else CAST(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO, false); }
+        }
+#undef CAST
+    }
+}

@@ -1,0 +1,33 @@
+// TEST HARNESS ONLY: plain-C++ stand-ins for voxel-rs_amd/csrc/hip/vx_platform.hpp (the gfx950 primitives the device-side
+// ray path is written in), so that tests/cpp/device_on_host.cpp can step the DEVICE header against the oracle on a machine
+// without a GPU. Found instead of the real one because the harness puts this directory first on its include path. Nothing
+// of the product includes or links this.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace vxd {
+
+struct buf_t { const uint8_t* p; uint32_t bytes; };
+inline buf_t make_buf(const void* p, uint32_t bytes) { return buf_t{static_cast<const uint8_t*>(p), bytes}; }
+// like the V#'s range check: a read that does not fit returns 0
+inline uint32_t buf_u32(buf_t b, uint32_t off) { uint32_t v = 0; if (uint64_t(off) + 4 <= b.bytes) std::memcpy(&v, b.p + off, 4); return v; }
+inline uint32_t buf_u8(buf_t b, uint32_t off) { return off < b.bytes ? b.p[off] : 0u; }
+inline uint4 buf_u128(buf_t b, uint32_t off) { uint4 v = {0, 0, 0, 0}; if (uint64_t(off) + 16 <= b.bytes) std::memcpy(&v, b.p + off, 16); return v; }
+inline uint2 buf_u64(buf_t b, uint32_t off) { uint2 v = {0, 0}; if (uint64_t(off) + 8 <= b.bytes) std::memcpy(&v, b.p + off, 8); return v; }
+inline uint2 mem_u64(const uint8_t* p) { uint2 v; std::memcpy(&v, p, 8); return v; }
+inline uint32_t mem_u32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+
+extern unsigned char* vx_smem;
+#define VX_AS_LDS
+#define VX_AS_PRIVATE
+
+inline uint32_t bit_at(uint32_t v, int pos) { return (v >> pos) & 1u; }
+inline void sched_fence() {}
+inline float gmin3(float x, float y, float z) { float m = y < x ? y : x; return z < m ? z : m; }
+inline float gmax3(float x, float y, float z) { float m = x < y ? y : x; return m < z ? z : m; }
+inline float glsl_pow(float x, float y) { return powf(x, y); }
+
+}  // namespace vxd

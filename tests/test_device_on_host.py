@@ -21,8 +21,10 @@ def devhost():
     so = BUILD / "libdevice_on_host.so"
     src = Path(ROOT) / "tests" / "cpp" / "device_on_host.cpp"
     hdr = Path(ROOT) / "voxel-rs_amd" / "csrc" / "hip" / "vx_device.hpp"
-    if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
-        cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", f"-I{ROOT}/include",
+    shim = Path(ROOT) / "tests" / "cpp" / "shims" / "vx_platform.hpp"
+    if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime, shim.stat().st_mtime):
+        # tests/cpp/shims comes first: its vx_platform.hpp (plain C++) is found instead of the product's (gfx950 built-ins)
+        cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", f"-I{ROOT}/include", f"-I{ROOT}/tests/cpp/shims",
                f"-I{ROOT}/voxel-rs_amd/csrc/hip", str(src), "-o", str(so)]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0, r.stdout
@@ -97,3 +99,110 @@ def test_device_traversal_on_host_heightfield_csvo(devhost, golden):
     assert (exp["dst"] > 0).sum() > 300
     bad = [i for i in range(len(tasks)) if got[i].tobytes() != exp[i].tobytes()]
     assert not bad, (len(bad), bad[:5])
+
+
+# ---- the traversal IMAGE of a world, walked by the device code the way a lane of the render kernel walks it ---------------------
+
+
+RESULT_DTYPE = np.dtype([("t", "<f4"), ("value", "<u4"), ("face_id", "<i4"), ("pos", "<f4", 3), ("uv", "<f4", 2), ("color", "<f4", 4), ("lod", "<f4"),
+                         ("inside_voxel", "<i4")])
+
+
+def image_cast(lib, fmt, world, mats, tex, mips, tasks, cast_translucent, layout, shallow):
+    from voxel_rs_amd import hip
+
+    frame = world.frame(pad_words=0)
+    head = 4 + (20 if fmt == "esvo" else 4)
+    image, origin = hip.traversal_image(1 if fmt == "esvo" else 2, frame, frame.size * 4 - head, layout=layout, with_origin=True)
+    image = np.concatenate([image, np.zeros(16, dtype=np.uint32)])  # the zero pad the context keeps behind the image
+    levels = orc.mip_chain(tex, mips)
+    chain = np.concatenate([lv.ravel() for lv in levels])
+    offsets = np.cumsum([0] + [lv.size for lv in levels[:-1]])
+    level_offset = (C.c_uint32 * 16)(*[int(o) for o in offsets])
+    out = np.zeros(len(tasks), dtype=RESULT_DTYPE)
+    steps = np.zeros(len(tasks), dtype=np.uint32)
+    lib.devhost_image_cast(1 if fmt == "esvo" else 2, layout, int(shallow), frame.ctypes.data_as(C.c_void_p), C.c_uint64(frame.size * 4),
+                           image.ctypes.data_as(C.c_void_p), C.c_uint64(image.size * 4), origin.ctypes.data_as(C.c_void_p),
+                           mats.ctypes.data_as(C.c_void_p), mats.size, chain.ctypes.data_as(C.c_void_p), tex.shape[2], tex.shape[1], tex.shape[0],
+                           len(levels), level_offset, tasks.ctypes.data_as(C.c_void_p), len(tasks), int(cast_translucent),
+                           out.ctypes.data_as(C.c_void_p), steps.ctypes.data_as(C.c_void_p))
+    return out, steps
+
+
+def oracle_cast(scene, tasks, cast_translucent):
+    exp = np.zeros(len(tasks), dtype=RESULT_DTYPE)
+    steps = np.zeros(len(tasks), dtype=np.uint32)
+    for i, t in enumerate(tasks):
+        ctr = orc.Counters()
+        r, _, _ = scene.intersect(t["pos"], t["dir"], float(t["max_dst"]), bool(cast_translucent), counters=ctr)
+        exp[i] = (r.t, r.value, r.face_id, list(r.pos), list(r.uv), list(r.color), r.lod, r.inside_voxel)
+        steps[i] = ctr.iterations
+    return exp, steps
+
+
+def assert_same_casts(got, gsteps, exp, esteps):
+    """Hit identity, every traversal float and the iteration count exactly; the sampled colour to 5e-6 (a trilinear sample blends
+    its texels in byte units on the device, vx_device.hpp: sample_linear_bytes)."""
+    exact = [n for n in RESULT_DTYPE.names if n != "color"]
+    bad = [i for i in range(len(exp)) if any(got[i][n].tobytes() != exp[i][n].tobytes() for n in exact) or gsteps[i] != esteps[i]
+           or np.abs(got[i]["color"] - exp[i]["color"]).max() > 5e-6]
+    assert not bad, (len(bad), bad[:5], got[bad[0]], exp[bad[0]], gsteps[bad[0]], esteps[bad[0]])
+
+
+@pytest.mark.parametrize("cast_translucent", [0, 1])
+@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("fmt", ["esvo", "csvo"])
+def test_image_traversal_with_rays_from_inside_voxels(devhost, golden, fmt, layout, cast_translucent):
+    """A dense random chunk: about one ray in five starts INSIDE a voxel and is led into it (svo.esvo.glsl:183-185,
+    svo.csvo.glsl:293-295). On the image of an ESVO world that is a walk through an empty node; on the image of a CSVO world the
+    ray makes an excursion onto the world's own bytes (phantom leaves included) and comes back. Results and iteration counts
+    are the oracle's on the world's own bytes."""
+    rng = np.random.default_rng(7)
+    pts = rng.integers(0, 32, size=(6000, 3))
+    blocks = [[int(x), int(y), int(z), int(rng.choice([1, 2, 3, 4]))] for x, y, z in pts]
+    svo_pos = (3, 2, 1)
+    scene, world = oracle_scene(golden, fmt, svo_pos, blocks)
+    tex, mips = golden_textures(golden)
+    mats = golden_materials(golden)
+    base = np.asarray(svo_pos, dtype=np.float32) * 32
+    tasks = random_tasks(rng, 1500, 0, 32)
+    tasks["pos"] += base
+    exp, esteps = oracle_cast(scene, tasks, cast_translucent)
+    assert (exp["inside_voxel"] != 0).sum() > 100 and (exp["t"] > 0).sum() > 300
+    for shallow in (True, False):
+        got, gsteps = image_cast(devhost, fmt, world, mats, tex, mips, tasks, cast_translucent, layout, shallow)
+        assert_same_casts(got, gsteps, exp, esteps)
+
+
+@pytest.mark.parametrize("fmt", ["esvo", "csvo"])
+@pytest.mark.parametrize("base,depth", [((200, 3, 201), 13), ((400, 3, 401), 14), ((800, 3, 801), 15)])
+def test_image_traversal_in_deep_worlds(devhost, golden, fmt, base, depth):
+    """Chunks far from the origin of a deep world: voxels sit on or below the last LDS-resident stack level, so the walk into a
+    voxel goes through the hand-over to the full stack (ESVO image at depth 14 and more) and the excursion returns to a node
+    below the resident levels (CSVO image at depth 14 and more)."""
+    rng = np.random.default_rng(11)
+    world = vra.World(1 if fmt == "esvo" else 2)
+    for dx in range(2):
+        chunk = vra.Chunk(base[0] + dx, base[1], base[2], 5)
+        for x in range(32):
+            for z in range(32):
+                for y in range(6 + int(rng.integers(0, 6))):
+                    chunk.set_block(x, y, z, int(rng.choice([1, 2, 3, 4])))
+        chunk.compact()
+        world.set_chunk((base[0] + dx, base[1], base[2]), chunk)
+    world.serialize()
+    assert world.depth == depth
+    tex, mips = golden_textures(golden)
+    mats = golden_materials(golden)
+    scene = orc.OracleScene(1 if fmt == "esvo" else 2, world.frame(), mats, tex, mips)
+    tasks = random_tasks(rng, 1200, 0, 1)
+    tasks["pos"] = (np.float32([32 * c for c in base]) + rng.uniform([0, 0, 0], [64, 14, 32], size=(len(tasks), 3))).astype(np.float32)
+    tasks["max_dst"] = -1
+    exp, esteps = oracle_cast(scene, tasks, 1)
+    assert (exp["inside_voxel"] != 0).sum() > 100
+    for layout in (1, 2):
+        got, gsteps = image_cast(devhost, fmt, world, mats, tex, mips, tasks, 1, layout, shallow=False)
+        assert_same_casts(got, gsteps, exp, esteps)
+    if depth <= (13 if fmt == "esvo" else 14):  # what vx_render takes for "no push below the resident levels" (vx_api.hip, launch_render)
+        got, gsteps = image_cast(devhost, fmt, world, mats, tex, mips, tasks, 1, 1, shallow=True)
+        assert_same_casts(got, gsteps, exp, esteps)

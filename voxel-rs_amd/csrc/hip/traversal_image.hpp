@@ -90,6 +90,9 @@ struct Octant {
     uint32_t lo[8] = {};
     uint16_t masks[8] = {};  // the child's own masks (nodes), filled in for chunks at placement
     uint8_t node_mask = 0, leaf_mask = 0, chunk_mask = 0;
+    // CSVO voxel parents (leaf-mask bytes, svo.csvo.glsl:114-115): where the byte is in the world, for the origin table --
+    // [0] = its byte pointer L, [1] = k << 29 | (L - the chunk's material section), k = its place among its depth-2 parent's bytes
+    uint32_t origin[2] = {};
 };
 
 // frame words an octant takes in the kOct64 layouts: {pointer | value, masks} entries, values only, or nothing
@@ -139,6 +142,12 @@ private:
             end_ = std::max(end_, ptr + 1);
             const uint32_t material_offset = b_.u16(pre_leaf + 1);
             const uint64_t leaf_index = ptr - (pre_leaf + 3);
+            if (leaf_index > 7 || ptr >= (uint64_t(1) << 31) || ptr - materials_ >= (uint64_t(1) << 29)) {
+                out_.too_deep = true;  // not a chunk the serializer wrote (csvo.rs:481-493): the origin table could not say where it is
+                return m;
+            }
+            out_.octants[at].origin[0] = uint32_t(ptr);
+            out_.octants[at].origin[1] = uint32_t(leaf_index << 29) | uint32_t(ptr - materials_);
             uint32_t preceding = 0;  // leaves before this byte under the depth-2 node
             for (uint64_t k = 0; k < leaf_index; ++k) preceding += uint32_t(__builtin_popcount(b_.u8(pre_leaf + 3 + k)));
             for (uint32_t c = 0; c < 8; ++c) {
@@ -265,6 +274,13 @@ private:
             if (!((child_mask >> c) & 1u)) continue;
             const uint32_t body = w_.at(octant + 4 + c);
             if ((leaf_mask >> c) & 1u) {
+                // A voxel has no masks of its own in anything the serializer writes (esvo.rs:465-485 ORs a child's masks into the header
+                // only for octants), so a ray led INTO a voxel walks an empty node (svo.esvo.glsl:183-185) -- which is what the image's
+                // traversal does for every voxel. A world where that is not so is traversed as bytes.
+                if ((w_.at(octant + (c >> 1)) >> ((c & 1u) * 16)) & 0xffffu) {
+                    out_.too_deep = true;
+                    return;
+                }
                 out_.octants[at].leaf_mask |= uint8_t(1u << c);
                 out_.octants[at].lo[c] = body;
                 continue;
@@ -360,6 +376,12 @@ public:
         }
         return out;
     }
+    // CSVO worlds in the kOct64 layouts: the origin table, two words per 32-byte unit of the frame (a quarter of its size). For
+    // the unit a voxel-parent octant starts at: where that leaf-mask byte is in the world's own bytes (Octant::origin). The
+    // renderer reads it when a ray is led into a voxel (vx_device.hpp, enter_voxel_on_bytes). Its dirty ranges are the frame's / 4.
+    const std::vector<uint32_t>& origin() const { return origin_; }
+    uint64_t origin_bytes() const { return origin_.size() * 4; }
+    bool has_origin() const { return !esvo_ && layout_ != kEsvo48; }
     size_t chunk_count() const { return chunks_.size(); }
     // levels of the imaged octree (the world's depth); no path of the image is longer
     uint32_t depth() const { return depth_; }
@@ -490,6 +512,7 @@ public:
             chunks_[todo[i].key] = pl;
         }
         if (frame_.size() < top) frame_.resize(top, 0u);
+        if (has_origin() && origin_.size() < frame_.size() / 4) origin_.resize(frame_.size() / 4, 0u);
         parallel(todo.size(), threads, [&](size_t i) { encode(built[i], placed[i].at); });
 
         // 4. the root octree is rewritten by every commit (csvo.rs:68-139 re-serializes it): so is its image
@@ -497,6 +520,7 @@ public:
         root_words_ = tree_words(root);
         root_at_ = alloc_.alloc(root_words_);
         if (frame_.size() < root_at_ + root_words_) frame_.resize(root_at_ + root_words_, 0u);
+        if (has_origin() && origin_.size() < (frame_.size() + 3) / 4) origin_.resize((frame_.size() + 3) / 4, 0u);
         for (Octant& o : root.octants)
             for (uint32_t c = 0; c < 8; ++c)
                 if ((o.chunk_mask >> c) & 1u) {
@@ -537,6 +561,7 @@ private:
         chunks_.clear();
         alloc_.reset(0);
         frame_.clear();
+        origin_.clear();
         dirty_.clear();
         root_at_ = root_words_ = 0;
         return false;
@@ -584,6 +609,11 @@ private:
                 const uint32_t words = oct64_words(o);
                 if (words == 8) {
                     for (uint32_t c = 0; c < 8; ++c) w[c] = ((o.leaf_mask >> c) & 1u) ? o.lo[c] : 0u;
+                    if (has_origin()) {
+                        const uint64_t unit = (at + where[i]) / 8;
+                        origin_[unit * 2] = o.origin[0];
+                        origin_[unit * 2 + 1] = o.origin[1];
+                    }
                     continue;
                 }
                 if (words == 0) continue;
@@ -623,6 +653,7 @@ private:
     Layout layout_;
     uint64_t first_word_;
     std::vector<uint32_t> frame_;
+    std::vector<uint32_t> origin_;
     std::vector<Range> dirty_;
     WordAllocator alloc_;
     std::unordered_map<uint32_t, Placed> chunks_;

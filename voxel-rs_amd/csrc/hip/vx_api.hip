@@ -6,12 +6,14 @@
 // There is no CPU path: without a HIP device every entry point fails with VX_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "traversal_image.hpp"
@@ -119,46 +121,19 @@ struct PersistentArgs {
     uint32_t refill_min, service_min;
 };
 
-// Pixels whose rays a traversal image cannot serve, handed from the image kernel to the kernel that re-renders them on the
-// world's own bytes.
-struct PixelList {
-    // Pixels a wave has to re-render, in chunks of 128 dwords that the wave chains together: [0] previous chunk + 1 (0 = none),
-    // [1] entries, [2..127] out_index values. Chunks come from a ring (`mask` + 1 of them, a power of two) through one counter
-    // that only ever grows; a wave touches nothing but its own chunks, so no wave ever waits for another. `report` (host memory,
-    // one word per wave, or null): how many pixels the wave re-rendered.
-    uint32_t* chunks;
-    uint32_t* next_chunk;
-    uint32_t mask;
-    uint32_t* report;
-};
-constexpr uint32_t kChunkDwords = 128, kChunkEntries = 126;
-
-// compact / row-major output index -> pixel coordinates (the inverse of the index computation in the refill)
-__device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t out_index, uint32_t& x, uint32_t& y) {
-    if (p.tile_count > 1) {
-        const uint32_t local_tile = out_index >> 10, in_y = (out_index >> 5) & 31u, in_x = out_index & 31u;
-        const uint32_t tile = local_tile * p.tile_count + p.tile_rank;
-        x = (tile % p.tiles_x) * kTile + in_x;
-        y = (tile / p.tiles_x) * kTile + in_y;
-    } else {
-        x = out_index % p.width;
-        y = out_index / p.width;
-    }
-}
-
-// FOREIGN (= the world's own format): SVO = VX_SVO_IMAGE and the rays walk the traversal image of the world (traversal_image.hpp). A ray that
-// is about to be led into the voxel it started in cannot be continued on the image: its pixel is dropped and noted in the
-// wave's own list (`todo`), and every wave, once the tile queue is empty and its rays are done, renders the pixels it noted
-// from scratch on the world's own bytes -- exactly what the reference does for them. (A second phase of the same waves, not a
-// second kernel: its registers overlay the first phase's instead of adding to them, and a frame stays one command.)
+// IMAGE = the rays walk the traversal image of the world (traversal_image.hpp) instead of its own bytes. FOREIGN (an image of a
+// CSVO world; = VX_SVO_CSVO): a ray that is about to be led into the voxel it started in makes that excursion on the world's own
+// bytes and comes back to the image (vx_device.hpp, enter_voxel_on_bytes) -- in the service phase, like every other rare and
+// expensive thing a ray can need. (The image of an ESVO world serves such rays itself.)
+// SHALLOW: no ray can push below the LDS-resident stack levels (the host knows the image's depth): no hand-over test in the loop.
 template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
-                                                        vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
-    static_assert((FOREIGN != 0) == (SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE) && !(FOREIGN && STATS),
-                  "image traversal <=> foreign handling; the instrumented kernel counts the reference's own fetches");
-    static_assert(FOREIGN == 0 || FOREIGN == VX_SVO_ESVO || FOREIGN == VX_SVO_CSVO, "FOREIGN names the world's own format");
-    static_assert(!SHALLOW || FOREIGN, "only a traversal image bounds how deep a ray can get");
-    const DevScene sc = FOREIGN ? make_image_scene(sa) : make_scene(sa);
+                                                        vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters) {
+    constexpr bool IMAGE = SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE;
+    static_assert(!(IMAGE && STATS), "the instrumented kernel counts the reference's own fetches: it walks the world's own bytes");
+    static_assert(FOREIGN == 0 || (IMAGE && FOREIGN == VX_SVO_CSVO), "FOREIGN: the image of a CSVO world");
+    static_assert(!SHALLOW || IMAGE, "only a traversal image bounds how deep a ray can get");
+    const DevScene sc = IMAGE ? make_image_scene(sa) : make_scene(sa);
     const uint32_t lane = threadIdx.x;
     StackSpill spill;
     Stack<64, false> st;       // all 23 levels: LDS, then the per-lane spill array
@@ -189,7 +164,6 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
     bool queue_empty = false;
-    uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
 
     for (;;) {
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
@@ -198,7 +172,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             if (tr.iter < uint32_t(kMaxSteps)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
                 tr.template step_with<false, STATS, false, FastStack, false, FOREIGN != 0>(sc, fast_st, nullptr, STATS ? &ctr : nullptr, [&](TravStatus s) {
                     state = LaneState(s);
-                    tr.iter = (s == kTravDeep ? tr.iter - 1 : tr.iter) | kParked;  // a handed-over iteration is counted by the step that repeats it
+                    tr.iter = (s == kTravDeep || s == kTravForeign ? tr.iter - 1 : tr.iter) | kParked;  // a handed-over iteration is counted by the step that repeats it
                 });
             }
             const unsigned long long trav = __ballot(tr.iter < uint32_t(kMaxSteps));
@@ -224,30 +198,18 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 state = LaneState(s);
                 break;
             }
+            if (FOREIGN && state == kForeign) --tr.iter;  // the excursion repeats this iteration
             if (state != kTrav) tr.iter |= kParked;
         }
 
-        // ---- rays that started inside a voxel (FOREIGN): their pixels are noted for the second phase, which renders them on the world's own bytes ----
-        if (FOREIGN) {
-            const unsigned long long fm = __ballot(state == kForeign);
-            if (fm) {
-                const uint32_t k = uint32_t(__popcll(fm));
-                if (my_chunk == 0 || my_fill + k > kChunkEntries) {  // a fresh chunk always has room for a whole wave
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(todo.next_chunk, 1u);
-                    c = __builtin_amdgcn_readfirstlane(c) & todo.mask;
-                    if (lane == 0) todo.chunks[size_t(c) * kChunkDwords] = my_chunk;
-                    my_chunk = c + 1;
-                    my_fill = 0;
-                }
-                uint32_t* chunk = todo.chunks + size_t(my_chunk - 1) * kChunkDwords;
-                if (state == kForeign) {
-                    chunk[2 + my_fill + __builtin_amdgcn_mbcnt_hi(uint32_t(fm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(fm), 0u))] = out_index;
-                    state = kIdle;
-                }
-                my_fill += k;
-                if (lane == 0) chunk[1] = my_fill;
-            }
+        // ---- rays that are led into a voxel (they started inside it), image of a CSVO world: the excursion on the world's own bytes ----
+        if (FOREIGN && state == kForeign) {
+            const DevScene sc_bytes = make_scene(sa);
+            tr.iter &= ~kParked;
+            const TravStatus s = enter_voxel_on_bytes(sc, sc_bytes, tr, st, true, res);
+            // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there
+            state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep) : (s == kTravAtLeaf ? kDone : kMissed);
+            if (state != kTrav) tr.iter |= kParked;
         }
 
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
@@ -375,33 +337,6 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if (__ballot(state != kIdle) == 0 && queue_empty) break;
     }
 
-    // ---- second phase (FOREIGN): the pixels this wave noted, whole, on the world's own bytes ----
-    if (FOREIGN) {
-        const DevScene sc_orig = make_scene(sa);
-        uint32_t re_rendered = 0;
-        for (uint32_t c = my_chunk; c != 0;) {
-            const uint32_t* chunk = todo.chunks + size_t(c - 1) * kChunkDwords;
-            const uint32_t n = __builtin_amdgcn_readfirstlane(chunk[1]);
-            c = __builtin_amdgcn_readfirstlane(chunk[0]);
-            re_rendered += n;
-            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                if (i0 + lane < n) {
-                    const uint32_t index = chunk[2 + i0 + lane];
-                    uint32_t x, y;
-                    out_index_to_xy(p, index, x, y);
-                    float color[4];
-                    vx_hit r;
-                    shade_pixel<FOREIGN ? FOREIGN : VX_SVO_ESVO, false>(sc_orig, p, x, y, st, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
-                    if (out) out[index] = make_float4(color[0], color[1], color[2], color[3]);
-                    if (HITS) hits[index] = r;
-                }
-            }
-        }
-        // how many pixels the image could not serve: the host steers by it (launch_render). A plain store per wave into pinned
-        // host memory: nothing for the stream to do after the kernel, nothing for the host to wait for.
-        if (todo.report && lane == 0) todo.report[blockIdx.x] = re_rendered;
-    }
-
     if (STATS) {
         uint32_t v[11] = {ctr.rays, ctr.iterations, ctr.pushes, ctr.leaf_tests, ctr.leaf_tests_trilinear, ctr.boundaries, ctr.csvo_header_bytes,
                           ctr.csvo_pointer_bytes, n_pixels, lit, shadow_rays};
@@ -490,6 +425,24 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneArgs sa, TraceArgs a, vx
     *n_frames = tk.n_frames;
 }
 
+// vx_commit's packed uploads: piece b of the table = {device address, offset in the packed payload, bytes}; source and
+// destination agree modulo 16 (the packer pads), so the middle of a piece moves as 16-byte words
+__global__ __launch_bounds__(256) void scatter_kernel(const uint64_t* __restrict__ table, const uint8_t* __restrict__ packed) {
+    const uint64_t dst = table[blockIdx.x * 3], src = table[blockIdx.x * 3 + 1], len = table[blockIdx.x * 3 + 2];
+    uint8_t* d = reinterpret_cast<uint8_t*>(dst);
+    const uint8_t* s = packed + src;
+    const uint32_t t = threadIdx.x;
+    const uint64_t to_aligned = (16u - (dst & 15u)) & 15u;
+    const uint32_t head = uint32_t(len < to_aligned ? len : to_aligned);
+    if (t < head) d[t] = s[t];
+    const uint64_t body = (len - head) / 16;
+    const uint4* s4 = reinterpret_cast<const uint4*>(s + head);
+    uint4* d4 = reinterpret_cast<uint4*>(d + head);
+    for (uint64_t i = t; i < body; i += 256) d4[i] = s4[i];
+    const uint32_t tail = uint32_t((len - head) & 15u);
+    if (t < tail) d[head + body * 16 + t] = s[head + body * 16 + t];
+}
+
 // scatter gathered compact tile lists back into a row-major image (one thread per pixel, float4 stores)
 __global__ __launch_bounds__(256) void assemble_kernel(const float4* __restrict__ tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width,
                                                        uint32_t height, uint32_t tiles_x, float4* __restrict__ out) {
@@ -549,11 +502,6 @@ struct vx_context {
     // Tickets drawn from each dispenser so far. A launch draws exactly total_subtiles + waves tickets (every wave draws one
     // ticket past the end before it stops), so the next launch on the same stream starts there and no reset is needed.
     uint32_t frame_tickets[kFrameStreams] = {};
-    uint32_t* d_frame_todo[kFrameStreams] = {};  // imaged contexts: [chunk counter][ring of 128-dword chunks] per stream
-    size_t frame_todo_pixels[kFrameStreams] = {};
-    uint32_t* d_main_todo = nullptr;
-    size_t main_todo_pixels = 0;
-
     uint32_t main_tickets = 0;
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
     int frames_in_flight = 2;           // 1 serialises frames on `stream` again (vx_set_frames_in_flight / VX_FRAMES_IN_FLIGHT)
@@ -579,26 +527,23 @@ struct vx_context {
     vximg::WorldImage image;
     uint8_t* d_image = nullptr;
     size_t d_image_capacity = 0;
+    uint8_t* d_origin = nullptr;  // CSVO worlds: the image's origin table (a quarter of the image's size)
+    size_t d_origin_capacity = 0;
+    size_t image_cap_bytes = 0;   // VX_IMAGE_CAP_BYTES: never allocate more than this for the image (tests of the fall-back)
+    // vx_commit's packed uploads: a small ring of pinned host buffers with their device twins, each guarded by an event
+    struct DeltaSlot { uint8_t* host = nullptr; uint8_t* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
+    static constexpr int kDeltaSlots = 3;
+    DeltaSlot delta[kDeltaSlots];
+    unsigned delta_next = 0;
+    bool big = false;             // an ESVO world buffer of 4 GiB and more: kernels on its own bytes use 64-bit addresses (VX_SVO_ESVO_BIG)
     bool image_enabled = true;  // VX_TRAVERSAL_IMAGE=0: traverse the world's own bytes
     bool image_ok = false;
-    // Steering by the share of pixels the image could not serve (rays that start inside voxels: DESIGN.md §9): after a frame with
-    // more than an eighth (CSVO) / a sixteenth (ESVO) of them the next kFramesOnBytes frames traverse the world's own bytes, then the
-    // image is tried again.
-    static constexpr int kFramesOnBytes = 30;
-    static constexpr uint32_t kMaxReportWaves = 8192;
-    uint32_t* h_re_rendered = nullptr;                    // pinned, [kFrameStreams + 1][kMaxReportWaves]: per stream, what each wave of its last image frame re-rendered
-    uint32_t* d_re_rendered = nullptr;                    // the same memory as the device sees it
-    uint32_t report_waves[kFrameStreams + 1] = {};        // waves of the image frame that last ran on the stream (0 = nothing to look at)
-    uint64_t ring_pixels[kFrameStreams + 1] = {};         // ... and its pixels
-    int frames_on_bytes = 0;
-    bool steer = true;           // VX_IMAGE_STEERING=0: always the image (tests, measurements)
-    bool eye_check = true;      // VX_EYE_CHECK=0: frames whose eye is inside a voxel go through the image kernel too (tests)
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
     uint32_t refill_min = 4, service_min = 28;
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int cu_count = 256;
-    int persistent_blocks[10][2][2] = {};  // [svo][hits][stats] resident 64-thread workgroups per CU, queried once
+    std::unordered_map<const void*, int> persistent_blocks;  // kernel -> resident 64-thread workgroups per CU, queried once
 
     bool profile = false;
     std::vector<ProfiledLaunch> launches;
@@ -608,13 +553,15 @@ struct vx_context {
 namespace {
 
 constexpr size_t kWorldPad = 16;
+constexpr size_t kImagePad = 64;  // zero bytes behind the image: an 8-byte entry load at the last octant's last child stays inside
+constexpr size_t kStagingSlack = 64;
 
 uint32_t header_bytes(const vx_context* c) { return c->svo_type == VX_SVO_ESVO ? 20u : 4u; }
 
 SceneArgs scene_of(const vx_context* c) {
     SceneArgs s = {};
     s.world = c->d_world;
-    s.world_bytes = uint32_t(c->capacity + kWorldPad);
+    s.world_bytes = uint64_t(c->capacity) + kWorldPad;
     s.materials = c->d_materials;
     s.n_materials = c->n_materials;
     s.tex = c->d_tex;
@@ -622,8 +569,18 @@ SceneArgs scene_of(const vx_context* c) {
     s.width = c->tex.width; s.height = c->tex.height; s.layers = c->tex.layers; s.levels = c->tex.levels;
     for (int l = 0; l < 16; ++l) s.level_offset[l] = c->tex.level_offset[l];
     s.image = c->image_ok ? c->d_image : nullptr;
-    s.image_bytes = c->image_ok ? c->image.frame_bytes() + kWorldPad : 0u;
+    s.image_bytes = c->image_ok ? c->image.frame_bytes() + kImagePad : 0u;
+    s.origin = c->image_ok ? c->d_origin : nullptr;
     return s;
+}
+
+// every stream a kernel of this context can be running on has drained (before freeing or replacing what kernels read)
+int drain_streams(vx_context* c) {
+    if (c->upload_stream) HIP_TRY(hipStreamSynchronize(c->upload_stream));
+    if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < vx_context::kFrameStreams; ++i)
+        if (c->frame_stream[i]) HIP_TRY(hipStreamSynchronize(c->frame_stream[i]));
+    return VX_OK;
 }
 
 int ensure(void** p, size_t* have, size_t need) {
@@ -641,6 +598,30 @@ int check_ready(vx_context* ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
     if (!ctx->committed) return fail(VX_ERR_STATE, "no SVO committed yet (call vx_commit / vx_commit_all first)");
     return VX_OK;
+}
+
+// The persistent render kernel for a context's world: on the world's own bytes (ESVO, ESVO beyond 4 GiB, CSVO), or on its
+// traversal image (byte-offset or wide layout; with the excursion onto the bytes for CSVO worlds; without the stack hand-over test
+// where the image's depth rules deep pushes out). The image-only build of the hot variants is held to 128 VGPRs (4 waves per SIMD).
+template <bool HITS, bool STATS>
+const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow) {
+    const bool esvo = ctx->svo_type == VX_SVO_ESVO;
+#define VX_K(...) reinterpret_cast<const void*>(&render_persistent<__VA_ARGS__>)
+    if (!imaged) {
+        constexpr int W = (!HITS && !STATS) ? 4 : 1;
+        if (!HITS && !STATS && ctx->min_waves != 4)
+            return esvo ? (ctx->big ? VX_K(VX_SVO_ESVO_BIG, false, false, 1) : VX_K(VX_SVO_ESVO, false, false, 1)) : VX_K(VX_SVO_CSVO, false, false, 1);
+        return esvo ? (ctx->big ? VX_K(VX_SVO_ESVO_BIG, HITS, STATS, W) : VX_K(VX_SVO_ESVO, HITS, STATS, W)) : VX_K(VX_SVO_CSVO, HITS, STATS, W);
+    }
+    constexpr int W = HITS ? 1 : 4;
+    const bool wide = ctx->image.layout() == vximg::kOct64Wide;  // an image beyond 4 GiB: octant indices, 64-bit addresses
+    if (esvo) {
+        if (wide) return shallow ? VX_K(VX_SVO_IMAGE_WIDE, HITS, false, W, 0, true) : VX_K(VX_SVO_IMAGE_WIDE, HITS, false, W, 0, false);
+        return shallow ? VX_K(VX_SVO_IMAGE, HITS, false, W, 0, true) : VX_K(VX_SVO_IMAGE, HITS, false, W, 0, false);
+    }
+    if (wide) return shallow ? VX_K(VX_SVO_IMAGE_WIDE, HITS, false, W, VX_SVO_CSVO, true) : VX_K(VX_SVO_IMAGE_WIDE, HITS, false, W, VX_SVO_CSVO, false);
+    return shallow ? VX_K(VX_SVO_IMAGE, HITS, false, W, VX_SVO_CSVO, true) : VX_K(VX_SVO_IMAGE, HITS, false, W, VX_SVO_CSVO, false);
+#undef VX_K
 }
 
 template <bool HITS, bool STATS>
@@ -664,7 +645,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         }
         HIP_TRY(hipEventRecord(ev.start, stream));
     }
-    if (ctx->kernel_version == 1) {
+    if (ctx->kernel_version == 1 && !ctx->big) {
         if (ctx->svo_type == VX_SVO_ESVO)
             hipLaunchKernelGGL((render_kernel<VX_SVO_ESVO, HITS, STATS>), grid, block, lds, stream, sc, p, reinterpret_cast<float4*>(out), hits, counters);
         else
@@ -672,53 +653,17 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
     } else {
         // persistent waves: as many 64-thread workgroups as the device keeps resident, fed from the sub-tile queue
         const size_t wave_lds = Stack<64>::kBytes;
-        const bool esvo = ctx->svo_type == VX_SVO_ESVO;
-        const void* fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, HITS, STATS>)
-                              : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, HITS, STATS>);
-        if (!HITS && !STATS && ctx->min_waves == 4)
-            fn = esvo ? reinterpret_cast<const void*>(&render_persistent<VX_SVO_ESVO, false, false, 4>)
-                      : reinterpret_cast<const void*>(&render_persistent<VX_SVO_CSVO, false, false, 4>);
         // Worlds are rendered from their traversal image; the instrumented variant stays on the world's own bytes so that its
         // counters are the reference's own fetches
-        bool imaged = !STATS && ctx->image_ok;
-        if (imaged) {
-            // an eye inside a voxel: every primary ray is an inside-voxel ray and would be re-rendered on the world's own bytes after
-            // a wasted start on the image (kTravForeign) -- such a frame goes to the kernel that traverses the bytes straight away
-            const float s = std::ldexp(1.0f, -int(ctx->image.depth()));
-            if (ctx->steer) {
-                // what did the image frame that last ran on this stream report? (It has finished, or nearly: a heuristic may look early.)
-                uint32_t* report = ctx->h_re_rendered + size_t(slot + 1) * vx_context::kMaxReportWaves;
-                if (ctx->report_waves[slot + 1]) {
-                    uint64_t re_rendered = 0;
-                    for (uint32_t i = 0; i < ctx->report_waves[slot + 1]; ++i) re_rendered += report[i];
-                    // break-even: a re-rendered pixel costs about three ordinary ones, a frame on the world's own bytes 1.1 (ESVO) /
-                    // 1.4 (CSVO) frames on the image
-                    if (re_rendered * (esvo ? 16 : 8) > ctx->ring_pixels[slot + 1]) ctx->frames_on_bytes = vx_context::kFramesOnBytes;
-                    ctx->report_waves[slot + 1] = 0;  // looked at
-                }
-                if (ctx->frames_on_bytes > 0) {
-                    --ctx->frames_on_bytes;
-                    imaged = false;
-                }
-            }
-            if (imaged && ctx->eye_check && ctx->image.point_in_voxel(p.ray_origin[0] * s + 1.0f, p.ray_origin[1] * s + 1.0f, p.ray_origin[2] * s + 1.0f)) imaged = false;
-        }
-        // The image holds at most `depth` levels (traversal_image.hpp) and its rays never descend into a leaf (kTravForeign), so the
-        // deepest PUSH is into a node one level above the voxels, at scale 24 - depth: up to kLdsLevels + 1 levels every stack slot
-        // a ray can touch is LDS resident.
-        const bool shallow = imaged && ctx->image.depth() <= uint32_t(kLdsLevels) + 1u;
-        if (imaged) {
-            const bool w4 = !HITS && ctx->min_waves == 4;
-            const bool wide = ctx->image.layout() == vximg::kOct64Wide;  // an image beyond 4 GiB: octant indices, 64-bit addresses
-#define VX_IMAGE_KERNEL(IMAGE, ORIG, MINW, SHALLOW) reinterpret_cast<const void*>(&render_persistent<IMAGE, HITS, false, MINW, ORIG, SHALLOW>)
-#define VX_IMAGE_KERNELS(IMAGE, ORIG) (shallow ? (w4 ? VX_IMAGE_KERNEL(IMAGE, ORIG, 4, true) : VX_IMAGE_KERNEL(IMAGE, ORIG, 1, true)) \
-                                               : (w4 ? VX_IMAGE_KERNEL(IMAGE, ORIG, 4, false) : VX_IMAGE_KERNEL(IMAGE, ORIG, 1, false)))
-            if (wide) fn = esvo ? VX_IMAGE_KERNELS(VX_SVO_IMAGE_WIDE, VX_SVO_ESVO) : VX_IMAGE_KERNELS(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO);
-            else fn = esvo ? VX_IMAGE_KERNELS(VX_SVO_IMAGE, VX_SVO_ESVO) : VX_IMAGE_KERNELS(VX_SVO_IMAGE, VX_SVO_CSVO);
-#undef VX_IMAGE_KERNELS
-#undef VX_IMAGE_KERNEL
-        }
-        int& per_cu = ctx->persistent_blocks[(imaged ? (shallow ? 4 : 2) + (ctx->image.layout() == vximg::kOct64Wide ? 4 : 0) : 0) + (esvo ? 0 : 1)][HITS][STATS];
+        const bool imaged = !STATS && ctx->image_ok;
+        // The image holds at most `depth` levels (traversal_image.hpp). The deepest PUSH of a ray on the image of an ESVO world is
+        // into a voxel (a ray that started inside it walks it as an empty node), out of a node at scale 23 - depth; on the image of a
+        // CSVO world such a ray leaves for its excursion instead, and the deepest PUSH is one level higher. Where that is an LDS
+        // resident slot (scales >= kLdsBaseScale) the loop needs no hand-over test.
+        const uint32_t depth = ctx->image.depth();
+        const bool shallow = imaged && depth <= uint32_t(kLdsLevels) + (ctx->svo_type == VX_SVO_CSVO ? 1u : 0u);
+        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow);
+        int& per_cu = ctx->persistent_blocks[fn];
         if (per_cu == 0) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, wave_lds) != hipSuccess || n <= 0) n = 8;
@@ -732,35 +677,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.service_min = ctx->service_min;
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
-        PixelList todo = {nullptr, nullptr, 0, nullptr};
-        if (imaged) {
-            // per stream: a ring of chunks behind a counter that only ever grows -- nothing to reset between frames. A finished
-            // chunk holds at least 63 pixels, every wave can have one unfinished one: pixels / 63 + waves chunks per launch at most.
-            uint32_t*& ring = slot >= 0 ? ctx->d_frame_todo[slot] : ctx->d_main_todo;
-            size_t& have = slot >= 0 ? ctx->frame_todo_pixels[slot] : ctx->main_todo_pixels;
-            const size_t need = size_t(p.n_local_tiles) * kTile * kTile / 63 + waves + 1;
-            if (have < need) {
-                if (ring) {
-                    HIP_TRY(hipStreamSynchronize(stream));
-                    (void)hipFree(ring);
-                    ring = nullptr;
-                }
-                size_t cap = 64;
-                while (cap < need) cap <<= 1;
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ring), (cap * kChunkDwords + 32) * sizeof(uint32_t)));  // [counter, pad][chunks...]
-                HIP_TRY(hipMemsetAsync(ring, 0, 32 * sizeof(uint32_t), stream));
-                have = cap;
-            }
-            if (ctx->steer && waves <= vx_context::kMaxReportWaves) {
-                todo.report = ctx->d_re_rendered + size_t(slot + 1) * vx_context::kMaxReportWaves;
-                ctx->report_waves[slot + 1] = waves;
-                ctx->ring_pixels[slot + 1] = uint64_t(p.n_local_tiles) * kTile * kTile;
-            }
-            todo.next_chunk = ring;
-            todo.chunks = ring + 32;
-            todo.mask = uint32_t(have - 1);
-        }
-        void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, &todo};
+        void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
         tickets += a.total_subtiles + waves;
     }
@@ -799,6 +716,63 @@ int fill_params(const vx_uniforms* u, uint32_t w, uint32_t h, uint32_t tile_rank
     return VX_OK;
 }
 
+// one contiguous piece of a commit: `bytes` from host memory `src` to device memory `dst`
+struct Upload {
+    uint8_t* dst;
+    const uint8_t* src;
+    uint64_t bytes;
+};
+constexpr uint64_t kDeltaLimit = 64ull << 20;  // commits up to this size travel packed (one transfer, one scatter kernel)
+constexpr uint64_t kPiece = 32768;             // bytes one workgroup of the scatter kernel moves
+
+template <class WAIT>
+int upload_packed(vx_context* ctx, const std::vector<Upload>& up, WAIT&& wait_for_frames) {
+    // layout: [piece table: 3 x u64 each][payload, every upload padded so that it starts at its destination's address modulo 16]
+    uint64_t pieces = 0;
+    for (const Upload& u : up) pieces += (u.bytes + kPiece - 1) / kPiece;
+    if (pieces == 0) return wait_for_frames();
+    uint64_t at = (pieces * 24 + 15) & ~uint64_t(15);
+    std::vector<uint64_t> where(up.size());
+    for (size_t i = 0; i < up.size(); ++i) {
+        at = ((at + 15) & ~uint64_t(15)) + (reinterpret_cast<uintptr_t>(up[i].dst) & 15u);
+        where[i] = at;
+        at += up[i].bytes;
+    }
+    const uint64_t total = at;
+    vx_context::DeltaSlot& slot = ctx->delta[ctx->delta_next++ % vx_context::kDeltaSlots];
+    if (slot.used) HIP_TRY(hipEventSynchronize(slot.done));  // (three commits ago: long done)
+    if (slot.cap < total) {
+        if (slot.host) (void)hipHostFree(slot.host);
+        if (slot.dev) (void)hipFree(slot.dev);
+        slot.host = slot.dev = nullptr;
+        slot.cap = 0;
+        const size_t cap = size_t(total + total / 2 + 4096);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&slot.host), cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot.dev), cap));
+        slot.cap = cap;
+    }
+    if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    uint64_t* table = reinterpret_cast<uint64_t*>(slot.host);
+    uint64_t k = 0;
+    for (size_t i = 0; i < up.size(); ++i) {
+        if (!up[i].bytes) continue;
+        std::memcpy(slot.host + where[i], up[i].src, up[i].bytes);
+        for (uint64_t off = 0; off < up[i].bytes; off += kPiece, ++k) {
+            table[k * 3] = reinterpret_cast<uintptr_t>(up[i].dst) + off;
+            table[k * 3 + 1] = where[i] + off;
+            table[k * 3 + 2] = std::min(kPiece, up[i].bytes - off);
+        }
+    }
+    // the transfer needs no fence (the device twin is private to this commit): it runs while frames in flight finish
+    HIP_TRY(hipMemcpyAsync(slot.dev, slot.host, total, hipMemcpyHostToDevice, ctx->upload_stream));
+    if (int rc = wait_for_frames()) return rc;
+    hipLaunchKernelGGL(scatter_kernel, dim3(uint32_t(pieces)), dim3(256), 0, ctx->upload_stream, reinterpret_cast<const uint64_t*>(slot.dev), slot.dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(slot.done, ctx->upload_stream));
+    slot.used = true;
+    return VX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -818,8 +792,12 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     *out = nullptr;
     if (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO) return fail(VX_ERR_INVALID_ARGUMENT, "svo_type must be VX_SVO_ESVO or VX_SVO_CSVO");
     if (capacity_bytes < 64) return fail(VX_ERR_INVALID_ARGUMENT, "capacity_bytes too small");
-    if (capacity_bytes >= (size_t(1) << 32) - 64)
-        return fail(VX_ERR_CAPACITY, "world buffers of 4 GiB and more are not supported yet (32-bit buffer-resource offsets)");
+    // CSVO pointers are 31-bit byte offsets (bit 31 flags an absolute one, csvo.rs:100-105), ESVO pointers 32-bit indices of
+    // 4-byte words (esvo.rs:74-101): nothing beyond 4 GiB / 16 GiB could be referenced
+    if (svo_type == VX_SVO_CSVO && capacity_bytes >= (size_t(1) << 32) - 64)
+        return fail(VX_ERR_CAPACITY, "a CSVO world buffer cannot exceed 4 GiB: its pointers are byte offsets of at most 31 bits");
+    if (svo_type == VX_SVO_ESVO && capacity_bytes > (size_t(1) << 34))
+        return fail(VX_ERR_CAPACITY, "an ESVO world buffer cannot exceed 16 GiB: its pointers are 32-bit indices of 4-byte words");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(VX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= n) return fail(VX_ERR_NO_DEVICE, "device index out of range");
@@ -831,6 +809,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     c->device = device;
     c->capacity = (capacity_bytes + 15) & ~size_t(15);
     c->stats.capacity_bytes = capacity_bytes;
+    c->big = c->capacity + kWorldPad >= (size_t(1) << 32);  // beyond a buffer resource's 32-bit offsets
     auto cleanup = [&](int code) {
         vx_destroy(c);
         return code;
@@ -843,8 +822,10 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
             return cleanup(e_ == hipErrorOutOfMemory ? VX_ERR_OUT_OF_MEMORY : VX_ERR_HIP);                                 \
         }                                                                                                                  \
     } while (0)
-    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->staging), c->capacity, hipHostMallocDefault));
-    std::memset(c->staging, 0, c->capacity);
+    // (kStagingSlack bytes more than the caller may use: the reference's own call, write_changes_to(ptr + 4, len - 1, ..), checks its
+    // ranges against a length that ignores the writer's header (svo.rs:180-181, esvo.rs:328) and can run that far past the end)
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->staging), c->capacity + kStagingSlack, hipHostMallocDefault));
+    std::memset(c->staging, 0, c->capacity + kStagingSlack);
     // kWorldPad zero bytes follow the buffer and are inside the descriptor's range: an unaligned dword read that straddles
     // the end then returns the real bytes plus zeros (what the word-wise reference reads), not an all-zero dword
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_world), c->capacity + kWorldPad));
@@ -879,12 +860,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (c->frames_in_flight < 1) c->frames_in_flight = 1;
         if (c->frames_in_flight > vx_context::kFrameStreams) c->frames_in_flight = vx_context::kFrameStreams;
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VX_EYE_CHECK")) c->eye_check = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VX_IMAGE_STEERING")) c->steer = std::atoi(e) != 0;
-        const size_t report_bytes = size_t(vx_context::kFrameStreams + 1) * vx_context::kMaxReportWaves * sizeof(uint32_t);
-        CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_re_rendered), report_bytes, hipHostMallocMapped));
-        std::memset(c->h_re_rendered, 0, report_bytes);
-        CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_re_rendered), c->h_re_rendered, 0));
+        if (const char* e = std::getenv("VX_IMAGE_CAP_BYTES")) c->image_cap_bytes = size_t(std::strtoull(e, nullptr, 10));
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)
         int wide_image = 0;
@@ -911,38 +887,48 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
 void vx_destroy(vx_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->upload_stream) (void)hipStreamSynchronize(c->upload_stream);
+    (void)drain_streams(c);  // nothing may still be reading what is freed below
     for (auto& l : c->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     for (auto& l : c->event_pool) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     if (c->staging) (void)hipHostFree(c->staging);
     void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_frame, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
-                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_main_todo};
+                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
-        if (c->frame_stream[i]) (void)hipStreamSynchronize(c->frame_stream[i]);
         if (c->d_frame_counter[i]) (void)hipFree(c->d_frame_counter[i]);
-        if (c->d_frame_todo[i]) (void)hipFree(c->d_frame_todo[i]);
         if (c->frame_done[i]) (void)hipEventDestroy(c->frame_done[i]);
         if (c->frame_stream[i]) (void)hipStreamDestroy(c->frame_stream[i]);
+    }
+    for (auto& d : c->delta) {
+        if (d.host) (void)hipHostFree(d.host);
+        if (d.dev) (void)hipFree(d.dev);
+        if (d.done) (void)hipEventDestroy(d.done);
     }
     if (c->upload_done) (void)hipEventDestroy(c->upload_done);
     if (c->render_done) (void)hipEventDestroy(c->render_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
-    if (c->h_re_rendered) (void)hipHostFree(c->h_re_rendered);  // (the frame streams, which copy into it, are gone)
     delete c;
 }
 
 int vx_set_materials(vx_context* ctx, const vx_material* rows, uint32_t count) {
     if (!ctx || !rows || count == 0) return fail(VX_ERR_INVALID_ARGUMENT, "materials: null or empty");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // the new table is complete before anything is swapped; the old one is freed once every frame in flight (they hold its address
+    // in their kernel arguments, on any of the frame streams) has finished
+    vx_material* fresh = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fresh), size_t(count) * sizeof(vx_material)));
+    if (hipMemcpy(fresh, rows, size_t(count) * sizeof(vx_material), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(fresh);
+        return fail(VX_ERR_HIP, "materials: upload failed");
+    }
+    if (int rc = drain_streams(ctx)) {
+        (void)hipFree(fresh);
+        return rc;
+    }
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
-    ctx->d_materials = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_materials), size_t(count) * sizeof(vx_material)));
-    HIP_TRY(hipMemcpy(ctx->d_materials, rows, size_t(count) * sizeof(vx_material), hipMemcpyHostToDevice));
+    ctx->d_materials = fresh;
     ctx->n_materials = count;
     return VX_OK;
 }
@@ -985,11 +971,19 @@ int vx_set_textures(vx_context* ctx, const uint8_t* rgba8, uint32_t width, uint3
                     }
                 }
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (total >= (size_t(1) << 32)) return fail(VX_ERR_CAPACITY, "textures: the mip chain exceeds 4 GiB");
+    uint8_t* fresh = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fresh), total));
+    if (hipMemcpy(fresh, chain.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(fresh);
+        return fail(VX_ERR_HIP, "textures: upload failed");
+    }
+    if (int rc = drain_streams(ctx)) {  // frames in flight sample the old chain (see vx_set_materials)
+        (void)hipFree(fresh);
+        return rc;
+    }
     if (ctx->d_tex) (void)hipFree(ctx->d_tex);
-    ctx->d_tex = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_tex), total));
-    HIP_TRY(hipMemcpy(ctx->d_tex, chain.data(), total, hipMemcpyHostToDevice));
+    ctx->d_tex = fresh;
     ctx->tex_bytes = uint32_t(total);
     ctx->tex = t;
     return VX_OK;
@@ -997,72 +991,148 @@ int vx_set_textures(vx_context* ctx, const uint8_t* rgba8, uint32_t width, uint3
 
 uint8_t* vx_staging_ptr(vx_context* ctx) { return ctx ? ctx->staging : nullptr; }
 size_t vx_capacity(const vx_context* ctx) { return ctx ? size_t(ctx->stats.capacity_bytes) : 0; }
+size_t vx_arena_capacity(const vx_context* ctx) { return ctx ? size_t(ctx->stats.capacity_bytes) - 4 - header_bytes(ctx) : 0; }
 
 int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes) {
     if (!ctx || (count && !ranges)) return fail(VX_ERR_INVALID_ARGUMENT, "commit: null argument");
     if (depth > uint32_t(kMaxScale)) return fail(VX_ERR_INVALID_ARGUMENT, "depth exceeds the traversal's 23-level limit (svo.esvo.glsl:21)");
     HIP_TRY(hipSetDevice(ctx->device));
     const uint64_t head = 4 + header_bytes(ctx);
+    const uint64_t arena = ctx->stats.capacity_bytes - head;
+    if (used_bytes > arena) return fail(VX_ERR_CAPACITY, "dst is not large enough: used_bytes exceeds the world buffer");
     for (uint32_t i = 0; i < count; ++i)
-        if (ranges[i].start + ranges[i].length > ctx->stats.capacity_bytes - head || ranges[i].start + ranges[i].length < ranges[i].start)
+        if (ranges[i].start + ranges[i].length > arena || ranges[i].start + ranges[i].length < ranges[i].start)
             return fail(VX_ERR_CAPACITY, "dst is not large enough: a dirty range exceeds the world buffer");
 
     // octree_scale = 2^-depth as f32 at byte 0 (svo.rs:173-175)
     const float scale = std::exp2(-float(depth));
     std::memcpy(ctx->staging, &scale, 4);
 
-    // render_fence.wait() (svo.rs:178): do not overwrite nodes a frame in flight is still traversing
-    if (ctx->render_recorded) HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, ctx->render_done, 0));
-    for (int i = 0; i < vx_context::kFrameStreams; ++i)
-        if (ctx->frame_recorded[i]) HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, ctx->frame_done[i], 0));
-    HIP_TRY(hipMemcpyAsync(ctx->d_world, ctx->staging, head, hipMemcpyHostToDevice, ctx->upload_stream));
-    for (uint32_t i = 0; i < count; ++i) {
-        if (!ranges[i].length) continue;
-        const uint64_t off = head + ranges[i].start;
-        HIP_TRY(hipMemcpyAsync(ctx->d_world + off, ctx->staging + off, ranges[i].length, hipMemcpyHostToDevice, ctx->upload_stream));
+    // What goes to the device: the writer's header, the dirty arena ranges (neighbours closer than 4 KiB travel as one: the
+    // staging mirror holds the whole world, so the bytes between them are the device's own), and the parts of the traversal image
+    // and its origin table that the image update below rewrites.
+    std::vector<Upload> up;
+    up.push_back(Upload{ctx->d_world, ctx->staging, head});
+    {
+        std::vector<vx_range> r(ranges, ranges + count);
+        std::sort(r.begin(), r.end(), [](const vx_range& x, const vx_range& y) { return x.start < y.start; });
+        for (size_t i = 0; i < r.size();) {
+            uint64_t lo = r[i].start, hi = r[i].start + r[i].length;
+            size_t j = i + 1;
+            while (j < r.size() && r[j].start <= hi + 4096) {
+                hi = std::max(hi, r[j].start + r[j].length);
+                ++j;
+            }
+            if (hi > lo) up.push_back(Upload{ctx->d_world + head + lo, ctx->staging + head + lo, hi - lo});
+            i = j;
+        }
     }
+
+    bool image_ok = false;
     if (ctx->image_enabled && ctx->kernel_version != 1) {
-        // re-lay the changed chunks (and the root octree, which every commit rewrites) out as octants and upload those
+        // re-lay the changed chunks (and the root octree, which every commit rewrites) out as octants
         std::vector<vximg::Range> changed(count);
         for (uint32_t i = 0; i < count; ++i) changed[i] = vximg::Range{ranges[i].start, ranges[i].length};
         const unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        ctx->image_ok = ctx->image.update(ctx->staging, used_bytes, changed.data(), changed.size(), threads);
-        if (!ctx->image_ok && ctx->image.too_big() && ctx->image.layout() == vximg::kOct64) {
+        image_ok = ctx->image.update(ctx->staging, used_bytes, changed.data(), changed.size(), threads);
+        if (!image_ok && ctx->image.too_big() && ctx->image.layout() == vximg::kOct64) {
             // past what 32-bit byte offsets reach: from here on octant indices (the image is rebuilt once, whole)
             ctx->image = vximg::WorldImage(ctx->svo_type, vximg::kOct64Wide);
-            ctx->image_ok = ctx->image.update(ctx->staging, used_bytes, nullptr, 0, threads);
+            image_ok = ctx->image.update(ctx->staging, used_bytes, nullptr, 0, threads);
         }
-        if (ctx->image_ok) {
-            const size_t need = ctx->image.frame_bytes() + kWorldPad;
-            bool whole = false;
-            if (need > ctx->d_image_capacity) {
-                if (ctx->d_image) {  // frames in flight still read the old image
-                    HIP_TRY(hipStreamSynchronize(ctx->stream));
-                    for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
-                    HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
-                    (void)hipFree(ctx->d_image);
-                    ctx->d_image = nullptr;
-                }
-                const size_t cap = need + need / 2 + (1 << 20);
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_image), cap));
-                HIP_TRY(hipMemsetAsync(ctx->d_image, 0, cap, ctx->upload_stream));
+    }
+    // The image is an accelerator: whatever goes wrong with it (a world that cannot be imaged, no device memory for it), the
+    // context falls back to traversing the world's own bytes -- with nothing of a half-made image left behind.
+    auto drop_image = [&]() {
+        image_ok = false;
+        if (ctx->d_image || ctx->d_origin) (void)drain_streams(ctx);  // frames in flight still walk it
+        if (ctx->d_image) (void)hipFree(ctx->d_image);
+        if (ctx->d_origin) (void)hipFree(ctx->d_origin);
+        ctx->d_image = ctx->d_origin = nullptr;
+        ctx->d_image_capacity = ctx->d_origin_capacity = 0;
+        const vximg::Layout layout = ctx->image.layout();
+        ctx->image = vximg::WorldImage(ctx->svo_type, layout);  // the next commit rebuilds it whole
+    };
+    bool whole_image = false;
+    if (image_ok) {
+        const size_t need = ctx->image.frame_bytes() + kImagePad;
+        const size_t need_origin = ctx->image.has_origin() ? ctx->image.origin_bytes() + kImagePad : 0;
+        if (need > ctx->d_image_capacity || need_origin > ctx->d_origin_capacity) {
+            // grow both (frames in flight still read the old ones: wait for them), then everything is uploaded again
+            (void)drain_streams(ctx);
+            if (ctx->d_image) (void)hipFree(ctx->d_image);
+            if (ctx->d_origin) (void)hipFree(ctx->d_origin);
+            ctx->d_image = ctx->d_origin = nullptr;
+            ctx->d_image_capacity = ctx->d_origin_capacity = 0;
+            const size_t cap = std::min(need + need / 2 + (1 << 20), ctx->image_cap_bytes ? ctx->image_cap_bytes : ~size_t(0));
+            const size_t cap_origin = need_origin ? cap / 4 + kImagePad : 0;
+            bool ok = cap >= need && hipMalloc(reinterpret_cast<void**>(&ctx->d_image), cap) == hipSuccess;
+            if (ok && cap_origin) ok = hipMalloc(reinterpret_cast<void**>(&ctx->d_origin), cap_origin) == hipSuccess;
+            if (ok) ok = hipMemsetAsync(ctx->d_image, 0, cap, ctx->upload_stream) == hipSuccess;
+            if (ok && cap_origin) ok = hipMemsetAsync(ctx->d_origin, 0, cap_origin, ctx->upload_stream) == hipSuccess;
+            if (ok) {
                 ctx->d_image_capacity = cap;
-                whole = true;
-            }
-            const uint8_t* src = reinterpret_cast<const uint8_t*>(ctx->image.frame().data());
-            if (whole) {
-                HIP_TRY(hipMemcpyAsync(ctx->d_image, src, ctx->image.frame_bytes(), hipMemcpyHostToDevice, ctx->upload_stream));
+                ctx->d_origin_capacity = cap_origin;
+                whole_image = true;
             } else {
-                for (const vximg::Range& r : ctx->image.dirty_bytes())
-                    HIP_TRY(hipMemcpyAsync(ctx->d_image + r.start, src + r.start, r.length, hipMemcpyHostToDevice, ctx->upload_stream));
+                (void)hipGetLastError();  // (an allocation failure is not the caller's error: the bytes path serves)
+                drop_image();
+            }
+        }
+    } else if (ctx->image_enabled && ctx->kernel_version != 1) {
+        drop_image();
+    }
+    if (image_ok) {
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(ctx->image.frame().data());
+        const uint8_t* osrc = reinterpret_cast<const uint8_t*>(ctx->image.origin().data());
+        if (whole_image) {
+            up.push_back(Upload{ctx->d_image, src, ctx->image.frame_bytes()});
+            if (ctx->image.has_origin()) up.push_back(Upload{ctx->d_origin, osrc, ctx->image.origin_bytes()});
+        } else {
+            for (const vximg::Range& r : ctx->image.dirty_bytes()) {
+                up.push_back(Upload{ctx->d_image + r.start, src + r.start, r.length});
+                // two origin words per 32-byte unit of the frame
+                if (ctx->image.has_origin()) up.push_back(Upload{ctx->d_origin + r.start / 4, osrc + r.start / 4, (r.length + 3) / 4});
             }
         }
     }
+
+    // render_fence.wait() (svo.rs:178), on the device: nothing of this commit may land while a frame in flight is still traversing
+    // the nodes it replaces
+    auto wait_for_frames = [&]() -> int {
+        if (ctx->render_recorded) HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, ctx->render_done, 0));
+        for (int i = 0; i < vx_context::kFrameStreams; ++i)
+            if (ctx->frame_recorded[i]) HIP_TRY(hipStreamWaitEvent(ctx->upload_stream, ctx->frame_done[i], 0));
+        return VX_OK;
+    };
+    uint64_t total = 0;
+    for (const Upload& u : up) total += u.bytes;
+    int rc = VX_OK;
+    if (total <= kDeltaLimit) {
+        // many small pieces: ONE packed transfer + one scatter kernel, and the caller's staging mirror is free as soon as this
+        // function returns (no wait for the device)
+        rc = upload_packed(ctx, up, wait_for_frames);
+    } else {
+        rc = wait_for_frames();
+        for (size_t i = 0; i < up.size() && rc == VX_OK; ++i)
+            if (up[i].bytes && hipMemcpyAsync(up[i].dst, up[i].src, up[i].bytes, hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess)
+                rc = fail(VX_ERR_HIP, std::string("commit: upload failed: ") + hipGetErrorString(hipGetLastError()));
+        // the caller may rewrite the staging mirror as soon as we return: wait for the copies to have read it
+        if (rc == VX_OK && hipStreamSynchronize(ctx->upload_stream) != hipSuccess) rc = fail(VX_ERR_HIP, "commit: upload failed");
+    }
+    if (rc != VX_OK) {
+        // the device copy of the image can no longer be trusted; the world's own bytes may be incomplete too, which the caller
+        // learns from the error -- a later commit of the same ranges repairs both
+        const std::string why = g_last_error;
+        drop_image();
+        ctx->image_ok = false;
+        g_last_error = why;
+        return rc;
+    }
+    ctx->image_ok = image_ok;
     HIP_TRY(hipEventRecord(ctx->upload_done, ctx->upload_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_done, 0));
     for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamWaitEvent(ctx->frame_stream[i], ctx->upload_done, 0));
-    // the caller may rewrite the staging mirror as soon as we return: wait for the copies to have read it
-    HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
 
     ctx->stats.depth = depth;
     ctx->stats.used_bytes = used_bytes;
@@ -1158,7 +1228,9 @@ int vx_raycast(vx_context* ctx, const vx_picker_task* tasks, uint32_t count, vx_
     const size_t lds = Stack<64>::kBytes;
     const SceneArgs sc = scene_of(ctx);
     const dim3 grid((count + 63) / 64), block(64);
-    if (ctx->svo_type == VX_SVO_ESVO)
+    if (ctx->big)
+        hipLaunchKernelGGL((picker_kernel<VX_SVO_ESVO_BIG>), grid, block, lds, ctx->stream, sc, ctx->d_tasks, count, ctx->d_results);
+    else if (ctx->svo_type == VX_SVO_ESVO)
         hipLaunchKernelGGL((picker_kernel<VX_SVO_ESVO>), grid, block, lds, ctx->stream, sc, ctx->d_tasks, count, ctx->d_results);
     else
         hipLaunchKernelGGL((picker_kernel<VX_SVO_CSVO>), grid, block, lds, ctx->stream, sc, ctx->d_tasks, count, ctx->d_results);
@@ -1194,7 +1266,10 @@ int vx_debug_trace(vx_context* ctx, const float pos[3], const float dir[3], floa
     a.cast_translucent = cast_translucent;
     const size_t lds = Stack<64>::kBytes;
     const SceneArgs sc = scene_of(ctx);
-    if (ctx->svo_type == VX_SVO_ESVO)
+    if (ctx->big)
+        hipLaunchKernelGGL((trace_kernel<VX_SVO_ESVO_BIG>), dim3(1), dim3(64), lds, ctx->stream, sc, a, ctx->d_trace_result, ctx->d_trace_frames, max_frames,
+                           ctx->d_trace_count);
+    else if (ctx->svo_type == VX_SVO_ESVO)
         hipLaunchKernelGGL((trace_kernel<VX_SVO_ESVO>), dim3(1), dim3(64), lds, ctx->stream, sc, a, ctx->d_trace_result, ctx->d_trace_frames, max_frames,
                            ctx->d_trace_count);
     else
@@ -1270,13 +1345,20 @@ int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_fl
     return VX_OK;
 }
 
-uint64_t vx_traversal_image(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words) {
+uint64_t vx_traversal_image_with_origin(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words,
+                                        uint64_t capacity_words, uint32_t* out_origin_words, uint64_t origin_capacity_words) {
     if (!world_frame || layout < 0 || layout > 2 || (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO)) return 0;
     vximg::WorldImage img(svo_type, layout == 0 ? vximg::kEsvo48 : (layout == 1 ? vximg::kOct64 : vximg::kOct64Wide));
     if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(16u, std::thread::hardware_concurrency())))) return 0;
     const std::vector<uint32_t>& f = img.frame();
     if (out_words && capacity_words >= f.size()) std::memcpy(out_words, f.data(), f.size() * 4);
+    const std::vector<uint32_t>& o = img.origin();
+    if (out_origin_words && origin_capacity_words >= o.size() && !o.empty()) std::memcpy(out_origin_words, o.data(), o.size() * 4);
     return f.size();
+}
+
+uint64_t vx_traversal_image(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words) {
+    return vx_traversal_image_with_origin(svo_type, world_frame, used_bytes, layout, out_words, capacity_words, nullptr, 0);
 }
 
 int vx_resolve_2x2(vx_context* ctx, const float* src_rgba32f, uint32_t width, uint32_t height, float* dst_rgba32f, void* stream) {

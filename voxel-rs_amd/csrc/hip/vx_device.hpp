@@ -11,10 +11,9 @@
 // (-ffp-contract=off); the plane-distance expressions use explicit fmaf exactly where the oracle does.
 #pragma once
 
-#ifndef VX_DEVICE_ON_HOST
-#include <hip/hip_runtime.h>
-#endif
 #include <stdint.h>
+
+#include <vx_platform.hpp>  // the gfx950 primitives this file is written in (buffer loads, LDS address spaces, v_min3 ...)
 
 #include "voxel_hip.h"
 
@@ -25,33 +24,6 @@ constexpr int kMaxScale = 23;         // svo.esvo.glsl:21
 constexpr float kEps = 1.1920929e-7f;  // exp2(-23), svo.esvo.glsl:24
 constexpr uint32_t kInvalidPtr = 0xffffffffu;
 
-// Buffer resources (128-bit V#) for everything the rays read: 32-bit byte offsets instead of 64-bit pointers and the
-// hardware's range check instead of explicit clamps -- an out-of-range read returns 0, which is also what the CPU
-// oracle defines for reads beyond the world buffer, unknown block ids and missing texels.
-#ifndef VX_DEVICE_ON_HOST
-typedef __amdgpu_buffer_rsrc_t buf_t;
-__device__ __forceinline__ buf_t make_buf(const void* p, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, int(bytes), 0x00020000);
-}
-__device__ __forceinline__ uint32_t buf_u32(buf_t b, uint32_t off) { return uint32_t(__builtin_amdgcn_raw_buffer_load_b32(b, int(off), 0, 0)); }
-__device__ __forceinline__ uint32_t buf_u8(buf_t b, uint32_t off) { return uint32_t(__builtin_amdgcn_raw_buffer_load_b8(b, int(off), 0, 0)); }
-__device__ __forceinline__ uint4 buf_u128(buf_t b, uint32_t off) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(b, int(off), 0, 0);
-    return make_uint4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ uint2 buf_u64(buf_t b, uint32_t off) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b64(b, int(off), 0, 0);
-    return make_uint2(v[0], v[1]);
-}
-#else
-struct buf_t { const uint8_t* p; uint32_t bytes; };
-inline buf_t make_buf(const void* p, uint32_t bytes) { return buf_t{static_cast<const uint8_t*>(p), bytes}; }
-inline uint32_t buf_u32(buf_t b, uint32_t off) { uint32_t v = 0; if (uint64_t(off) + 4 <= b.bytes) std::memcpy(&v, b.p + off, 4); return v; }
-inline uint32_t buf_u8(buf_t b, uint32_t off) { return off < b.bytes ? b.p[off] : 0u; }
-inline uint4 buf_u128(buf_t b, uint32_t off) { uint4 v = {0, 0, 0, 0}; if (uint64_t(off) + 16 <= b.bytes) std::memcpy(&v, b.p + off, 16); return v; }
-inline uint2 buf_u64(buf_t b, uint32_t off) { uint2 v = {0, 0}; if (uint64_t(off) + 8 <= b.bytes) std::memcpy(&v, b.p + off, 8); return v; }
-#endif
-
 struct DevTextures {
     buf_t buf;                // mip chain, level l at level_offset[l], layout [layer][y][x][4]
     uint32_t width, height, layers, levels;
@@ -59,18 +31,24 @@ struct DevTextures {
 };
 
 struct DevScene {
-    buf_t world;              // device copy of the mapped world buffer, byte 0 = f32 octree_scale (< 4 GiB)
+    buf_t world;              // device copy of the mapped world buffer, byte 0 = f32 octree_scale (the first 4 GiB of it)
     buf_t materials;          // vx_material rows
     float octree_scale;       // = world[0]
     uint32_t root_ptr;        // CSVO: world[1]
     DevTextures tex;
-    const uint8_t* wide;      // VX_SVO_IMAGE_WIDE: the traversal image behind a plain 64-bit pointer (it may exceed 4 GiB)
+    // buffers that outgrow a V#'s 32-bit offsets are read through a plain 64-bit pointer: the traversal image in its wide layout
+    // (VX_SVO_IMAGE_WIDE), and an ESVO world of 4 GiB and more (VX_SVO_ESVO_BIG; descriptors[] indices stay 32 bits: 16 GiB)
+    const uint8_t* wide;
+    uint64_t wide_bytes;
+    // CSVO worlds only: where the image's voxel-parent octants come from in the world's own bytes (traversal_image.hpp, origin
+    // table), two dwords per 32-byte unit of the image -- read when a ray is led INTO a voxel (Trav::enter_voxel_on_bytes)
+    const uint8_t* origin;
 };
 
 // what the host passes to a kernel; expanded into a DevScene (descriptors in SGPRs) at kernel entry
 struct SceneArgs {
     const uint8_t* world;
-    uint32_t world_bytes;
+    uint64_t world_bytes;
     const vx_material* materials;
     uint32_t n_materials;
     const uint8_t* tex;
@@ -79,44 +57,45 @@ struct SceneArgs {
     uint32_t level_offset[16];
     const uint8_t* image;   // the traversal image of the world (traversal_image.hpp), or null
     uint64_t image_bytes;
+    const uint8_t* origin;  // its origin table (CSVO worlds), or null
 };
+
+__device__ __forceinline__ uint32_t clamp_u32(uint64_t v) { return v < 0xffffffffull ? uint32_t(v) : 0xffffffffu; }
 
 __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
     DevScene sc;
-    sc.world = make_buf(a.world, a.world_bytes);
+    sc.world = make_buf(a.world, clamp_u32(a.world_bytes));
     sc.materials = make_buf(a.materials, a.n_materials * uint32_t(sizeof(vx_material)));
     sc.tex.buf = make_buf(a.tex, a.tex_bytes);
     sc.tex.width = a.width; sc.tex.height = a.height; sc.tex.layers = a.layers; sc.tex.levels = a.levels;
     sc.tex.level_offset = a.level_offset;
     sc.octree_scale = __uint_as_float(buf_u32(sc.world, 0));
     sc.root_ptr = buf_u32(sc.world, 4);
-    sc.wide = nullptr;
+    sc.wide = a.world;
+    sc.wide_bytes = a.world_bytes;
+    sc.origin = nullptr;
     return sc;
 }
 
 // the same scene with the traversal image in place of the world buffer
 __device__ __forceinline__ DevScene make_image_scene(const SceneArgs& a) {
-    SceneArgs b = a;
-    b.world = a.image;
-    b.world_bytes = a.image_bytes < 0xffffffffull ? uint32_t(a.image_bytes) : 0xffffffffu;  // (a wide image is not read through this)
-    DevScene sc = make_scene(b);
-    sc.tex.level_offset = a.level_offset;  // (make_scene took the address of the copy's array)
+    DevScene sc;
+    sc.world = make_buf(a.image, clamp_u32(a.image_bytes));  // (a wide image is not read through this)
+    sc.materials = make_buf(a.materials, a.n_materials * uint32_t(sizeof(vx_material)));
+    sc.tex.buf = make_buf(a.tex, a.tex_bytes);
+    sc.tex.width = a.width; sc.tex.height = a.height; sc.tex.layers = a.layers; sc.tex.levels = a.levels;
+    sc.tex.level_offset = a.level_offset;
+    sc.octree_scale = __uint_as_float(buf_u32(sc.world, 0));
+    sc.root_ptr = 0;
     sc.wide = a.image;
+    sc.wide_bytes = a.image_bytes;
+    sc.origin = a.origin;
     return sc;
 }
 
 // wide images: pointers count 32-byte units from the start of the image (the header is unit 0)
-#ifndef VX_DEVICE_ON_HOST
-__device__ __forceinline__ uint2 wide_entry(const DevScene& sc, uint32_t octant, uint32_t child) {
-    return *reinterpret_cast<const uint2*>(sc.wide + (uint64_t(octant) << 5) + child * 8u);
-}
-__device__ __forceinline__ uint32_t wide_u32(const DevScene& sc, uint32_t octant, uint32_t byte) {
-    return *reinterpret_cast<const uint32_t*>(sc.wide + (uint64_t(octant) << 5) + byte);
-}
-#else
-inline uint2 wide_entry(const DevScene& sc, uint32_t octant, uint32_t child) { uint2 v; std::memcpy(&v, sc.wide + (uint64_t(octant) << 5) + child * 8u, 8); return v; }
-inline uint32_t wide_u32(const DevScene& sc, uint32_t octant, uint32_t byte) { uint32_t v; std::memcpy(&v, sc.wide + (uint64_t(octant) << 5) + byte, 4); return v; }
-#endif
+__device__ __forceinline__ uint2 wide_entry(const DevScene& sc, uint32_t octant, uint32_t child) { return mem_u64(sc.wide + (uint64_t(octant) << 5) + child * 8u); }
+__device__ __forceinline__ uint32_t wide_u32(const DevScene& sc, uint32_t octant, uint32_t byte) { return mem_u32(sc.wide + (uint64_t(octant) << 5) + byte); }
 
 struct Result {
     float t;
@@ -142,19 +121,6 @@ struct Counters {  // per-thread, reduced by the instrumented kernel
 // pushes are kept too -- in a per-thread spill array that ordinary rays never touch.
 constexpr int kLdsLevels = 13;
 constexpr int kLdsBaseScale = kMaxScale - kLdsLevels;  // scales [kLdsBaseScale, 22] are LDS resident
-
-// LDS and scratch are reached through address-space-qualified pointers only: a generic pointer would turn every stack
-// access into a flat_ instruction plus an aperture test.
-#ifndef VX_DEVICE_ON_HOST
-// the one dynamic-LDS array of every kernel in this library (16-byte aligned base, cdna guide G17)
-extern __shared__ __attribute__((aligned(16))) unsigned char vx_smem[];
-#define VX_AS_LDS __attribute__((address_space(3)))
-#define VX_AS_PRIVATE __attribute__((address_space(5)))
-#else
-extern unsigned char* vx_smem;
-#define VX_AS_LDS
-#define VX_AS_PRIVATE
-#endif
 
 // per-thread backing store for the levels below the LDS-resident ones (lives in scratch)
 struct StackSpill {
@@ -202,40 +168,9 @@ struct Stack {
     }
 };
 
-// bit `pos` of `v` (one v_bfe_u32)
-#ifndef VX_DEVICE_ON_HOST
-__device__ __forceinline__ uint32_t bit_at(uint32_t v, int pos) { return __builtin_amdgcn_ubfe(v, uint32_t(pos), 1u); }
-#else
-inline uint32_t bit_at(uint32_t v, int pos) { return (v >> pos) & 1u; }
-#endif
-
-// instruction-scheduling fence: nothing is moved across it (orders memory requests against the arithmetic that hides them)
-#ifndef VX_DEVICE_ON_HOST
-__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-#else
-inline void sched_fence() {}
-#endif
-
 __device__ __forceinline__ float gmin(float x, float y) { return y < x ? y : x; }  // GLSL min
 __device__ __forceinline__ float gmax(float x, float y) { return x < y ? y : x; }  // GLSL max
 __device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
-// min / max of three plane distances. The operands are never NaN or -0 for finite rays (p >= 1, t_coef != 0: see
-// Trav::init), where the hardware's single v_min3/v_max3 and the GLSL chain agree bit for bit.
-#ifndef VX_DEVICE_ON_HOST
-__device__ __forceinline__ float gmin3(float x, float y, float z) {
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
-    return r;
-}
-__device__ __forceinline__ float gmax3(float x, float y, float z) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
-    return r;
-}
-#else
-inline float gmin3(float x, float y, float z) { return gmin(gmin(x, y), z); }
-inline float gmax3(float x, float y, float z) { return gmax(gmax(x, y), z); }
-#endif
 __device__ __forceinline__ uint32_t low_bits(int n) { return n >= 32 ? 0xffffffffu : (n <= 0 ? 0u : ((1u << n) - 1u)); }
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float(uint32_t(e + 127) << 23); }
 __device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
@@ -426,9 +361,11 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
 //         (and on the stack); the pointer-table entry is only read by the iteration that descends through it.
 // kTravDeep (fast stacks only): the next PUSH would leave the LDS-resident levels; the cursor is untouched and the caller
 // continues this ray with a full stack.
-// kTravForeign (FOREIGN steps only, i.e. a traversal image): the ray is about to be led INTO a leaf (it started inside that
-// voxel, svo.esvo.glsl:183-185); what follows depends on the bytes behind the leaf in the world's own format, so the caller
-// restarts this ray on the original buffer.
+// kTravForeign (FOREIGN steps only: the traversal image of a CSVO world): the ray is about to be led INTO a voxel (it started
+// inside it, svo.csvo.glsl:293-295). What the reference does in there depends on the bytes that follow the voxel's parent in the
+// world's own buffer (read_next_ptr, svo.csvo.glsl:107-115, applied below the leaves), so the caller lets the ray make that
+// excursion on the world's own bytes and bring it back to the image (enter_voxel_on_bytes). The iteration is repeated there: the
+// caller takes `iter` back by one, as for kTravDeep. (An ESVO world's image needs none of this: see the PUSH in step_with.)
 // (the values are the render kernel's lane states -- kTrav, kLeaf, kMissed, kDeep, kForeign -- so that it can store a status as is)
 enum TravStatus : int { kTravContinue = 1, kTravAtLeaf = 2, kTravFinished = 4, kTravDeep = 5, kTravForeign = 6 };
 enum LeafOutcome : int { kLeafHit = 0, kLeafPassed = 1, kLeafPassedAndFinished = 2 };
@@ -449,12 +386,25 @@ typedef VX_AS_PRIVATE TraceSink* TracePtr;
 #define VX_SVO_IMAGE 3
 // the same with octant INDICES for pointers and 64-bit addressing: images beyond 4 GiB (traversal_image.hpp, kOct64Wide)
 #define VX_SVO_IMAGE_WIDE 4
+// an ESVO world buffer of 4 GiB and more: the reference's format unchanged (descriptors[] indices are 32 bits, esvo.rs:74-101),
+// read through a 64-bit pointer with an explicit range check instead of the V#'s
+#define VX_SVO_ESVO_BIG 5
 
 template <int SVO>
 struct Trav {
     static constexpr bool CSVO = SVO == VX_SVO_CSVO;
     static constexpr bool WIDE = SVO == VX_SVO_IMAGE_WIDE;
     static constexpr bool IMG = SVO == VX_SVO_IMAGE || WIDE;
+    static constexpr bool BIG = SVO == VX_SVO_ESVO_BIG;
+
+    // ESVO: descriptors[index] (svo.esvo.glsl:3-6); beyond the buffer reads 0 either way
+    __device__ __forceinline__ static uint32_t word(const DevScene& sc, uint32_t index) {
+        if (BIG) {
+            const uint64_t off = 4ull + uint64_t(index) * 4ull;
+            return off + 4ull <= sc.wide_bytes ? mem_u32(sc.wide + off) : 0u;
+        }
+        return esvo_word(sc, index);
+    }
 
     float rox, roy, roz, rdx, rdy, rdz;   // origin in [1,2) space, epsilon-clamped direction
     float tcx, tcy, tcz, tbx, tby, tbz;   // t(x) = x * t_coef - t_bias per axis
@@ -493,14 +443,6 @@ struct Trav {
         max_dst = max_dst_in * octree_scale;
         rox += 1.0f; roy += 1.0f; roz += 1.0f;
 
-        scale = kMaxScale - 1;
-        scale_exp2 = 0.5f;
-        last_leaf_value = 0xffffffffu;
-        flags = 0;
-        material_section_ptr = kInvalidPtr;
-        pre_leaf_pointer = kInvalidPtr;
-        iter = 0;
-
         rdx = rd_in[0]; rdy = rd_in[1]; rdz = rd_in[2];
         const uint32_t eps_bits = __float_as_uint(kEps) & 0x7fffffffu;
         if (fabsf(rdx) < kEps) rdx = __uint_as_float(eps_bits | (__float_as_uint(rdx) & 0x80000000u));
@@ -514,6 +456,20 @@ struct Trav {
         if (rdx > 0.0f) { octant_mask ^= 1; tbx = __builtin_fmaf(3.0f, tcx, -tbx); }
         if (rdy > 0.0f) { octant_mask ^= 2; tby = __builtin_fmaf(3.0f, tcy, -tby); }
         if (rdz > 0.0f) { octant_mask ^= 4; tbz = __builtin_fmaf(3.0f, tcz, -tbz); }
+        start<TRACE>(sc, tk);
+    }
+
+    // The cursor at the root, for the ray whose constants (origin, direction, t_coef, t_bias, octant_mask, max_dst) are in place:
+    // the second half of the reference's set-up (svo.esvo.glsl:126-150). Also how a ray is started over (enter_voxel_on_bytes).
+    template <bool TRACE = false>
+    __device__ __forceinline__ void start(const DevScene& sc, TracePtr tk = nullptr) {
+        scale = kMaxScale - 1;
+        scale_exp2 = 0.5f;
+        last_leaf_value = 0xffffffffu;
+        flags = 0;
+        material_section_ptr = kInvalidPtr;
+        pre_leaf_pointer = kInvalidPtr;
+        iter = 0;
 
         t_min = gmax(gmax(__builtin_fmaf(2.0f, tcx, -tbx), __builtin_fmaf(2.0f, tcy, -tby)), __builtin_fmaf(2.0f, tcz, -tbz));
         t_min = gmax(0.0f, t_min);
@@ -528,7 +484,7 @@ struct Trav {
 
         if (CSVO) {
             ptr = sc.root_ptr;
-            depth = 127u - ((__float_as_uint(octree_scale) >> 23) & 0xffu);  // svo.csvo.glsl:254
+            depth = 127u - ((__float_as_uint(sc.octree_scale) >> 23) & 0xffu);  // svo.csvo.glsl:254
             node = csvo_header(sc);
             if (depth == 2) pre_leaf_pointer = ptr;
         } else if (IMG) {
@@ -538,8 +494,8 @@ struct Trav {
         } else {
             // the reference starts at (ptr 0, parent_octant_idx 0): the preamble is an octant whose only child is the root
             depth = 0;
-            node = esvo_word(sc, 0);
-            const uint32_t w = esvo_word(sc, 4);
+            node = word(sc, 0);
+            const uint32_t w = word(sc, 4);
             ptr = (w & 0x80000000u) ? 4u + (w & 0x7fffffffu) : w;
             if (TRACE) { tk->ref_ptr = 0; tk->ref_aux = 0; }
         }
@@ -715,11 +671,16 @@ struct Trav {
                 // one aligned 8-byte entry: the child's octant and the child's masks (no clamp: image pointers are valid by construction)
                 const uint2 e = WIDE ? wide_entry(sc, ptr, octant_idx) : buf_u64(sc.world, ptr + octant_idx * 8u);
                 w0 = e.x;
-                w1 = e.y;
+                // A ray that starts inside a voxel is led INTO it (the leaf was not accepted above: t_min <= 0). In an ESVO world a voxel's
+                // own masks are zero in everything the serializer writes (esvo.rs:465-485 never ORs a leaf's masks into its parent's
+                // header; the transcoder refuses worlds where that is not so), so the reference walks the voxel as an empty node: so
+                // do we, whatever the entry holds (an octant of voxels has values where others have entries). The pointer is never used.
+                // The image of a CSVO world never gets here (FOREIGN: Trav::enter_voxel_on_bytes).
+                w1 = (!FOREIGN && is_leaf) ? 0u : e.y;
             } else if (!CSVO) {
                 // the child's pointer word and the header word with its masks, both in the octant at `ptr`
-                w0 = esvo_word(sc, ptr + 4 + octant_idx);
-                w1 = esvo_word(sc, ptr + (octant_idx >> 1));
+                w0 = word(sc, ptr + 4 + octant_idx);
+                w1 = word(sc, ptr + (octant_idx >> 1));
             } else {
                 // read_next_ptr (svo.csvo.glsl:53-116) with the (normalised) header already at hand: internal nodes (2-byte
                 // header, 1/2/4-byte table entries) and the depth-3 level (1-byte header, 1-byte entries) are the same
@@ -805,7 +766,7 @@ struct Trav {
         const uint32_t value = CSVO  ? csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx)
                                : WIDE ? wide_u32(sc, ptr, octant_idx * image_value_stride())
                                : IMG  ? buf_u32(sc.world, ptr + octant_idx * image_value_stride())
-                                     : esvo_word(sc, ptr + 4 + octant_idx);
+                                     : word(sc, ptr + 4 + octant_idx);
 
         const float ex = __builtin_fmaf(px + scale_exp2, tcx, -tbx);
         const float ey = __builtin_fmaf(py + scale_exp2, tcy, -tby);
@@ -874,6 +835,121 @@ struct Trav {
     }
 };
 
+// ---- CSVO worlds on their image: a ray that is led into a voxel ------------------------------------------------------
+//
+// The image cursor `tr` stopped with kTravForeign: child `idx` of the node it examines (a voxel's parent, i.e. the image of a
+// leaf-mask byte L of the world, svo.csvo.glsl:114-115) is a voxel the ray's origin lies in. The reference now PUSHes into the
+// voxel: it takes the byte at L + 3 + popcount(L's mask below idx) for the voxel's "node" and keeps going on whatever follows
+// (phantom leaves with materials looked up through read_leaf included) until the ray steps out of the voxel. That walk only
+// makes sense on the world's own bytes, so it is made there, with the reference's own cursor, from exactly the state the image
+// cursor is in -- the image's origin table (traversal_image.hpp) says where L, its depth-2 parent and the chunk's material
+// section are in the world. It ends when (a) a POP brings the ray back to the voxel's parent or above: from there on every
+// node is a real one again and the ray continues on the image (kTravContinue: `tr` is the cursor to go on with; the stack
+// slots at and above the parent's scale hold image entries, the excursion only ever writes below them); (b) a phantom leaf
+// is accepted (kTravAtLeaf: `res` is the hit); (c) the ray ends (kTravFinished: a miss).
+// `st` is a full stack (the excursion can go below the LDS-resident levels). The iteration `tr` stopped in is repeated here, so
+// `tr.iter` must not count it (the caller took it back, as for kTravDeep); on return `tr.iter` counts everything that ran.
+template <int IMGSVO, class ST, bool LIMIT = false>
+__device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, const DevScene& bytes, Trav<IMGSVO>& tr, const ST& st,
+                                                           bool cast_translucent, Result& res) {
+    static_assert(!ST::kFast, "the excursion needs every stack level");
+    typedef Trav<VX_SVO_CSVO> ByteTrav;
+    const int parent_scale = tr.scale;
+    const uint32_t img_ptr = tr.ptr, img_node = tr.node;
+    const float parent_t_max = tr.t_max;
+
+    ByteTrav tb;
+    tb.rox = tr.rox; tb.roy = tr.roy; tb.roz = tr.roz; tb.rdx = tr.rdx; tb.rdy = tr.rdy; tb.rdz = tr.rdz;
+    tb.tcx = tr.tcx; tb.tcy = tr.tcy; tb.tcz = tr.tcz; tb.tbx = tr.tbx; tb.tby = tr.tby; tb.tbz = tr.tbz;
+    tb.px = tr.px; tb.py = tr.py; tb.pz = tr.pz;
+    tb.t_min = tr.t_min; tb.t_max = tr.t_max; tb.h = tr.h; tb.scale_exp2 = tr.scale_exp2; tb.max_dst = tr.max_dst;
+    tb.last_leaf_value = tr.last_leaf_value; tb.flags = tr.flags;
+    tb.scale = tr.scale; tb.octant_mask = tr.octant_mask; tb.iter = tr.iter;
+    tb.idx = tr.idx_from_position();  // (the image cursor reads the child index off the position)
+    // origin table: two dwords per 32-byte unit of the image, [0] = byte pointer of L, [1] = k << 29 | (L - material section),
+    // k = L's place among its depth-2 parent's leaf-mask bytes
+    const uint64_t unit = Trav<IMGSVO>::WIDE ? uint64_t(tr.ptr) : uint64_t(tr.ptr >> 5);
+    const uint32_t o0 = mem_u32(img.origin + unit * 8u), o1 = mem_u32(img.origin + unit * 8u + 4u);
+    tb.ptr = o0;
+    tb.depth = 1;
+    tb.material_section_ptr = o0 - (o1 & 0x1fffffffu);
+    tb.pre_leaf_pointer = o0 - 3u - (o1 >> 29);
+    tb.node = tb.csvo_header(bytes);
+
+    // Back among real nodes. The byte cursor carries two pieces of state besides its stack that the walk inside the voxel may have
+    // overwritten (a phantom depth-2 node, a phantom chunk boundary): `pre_leaf_pointer` and `material_section_ptr`, which say where
+    // read_leaf finds a voxel's material (svo.csvo.glsl:119-133). The reference goes on with whatever they hold now. If that is what
+    // they held before -- or, for pre_leaf_pointer, if the ray is back above the voxel's parent, where the next depth-2 node it
+    // enters sets it afresh (svo.csvo.glsl:283) -- the rest of the ray is what the image gives. If not, the voxels it hits from here
+    // on report materials read through the overwritten pointers: such a ray is started over and run on the world's own bytes
+    // from the root (the reference's cursor throughout; `false` is returned and `tb` is at the root again).
+    const uint32_t true_material_section = tb.material_section_ptr, true_pre_leaf = tb.pre_leaf_pointer;
+    auto back_on_image = [&](bool popped) -> bool {
+        if (tb.material_section_ptr != true_material_section || (tb.scale == parent_scale && tb.pre_leaf_pointer != true_pre_leaf)) {
+            tb.start(bytes);
+            return false;
+        }
+        tr.px = tb.px; tr.py = tb.py; tr.pz = tb.pz;
+        tr.t_min = tb.t_min; tr.h = tb.h; tr.scale = tb.scale; tr.scale_exp2 = tb.scale_exp2;
+        tr.last_leaf_value = tb.last_leaf_value; tr.flags = tb.flags; tr.iter = tb.iter;
+        if (popped) {  // the slot the POP read holds an image entry (the byte cursor misread it): read it as one
+            uint32_t a;
+            st.pop(tb.scale, tr.ptr, tr.t_max, a);
+            tr.node = a;
+        }
+        return true;
+    };
+    // the rest of a ray that was started over: the reference's loop on the world's own bytes
+    auto whole_ray_on_bytes = [&]() -> TravStatus {
+        for (;;) {
+            TravStatus w = tb.template step<false, false, LIMIT, ST>(bytes, st, nullptr, nullptr);
+            if (w == kTravAtLeaf) {
+                const LeafOutcome o = tb.template leaf_test<false, false>(bytes, st, cast_translucent, res, nullptr, nullptr);
+                if (o == kLeafHit) {
+                    tr.iter = tb.iter;
+                    return kTravAtLeaf;
+                }
+                w = o == kLeafPassed ? kTravContinue : kTravFinished;
+            }
+            if (w == kTravFinished) {
+                tr.flags = tb.flags;
+                tr.iter = tb.iter;
+                return kTravFinished;
+            }
+        }
+    };
+
+    // the iteration the image cursor stopped in, again: PUSH into the voxel -- or ADVANCE, if the voxel's span is empty
+    TravStatus s = tb.template step<false, false, LIMIT, ST>(bytes, st, nullptr, nullptr);
+    if (s == kTravFinished) {
+        tr.flags = tb.flags;  // (inside_voxel is part of a miss)
+        tr.iter = tb.iter;
+        return kTravFinished;
+    }
+    if (tb.scale >= parent_scale)  // advanced to a sibling (still at the voxel's parent: the image cursor's node is the same), or popped
+        return back_on_image(tb.scale > parent_scale) ? kTravContinue : whole_ray_on_bytes();
+    // inside the voxel. The PUSH wrote the parent's entry as the byte cursor sees it (where the reference's `tc_max < h` let it):
+    // the way back needs the image's (writing it where the reference wrote nothing is harmless: such a slot is never popped)
+    st.push(parent_scale, img_ptr, parent_t_max, img_node);
+    for (;;) {
+        s = tb.template step<false, false, LIMIT, ST>(bytes, st, nullptr, nullptr);
+        if (s == kTravAtLeaf) {
+            const LeafOutcome o = tb.template leaf_test<false, false>(bytes, st, cast_translucent, res, nullptr, nullptr);
+            if (o == kLeafHit) {
+                tr.iter = tb.iter;
+                return kTravAtLeaf;
+            }
+            s = o == kLeafPassed ? kTravContinue : kTravFinished;
+        }
+        if (s == kTravFinished) {
+            tr.flags = tb.flags;  // (inside_voxel is part of a miss)
+            tr.iter = tb.iter;
+            return kTravFinished;
+        }
+        if (tb.scale >= parent_scale) return back_on_image(true) ? kTravContinue : whole_ray_on_bytes();
+    }
+}
+
 __device__ __forceinline__ void result_miss(Result& res, bool inside_voxel) {
     res.t = -1.0f;
     res.value = 0;
@@ -918,15 +994,6 @@ struct RenderParams {
     uint32_t tiles_x, tiles_y;
     uint32_t tile_rank, tile_count, n_local_tiles;
 };
-
-// pow() as GLSL defines it -- exp2(y * log2(x)), x >= 0 -- on the hardware's log2/exp2 (1 ulp each): within 1.2e-7 absolute of
-// the correctly rounded x^y for x in [0, 1 + 1e-4], y in [0, 1000] (27 M points measured on gfx950), at 5 instructions instead
-// of the ~170 of a correctly rounded powf. Colour only (the specular term), inside the stated colour tolerance.
-#ifndef VX_DEVICE_ON_HOST
-__device__ __forceinline__ float glsl_pow(float x, float y) { return y == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
-#else
-inline float glsl_pow(float x, float y) { return powf(x, y); }
-#endif
 
 __device__ __forceinline__ float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void normalize3(const float v[3], float out[3]) {

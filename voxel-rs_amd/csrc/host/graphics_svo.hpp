@@ -135,8 +135,8 @@ public:
     // Svo::update (svo.rs:171-189)
     void update(WorldSvoSource& svo) {
         const std::vector<Range> dirty = svo.updated_ranges();
-        const size_t cap = vx_capacity(ctx_);
-        if (!svo.write_changes_to(vx_staging_ptr(ctx_) + 4, cap - 1, true)) fail("dst is not large enough");
+        // dst_len: the room behind the writer's header, which is what the writers check their ranges against (esvo.rs:328)
+        if (!svo.write_changes_to(vx_staging_ptr(ctx_) + 4, vx_arena_capacity(ctx_), true)) fail("dst is not large enough");
         std::vector<vx_range> ranges;
         for (const Range& r : dirty) ranges.push_back(vx_range{r.start, r.length});
         check(vx_commit(ctx_, svo.depth(), ranges.data(), uint32_t(ranges.size()), svo.size_in_bytes()));

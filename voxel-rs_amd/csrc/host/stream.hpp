@@ -157,8 +157,7 @@ public:
             }
             st.ranges = uint32_t(ranges.size());
             if (ctx) {
-                const size_t cap = vx_capacity(ctx);
-                if (!world_.write_changes_to(vx_staging_ptr(ctx) + 4, cap - 1, true)) throw std::runtime_error("world buffer capacity exceeded");
+                if (!world_.write_changes_to(vx_staging_ptr(ctx) + 4, vx_arena_capacity(ctx), true)) throw std::runtime_error("world buffer capacity exceeded");
                 if (vx_commit(ctx, world_.depth(), ranges.data(), uint32_t(ranges.size()), world_.size_in_bytes()) != VX_OK) throw std::runtime_error(vx_last_error());
             } else if (on_dry_commit) {
                 on_dry_commit(world_, ranges);  // host-only tests: someone else plays the device (must consume the ranges)

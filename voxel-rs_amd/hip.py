@@ -79,6 +79,8 @@ SYMBOLS = {
     "vx_wait_event": (_int, [_vp, _vp]),
     "vx_stream_wait_render": (_int, [_vp, _vp]),
     "vx_traversal_image": (_u64, [_int, _vp, _u64, _int, _vp, _u64]),
+    "vx_traversal_image_with_origin": (_u64, [_int, _vp, _u64, _int, _vp, _u64, _vp, _u64]),
+    "vx_arena_capacity": (_sz, [_vp]),
     "vx_resolve_2x2": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "vx_assemble_tiles": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "vx_assemble_tiles_on": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp]),
@@ -134,16 +136,19 @@ def local_tile_count(width, height, rank, count):
     return lib().vx_local_tile_count(width, height, rank, count)
 
 
-def traversal_image(svo_type, world_frame_words, used_bytes, layout=0):
+def traversal_image(svo_type, world_frame_words, used_bytes, layout=0, with_origin=False):
     """vx_traversal_image: world frame (uint32 words: scale, header, arena...) -> traversal image (uint32 words);
-    layout 0 = ESVO frame (walkable by any ESVO traversal), 1 = the 64-byte-octant layout the renderer walks."""
+    layout 0 = ESVO frame (walkable by any ESVO traversal), 1 = the 64-byte-octant layout the renderer walks, 2 = the same
+    with 32-byte units for pointers. with_origin: also the origin table (CSVO worlds, layouts 1 and 2; else all zeros)."""
     f = np.ascontiguousarray(world_frame_words, dtype=np.uint32)
     n = lib().vx_traversal_image(svo_type, f.ctypes.data_as(_vp), used_bytes, layout, None, 0)
     if n == 0:
         raise ValueError("this world frame cannot be imaged")
     out = np.zeros(n, dtype=np.uint32)
-    lib().vx_traversal_image(svo_type, f.ctypes.data_as(_vp), used_bytes, layout, out.ctypes.data_as(_vp), n)
-    return out
+    origin = np.zeros((n + 3) // 4, dtype=np.uint32)
+    lib().vx_traversal_image_with_origin(svo_type, f.ctypes.data_as(_vp), used_bytes, layout, out.ctypes.data_as(_vp), n,
+                                         origin.ctypes.data_as(_vp), origin.size)
+    return (out, origin) if with_origin else out
 
 
 class Svo:
@@ -176,9 +181,8 @@ class Svo:
     # -- Svo::update (svo.rs:171-189) ---------------------------------------------------------------------
     def update(self, world):
         ranges = world.updated_ranges()
-        cap = lib().vx_capacity(self._h)
         staging = lib().vx_staging_ptr(self._h)
-        world.write_changes_to(staging + 4, cap - 1, True)
+        world.write_changes_to(staging + 4, lib().vx_arena_capacity(self._h), True)
         arr = (Range * max(len(ranges), 1))()
         for i, (s, n) in enumerate(ranges):
             arr[i].start, arr[i].length = s, n
