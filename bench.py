@@ -44,18 +44,31 @@ def algorithmic_bytes(fmt, c):
 
 
 def measured_traffic(fmt):
-    """HBM-side bytes per launch of the render kernel on this workload, from the committed rocprofv3 --pmc passes of this
-    same command (profiles/profile.sh -> profiles/round1/traffic.json); PMC counters cannot be read from inside this run."""
-    try:
-        return json.loads((ROOT / "profiles" / "round1" / "traffic.json").read_text())[fmt]["bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM-side bytes per launch of the render kernel on this workload: a STORED artifact -- the committed rocprofv3 --pmc passes
+    of this same command (profiles/profile.sh -> profiles/round2/traffic.json, which names the commit it was measured at); PMC
+    counters cannot be read from inside this run. Returns (bytes, source) or (None, None)."""
+    for rnd in ("round2", "round1"):
+        try:
+            t = json.loads((ROOT / "profiles" / rnd / "traffic.json").read_text())
+            return t[fmt]["bytes_per_launch"], f"profiles/{rnd}/traffic.json" + (f" @ {t['commit']}" if "commit" in t else "")
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def image_model_bytes(c):
+    """What the kernel that is TIMED fetches by the same accounting: it walks the traversal image, whichever format the world is
+    in -- one 8-byte entry per PUSH, a 4-byte value + the 32-byte material row + texel(s) per leaf test, nothing per iteration --
+    plus the same per-pixel terms."""
+    nearest = c["leaf_tests"] - c["leaf_tests_trilinear"]
+    return 8 * c["pushes"] + c["leaf_tests"] * (4 + 32) + nearest * 4 + c["leaf_tests_trilinear"] * 32 + 16 * c["pixels"] + c["lit_pixels"] * (32 + 4)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=25, help="the timed block of --steps frames is run this many times; the MEDIAN block is reported")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--width", type=int, default=1920)
@@ -68,6 +81,8 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (tile lists, RCCL gather, assembly) even with one rank; needs a torch.distributed.run launch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock target for the cpu_baseline sample (all host cores)")
+    ap.add_argument("--textures", choices=["assets", "procedural"], default="assets",
+                    help="assets: the reference's own 64x64 textures (tests/golden/textures) for the blocks the terrain uses")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,7 +123,8 @@ def main():
     world = vra.World(fmt)
     st = world.build_heightfield(args.depth)
     build_s = time.time() - t0
-    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    tex = scenes.asset_textures() if args.textures == "assets" else scenes.synthetic_textures()
+    mats = scenes.synthetic_materials()
     svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20), device=local_rank)
     svo.set_materials(mats)
     svo.set_textures(tex, 6)
@@ -190,25 +206,50 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # The timed block -- exactly --steps frames between two barriers -- is run --repeats times back to back and the MEDIAN block is
+    # what is reported: 50 frames are 25 ms of GPU time, too little for one sample to stand on.
     svo.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    enqueue_s = time.perf_counter() - t0  # host time to issue the steps (a lower bound of the step time: the loop is asynchronous)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    blocks, enqueue = [], []
+    for _ in range(max(args.repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        enqueue.append(time.perf_counter() - t0)  # host time to issue the steps (the loop is asynchronous)
+        barrier()
+        blocks.append(time.perf_counter() - t0)
     kernel_ms, launches = svo.profile_read()
     svo.profile_enable(False)
+    enqueue_s = sorted(enqueue)[len(enqueue) // 2]
 
-    stats = torch.tensor([elapsed, float(my_rays), float(my_bytes), kernel_ms / max(launches, 1)], dtype=torch.float64, device="cuda")
+    # One frame at a time (outside the timed region): with several frames in flight a kernel's HIP-event span includes the time it
+    # shares the device with its neighbours, so the kernel's OWN duration -- what the roofline fraction is defined on -- is measured
+    # with the frames serialised on one stream.
+    svo.sync()
+    svo.set_frames_in_flight(1)
+    for _ in range(3):
+        step()
+    barrier()
+    svo.profile_enable(True)
+    for _ in range(20):
+        step()
+    barrier()
+    exclusive_ms, exclusive_launches = svo.profile_read()
+    svo.profile_enable(False)
+    svo.set_frames_in_flight(FRAMES)
+    kernel_exclusive_ms = exclusive_ms / max(exclusive_launches, 1)
+
+    times = torch.tensor(blocks, dtype=torch.float64, device="cuda")
+    stats = torch.tensor([float(my_rays), float(my_bytes), kernel_ms / max(launches, 1), kernel_exclusive_ms], dtype=torch.float64, device="cuda")
     if dist is not None:
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)  # per block: the slowest rank
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, total_rays = float(mx[0]), float(sm[1])
+        total_rays = float(sm[0])
     else:
         total_rays = float(my_rays)
+    block_s = sorted(float(t) for t in times)
+    elapsed = block_s[len(block_s) // 2]
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -233,13 +274,21 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (ms_per_step * 1e-3) / 1e6  # Mrays/s, whole job
     kernel_avg_ms = kernel_ms / max(launches, 1)
-    achieved = my_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+    achieved = my_bytes / (kernel_exclusive_ms * 1e-3) / 1e9 if kernel_exclusive_ms > 0 else 0.0
+    traffic, traffic_source = measured_traffic(args.format) if (W, H, args.depth, world_size) == (1920, 1080, 12, 1) else (None, None)
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": measured_traffic(args.format) if (W, H, args.depth, world_size) == (1920, 1080, 12, 1) else None, "kernel": "render_persistent", "kernel_avg_ms": round(kernel_avg_ms, 4), "launches": launches,
+                "traffic": traffic, "traffic_source": traffic_source, "kernel": "render_persistent",
+                # achieved = algorithmic bytes per launch / the kernel's own duration: one frame at a time on one stream, HIP events around
+                # each launch (20 launches after the timed region); the same figure as rocprofv3's average with VX_FRAMES_IN_FLIGHT=1
+                "kernel_exclusive_ms": round(kernel_exclusive_ms, 4),
+                # per-launch event span inside the timed region: with frames in flight the spans overlap (span x launches > elapsed)
+                "kernel_span_ms_in_flight": round(kernel_avg_ms, 4), "launches": launches,
                 "algorithmic_bytes_per_launch": int(my_bytes), "bytes_per_ray": round(my_bytes / max(my_rays, 1), 2),
-                # two frames are in flight: the per-launch spans above overlap (span x launches > elapsed). What the
-                # device sustains over the timed region is bytes x launches / elapsed:
-                "frames_in_flight": FRAMES, **({"frames_per_gather": GROUP} if sharded else {}), "sustained_GBps": round(my_bytes * launches / max(elapsed, 1e-9) / 1e9, 3)}
+                "byte_model": "the reference's own fetches (SURVEY.md 8d), counted by the instrumented kernel on the world's own bytes",
+                "image_model_bytes_per_launch": int(image_model_bytes(counters)),
+                "frames_in_flight": FRAMES, **({"frames_per_gather": GROUP} if sharded else {}),
+                # what the device sustains over the median timed block: bytes x frames / elapsed
+                "sustained_GBps": round(my_bytes * args.steps / max(elapsed, 1e-9) / 1e9, 3)}
 
     cpu = None
     if not args.no_cpu_baseline and world_size == 1:  # rank 0 at N = 1 only: a baseline of the workload, not of the scaling run
@@ -273,17 +322,32 @@ def main():
                 scene.render(ou, W, H, rect=(0, max(y0, 0), W, min(y0 + band_h, H)), want_hits=False, counters=cc, threads=cores)
             cpu_s = time.perf_counter() - t0
             sample = f"{bands} bands x {band_h} rows of the {W}x{H} frame"
+        # and on ONE thread ("1 thread, and all host cores"): bands of rows spread over the frame, about 4 s of work
+        c1 = orc.Counters()
+        t0 = time.perf_counter()
+        scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 2), want_hits=False, counters=c1, threads=1)
+        per_row_s = (time.perf_counter() - t0) / 2
+        rows = max(2, min(H // 8, int(4.0 / max(per_row_s, 1e-6)) // 8))
+        c1 = orc.Counters()
+        t0 = time.perf_counter()
+        for b in range(8):
+            y0 = int((b + 0.5) * H / 8) - rows // 2
+            scene.render(ou, W, H, rect=(0, max(y0, 0), W, min(y0 + rows, H)), want_hits=False, counters=c1, threads=1)
+        one_s = time.perf_counter() - t0
         cpu = {"value": round(cc.rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-               "sample": f"{sample}: {cc.rays} rays in {cpu_s:.2f} s (C restatement of the GLSL path, OpenMP; the reference has no CPU raycast)"}
+               "sample": f"{sample}: {cc.rays} rays in {cpu_s:.2f} s (C restatement of the GLSL path, OpenMP; the reference has no CPU raycast)",
+               "single_thread": {"value": round(c1.rays / one_s / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                                 "sample": f"8 bands x {rows} rows of the {W}x{H} frame: {c1.rays} rays in {one_s:.2f} s"}}
 
     out = {
         "metric": "Mrays/sec (primary+shadow) at 1920x1080, depth-12 SVO; achieved HBM GB/s",
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+        "repeats": len(block_s), "block_ms_min_median_max": [round(block_s[0] * 1e3, 3), round(elapsed * 1e3, 3), round(block_s[-1] * 1e3, 3)],
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"C3: {W}x{H} primary + 1 shadow ray per lit pixel, textured + normal-mapped shading, depth-{args.depth} SVO "
                                f"({args.format.upper()} nodes), 1 frame per step", "svo_format": args.format, "svo_bytes": world.size_in_bytes,
-                   "leaves": st["leaves"], "chunks": st["chunks"], "rays_per_frame": int(total_rays), "primary_rays": W * H,
+                   "leaves": st["leaves"], "chunks": st["chunks"], "textures": args.textures, "rays_per_frame": int(total_rays), "primary_rays": W * H,
                    "parallelism": f"screen tiles (32x32, interleaved) over {world_size} GPU(s), SVO replicated, RCCL gather to rank 0",
                    **({"sharded_frame_identical_to_whole_render": sharded_frame_identical} if sharded else {}),
                    "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 3),

@@ -266,6 +266,15 @@ int vx_render_counters(vx_context* ctx, const vx_uniforms* uniforms, uint32_t wi
 int vx_profile_enable(vx_context* ctx, int enabled);
 /* Sum of the bracketed kernel durations (ms) and their count since the last call; synchronises. */
 int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches);
+/* What vx_render walks after the last commit: [0] 0 = the world's own bytes (no image: switched off, or the world cannot be
+ * imaged), 1 = the traversal image with byte offsets, 2 = its layout for more than 4 GiB (32-byte units behind a 64-bit pointer);
+ * [1] bytes of the image, [2] bytes of its origin table (CSVO worlds), [3] chunks it holds. */
+int vx_image_info(const vx_context* ctx, uint64_t out[4]);
+/* CSVO worlds rendered from their traversal image: since creation (or the last reset), [0] rays that were led into the voxel they
+ * started in and made that walk on the world's own bytes, [1] those of them that had to be started over on the bytes (the walk
+ * overwrote cursor state the rest of the ray depends on), [2] service phases of the render kernel that had such rays. Waits for
+ * every frame in flight. */
+int vx_excursion_counters(vx_context* ctx, uint64_t out[3], int reset);
 /* hipStream_t the context launches on (as void*), for callers that order their own work after it. */
 void* vx_stream(vx_context* ctx);
 int vx_device(const vx_context* ctx);

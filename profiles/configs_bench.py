@@ -59,7 +59,8 @@ def main():
         world, st, svo = worlds[depth]
         W, H = w * ss, h * ss
         u = scenes.bench_camera(depth, st["h_max"], W, H, shadow_distance=3.0e38, render_shadows=shadows)
-        rays = svo.render_counters(u, W, H)["rays"]
+        counters = svo.render_counters(u, W, H)
+        rays = counters["rays"]
         big = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
         small = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") if ss > 1 else None
         torch.cuda.synchronize()
@@ -75,15 +76,21 @@ def main():
             frame(i)
         svo.sync()
         torch.cuda.synchronize()
+        svo.excursion_counters(reset=True)
         t0 = time.perf_counter()
         for i in range(args.steps):
             frame(i)
         svo.sync()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / args.steps
+        exc = svo.excursion_counters()
         print(json.dumps({"config": name, "format": args.format, "depth": depth, "width": w, "height": h, "supersample": ss, "shadows": shadows,
                           "world_MB": round(world.size_in_bytes / 1e6, 1), "rays_per_frame": int(rays), "ms_per_frame": round(ms, 4),
-                          "Mrays_per_s": round(rays / ms / 1e3, 1)}), flush=True)
+                          "Mrays_per_s": round(rays / ms / 1e3, 1),
+                          # work per ray grows with the depth of the tree: iterations of the traversal loop per second compare across configurations
+                          "iterations_per_ray": round(counters["iterations"] / rays, 1), "Giterations_per_s": round(counters["iterations"] / ms / 1e6, 2),
+                          "rays_led_into_a_voxel_per_frame": exc["rays"] // args.steps, "of_which_started_over": exc["started_over"] // args.steps,
+                          "image": svo.image_info()}), flush=True)
 
 
 if __name__ == "__main__":

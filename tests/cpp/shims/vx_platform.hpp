@@ -23,6 +23,7 @@ inline uint32_t mem_u32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); r
 extern unsigned char* vx_smem;
 #define VX_AS_LDS
 #define VX_AS_PRIVATE
+#define VX_NOINLINE
 
 inline uint32_t bit_at(uint32_t v, int pos) { return (v >> pos) & 1u; }
 inline void sched_fence() {}

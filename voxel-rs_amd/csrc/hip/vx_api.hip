@@ -119,6 +119,7 @@ struct PersistentArgs {
     uint32_t ticket_base;
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
+    unsigned long long* excursions;  // [0] rays that made the excursion into a voxel on the world's bytes, [1] of which started over, [2] service phases with any
 };
 
 // IMAGE = the rays walk the traversal image of the world (traversal_image.hpp) instead of its own bytes. FOREIGN (an image of a
@@ -150,7 +151,6 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
     Trav<SVO> tr;
     tr.iter = kParked;
-    Result res;
     int state = kIdle;
     bool shadow_ray = false;
     uint32_t out_index = 0;
@@ -183,6 +183,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             if (trav == 0 || 64u - uint32_t(__popcll(trav)) >= park_limit) break;
         }
         if (STATS) ++services;
+        // what a ray found: produced (leaf test, miss) and consumed (shading) within this service phase, never carried into the loop
+        Result res;
         if (state == kTrav && tr.iter >= uint32_t(kMaxSteps)) {  // the cap ended this ray
             state = kMissed;
             tr.iter |= kParked;
@@ -203,15 +205,24 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         }
 
         // ---- rays that are led into a voxel (they started inside it), image of a CSVO world: the excursion on the world's own bytes ----
-        if (FOREIGN && state == kForeign) {
-            const DevScene sc_bytes = make_scene(sa);
-            tr.iter &= ~kParked;
-            const TravStatus s = enter_voxel_on_bytes(sc, sc_bytes, tr, st, true, res);
-            // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there
-            state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep) : (s == kTravAtLeaf ? kDone : kMissed);
-            if (state != kTrav) tr.iter |= kParked;
+        if (FOREIGN && __ballot(state == kForeign)) {
+            const unsigned long long fm = __ballot(state == kForeign);
+            bool started_over = false;
+            if (state == kForeign) {
+                const DevScene sc_bytes = make_scene(sa);
+                tr.iter &= ~kParked;
+                const TravStatus s = enter_voxel_on_bytes(sc, sc_bytes, tr, st, true, res, &started_over);
+                // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there
+                state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep) : (s == kTravAtLeaf ? kDone : kMissed);
+                if (state != kTrav) tr.iter |= kParked;
+            }
+            const unsigned long long om = __ballot(started_over);
+            if (lane == 0) {  // (three atomics per service phase that has such rays: measurement for free)
+                atomicAdd(&a.excursions[0], (unsigned long long)__popcll(fm));
+                if (om) atomicAdd(&a.excursions[1], (unsigned long long)__popcll(om));
+                atomicAdd(&a.excursions[2], 1ull);
+            }
         }
-
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
         if (state == kLeaf) {
             tr.iter &= ~kParked;
@@ -523,6 +534,7 @@ struct vx_context {
     unsigned long long* d_counters = nullptr;
 
     uint32_t* d_work_counter = nullptr;
+    unsigned long long* d_excursions = nullptr;  // [3], see PersistentArgs
     // the traversal image of the world (traversal_image.hpp), rebuilt for the changed chunks by every commit
     vximg::WorldImage image;
     uint8_t* d_image = nullptr;
@@ -675,6 +687,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.total_subtiles = p.n_local_tiles * 16;
         a.refill_min = ctx->refill_min;
         a.service_min = ctx->service_min;
+        a.excursions = ctx->d_excursions;
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters};
@@ -850,6 +863,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
     CREATE_TRY(hipMemset(c->d_work_counter, 0, sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_excursions), 4 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(c->d_excursions, 0, 4 * sizeof(unsigned long long)));
     {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
@@ -892,7 +907,7 @@ void vx_destroy(vx_context* c) {
     for (auto& l : c->event_pool) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     if (c->staging) (void)hipHostFree(c->staging);
     void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_frame, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
-                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin};
+                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin, c->d_excursions};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
@@ -1392,6 +1407,26 @@ int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches) 
     *kernel_ms_sum = sum;
     *launches = uint32_t(ctx->launches.size());
     ctx->launches.clear();
+    return VX_OK;
+}
+
+int vx_image_info(const vx_context* ctx, uint64_t out[4]) {
+    if (!ctx || !out) return fail(VX_ERR_INVALID_ARGUMENT, "image_info: null argument");
+    out[0] = ctx->image_ok ? (ctx->image.layout() == vximg::kOct64Wide ? 2u : 1u) : 0u;
+    out[1] = ctx->image_ok ? ctx->image.frame_bytes() : 0u;
+    out[2] = ctx->image_ok && ctx->image.has_origin() ? ctx->image.origin_bytes() : 0u;
+    out[3] = ctx->image_ok ? ctx->image.chunk_count() : 0u;
+    return VX_OK;
+}
+
+int vx_excursion_counters(vx_context* ctx, uint64_t out[3], int reset) {
+    if (!ctx || !out) return fail(VX_ERR_INVALID_ARGUMENT, "excursion_counters: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = drain_streams(ctx)) return rc;
+    unsigned long long h[4] = {};
+    HIP_TRY(hipMemcpy(h, ctx->d_excursions, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    if (reset) HIP_TRY(hipMemset(ctx->d_excursions, 0, sizeof h));
     return VX_OK;
 }
 

@@ -851,13 +851,14 @@ struct Trav {
 // `tr.iter` must not count it (the caller took it back, as for kTravDeep); on return `tr.iter` counts everything that ran.
 template <int IMGSVO, class ST, bool LIMIT = false>
 __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, const DevScene& bytes, Trav<IMGSVO>& tr, const ST& st,
-                                                           bool cast_translucent, Result& res) {
+                                                           bool cast_translucent, Result& res, bool* started_over = nullptr) {
     static_assert(!ST::kFast, "the excursion needs every stack level");
     typedef Trav<VX_SVO_CSVO> ByteTrav;
     const int parent_scale = tr.scale;
     const uint32_t img_ptr = tr.ptr, img_node = tr.node;
     const float parent_t_max = tr.t_max;
 
+    // (every field of `tr` is written back from `tb` at the single exit below: nothing of `tr` is live while the byte cursor runs)
     ByteTrav tb;
     tb.rox = tr.rox; tb.roy = tr.roy; tb.roz = tr.roz; tb.rdx = tr.rdx; tb.rdy = tr.rdy; tb.rdz = tr.rdz;
     tb.tcx = tr.tcx; tb.tcy = tr.tcy; tb.tcz = tr.tcz; tb.tbx = tr.tbx; tb.tby = tr.tby; tb.tbz = tr.tbz;
@@ -875,79 +876,64 @@ __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, 
     tb.material_section_ptr = o0 - (o1 & 0x1fffffffu);
     tb.pre_leaf_pointer = o0 - 3u - (o1 >> 29);
     tb.node = tb.csvo_header(bytes);
-
-    // Back among real nodes. The byte cursor carries two pieces of state besides its stack that the walk inside the voxel may have
-    // overwritten (a phantom depth-2 node, a phantom chunk boundary): `pre_leaf_pointer` and `material_section_ptr`, which say where
-    // read_leaf finds a voxel's material (svo.csvo.glsl:119-133). The reference goes on with whatever they hold now. If that is what
-    // they held before -- or, for pre_leaf_pointer, if the ray is back above the voxel's parent, where the next depth-2 node it
-    // enters sets it afresh (svo.csvo.glsl:283) -- the rest of the ray is what the image gives. If not, the voxels it hits from here
-    // on report materials read through the overwritten pointers: such a ray is started over and run on the world's own bytes
-    // from the root (the reference's cursor throughout; `false` is returned and `tb` is at the root again).
+    // The byte cursor carries two pieces of state besides its stack that the walk inside the voxel may overwrite (a phantom depth-2
+    // node, a phantom chunk boundary): `pre_leaf_pointer` and `material_section_ptr`, which say where read_leaf finds a voxel's
+    // material (svo.csvo.glsl:119-133). The reference goes on with whatever they hold when the ray is back among real nodes. If that
+    // is what they held before -- or, for pre_leaf_pointer, if the ray is back above the voxel's parent, where the next depth-2 node
+    // it enters sets it afresh (svo.csvo.glsl:283) -- the rest of the ray is what the image gives. If not, the voxels it hits from
+    // there on report materials read through the overwritten pointers: such a ray is started over and run on the world's own bytes
+    // from the root, with the reference's cursor throughout (`for_good`).
     const uint32_t true_material_section = tb.material_section_ptr, true_pre_leaf = tb.pre_leaf_pointer;
-    auto back_on_image = [&](bool popped) -> bool {
-        if (tb.material_section_ptr != true_material_section || (tb.scale == parent_scale && tb.pre_leaf_pointer != true_pre_leaf)) {
-            tb.start(bytes);
-            return false;
-        }
-        tr.px = tb.px; tr.py = tb.py; tr.pz = tb.pz;
-        tr.t_min = tb.t_min; tr.h = tb.h; tr.scale = tb.scale; tr.scale_exp2 = tb.scale_exp2;
-        tr.last_leaf_value = tb.last_leaf_value; tr.flags = tb.flags; tr.iter = tb.iter;
-        if (popped) {  // the slot the POP read holds an image entry (the byte cursor misread it): read it as one
-            uint32_t a;
-            st.pop(tb.scale, tr.ptr, tr.t_max, a);
-            tr.node = a;
-        }
-        return true;
-    };
-    // the rest of a ray that was started over: the reference's loop on the world's own bytes
-    auto whole_ray_on_bytes = [&]() -> TravStatus {
-        for (;;) {
-            TravStatus w = tb.template step<false, false, LIMIT, ST>(bytes, st, nullptr, nullptr);
-            if (w == kTravAtLeaf) {
-                const LeafOutcome o = tb.template leaf_test<false, false>(bytes, st, cast_translucent, res, nullptr, nullptr);
-                if (o == kLeafHit) {
-                    tr.iter = tb.iter;
-                    return kTravAtLeaf;
-                }
-                w = o == kLeafPassed ? kTravContinue : kTravFinished;
-            }
-            if (w == kTravFinished) {
-                tr.flags = tb.flags;
-                tr.iter = tb.iter;
-                return kTravFinished;
-            }
-        }
-    };
 
-    // the iteration the image cursor stopped in, again: PUSH into the voxel -- or ADVANCE, if the voxel's span is empty
-    TravStatus s = tb.template step<false, false, LIMIT, ST>(bytes, st, nullptr, nullptr);
-    if (s == kTravFinished) {
-        tr.flags = tb.flags;  // (inside_voxel is part of a miss)
-        tr.iter = tb.iter;
-        return kTravFinished;
-    }
-    if (tb.scale >= parent_scale)  // advanced to a sibling (still at the voxel's parent: the image cursor's node is the same), or popped
-        return back_on_image(tb.scale > parent_scale) ? kTravContinue : whole_ray_on_bytes();
-    // inside the voxel. The PUSH wrote the parent's entry as the byte cursor sees it (where the reference's `tc_max < h` let it):
-    // the way back needs the image's (writing it where the reference wrote nothing is harmless: such a slot is never popped)
-    st.push(parent_scale, img_ptr, parent_t_max, img_node);
+    TravStatus outcome;
+    bool first = true, for_good = false;
     for (;;) {
-        s = tb.template step<false, false, LIMIT, ST>(bytes, st, nullptr, nullptr);
+        // first trip: the iteration the image cursor stopped in, again -- PUSH into the voxel, or ADVANCE if the voxel's span is empty
+        TravStatus s = tb.template step<false, false, LIMIT, ST>(bytes, st, nullptr, nullptr);
         if (s == kTravAtLeaf) {
             const LeafOutcome o = tb.template leaf_test<false, false>(bytes, st, cast_translucent, res, nullptr, nullptr);
             if (o == kLeafHit) {
-                tr.iter = tb.iter;
-                return kTravAtLeaf;
+                outcome = kTravAtLeaf;
+                break;
             }
             s = o == kLeafPassed ? kTravContinue : kTravFinished;
         }
         if (s == kTravFinished) {
-            tr.flags = tb.flags;  // (inside_voxel is part of a miss)
-            tr.iter = tb.iter;
-            return kTravFinished;
+            outcome = kTravFinished;
+            break;
         }
-        if (tb.scale >= parent_scale) return back_on_image(true) ? kTravContinue : whole_ray_on_bytes();
+        if (for_good) continue;
+        const bool was_first = first;
+        first = false;
+        if (tb.scale < parent_scale) {
+            // inside the voxel. The PUSH wrote the parent's entry as the byte cursor sees it (where the reference's `tc_max < h` let
+            // it): the way back needs the image's (writing it where the reference wrote nothing is harmless: such a slot is never popped)
+            if (was_first) st.push(parent_scale, img_ptr, parent_t_max, img_node);
+            continue;
+        }
+        // back among real nodes
+        if (tb.material_section_ptr != true_material_section || (tb.scale == parent_scale && tb.pre_leaf_pointer != true_pre_leaf)) {
+            tb.start(bytes);
+            for_good = true;
+            continue;
+        }
+        if (was_first && tb.scale == parent_scale) {  // advanced to a sibling voxel: still at the voxel's parent, whose image node is the same
+            tb.ptr = img_ptr;
+            tb.node = img_node;
+        } else {  // the slot the POP read holds an image entry (the byte cursor misread it): read it as one
+            uint32_t a;
+            st.pop(tb.scale, tb.ptr, tb.t_max, a);
+            tb.node = a;
+        }
+        outcome = kTravContinue;
+        break;
     }
+    tr.px = tb.px; tr.py = tb.py; tr.pz = tb.pz;
+    tr.t_min = tb.t_min; tr.t_max = tb.t_max; tr.h = tb.h; tr.scale = tb.scale; tr.scale_exp2 = tb.scale_exp2;
+    tr.ptr = tb.ptr; tr.node = tb.node;
+    tr.last_leaf_value = tb.last_leaf_value; tr.flags = tb.flags; tr.iter = tb.iter;
+    if (started_over) *started_over = for_good;
+    return outcome;
 }
 
 __device__ __forceinline__ void result_miss(Result& res, bool inside_voxel) {

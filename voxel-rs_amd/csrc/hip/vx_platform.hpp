@@ -39,6 +39,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char vx_smem[];
 #define VX_AS_LDS __attribute__((address_space(3)))
 #define VX_AS_PRIVATE __attribute__((address_space(5)))
 
+// a real call instead of inlined code: for rare, register-hungry paths that must not weigh on the loops around them
+#define VX_NOINLINE __attribute__((noinline))
+
 // bit `pos` of `v` (one v_bfe_u32)
 __device__ __forceinline__ uint32_t bit_at(uint32_t v, int pos) { return __builtin_amdgcn_ubfe(v, uint32_t(pos), 1u); }
 

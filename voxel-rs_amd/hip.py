@@ -86,6 +86,8 @@ SYMBOLS = {
     "vx_assemble_tiles_on": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp]),
     "vx_local_tile_count": (_u32, [_u32, _u32, _u32, _u32]),
     "vx_render_counters": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, _u32, _u32, C.POINTER(Counters)]),
+    "vx_excursion_counters": (_int, [_vp, C.POINTER(_u64 * 3), _int]),
+    "vx_image_info": (_int, [_vp, C.POINTER(_u64 * 4)]),
     "vx_profile_enable": (_int, [_vp, _int]),
     "vx_profile_read": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32)]),
     "vx_stream": (_vp, [_vp]),
@@ -273,6 +275,16 @@ class Svo:
     def stream_wait_render(self, stream):
         """Makes the raw hipStream_t `stream` wait for the most recently issued render."""
         _check(lib().vx_stream_wait_render(self._h, _vp(stream)))
+
+    def image_info(self):
+        out = (_u64 * 4)()
+        _check(lib().vx_image_info(self._h, C.byref(out)))
+        return {"layout": int(out[0]), "image_bytes": int(out[1]), "origin_bytes": int(out[2]), "chunks": int(out[3])}
+
+    def excursion_counters(self, reset=True):
+        out = (_u64 * 3)()
+        _check(lib().vx_excursion_counters(self._h, C.byref(out), int(reset)))
+        return {"rays": int(out[0]), "started_over": int(out[1]), "service_phases": int(out[2])}
 
     def profile_enable(self, on=True):
         _check(lib().vx_profile_enable(self._h, int(on)))

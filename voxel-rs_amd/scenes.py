@@ -63,6 +63,27 @@ def synthetic_textures(seed=1, size=64):
     return layers
 
 
+def asset_textures(directory=None, seed=1, size=64):
+    """The 25-layer table with the reference's own 64x64 textures where the repository carries them as test fixtures
+    (tests/golden/textures: dirt, grass_side, grass_top, stone and their normal maps -- byte-identical copies of
+    assets/textures/*.png, the eight the reference's render test loads, src/graphics/svo.rs:347-360) and the procedural stand-ins
+    for the rest. Flipped vertically like TextureArrayBuilder does (texture_array.rs:92,126): row 0 = bottom. The benchmark's
+    terrain only uses grass, dirt and stone, i.e. only real textures."""
+    from pathlib import Path
+
+    from PIL import Image
+
+    directory = Path(directory) if directory else Path(__file__).resolve().parent.parent / "tests" / "golden" / "textures"
+    layers = synthetic_textures(seed, size)
+    for li, name in enumerate(TEXTURE_NAMES):
+        f = directory / (name[:-7] + "_n.png" if name.endswith("_normal") else name + ".png")
+        if f.exists():
+            im = np.asarray(Image.open(f).convert("RGBA"), dtype=np.uint8)
+            if im.shape == (size, size, 4):
+                layers[li] = im[::-1]
+    return layers
+
+
 def synthetic_materials():
     """13 rows indexed by BlockId with the specular parameters and face/texture wiring of content.rs:48-60."""
     idx = {n: i for i, n in enumerate(TEXTURE_NAMES)}
