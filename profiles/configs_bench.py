@@ -90,6 +90,7 @@ def main():
                           # work per ray grows with the depth of the tree: iterations of the traversal loop per second compare across configurations
                           "iterations_per_ray": round(counters["iterations"] / rays, 1), "Giterations_per_s": round(counters["iterations"] / ms / 1e6, 2),
                           "rays_led_into_a_voxel_per_frame": exc["rays"] // args.steps, "of_which_started_over": exc["started_over"] // args.steps,
+                          "excursion_phases_per_frame": exc["service_phases"] // args.steps, "iterations_on_bytes_per_frame": exc["iterations_on_bytes"] // args.steps,
                           "image": svo.image_info()}), flush=True)
 
 

@@ -119,7 +119,8 @@ struct PersistentArgs {
     uint32_t ticket_base;
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
-    unsigned long long* excursions;  // [0] rays that made the excursion into a voxel on the world's bytes, [1] of which started over, [2] service phases with any
+    uint32_t foreign_min;     // images of CSVO worlds: rays led into a voxel wait until this many of a wave's lanes are, and go together
+    unsigned long long* excursions;  // [0] rays that made the excursion into a voxel on the world's bytes, [1] of which started over, [2] service phases that ran excursions, [3] loop iterations made on the bytes
 };
 
 // IMAGE = the rays walk the traversal image of the world (traversal_image.hpp) instead of its own bytes. FOREIGN (an image of a
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
     for (;;) {
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
-        const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle)));  // idle lanes are not waiting for anything
+        // idle lanes are not waiting for anything; lanes that wait for company before their excursion (FOREIGN) are not waiting for service
+        const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle || (FOREIGN && state == kForeign))));
         for (;;) {
             if (tr.iter < uint32_t(kMaxSteps)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
                 tr.template step_with<false, STATS, false, FastStack, false, FOREIGN != 0>(sc, fast_st, nullptr, STATS ? &ctr : nullptr, [&](TravStatus s) {
@@ -205,24 +207,35 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         }
 
         // ---- rays that are led into a voxel (they started inside it), image of a CSVO world: the excursion on the world's own bytes ----
-        if (FOREIGN && __ballot(state == kForeign)) {
+        // The walk runs with only these lanes active, so they go together: a lane waits (parked, at no cost to the loop) until
+        // foreign_min lanes of the wave are there, or until no lane is left that could traverse meanwhile.
+        if (FOREIGN) {
             const unsigned long long fm = __ballot(state == kForeign);
-            bool started_over = false;
-            if (state == kForeign) {
-                const DevScene sc_bytes = make_scene(sa);
-                tr.iter &= ~kParked;
-                const TravStatus s = enter_voxel_on_bytes(sc, sc_bytes, tr, st, true, res, &started_over);
-                // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there
-                state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep) : (s == kTravAtLeaf ? kDone : kMissed);
-                if (state != kTrav) tr.iter |= kParked;
-            }
-            const unsigned long long om = __ballot(started_over);
-            if (lane == 0) {  // (three atomics per service phase that has such rays: measurement for free)
-                atomicAdd(&a.excursions[0], (unsigned long long)__popcll(fm));
-                if (om) atomicAdd(&a.excursions[1], (unsigned long long)__popcll(om));
-                atomicAdd(&a.excursions[2], 1ull);
+            if (fm && (uint32_t(__popcll(fm)) >= a.foreign_min || __ballot(state == kTrav || state == kLeaf || state == kDone || state == kMissed || state == kDeep) == 0)) {
+                bool started_over = false;
+                uint32_t on_bytes = 0;
+                if (state == kForeign) {
+                    const DevScene sc_bytes = make_scene(sa);
+                    tr.iter &= ~kParked;
+                    const uint32_t before = tr.iter;
+                    const TravStatus s = enter_voxel_on_bytes(sc, sc_bytes, tr, st, true, res, &started_over);
+                    on_bytes = started_over ? tr.iter : tr.iter - before;
+                    // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there
+                    state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep) : (s == kTravAtLeaf ? kDone : kMissed);
+                    if (state != kTrav) tr.iter |= kParked;
+                }
+                const unsigned long long om = __ballot(started_over);
+                unsigned long long sum = on_bytes;
+                for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+                if (lane == 0) {  // (a few atomics per service phase that has such rays: measurement for free)
+                    atomicAdd(&a.excursions[0], (unsigned long long)__popcll(fm));
+                    if (om) atomicAdd(&a.excursions[1], (unsigned long long)__popcll(om));
+                    atomicAdd(&a.excursions[2], 1ull);
+                    atomicAdd(&a.excursions[3], sum);
+                }
             }
         }
+
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
         if (state == kLeaf) {
             tr.iter &= ~kParked;
@@ -551,7 +564,7 @@ struct vx_context {
     bool image_enabled = true;  // VX_TRAVERSAL_IMAGE=0: traverse the world's own bytes
     bool image_ok = false;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
-    uint32_t refill_min = 4, service_min = 28;
+    uint32_t refill_min = 4, service_min = 28, foreign_min = 24;
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int cu_count = 256;
@@ -687,6 +700,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.total_subtiles = p.n_local_tiles * 16;
         a.refill_min = ctx->refill_min;
         a.service_min = ctx->service_min;
+        a.foreign_min = ctx->foreign_min;
         a.excursions = ctx->d_excursions;
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
@@ -884,6 +898,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
+        if (const char* e = std::getenv("VX_FOREIGN_MIN")) c->foreign_min = uint32_t(std::max(1, std::min(64, std::atoi(e))));
         if (c->refill_min < 1) c->refill_min = 1;
         if (c->refill_min > 64) c->refill_min = 64;
         if (c->service_min < 1) c->service_min = 1;
@@ -1419,13 +1434,13 @@ int vx_image_info(const vx_context* ctx, uint64_t out[4]) {
     return VX_OK;
 }
 
-int vx_excursion_counters(vx_context* ctx, uint64_t out[3], int reset) {
+int vx_excursion_counters(vx_context* ctx, uint64_t out[4], int reset) {
     if (!ctx || !out) return fail(VX_ERR_INVALID_ARGUMENT, "excursion_counters: null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     if (int rc = drain_streams(ctx)) return rc;
     unsigned long long h[4] = {};
     HIP_TRY(hipMemcpy(h, ctx->d_excursions, sizeof h, hipMemcpyDeviceToHost));
-    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
     if (reset) HIP_TRY(hipMemset(ctx->d_excursions, 0, sizeof h));
     return VX_OK;
 }

@@ -86,7 +86,7 @@ SYMBOLS = {
     "vx_assemble_tiles_on": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp]),
     "vx_local_tile_count": (_u32, [_u32, _u32, _u32, _u32]),
     "vx_render_counters": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, _u32, _u32, C.POINTER(Counters)]),
-    "vx_excursion_counters": (_int, [_vp, C.POINTER(_u64 * 3), _int]),
+    "vx_excursion_counters": (_int, [_vp, C.POINTER(_u64 * 4), _int]),
     "vx_image_info": (_int, [_vp, C.POINTER(_u64 * 4)]),
     "vx_profile_enable": (_int, [_vp, _int]),
     "vx_profile_read": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32)]),
@@ -282,9 +282,9 @@ class Svo:
         return {"layout": int(out[0]), "image_bytes": int(out[1]), "origin_bytes": int(out[2]), "chunks": int(out[3])}
 
     def excursion_counters(self, reset=True):
-        out = (_u64 * 3)()
+        out = (_u64 * 4)()
         _check(lib().vx_excursion_counters(self._h, C.byref(out), int(reset)))
-        return {"rays": int(out[0]), "started_over": int(out[1]), "service_phases": int(out[2])}
+        return {"rays": int(out[0]), "started_over": int(out[1]), "service_phases": int(out[2]), "iterations_on_bytes": int(out[3])}
 
     def profile_enable(self, on=True):
         _check(lib().vx_profile_enable(self._h, int(on)))
