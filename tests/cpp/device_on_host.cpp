@@ -69,7 +69,7 @@ extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t worl
 // number of loop iterations.
 template <int IMG, int FOREIGN, bool SHALLOW>
 static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float pos[3], const float dir[3], float max_dst, bool cast_translucent,
-                       vx_result* out, uint32_t* steps) {
+                       bool restart_in_place, vx_result* out, uint32_t* steps) {
     StackSpill spill;
     Stack<1, false> st;
     typedef Stack<1, true, SHALLOW> FastStack;
@@ -101,7 +101,22 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
             continue;
         }
         if (s == kTravForeign) {
-            s = enter_voxel_on_bytes<IMG, Stack<1, false>, true>(sc, sc_bytes, tr, st, cast_translucent, res);
+            if (restart_in_place) {
+                s = enter_voxel_on_bytes<IMG, Stack<1, false>, true, true>(sc, sc_bytes, tr, st, cast_translucent, res);
+            } else {
+                // what the render kernel does: a ray whose walk inside the voxel overwrote the byte cursor's leaf pointers is given up
+                // here and run whole on the world's own bytes later (its pixel goes on the wave's list)
+                s = enter_voxel_on_bytes<IMG, Stack<1, false>, true, false>(sc, sc_bytes, tr, st, cast_translucent, res);
+                if (s == kTravForeign) {
+                    uint32_t n = 0;
+                    intersect<VX_SVO_CSVO, false, false, true>(sc_bytes, pos, dir, max_dst, cast_translucent, st, res, n, nullptr, nullptr);
+                    out->t = res.t; out->value = res.value; out->face_id = res.face_id;
+                    std::memcpy(out->pos, res.pos, 12); std::memcpy(out->uv, res.uv, 8); std::memcpy(out->color, res.color, 16);
+                    out->lod = res.lod; out->inside_voxel = res.inside_voxel ? 1 : 0;
+                    *steps = n;
+                    return;
+                }
+            }
             if (s == kTravAtLeaf) { hit = true; break; }
             continue;
         }
@@ -121,7 +136,7 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
 }
 
 // layout: 1 = byte-offset image (VX_SVO_IMAGE), 2 = wide image (VX_SVO_IMAGE_WIDE); svo_type = the world's own format
-extern "C" void devhost_image_cast(int svo_type, int layout, int shallow, const uint8_t* world, uint64_t world_bytes, const uint8_t* image, uint64_t image_bytes,
+extern "C" void devhost_image_cast(int svo_type, int layout, int shallow, int restart_in_place, const uint8_t* world, uint64_t world_bytes, const uint8_t* image, uint64_t image_bytes,
                                    const uint8_t* origin, const vx_material* mats, uint32_t n_mats, const uint8_t* tex, uint32_t tw, uint32_t th,
                                    uint32_t layers, uint32_t levels, const uint32_t* level_offset, const vx_picker_task* tasks, uint32_t n,
                                    int cast_translucent, vx_result* results, uint32_t* steps) {
@@ -140,7 +155,7 @@ extern "C" void devhost_image_cast(int svo_type, int layout, int shallow, const 
     vx_smem = lds.data();
     for (uint32_t i = 0; i < n; ++i) {
         const bool ct = cast_translucent != 0;
-#define CAST(IMG, FOREIGN, SHALLOW) image_cast<IMG, FOREIGN, SHALLOW>(sc, sc_bytes, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, ct, &results[i], &steps[i])
+#define CAST(IMG, FOREIGN, SHALLOW) image_cast<IMG, FOREIGN, SHALLOW>(sc, sc_bytes, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, ct, restart_in_place != 0, &results[i], &steps[i])
         if (svo_type == 1) {
             if (layout == 1) { if (shallow) CAST(VX_SVO_IMAGE, 0, true); else CAST(VX_SVO_IMAGE, 0, false); }
             else { if (shallow) CAST(VX_SVO_IMAGE_WIDE, 0, true); else CAST(VX_SVO_IMAGE_WIDE, 0, false); }

@@ -123,6 +123,33 @@ struct PersistentArgs {
     unsigned long long* excursions;  // [0] rays that made the excursion into a voxel on the world's bytes, [1] of which started over, [2] service phases that ran excursions, [3] loop iterations made on the bytes
 };
 
+// Images of CSVO worlds: pixels a wave gave up on the image (a ray's walk inside the voxel it started in overwrote what the rest of
+// the ray depends on, vx_device.hpp: enter_voxel_on_bytes) -- a few in a thousand. The wave renders them whole on the world's own
+// bytes once the tile queue is empty and its rays are done (a second phase of the same kernel, not a second kernel: its registers
+// overlay the first phase's, and a frame stays one command).
+struct PixelList {
+    // in chunks of 128 dwords that the wave chains together: [0] previous chunk + 1 (0 = none), [1] entries, [2..127] out_index
+    // values. Chunks come from a ring (`mask` + 1 of them, a power of two) through one counter that only ever grows; a wave touches
+    // nothing but its own chunks, so no wave ever waits for another.
+    uint32_t* chunks;
+    uint32_t* next_chunk;
+    uint32_t mask;
+};
+constexpr uint32_t kChunkDwords = 128, kChunkEntries = 126;
+
+// compact / row-major output index -> pixel coordinates (the inverse of the index computation in the refill)
+__device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t out_index, uint32_t& x, uint32_t& y) {
+    if (p.tile_count > 1) {
+        const uint32_t local_tile = out_index >> 10, in_y = (out_index >> 5) & 31u, in_x = out_index & 31u;
+        const uint32_t tile = local_tile * p.tile_count + p.tile_rank;
+        x = (tile % p.tiles_x) * kTile + in_x;
+        y = (tile / p.tiles_x) * kTile + in_y;
+    } else {
+        x = out_index % p.width;
+        y = out_index / p.width;
+    }
+}
+
 // IMAGE = the rays walk the traversal image of the world (traversal_image.hpp) instead of its own bytes. FOREIGN (an image of a
 // CSVO world; = VX_SVO_CSVO): a ray that is about to be led into the voxel it started in makes that excursion on the world's own
 // bytes and comes back to the image (vx_device.hpp, enter_voxel_on_bytes) -- in the service phase, like every other rare and
@@ -130,7 +157,7 @@ struct PersistentArgs {
 // SHALLOW: no ray can push below the LDS-resident stack levels (the host knows the image's depth): no hand-over test in the loop.
 template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
-                                                        vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters) {
+                                                        vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
     constexpr bool IMAGE = SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE;
     static_assert(!(IMAGE && STATS), "the instrumented kernel counts the reference's own fetches: it walks the world's own bytes");
     static_assert(FOREIGN == 0 || (IMAGE && FOREIGN == VX_SVO_CSVO), "FOREIGN: the image of a CSVO world");
@@ -165,6 +192,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
     bool queue_empty = false;
+    uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
 
     for (;;) {
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
@@ -212,24 +240,41 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if (FOREIGN) {
             const unsigned long long fm = __ballot(state == kForeign);
             if (fm && (uint32_t(__popcll(fm)) >= a.foreign_min || __ballot(state == kTrav || state == kLeaf || state == kDone || state == kMissed || state == kDeep) == 0)) {
-                bool started_over = false;
                 uint32_t on_bytes = 0;
+                bool given_up = false;
                 if (state == kForeign) {
                     const DevScene sc_bytes = make_scene(sa);
                     tr.iter &= ~kParked;
                     const uint32_t before = tr.iter;
-                    const TravStatus s = enter_voxel_on_bytes(sc, sc_bytes, tr, st, true, res, &started_over);
-                    on_bytes = started_over ? tr.iter : tr.iter - before;
-                    // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there
-                    state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep) : (s == kTravAtLeaf ? kDone : kMissed);
+                    const TravStatus s = enter_voxel_on_bytes<SVO, Stack<64, false>, false, false>(sc, sc_bytes, tr, st, true, res);
+                    on_bytes = tr.iter - before;
+                    // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there / given up (the pixel's turn comes later)
+                    given_up = s == kTravForeign;
+                    state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep)
+                                               : (s == kTravAtLeaf ? kDone : (s == kTravFinished ? kMissed : kIdle));
                     if (state != kTrav) tr.iter |= kParked;
                 }
-                const unsigned long long om = __ballot(started_over);
+                const unsigned long long gm = __ballot(given_up);
+                if (gm) {
+                    const uint32_t k = uint32_t(__popcll(gm));
+                    if (my_chunk == 0 || my_fill + k > kChunkEntries) {  // a fresh chunk always has room for a whole wave
+                        uint32_t c = 0;
+                        if (lane == 0) c = atomicAdd(todo.next_chunk, 1u);
+                        c = __builtin_amdgcn_readfirstlane(c) & todo.mask;
+                        if (lane == 0) todo.chunks[size_t(c) * kChunkDwords] = my_chunk;
+                        my_chunk = c + 1;
+                        my_fill = 0;
+                    }
+                    uint32_t* chunk = todo.chunks + size_t(my_chunk - 1) * kChunkDwords;
+                    if (given_up) chunk[2 + my_fill + __builtin_amdgcn_mbcnt_hi(uint32_t(gm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(gm), 0u))] = out_index;
+                    my_fill += k;
+                    if (lane == 0) chunk[1] = my_fill;
+                }
                 unsigned long long sum = on_bytes;
                 for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
                 if (lane == 0) {  // (a few atomics per service phase that has such rays: measurement for free)
                     atomicAdd(&a.excursions[0], (unsigned long long)__popcll(fm));
-                    if (om) atomicAdd(&a.excursions[1], (unsigned long long)__popcll(om));
+                    if (gm) atomicAdd(&a.excursions[1], (unsigned long long)__popcll(gm));
                     atomicAdd(&a.excursions[2], 1ull);
                     atomicAdd(&a.excursions[3], sum);
                 }
@@ -359,6 +404,28 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             state = kTrav;
         }
         if (__ballot(state != kIdle) == 0 && queue_empty) break;
+    }
+
+    // ---- second phase (FOREIGN): the pixels this wave gave up on the image, whole, on the world's own bytes ----
+    if (FOREIGN) {
+        const DevScene sc_bytes = make_scene(sa);
+        for (uint32_t c = my_chunk; c != 0;) {
+            const uint32_t* chunk = todo.chunks + size_t(c - 1) * kChunkDwords;
+            const uint32_t n = __builtin_amdgcn_readfirstlane(chunk[1]);
+            c = __builtin_amdgcn_readfirstlane(chunk[0]);
+            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                if (i0 + lane < n) {
+                    const uint32_t index = chunk[2 + i0 + lane];
+                    uint32_t x, y;
+                    out_index_to_xy(p, index, x, y);
+                    float color[4];
+                    vx_hit r;
+                    shade_pixel<FOREIGN ? FOREIGN : VX_SVO_CSVO, false>(sc_bytes, p, x, y, st, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
+                    if (out) out[index] = make_float4(color[0], color[1], color[2], color[3]);
+                    if (HITS) hits[index] = r;
+                }
+            }
+        }
     }
 
     if (STATS) {
@@ -526,6 +593,10 @@ struct vx_context {
     // Tickets drawn from each dispenser so far. A launch draws exactly total_subtiles + waves tickets (every wave draws one
     // ticket past the end before it stops), so the next launch on the same stream starts there and no reset is needed.
     uint32_t frame_tickets[kFrameStreams] = {};
+    uint32_t* d_frame_todo[kFrameStreams] = {};  // images of CSVO worlds: [chunk counter][ring of 128-dword chunks] per stream (PixelList)
+    size_t frame_todo_chunks[kFrameStreams] = {};
+    uint32_t* d_main_todo = nullptr;
+    size_t main_todo_chunks = 0;
     uint32_t main_tickets = 0;
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
     int frames_in_flight = 2;           // 1 serialises frames on `stream` again (vx_set_frames_in_flight / VX_FRAMES_IN_FLIGHT)
@@ -704,7 +775,31 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.excursions = ctx->d_excursions;
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
-        void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters};
+        PixelList todo = {nullptr, nullptr, 0};
+        if (imaged && ctx->svo_type == VX_SVO_CSVO) {
+            // per stream: a ring of chunks behind a counter that only ever grows -- nothing to reset between frames. A finished
+            // chunk holds at least 63 pixels, every wave can have one unfinished one: pixels / 63 + waves chunks per launch at most.
+            uint32_t*& ring = slot >= 0 ? ctx->d_frame_todo[slot] : ctx->d_main_todo;
+            size_t& have = slot >= 0 ? ctx->frame_todo_chunks[slot] : ctx->main_todo_chunks;
+            const size_t need = size_t(p.n_local_tiles) * kTile * kTile / 63 + waves + 1;
+            if (have < need) {
+                if (ring) {
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    (void)hipFree(ring);
+                    ring = nullptr;
+                    have = 0;
+                }
+                size_t cap = 64;
+                while (cap < need) cap <<= 1;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ring), (cap * kChunkDwords + 32) * sizeof(uint32_t)));  // [counter, pad][chunks...]
+                HIP_TRY(hipMemsetAsync(ring, 0, 32 * sizeof(uint32_t), stream));
+                have = cap;
+            }
+            todo.next_chunk = ring;
+            todo.chunks = ring + 32;
+            todo.mask = uint32_t(have - 1);
+        }
+        void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, &todo};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
         tickets += a.total_subtiles + waves;
     }
@@ -922,11 +1017,12 @@ void vx_destroy(vx_context* c) {
     for (auto& l : c->event_pool) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     if (c->staging) (void)hipHostFree(c->staging);
     void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_frame, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
-                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin, c->d_excursions};
+                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin, c->d_excursions, c->d_main_todo};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
         if (c->d_frame_counter[i]) (void)hipFree(c->d_frame_counter[i]);
+        if (c->d_frame_todo[i]) (void)hipFree(c->d_frame_todo[i]);
         if (c->frame_done[i]) (void)hipEventDestroy(c->frame_done[i]);
         if (c->frame_stream[i]) (void)hipStreamDestroy(c->frame_stream[i]);
     }

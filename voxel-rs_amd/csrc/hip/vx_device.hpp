@@ -846,12 +846,13 @@ struct Trav {
 // section are in the world. It ends when (a) a POP brings the ray back to the voxel's parent or above: from there on every
 // node is a real one again and the ray continues on the image (kTravContinue: `tr` is the cursor to go on with; the stack
 // slots at and above the parent's scale hold image entries, the excursion only ever writes below them); (b) a phantom leaf
-// is accepted (kTravAtLeaf: `res` is the hit); (c) the ray ends (kTravFinished: a miss).
+// is accepted (kTravAtLeaf: `res` is the hit); (c) the ray ends (kTravFinished: a miss); (d) the walk overwrote cursor state
+// that the rest of the ray depends on (below).
 // `st` is a full stack (the excursion can go below the LDS-resident levels). The iteration `tr` stopped in is repeated here, so
 // `tr.iter` must not count it (the caller took it back, as for kTravDeep); on return `tr.iter` counts everything that ran.
-template <int IMGSVO, class ST, bool LIMIT = false>
+template <int IMGSVO, class ST, bool LIMIT = false, bool RESTART = true>
 __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, const DevScene& bytes, Trav<IMGSVO>& tr, const ST& st,
-                                                           bool cast_translucent, Result& res, bool* started_over = nullptr) {
+                                                           bool cast_translucent, Result& res) {
     static_assert(!ST::kFast, "the excursion needs every stack level");
     typedef Trav<VX_SVO_CSVO> ByteTrav;
     const int parent_scale = tr.scale;
@@ -881,8 +882,9 @@ __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, 
     // material (svo.csvo.glsl:119-133). The reference goes on with whatever they hold when the ray is back among real nodes. If that
     // is what they held before -- or, for pre_leaf_pointer, if the ray is back above the voxel's parent, where the next depth-2 node
     // it enters sets it afresh (svo.csvo.glsl:283) -- the rest of the ray is what the image gives. If not, the voxels it hits from
-    // there on report materials read through the overwritten pointers: such a ray is started over and run on the world's own bytes
-    // from the root, with the reference's cursor throughout (`for_good`).
+    // there on report materials read through the overwritten pointers: such a ray has to be run on the world's own bytes from the
+    // root, with the reference's cursor throughout. RESTART: that is done here and now (`for_good`); otherwise kTravForeign is
+    // returned and the caller sees to it (the render kernel, whose lanes walk in lockstep, puts the pixel on a list for later).
     const uint32_t true_material_section = tb.material_section_ptr, true_pre_leaf = tb.pre_leaf_pointer;
 
     TravStatus outcome;
@@ -913,6 +915,10 @@ __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, 
         }
         // back among real nodes
         if (tb.material_section_ptr != true_material_section || (tb.scale == parent_scale && tb.pre_leaf_pointer != true_pre_leaf)) {
+            if (!RESTART) {
+                outcome = kTravForeign;
+                break;
+            }
             tb.start(bytes);
             for_good = true;
             continue;
@@ -932,7 +938,6 @@ __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, 
     tr.t_min = tb.t_min; tr.t_max = tb.t_max; tr.h = tb.h; tr.scale = tb.scale; tr.scale_exp2 = tb.scale_exp2;
     tr.ptr = tb.ptr; tr.node = tb.node;
     tr.last_leaf_value = tb.last_leaf_value; tr.flags = tb.flags; tr.iter = tb.iter;
-    if (started_over) *started_over = for_good;
     return outcome;
 }
 
