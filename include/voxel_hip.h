@@ -271,7 +271,7 @@ int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches);
  * [1] bytes of the image, [2] bytes of its origin table (CSVO worlds), [3] chunks it holds. */
 int vx_image_info(const vx_context* ctx, uint64_t out[4]);
 /* CSVO worlds rendered from their traversal image: since creation (or the last reset), [0] rays that were led into the voxel they
- * started in and made that walk on the world's own bytes, [1] those of them that had to be started over on the bytes (the walk
+ * started in and made that walk on the world's own bytes, [1] those of them whose pixel was rendered again on the bytes (the walk
  * overwrote cursor state the rest of the ray depends on), [2] service phases of the render kernel that ran such walks (the rays of a
  * wave go together), [3] loop iterations made on the world's own bytes. Waits for every frame in flight. */
 int vx_excursion_counters(vx_context* ctx, uint64_t out[4], int reset);

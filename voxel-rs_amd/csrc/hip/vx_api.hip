@@ -635,7 +635,7 @@ struct vx_context {
     bool image_enabled = true;  // VX_TRAVERSAL_IMAGE=0: traverse the world's own bytes
     bool image_ok = false;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
-    uint32_t refill_min = 4, service_min = 28, foreign_min = 24;
+    uint32_t refill_min = 4, service_min = 28, foreign_min = 32;
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int cu_count = 256;
@@ -972,8 +972,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
     CREATE_TRY(hipMemset(c->d_work_counter, 0, sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_excursions), 4 * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemset(c->d_excursions, 0, 4 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_excursions), 8 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(c->d_excursions, 0, 8 * sizeof(unsigned long long)));
     {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
@@ -1534,7 +1534,7 @@ int vx_excursion_counters(vx_context* ctx, uint64_t out[4], int reset) {
     if (!ctx || !out) return fail(VX_ERR_INVALID_ARGUMENT, "excursion_counters: null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     if (int rc = drain_streams(ctx)) return rc;
-    unsigned long long h[4] = {};
+    unsigned long long h[8] = {};
     HIP_TRY(hipMemcpy(h, ctx->d_excursions, sizeof h, hipMemcpyDeviceToHost));
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
     if (reset) HIP_TRY(hipMemset(ctx->d_excursions, 0, sizeof h));
