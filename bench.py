@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames the renderer keeps in flight (1..8); default: the library's own (2) on one GPU, max(3, N) when the frame is sharded over N")
     ap.add_argument("--gather-group", type=int, default=0, help="sharded: frames per gather (default 1)")
+    ap.add_argument("--gather", choices=["library", "torch"], default="library",
+                    help="sharded: the exchange step -- library: vx_gather_tiles (RCCL send/receive owned by the render context); torch: torch.distributed.gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (tile lists, RCCL gather, assembly) even with one rank; needs a torch.distributed.run launch")
@@ -146,13 +148,21 @@ def main():
         def render_tiles(tiles):
             svo.render_device(uniforms, W, H, tiles.data_ptr(), tile_rank=rank, tile_count=world_size)
 
-        def assemble(gathered, image):
-            # on the collective's stream: ordered after the gather by construction, and the render streams stay free for the
-            # next frame's tiles. `gathered` is [rank][tile]... with the ranks a whole group of frames apart.
-            svo.assemble_tiles(gathered.data_ptr(), gathered.stride(0), world_size, W, H, image.data_ptr(),
-                               stream=torch.cuda.current_stream().cuda_stream)
+        library_gather = args.gather == "library"
+        if library_gather:
+            # the render context owns the RCCL communicator the tiles travel over (vx_comm_init); torch.distributed only carries the
+            # id to the ranks and the barriers / statistics of this script
+            uid = [hip.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            svo.comm_init(world_size, rank, uid[0])
+        exchange_stream = svo.comm_stream if library_gather else torch.cuda.current_stream().cuda_stream
 
-        # The renderer runs frames on its own streams; the gather and the assembly run on torch's. One tile buffer per frame
+        def assemble(gathered, image):
+            # on the exchange's stream: ordered after the gather by construction, and the render streams stay free for the
+            # next frame's tiles. `gathered` is [rank][tile]... with the ranks a whole group of frames apart.
+            svo.assemble_tiles(gathered.data_ptr(), gathered.stride(0), world_size, W, H, image.data_ptr(), stream=exchange_stream)
+
+        # The renderer runs frames on its own streams; the gather and the assembly run on the communicator's. One tile buffer per frame
         # in flight: a render only has to wait for the collective that last read its buffer.
         # frames in flight: the smaller a rank's share of the frame, the longer its tail relative to its body (a frame cannot
         # finish before its longest ray) and the more frames it takes to keep the device full
@@ -164,20 +174,31 @@ def main():
         svo.set_frames_in_flight(FRAMES)
         exchange_done = [torch.cuda.Event() for _ in range(FRAMES // GROUP)]
         recorded = [False] * (FRAMES // GROUP)
+        tickets = {}
 
         def before_render(g):
-            if recorded[g]:
+            if library_gather:
+                if g in tickets:
+                    svo.wait_gather(tickets[g])
+            elif recorded[g]:
                 svo.wait_event(exchange_done[g].cuda_event)
 
         def after_render():
-            svo.stream_wait_render(torch.cuda.current_stream().cuda_stream)
+            if not library_gather:
+                svo.stream_wait_render(torch.cuda.current_stream().cuda_stream)
 
         def after_exchange(g):
-            exchange_done[g].record(torch.cuda.current_stream())
-            recorded[g] = True
+            if not library_gather:
+                exchange_done[g].record(torch.cuda.current_stream())
+                recorded[g] = True
+
+        def gather(tiles, gathered):
+            g = sharder._g  # (the group being exchanged; a later render into its lists waits for this gather to have read them)
+            tickets[g] = svo.gather_tiles(tiles.data_ptr(), tiles.numel() * 4, gathered.data_ptr() if rank == 0 else None, root=0)
 
         sharder = FrameSharder(W, H, rank, world_size, dist, "cuda", render_tiles, assemble, before_render=before_render,
-                               after_render=after_render, after_exchange=after_exchange, buffers=FRAMES, group=GROUP)
+                               after_render=after_render, after_exchange=after_exchange, buffers=FRAMES, group=GROUP,
+                               gather=gather if library_gather else None)
         step = sharder.step
         flush = sharder.flush
     else:
@@ -348,7 +369,9 @@ def main():
         "config": {"workload": f"C3: {W}x{H} primary + 1 shadow ray per lit pixel, textured + normal-mapped shading, depth-{args.depth} SVO "
                                f"({args.format.upper()} nodes), 1 frame per step", "svo_format": args.format, "svo_bytes": world.size_in_bytes,
                    "leaves": st["leaves"], "chunks": st["chunks"], "textures": args.textures, "rays_per_frame": int(total_rays), "primary_rays": W * H,
-                   "parallelism": f"screen tiles (32x32, interleaved) over {world_size} GPU(s), SVO replicated, RCCL gather to rank 0",
+                   "parallelism": f"screen tiles (32x32, Morton order, round-robin) over {world_size} GPU(s), SVO replicated, RCCL gather to rank 0",
+                   **({"rccl_ranks": world_size, "gather": "vx_gather_tiles (grouped ncclSend/ncclRecv on the render context's own communicator)" if args.gather == "library"
+                       else "torch.distributed.gather (nccl backend)"} if sharded else {}),
                    **({"sharded_frame_identical_to_whole_render": sharded_frame_identical} if sharded else {}),
                    "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 3),
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4)},

@@ -35,6 +35,11 @@ typedef enum vx_status {
 } vx_status;
 
 typedef enum vx_memory { VX_MEM_HOST = 0, VX_MEM_DEVICE = 1 } vx_memory;
+/* Pixel format of a render target. RGBA32F is the reference's framebuffer (the image2D of world.glsl:10, row 0 = bottom); RGBA8 is
+ * what Framebuffer::as_image reads back from it (src/graphics/framebuffer.rs:97-111): glReadPixels(RGBA, UNSIGNED_BYTE) -- clamp
+ * to [0,1], round to the nearest of 255 steps, NaN -> 0 -- flipped vertically, so a whole image has its TOP row first. A quarter
+ * of the bytes for a presenting embedder's read-back and for the multi-GPU gather. */
+typedef enum vx_format { VX_FORMAT_RGBA32F = 0, VX_FORMAT_RGBA8 = 1 } vx_format;
 
 typedef struct vx_context vx_context; /* replaces `struct Svo` (svo.rs:56-73): owns every device object */
 
@@ -136,17 +141,19 @@ typedef struct vx_counters {
     uint64_t tail_wave_steps, tail_iterations;
 } vx_counters;
 
-/* Where vx_render writes. Tiles are 32x32 pixels, numbered row-major from the bottom-left; a context renders
- * the tiles t with t % tile_count == tile_rank (multi-GPU screen sharding; 0/1 = whole image).
- *   tile_count <= 1: rgba32f is width*height RGBA32F pixels, row 0 = bottom -- the image2D of world.glsl:10.
- *   tile_count  > 1: rgba32f is a compact tile list: local tile k (global tile k*tile_count + tile_rank)
- *                    occupies floats [k*4096, (k+1)*4096), pixel (x,y) of the tile at (y*32+x)*4.
+/* Where vx_render writes. Tiles are 32x32 pixels; the image's tiles are taken in MORTON order of their (x, y) (vx_tile_order: any
+ * run of consecutive places is a compact patch of the screen) and shared out round-robin: a context renders the tiles at the places
+ * j with j % tile_count == tile_rank (multi-GPU screen sharding; 0/1 = whole image).
+ *   tile_count <= 1: the target is width*height pixels -- RGBA32F: row 0 = bottom, the image2D of world.glsl:10; RGBA8: row 0 = top.
+ *   tile_count  > 1: the target is a compact tile list: local tile k (the tile at place k*tile_count + tile_rank) occupies pixels
+ *                    [k*1024, (k+1)*1024), pixel (x,y) of the tile (y counted from the bottom) at y*32+x.
  * hits (optional) uses the same indexing with vx_hit elements. */
 typedef struct vx_target {
-    void* rgba32f;
+    void* rgba32f;  /* the pixels, in `format` */
     vx_hit* hits;
     int32_t memory; /* vx_memory of both pointers */
     uint32_t tile_rank, tile_count;
+    int32_t format; /* vx_format; 0 = RGBA32F */
 } vx_target;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
@@ -225,7 +232,45 @@ int vx_set_frames_in_flight(vx_context* ctx, int frames);
 int vx_wait_event(vx_context* ctx, void* hip_event);
 int vx_stream_wait_render(vx_context* ctx, void* stream);
 
-/* ---- multi-GPU image assembly ----------------------------------------------------------------------------- */
+/* ---- pipelined presentation --------------------------------------------------------------------------------- */
+
+/* For an embedder that shows every frame (the reference blits its framebuffer, src/gamelogic/world.rs:269-283): vx_present_begin
+ * enqueues the frame on one of the frame streams and its read-back into pinned host memory on a copy stream behind it, and
+ * returns a slot (0..3, in rotation); vx_present_wait blocks until that slot's image is in place and returns it (valid until the
+ * slot comes round again, i.e. for the next three vx_present_begin calls). Begin frame k+1, then wait for frame k: the read-back
+ * of one frame runs beside the kernel of the next. */
+int vx_present_begin(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, int format, int* out_slot);
+int vx_present_wait(vx_context* ctx, int slot, const void** pixels, size_t* bytes);
+
+/* ---- multi-GPU: tiles, gather, assembly ------------------------------------------------------------------------- */
+
+/* The shared sequence of an image's tiles: out[j] = row-major id (ty * tiles_x + tx, from the bottom-left) of the tile at place j
+ * of the Morton order. Returns the number of tiles; fills `out` when capacity suffices. Pure host function. */
+uint32_t vx_tile_order(uint32_t width, uint32_t height, uint32_t* out, uint32_t capacity);
+
+/* The handle owns the RCCL communicator the finished tiles travel over (SURVEY.md 8b "Ownership"; one process per GPU):
+ *   vx_comm_unique_id   on ONE rank: a fresh 128-byte id (ncclGetUniqueId), which the caller hands to every rank by its own means
+ *   vx_comm_init        on every rank, collectively: ncclCommInitRank on this context's device
+ *   vx_gather_tiles     the one exchange step of the path: this rank's compact tile list (`bytes_per_rank` bytes of device
+ *                       memory, the same on every rank) goes to `root`, which receives rank r's list at gathered + r *
+ *                       bytes_per_rank -- grouped ncclSend / ncclRecv, every peer straight to the root over its own xGMI link, on
+ *                       the communicator's stream and ordered behind every vx_render issued so far (the list's among them). Returns
+ *                       after enqueueing; *out_ticket (optional) names the gather for vx_wait_gather
+ *   vx_wait_gather      the NEXT vx_render waits (on the device) for that gather: call it before rendering into a tile list a
+ *                       gather may still be reading
+ *   vx_comm_stream      the communicator's hipStream_t: vx_assemble_tiles_on(.., vx_comm_stream(ctx)) is ordered behind the gather
+ * RCCL is opened at run time (dlopen of librccl.so.1) by the first of these calls; a single-GPU deployment needs none. */
+#define VX_COMM_ID_BYTES 128
+int vx_comm_unique_id(void* out_id, size_t bytes);
+int vx_comm_init(vx_context* ctx, int nranks, int rank, const void* unique_id);
+int vx_comm_destroy(vx_context* ctx);
+int vx_comm_info(const vx_context* ctx, int* nranks, int* rank);
+int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank, void* gathered, int root, int* out_ticket);
+int vx_wait_gather(vx_context* ctx, int ticket);
+void* vx_comm_stream(vx_context* ctx);
+/* vx_assemble_tiles for either pixel format: stride in PIXELS between the ranks' lists; an RGBA8 image comes out top row first. */
+int vx_assemble_tiles_format(vx_context* ctx, const void* tiles, uint64_t stride_pixels, uint32_t tile_count, uint32_t width, uint32_t height, void* out,
+                             int format, void* stream);
 
 /* Scatters `tile_count` gathered compact tile lists (rank r's list at tiles + r*stride_floats) into a
  * width*height RGBA32F image; all pointers are device memory on this context's device. */

@@ -12,6 +12,8 @@
 #define __constant__ static const
 #define __restrict__
 struct uint4 { uint32_t x, y, z, w; };
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct uint2 { uint32_t x, y; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 static inline uint32_t __popc(uint32_t v) { return uint32_t(__builtin_popcount(v)); }

@@ -66,3 +66,41 @@ def test_local_tile_count():
     assert sum(hip.local_tile_count(1920, 1080, r, 8) for r in range(8)) == 60 * 34
     assert hip.local_tile_count(200, 120, 2, 3) == (7 * 4 - 2 + 2) // 3
     assert np.isfinite(1.0)
+
+
+def test_tile_order_is_a_morton_sequence_shared_with_the_host_side():
+    """vx_tile_order (what vx_render and vx_assemble_tiles use) = voxel_rs_amd.sharding.tile_order (what the host-side sharding
+    helpers and the gloo tests use); consecutive places are neighbours on the screen (Z-order)."""
+    from voxel_rs_amd import hip, sharding
+
+    for w, h in ((1920, 1080), (3840, 2160), (7680, 4320), (200, 120), (33, 31), (64, 64), (31, 2000)):
+        order = hip.tile_order(w, h)
+        assert list(order) == sharding.tile_order(w, h)
+        assert sorted(order) == list(range(len(order)))
+    order = hip.tile_order(128, 128)  # 4 x 4 tiles: the textbook Z
+    assert list(order) == [0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15]
+    # eight ranks at 1080p: every rank's tiles are spread over the whole screen (no rank owns a band)
+    tx = 60
+    for r in range(8):
+        mine = hip.tile_order(1920, 1080)[r::8]
+        assert (mine % tx).min() < 8 and (mine % tx).max() > 51 and (mine // tx).min() < 4 and (mine // tx).max() > 29
+
+
+def test_comm_entry_points_reject_bad_arguments():
+    """The RCCL side of the ABI (vx_comm_*, vx_gather_tiles, vx_wait_gather) exists and fails cleanly without a context, a
+    communicator or a GPU -- no call reaches RCCL here."""
+    from voxel_rs_amd import hip
+
+    L = hip.lib()
+    assert L.vx_comm_unique_id(None, 128) == 1 and b"128" in L.vx_last_error()
+    small = C.create_string_buffer(16)
+    assert L.vx_comm_unique_id(small, 16) == 1
+    ident = C.create_string_buffer(hip.VX_COMM_ID_BYTES)
+    assert L.vx_comm_init(None, 2, 0, ident) == 1
+    assert L.vx_comm_destroy(None) == 1
+    assert L.vx_gather_tiles(None, None, 0, None, 0, None) == 1
+    assert L.vx_wait_gather(None, 0) == 1
+    assert L.vx_comm_stream(None) is None
+    n, r = C.c_int(-1), C.c_int(-1)
+    assert L.vx_comm_info(None, C.byref(n), C.byref(r)) == 1
+    assert L.vx_present_wait(None, 0, None, None) == 1

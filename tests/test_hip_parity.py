@@ -444,3 +444,186 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
         assert np.array_equal(np.isnan(r[0]), np.isnan(results[0][0]))
         print("max colour difference between kernel versions:", np.nanmax(np.abs(r[0] - results[0][0])))
         assert np.nanmax(np.abs(r[0] - results[0][0])) <= COLOR_TOL
+
+
+# ---- output formats, presentation ring, lifetime, fall-back, the library's own gather ---------------------------------------------
+
+
+def as_image(img):
+    """Framebuffer::as_image (src/graphics/framebuffer.rs:97-111): RGBA8 read-back (clamp, round to nearest of 255 steps), flipped."""
+    v = np.where(np.isnan(img), np.float32(0), img).astype(np.float32)
+    v = np.clip(v, np.float32(0), np.float32(1))
+    return (v * np.float32(255) + np.float32(0.5)).astype(np.uint8)[::-1]
+
+
+def heightfield_svo(hip, fmt, depth=8):
+    from voxel_rs_amd import scenes
+
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(depth, threads=4)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+    return world, st, svo, tex, mats
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_rgba8_target_is_as_image_of_the_float_frame(hip, fmt):
+    import torch
+    from voxel_rs_amd import scenes
+
+    world, st, svo, tex, mats = heightfield_svo(hip, fmt)
+    w, h = 200, 120
+    u = scenes.bench_camera(8, st["h_max"], w, h)
+    img, _ = svo.render(u, w, h)
+    img8, _ = svo.render(u, w, h, fmt=hip.VX_FORMAT_RGBA8)
+    assert img8.dtype == np.uint8 and img8.tobytes() == as_image(img).tobytes()
+    # against the oracle's frame read back the same way: equal but for colours within 5e-6 of a rounding step
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    cimg, _ = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h, want_hits=False)
+    d = np.abs(img8.astype(np.int32) - as_image(cimg).astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    # tile lists in RGBA8, assembled: the same image
+    count = 3
+    per = max(hip.local_tile_count(w, h, r, count) for r in range(count))
+    gathered = torch.zeros((count, per, 32, 32), dtype=torch.int32, device="cuda")
+    out = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for r in range(count):
+        svo.render_device(u, w, h, gathered[r].data_ptr(), tile_rank=r, tile_count=count, fmt=hip.VX_FORMAT_RGBA8)
+    svo.stream_wait_render(svo.stream)
+    svo.sync()
+    svo.assemble_tiles_format(gathered.data_ptr(), per * 32 * 32, count, w, h, out.data_ptr(), hip.VX_FORMAT_RGBA8, svo.stream)
+    svo.sync()
+    assert out.cpu().numpy().view(np.uint8).reshape(h, w, 4).tobytes() == img8.tobytes()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_presentation_ring(hip, fmt):
+    """vx_present_begin / vx_present_wait: frame k+1 is begun before frame k is waited for; every frame is the frame."""
+    from voxel_rs_amd import scenes
+
+    world, st, svo, tex, mats = heightfield_svo(hip, fmt)
+    w, h = 320, 180
+    cams = [scenes.bench_camera(8, st["h_max"] + 3 * i, w, h) for i in range(9)]
+    for out_fmt in (hip.VX_FORMAT_RGBA8, hip.VX_FORMAT_RGBA32F):
+        expect = [svo.render(u, w, h, fmt=out_fmt)[0] for u in cams]
+        slots = [svo.present_begin(cams[0], w, h, out_fmt)]
+        for k in range(1, len(cams)):
+            slots.append(svo.present_begin(cams[k], w, h, out_fmt))
+            got = svo.present_wait(slots[k - 1], w, h, out_fmt)
+            assert got.tobytes() == expect[k - 1].tobytes(), (out_fmt, k)
+        assert svo.present_wait(slots[-1], w, h, out_fmt).tobytes() == expect[-1].tobytes()
+        assert len(set(slots[:4])) == 4
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_swapping_materials_and_textures_with_eight_frames_in_flight(hip, fmt):
+    """vx_set_materials / vx_set_textures while frames are in flight on all eight frame streams: the old tables stay alive until
+    those frames are done (they are in the kernels' arguments), every frame shows exactly one generation of them."""
+    import torch
+    from voxel_rs_amd import scenes
+
+    world, st, svo, tex, mats = heightfield_svo(hip, fmt)
+    w, h = 480, 270
+    u = scenes.bench_camera(8, st["h_max"], w, h)
+    mats_b = mats.copy()
+    mats_b["specular_strength"] = 0.9
+    mats_b["tex_top"][1], mats_b["tex_side"][1] = mats["tex_side"][3], mats["tex_top"][3]  # grass wears stone
+    tex_b = tex.copy()
+    tex_b[..., 0] = tex[..., 2]  # red <- blue
+    frame_a = svo.render(u, w, h)[0]
+    svo.set_materials(mats_b)
+    svo.set_textures(tex_b, 6)
+    frame_b = svo.render(u, w, h)[0]
+    assert np.nanmax(np.abs(frame_a - frame_b)) > 0.05
+    svo.set_frames_in_flight(8)
+    targets = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(16)]
+    torch.cuda.synchronize()
+    for rounds in range(3):
+        svo.set_materials(mats)
+        svo.set_textures(tex, 6)
+        for t in targets[:8]:
+            svo.render_device(u, w, h, t.data_ptr())
+        svo.set_materials(mats_b)  # eight frames in flight on eight streams read the tables this replaces
+        svo.set_textures(tex_b, 6)
+        for t in targets[8:]:
+            svo.render_device(u, w, h, t.data_ptr())
+        svo.sync()
+        for i, t in enumerate(targets):
+            got, exp = t.cpu().numpy(), (frame_a if i < 8 else frame_b)
+            assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.nanmax(np.abs(got - exp)) == 0.0, (rounds, i)
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_image_that_does_not_fit_falls_back_to_the_worlds_bytes(hip, fmt, monkeypatch):
+    """The traversal image is an accelerator: when its device allocation fails (here: capped), the context renders from the world's
+    own bytes -- same frames -- and a later commit that fits brings the image back."""
+    from voxel_rs_amd import scenes
+
+    monkeypatch.setenv("VX_IMAGE_CAP_BYTES", "4096")
+    world, st, svo, tex, mats = heightfield_svo(hip, fmt)
+    assert svo.image_info()["layout"] == 0
+    w, h = 160, 96
+    u = scenes.bench_camera(8, st["h_max"], w, h)
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    img, hits = svo.render(u, w, h, want_hits=True)
+    cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
+    compare_frames(img, hits, cimg, chits)
+    # one more chunk, committed incrementally into the context that has no image: still the oracle's frame
+    extra = vra.Chunk(1, 7, 1, 5)
+    extra.apply_blocks([dict(box=[[0, 32], [0, 8], [0, 32]], id=3)])
+    extra.compact()
+    world.set_chunk((1, 7, 1), extra)
+    world.serialize()
+    svo.update(world)
+    assert svo.image_info()["layout"] == 0
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    img, hits = svo.render(u, w, h, want_hits=True)
+    cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
+    compare_frames(img, hits, cimg, chits)
+    monkeypatch.delenv("VX_IMAGE_CAP_BYTES")
+    svo2 = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo2.set_materials(mats)
+    svo2.set_textures(tex, 6)
+    svo2.update_full(world)
+    assert svo2.image_info()["layout"] == 1
+    img2, hits2 = svo2.render(u, w, h, want_hits=True)
+    assert hits2.tobytes() == hits.tobytes()
+
+
+def test_the_librarys_gather_with_one_rank(hip):
+    """vx_comm_init / vx_gather_tiles / vx_wait_gather on a one-rank communicator (RCCL opened at run time): the root's own share is
+    its tile list; assembled on the communicator's stream it is the frame. (More ranks need more GPUs: the N > 1 arithmetic is
+    covered on CPU by tests/test_sharding.py.)"""
+    import torch
+    from voxel_rs_amd import scenes
+
+    world, st, svo, tex, mats = heightfield_svo(hip, "csvo")
+    w, h = 200, 120
+    u = scenes.bench_camera(8, st["h_max"], w, h)
+    full, _ = svo.render(u, w, h)
+    svo.comm_init(1, 0, hip.comm_unique_id())
+    with pytest.raises(hip.VoxelHipError, match="already has a communicator"):
+        svo.comm_init(1, 0, hip.comm_unique_id())
+    # "two ranks" rendered by this one GPU, each share gathered separately through the communicator (root = the only rank)
+    count = 2
+    per = max(hip.local_tile_count(w, h, r, count) for r in range(count))
+    lists = torch.zeros((count, per, 32, 32, 4), dtype=torch.float32, device="cuda")
+    gathered = torch.zeros((count, per, 32, 32, 4), dtype=torch.float32, device="cuda")
+    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    tickets = {}
+    for frame in range(3):
+        for r in range(count):
+            if r in tickets:
+                svo.wait_gather(tickets[r])  # the list this render overwrites may still be read by the previous frame's gather
+            svo.render_device(u, w, h, lists[r].data_ptr(), tile_rank=r, tile_count=count)
+            tickets[r] = svo.gather_tiles(lists[r].data_ptr(), per * 32 * 32 * 16, gathered[r].data_ptr(), root=0)
+        svo.assemble_tiles(gathered.data_ptr(), per * 32 * 32 * 4, count, w, h, out.data_ptr(), stream=svo.comm_stream)
+    svo.sync()
+    assert out.cpu().numpy().tobytes() == full.tobytes()
+    svo.comm_destroy()
+    svo.comm_destroy()

@@ -5,6 +5,8 @@
 // render kernel; glDispatchCompute(picker.glsl) -> picker kernel; glFenceSync/glClientWaitSync -> HIP events.
 // There is no CPU path: without a HIP device every entry point fails with VX_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: RCCL itself is opened at run time by vx_comm_init (a single-GPU deployment needs none)
 
 #include <algorithm>
 #include <cmath>
@@ -61,7 +63,9 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
     // block -> (local tile, 16x16 sub-block) -> pixel
     const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t local_tile = b >> 2, sub = b & 3u;
-    const uint32_t tile = local_tile * p.tile_count + p.tile_rank;
+    const uint32_t seq = local_tile * p.tile_count + p.tile_rank;
+    const bool tile_valid = seq < p.tiles_x * p.tiles_y;
+    const uint32_t tile = p.tile_count > 1 ? (tile_valid ? p.tile_order[seq] : 0u) : seq;
     const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     uint32_t lx, ly;
@@ -69,7 +73,6 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
     const uint32_t in_x = (sub & 1u) * kBlockEdge + (wave & 1u) * 8 + lx;  // position inside the 32x32 tile
     const uint32_t in_y = (sub >> 1) * kBlockEdge + (wave >> 1) * 8 + ly;
     const uint32_t x = tx * kTile + in_x, y = ty * kTile + in_y;
-    const bool tile_valid = tile < p.tiles_x * p.tiles_y;
     const bool active = tile_valid && x < p.width && y < p.height;
 
     Counters ctr = {};
@@ -78,13 +81,14 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
         float color[4];
         vx_hit rec;
         shade_pixel<SVO, STATS>(sc, p, x, y, st, color, HITS ? &rec : nullptr, STATS ? &ctr : nullptr, &lit, &shadow_rays);
-        const size_t index = p.tile_count > 1 ? size_t(local_tile) * (kTile * kTile) + in_y * kTile + in_x : size_t(y) * p.width + x;
-        if (out) out[index] = make_float4(color[0], color[1], color[2], color[3]);
+        const size_t index = p.tile_count > 1 ? size_t(local_tile) * (kTile * kTile) + in_y * kTile + in_x : size_t(image_index(p, x, y));
+        if (out) store_pixel(p, out, index, color);
         if (HITS) hits[index] = rec;
     } else if (tile_valid && p.tile_count > 1) {
         // pixels of an edge tile that fall outside the image: keep the compact tile list fully defined
         const size_t index = size_t(local_tile) * (kTile * kTile) + in_y * kTile + in_x;
-        if (out) out[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (out) store_pixel(p, out, index, zero);
         if (HITS) memset(&hits[index], 0, sizeof(vx_hit));
     }
 
@@ -141,12 +145,13 @@ constexpr uint32_t kChunkDwords = 128, kChunkEntries = 126;
 __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t out_index, uint32_t& x, uint32_t& y) {
     if (p.tile_count > 1) {
         const uint32_t local_tile = out_index >> 10, in_y = (out_index >> 5) & 31u, in_x = out_index & 31u;
-        const uint32_t tile = local_tile * p.tile_count + p.tile_rank;
+        const uint32_t tile = p.tile_order[local_tile * p.tile_count + p.tile_rank];
         x = (tile % p.tiles_x) * kTile + in_x;
         y = (tile / p.tiles_x) * kTile + in_y;
     } else {
         x = out_index % p.width;
         y = out_index / p.width;
+        if (p.rgba8) y = p.height - 1u - y;
     }
 }
 
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 }
             }
             if (write) {
-                if (out) out[out_index] = make_float4(color[0], color[1], color[2], color[3]);
+                if (out) store_pixel(p, out, out_index, color);
                 if (HITS) {
                     rec.steps = steps;
                     hits[out_index] = rec;
@@ -371,14 +376,14 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 if (state == kIdle && !new_ray && k < 64) {
                     // sub-tile -> pixel: 32x32 tile (sharding unit), 4x4 sub-tiles in Morton order, 8x8 pixels in Morton order
                     const uint32_t local_tile = sub >> 4, s = sub & 15u;
-                    const uint32_t tile = local_tile * p.tile_count + p.tile_rank;
+                    const uint32_t tile = p.tile_count > 1 ? p.tile_order[local_tile * p.tile_count + p.tile_rank] : local_tile;
                     const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
                     const uint32_t sx = (s & 1u) | ((s >> 1) & 2u), sy = ((s >> 1) & 1u) | ((s >> 2) & 2u);
                     uint32_t lx, ly;
                     lane_to_xy(k, lx, ly);
                     const uint32_t in_x = sx * 8 + lx, in_y = sy * 8 + ly;
                     const uint32_t px_x = tx * kTile + in_x, px_y = ty * kTile + in_y;
-                    out_index = p.tile_count > 1 ? local_tile * (kTile * kTile) + in_y * kTile + in_x : px_y * p.width + px_x;
+                    out_index = p.tile_count > 1 ? local_tile * (kTile * kTile) + in_y * kTile + in_x : image_index(p, px_x, px_y);
                     if (px_x < p.width && px_y < p.height) {
                         primary_ray(p, px_x, px_y, new_ro, new_rd);
                         primary_rd[0] = new_rd[0]; primary_rd[1] = new_rd[1]; primary_rd[2] = new_rd[2];
@@ -388,7 +393,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                         if (STATS) { ctr.rays++; ++n_pixels; }
                     } else if (p.tile_count > 1) {
                         // padding pixel of an edge tile: keep the compact tile list fully defined
-                        if (out) out[out_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (out) store_pixel(p, out, out_index, zero);
                         if (HITS) memset(&hits[out_index], 0, sizeof(vx_hit));
                     }
                 }
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     float color[4];
                     vx_hit r;
                     shade_pixel<FOREIGN ? FOREIGN : VX_SVO_CSVO, false>(sc_bytes, p, x, y, st, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
-                    if (out) out[index] = make_float4(color[0], color[1], color[2], color[3]);
+                    if (out) store_pixel(p, out, index, color);
                     if (HITS) hits[index] = r;
                 }
             }
@@ -534,13 +540,24 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint64_t* __restrict
     if (t < tail) d[head + body * 16 + t] = s[head + body * 16 + t];
 }
 
-// scatter gathered compact tile lists back into a row-major image (one thread per pixel, float4 stores)
+// scatter gathered compact tile lists back into a row-major image (one thread per pixel, float4 stores); `inverse` = place of
+// every tile in the Morton sequence the ranks share out (place j: rank j % tile_count, its local tile j / tile_count)
 __global__ __launch_bounds__(256) void assemble_kernel(const float4* __restrict__ tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width,
-                                                       uint32_t height, uint32_t tiles_x, float4* __restrict__ out) {
+                                                       uint32_t height, uint32_t tiles_x, const uint32_t* __restrict__ inverse, float4* __restrict__ out) {
     const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15u), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= width || y >= height) return;
-    const uint32_t tile = (y / kTile) * tiles_x + (x / kTile);
-    const uint32_t rank = tile % tile_count, local = tile / tile_count;
+    const uint32_t j = inverse[(y / kTile) * tiles_x + (x / kTile)];
+    const uint32_t rank = j % tile_count, local = j / tile_count;
+    out[size_t(y) * width + x] = tiles[rank * stride_px + size_t(local) * (kTile * kTile) + (y % kTile) * kTile + (x % kTile)];
+}
+
+// the same for RGBA8 tile lists and image (vx_target.format = VX_FORMAT_RGBA8)
+__global__ __launch_bounds__(256) void assemble_kernel_rgba8(const uint32_t* __restrict__ tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width,
+                                                             uint32_t height, uint32_t tiles_x, const uint32_t* __restrict__ inverse, uint32_t* __restrict__ out) {
+    const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15u), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= width || y >= height) return;
+    const uint32_t j = inverse[(y / kTile) * tiles_x + (x / kTile)];
+    const uint32_t rank = j % tile_count, local = j / tile_count;
     out[size_t(y) * width + x] = tiles[rank * stride_px + size_t(local) * (kTile * kTile) + (y % kTile) * kTile + (x % kTile)];
 }
 
@@ -599,6 +616,7 @@ struct vx_context {
     size_t main_todo_chunks = 0;
     uint32_t main_tickets = 0;
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
+    hipEvent_t pending_gather = nullptr;  // vx_wait_gather: the gather that still reads the tile list the next render overwrites
     int frames_in_flight = 2;           // 1 serialises frames on `stream` again (vx_set_frames_in_flight / VX_FRAMES_IN_FLIGHT)
     unsigned frame_index = 0;
     int last_frame_slot = -1;           // slot of the most recent pipelined render, -1 = it ran on `stream`
@@ -641,6 +659,27 @@ struct vx_context {
     int cu_count = 256;
     std::unordered_map<const void*, int> persistent_blocks;  // kernel -> resident 64-thread workgroups per CU, queried once
 
+    // screen sharding: the Morton order of an image's tiles and its inverse, on the device, per image size seen
+    struct TileTable { uint32_t tiles_x = 0, tiles_y = 0; uint32_t* d_order = nullptr; uint32_t* d_inverse = nullptr; };
+    std::vector<TileTable> tile_tables;
+
+    // multi-GPU: the RCCL communicator over which the finished tiles are gathered (vx_comm_init), its stream and the events that
+    // say when a gather has read its tile list
+    ncclComm_t comm = nullptr;
+    int comm_ranks = 0, comm_rank = 0;
+    hipStream_t comm_stream = nullptr;
+    static constexpr int kGatherEvents = 16;
+    hipEvent_t gather_done[kGatherEvents] = {};
+    unsigned gather_index = 0;
+
+    // pipelined presentation (vx_present_begin / vx_present_wait): per slot a device frame and its pinned host twin; the read-back
+    // runs on its own stream behind the frame's kernel, beside the next frame's
+    static constexpr int kPresentSlots = 4;
+    struct PresentSlot { void* dev = nullptr; void* host = nullptr; size_t cap = 0, bytes = 0; hipEvent_t copied = nullptr; bool busy = false; };
+    PresentSlot present[kPresentSlots];
+    unsigned present_next = 0;
+    hipStream_t copy_stream = nullptr;
+
     bool profile = false;
     std::vector<ProfiledLaunch> launches;
     std::vector<ProfiledLaunch> event_pool;
@@ -676,6 +715,52 @@ int drain_streams(vx_context* c) {
     if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < vx_context::kFrameStreams; ++i)
         if (c->frame_stream[i]) HIP_TRY(hipStreamSynchronize(c->frame_stream[i]));
+    if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    return VX_OK;
+}
+
+// Morton (Z-order) sequence of an image's 32x32 tiles: tile (tx, ty) sorts by the interleaved bits of its coordinates, so any run
+// of consecutive places covers a compact patch of the screen and the ranks that share the places out round-robin each get an
+// even sample of every region. order[j] = row-major id of the tile at place j; inverse[id] = j.
+void tile_order_host(uint32_t tiles_x, uint32_t tiles_y, std::vector<uint32_t>& order, std::vector<uint32_t>& inverse) {
+    auto spread = [](uint32_t v) {  // bits of a 16-bit value to the even bit positions
+        v &= 0xffffu;
+        v = (v | (v << 8)) & 0x00ff00ffu;
+        v = (v | (v << 4)) & 0x0f0f0f0fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        return (v | (v << 1)) & 0x55555555u;
+    };
+    const uint32_t n = tiles_x * tiles_y;
+    std::vector<uint64_t> keyed(n);
+    for (uint32_t t = 0; t < n; ++t) keyed[t] = (uint64_t(spread(t % tiles_x) | (spread(t / tiles_x) << 1)) << 32) | t;
+    std::sort(keyed.begin(), keyed.end());
+    order.resize(n);
+    inverse.resize(n);
+    for (uint32_t j = 0; j < n; ++j) {
+        order[j] = uint32_t(keyed[j]);
+        inverse[order[j]] = j;
+    }
+}
+
+int tile_table(vx_context* ctx, uint32_t tiles_x, uint32_t tiles_y, const vx_context::TileTable** out) {
+    for (const auto& t : ctx->tile_tables)
+        if (t.tiles_x == tiles_x && t.tiles_y == tiles_y) {
+            *out = &t;
+            return VX_OK;
+        }
+    std::vector<uint32_t> order, inverse;
+    tile_order_host(tiles_x, tiles_y, order, inverse);
+    vx_context::TileTable t;
+    t.tiles_x = tiles_x;
+    t.tiles_y = tiles_y;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d_order), order.size() * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d_inverse), inverse.size() * 4));
+    HIP_TRY(hipMemcpy(t.d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_inverse, inverse.data(), inverse.size() * 4, hipMemcpyHostToDevice));
+    ctx->tile_tables.reserve(16);  // (pointers into the vector are handed out: a context sees a handful of sizes)
+    ctx->tile_tables.push_back(t);
+    *out = &ctx->tile_tables.back();
     return VX_OK;
 }
 
@@ -819,8 +904,10 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
     return VX_OK;
 }
 
-int fill_params(const vx_uniforms* u, uint32_t w, uint32_t h, uint32_t tile_rank, uint32_t tile_count, RenderParams& p) {
+int fill_params(vx_context* ctx, const vx_uniforms* u, uint32_t w, uint32_t h, uint32_t tile_rank, uint32_t tile_count, int format, RenderParams& p) {
     if (!u || w == 0 || h == 0) return fail(VX_ERR_INVALID_ARGUMENT, "bad uniforms or size");
+    if (uint64_t(w) * h >= (uint64_t(1) << 31)) return fail(VX_ERR_INVALID_ARGUMENT, "image too large (pixel indices are 31 bits)");
+    if (format != VX_FORMAT_RGBA32F && format != VX_FORMAT_RGBA8) return fail(VX_ERR_INVALID_ARGUMENT, "unknown target format");
     if (tile_count == 0) tile_count = 1;
     if (tile_rank >= tile_count) return fail(VX_ERR_INVALID_ARGUMENT, "tile_rank >= tile_count");
     p.u = *u;
@@ -835,6 +922,13 @@ int fill_params(const vx_uniforms* u, uint32_t w, uint32_t h, uint32_t tile_rank
     p.tile_rank = tile_rank;
     p.tile_count = tile_count;
     p.n_local_tiles = vx_local_tile_count(w, h, tile_rank, tile_count);
+    p.tile_order = nullptr;
+    p.rgba8 = format == VX_FORMAT_RGBA8 ? 1u : 0u;
+    if (tile_count > 1) {
+        const vx_context::TileTable* t = nullptr;
+        if (int rc = tile_table(ctx, p.tiles_x, p.tiles_y, &t)) return rc;
+        p.tile_order = t->d_order;
+    }
     return VX_OK;
 }
 
@@ -894,6 +988,40 @@ int upload_packed(vx_context* ctx, const std::vector<Upload>& up, WAIT&& wait_fo
     slot.used = true;
     return VX_OK;
 }
+
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+
+// RCCL is opened when the first communicator is asked for. By its soname: a process that already has one loaded (PyTorch brings
+// its own copy) shares that one.
+int rccl_open() {
+    if (g_rccl.lib) return VX_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(VX_ERR_STATE, std::string("RCCL is not available: ") + dlerror());
+#define VX_SYM(name)                                                                                  \
+    g_rccl.name = reinterpret_cast<decltype(g_rccl.name)>(dlsym(h, "nccl" #name));                     \
+    if (!g_rccl.name) return fail(VX_ERR_STATE, "RCCL lacks nccl" #name)
+    VX_SYM(GetUniqueId); VX_SYM(CommInitRank); VX_SYM(CommDestroy); VX_SYM(GroupStart); VX_SYM(GroupEnd); VX_SYM(Send); VX_SYM(Recv); VX_SYM(GetErrorString);
+#undef VX_SYM
+    g_rccl.lib = h;
+    return VX_OK;
+}
+#define NCCL_TRY(call)                                                                                                   \
+    do {                                                                                                                 \
+        ncclResult_t r_ = (call);                                                                                        \
+        if (r_ != ncclSuccess) return fail(VX_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_));         \
+    } while (0)
 
 }  // namespace
 
@@ -1025,6 +1153,20 @@ void vx_destroy(vx_context* c) {
         if (c->d_frame_todo[i]) (void)hipFree(c->d_frame_todo[i]);
         if (c->frame_done[i]) (void)hipEventDestroy(c->frame_done[i]);
         if (c->frame_stream[i]) (void)hipStreamDestroy(c->frame_stream[i]);
+    }
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    for (auto& e : c->gather_done)
+        if (e) (void)hipEventDestroy(e);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    for (auto& ps : c->present) {
+        if (ps.dev) (void)hipFree(ps.dev);
+        if (ps.host) (void)hipHostFree(ps.host);
+        if (ps.copied) (void)hipEventDestroy(ps.copied);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (auto& t : c->tile_tables) {
+        if (t.d_order) (void)hipFree(t.d_order);
+        if (t.d_inverse) (void)hipFree(t.d_inverse);
     }
     for (auto& d : c->delta) {
         if (d.host) (void)hipHostFree(d.host);
@@ -1281,13 +1423,15 @@ int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint
     if (int rc = check_ready(ctx)) return rc;
     if (!target || !target->rgba32f) return fail(VX_ERR_INVALID_ARGUMENT, "render: null target");
     RenderParams p;
-    if (int rc = fill_params(uniforms, width, height, target->tile_rank, target->tile_count, p)) return rc;
+    if (int rc = fill_params(ctx, uniforms, width, height, target->tile_rank, target->tile_count, target->format, p)) return rc;
+    if (p.rgba8 && ctx->kernel_version == 1) return fail(VX_ERR_INVALID_ARGUMENT, "the one-thread-per-pixel kernel (VX_RENDER_KERNEL=1) writes RGBA32F only");
     const size_t pixels = p.tile_count > 1 ? size_t(p.n_local_tiles) * kTile * kTile : size_t(width) * height;
+    const size_t pixel_bytes = p.rgba8 ? 4 : 16;
 
     float* out = static_cast<float*>(target->rgba32f);
     vx_hit* hits = target->hits;
     if (target->memory == VX_MEM_HOST) {
-        if (int rc = ensure(reinterpret_cast<void**>(&ctx->d_frame), &ctx->d_frame_bytes, pixels * 16)) return rc;
+        if (int rc = ensure(reinterpret_cast<void**>(&ctx->d_frame), &ctx->d_frame_bytes, pixels * pixel_bytes)) return rc;
         out = ctx->d_frame;
         if (hits) {
             if (int rc = ensure(reinterpret_cast<void**>(&ctx->d_hits), &ctx->d_hits_bytes, pixels * sizeof(vx_hit))) return rc;
@@ -1300,17 +1444,66 @@ int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint
         // ordered after whatever the caller put on `stream` before the PREVIOUS frame on this slot was issued is implied by
         // stream order; explicit cross-stream dependencies come in through vx_wait_event
         if (ctx->pending_wait) HIP_TRY(hipStreamWaitEvent(ctx->frame_stream[slot], ctx->pending_wait, 0));
-    } else if (ctx->pending_wait) {
-        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->pending_wait, 0));
+        if (ctx->pending_gather) HIP_TRY(hipStreamWaitEvent(ctx->frame_stream[slot], ctx->pending_gather, 0));
+    } else {
+        if (ctx->pending_wait) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->pending_wait, 0));
+        if (ctx->pending_gather) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->pending_gather, 0));
     }
     ctx->pending_wait = nullptr;
+    ctx->pending_gather = nullptr;
     const int rc = hits ? launch_render<true, false>(ctx, p, out, hits, nullptr) : launch_render<false, false>(ctx, p, out, nullptr, nullptr, slot);
     if (rc) return rc;
     if (target->memory == VX_MEM_HOST) {
-        HIP_TRY(hipMemcpyAsync(target->rgba32f, ctx->d_frame, pixels * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(target->rgba32f, ctx->d_frame, pixels * pixel_bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (target->hits) HIP_TRY(hipMemcpyAsync(target->hits, ctx->d_hits, pixels * sizeof(vx_hit), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    return VX_OK;
+}
+
+// ---- pipelined presentation ------------------------------------------------------------------------------------------
+
+int vx_present_begin(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, int format, int* out_slot) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!out_slot) return fail(VX_ERR_INVALID_ARGUMENT, "present: null slot");
+    RenderParams p;
+    if (int rc = fill_params(ctx, uniforms, width, height, 0, 1, format, p)) return rc;
+    if (ctx->kernel_version == 1) return fail(VX_ERR_STATE, "presentation needs the persistent kernel");
+    const size_t bytes = size_t(width) * height * (p.rgba8 ? 4 : 16);
+    const int k = int(ctx->present_next++ % unsigned(vx_context::kPresentSlots));
+    vx_context::PresentSlot& ps = ctx->present[k];
+    if (ps.busy) HIP_TRY(hipEventSynchronize(ps.copied));  // the slot's previous image has to have left the device frame
+    if (ps.cap < bytes) {
+        if (ps.dev) (void)hipFree(ps.dev);
+        if (ps.host) (void)hipHostFree(ps.host);
+        ps.dev = ps.host = nullptr;
+        ps.cap = 0;
+        HIP_TRY(hipMalloc(&ps.dev, bytes));
+        HIP_TRY(hipHostMalloc(&ps.host, bytes, hipHostMallocDefault));
+        ps.cap = bytes;
+    }
+    if (!ps.copied) HIP_TRY(hipEventCreateWithFlags(&ps.copied, hipEventDisableTiming));
+    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    // the frame on a frame stream (in rotation with the other frames in flight), its read-back on the copy stream behind it
+    const int slot = ctx->frames_in_flight > 1 ? int(ctx->frame_index++ % unsigned(ctx->frames_in_flight)) : -1;
+    if (int rc = launch_render<false, false>(ctx, p, static_cast<float*>(ps.dev), nullptr, nullptr, slot)) return rc;
+    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, slot >= 0 ? ctx->frame_done[slot] : ctx->render_done, 0));
+    HIP_TRY(hipMemcpyAsync(ps.host, ps.dev, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    HIP_TRY(hipEventRecord(ps.copied, ctx->copy_stream));
+    ps.bytes = bytes;
+    ps.busy = true;
+    *out_slot = k;
+    return VX_OK;
+}
+
+int vx_present_wait(vx_context* ctx, int slot, const void** pixels, size_t* bytes) {
+    if (!ctx || slot < 0 || slot >= vx_context::kPresentSlots || !pixels) return fail(VX_ERR_INVALID_ARGUMENT, "present_wait: bad argument");
+    vx_context::PresentSlot& ps = ctx->present[slot];
+    if (!ps.busy) return fail(VX_ERR_STATE, "present_wait: nothing was begun on this slot");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ps.copied));
+    *pixels = ps.host;
+    if (bytes) *bytes = ps.bytes;
     return VX_OK;
 }
 
@@ -1319,7 +1512,7 @@ int vx_render_counters(vx_context* ctx, const vx_uniforms* uniforms, uint32_t wi
     if (int rc = check_ready(ctx)) return rc;
     if (!out) return fail(VX_ERR_INVALID_ARGUMENT, "counters: null output");
     RenderParams p;
-    if (int rc = fill_params(uniforms, width, height, tile_rank, tile_count, p)) return rc;
+    if (int rc = fill_params(ctx, uniforms, width, height, tile_rank, tile_count, VX_FORMAT_RGBA32F, p)) return rc;
     HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
     const bool was = ctx->profile;
     ctx->profile = false;
@@ -1420,6 +1613,8 @@ int vx_sync(vx_context* ctx) {
     HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
+    if (ctx->copy_stream) HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+    if (ctx->comm_stream) HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
     return VX_OK;
 }
 
@@ -1461,15 +1656,124 @@ int vx_assemble_tiles(vx_context* ctx, const float* tiles, uint64_t stride_float
 
 int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
                          float* out_rgba32f, void* stream) {
-    if (!ctx || !tiles || !out_rgba32f || !tile_count || !width || !height || (stride_floats & 3))
+    return vx_assemble_tiles_format(ctx, tiles, stride_floats / 4, tile_count, width, height, out_rgba32f, VX_FORMAT_RGBA32F, stream);
+}
+
+int vx_assemble_tiles_format(vx_context* ctx, const void* tiles, uint64_t stride_pixels, uint32_t tile_count, uint32_t width, uint32_t height, void* out,
+                             int format, void* stream) {
+    if (!ctx || !tiles || !out || !tile_count || !width || !height || (format != VX_FORMAT_RGBA32F && format != VX_FORMAT_RGBA8))
         return fail(VX_ERR_INVALID_ARGUMENT, "assemble_tiles: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t tiles_x = (width + kTile - 1) / kTile, tiles_y = (height + kTile - 1) / kTile;
+    const vx_context::TileTable* t = nullptr;
+    if (int rc = tile_table(ctx, tiles_x, tiles_y, &t)) return rc;
     const dim3 grid((width + 15) / 16, (height + 15) / 16), block(256);
-    hipLaunchKernelGGL(assemble_kernel, grid, block, 0, static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(tiles), stride_floats / 4, tile_count, width, height,
-                       (width + kTile - 1) / kTile, reinterpret_cast<float4*>(out_rgba32f));
+    if (format == VX_FORMAT_RGBA8)
+        hipLaunchKernelGGL(assemble_kernel_rgba8, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const uint32_t*>(tiles), stride_pixels, tile_count,
+                           width, height, tiles_x, t->d_inverse, static_cast<uint32_t*>(out));
+    else
+        hipLaunchKernelGGL(assemble_kernel, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const float4*>(tiles), stride_pixels, tile_count, width,
+                           height, tiles_x, t->d_inverse, static_cast<float4*>(out));
     HIP_TRY(hipGetLastError());
     return VX_OK;
 }
+
+uint32_t vx_tile_order(uint32_t width, uint32_t height, uint32_t* out, uint32_t capacity) {
+    const uint32_t tiles_x = (width + kTile - 1) / kTile, tiles_y = (height + kTile - 1) / kTile;
+    if (out && capacity >= tiles_x * tiles_y) {
+        std::vector<uint32_t> order, inverse;
+        tile_order_host(tiles_x, tiles_y, order, inverse);
+        std::memcpy(out, order.data(), order.size() * 4);
+    }
+    return tiles_x * tiles_y;
+}
+
+// ---- multi-GPU: the gather of the finished tiles over RCCL ---------------------------------------------------------------------
+
+int vx_comm_unique_id(void* out_id, size_t bytes) {
+    if (!out_id || bytes < sizeof(ncclUniqueId)) return fail(VX_ERR_INVALID_ARGUMENT, "comm_unique_id: needs VX_COMM_ID_BYTES (128) bytes");
+    if (int rc = rccl_open()) return rc;
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    std::memcpy(out_id, &id, sizeof id);
+    return VX_OK;
+}
+
+int vx_comm_init(vx_context* ctx, int nranks, int rank, const void* unique_id) {
+    if (!ctx || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) return fail(VX_ERR_INVALID_ARGUMENT, "comm_init: bad argument");
+    if (ctx->comm) return fail(VX_ERR_STATE, "comm_init: this context already has a communicator");
+    if (int rc = rccl_open()) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(g_rccl.CommInitRank(&comm, nranks, id, rank));
+    if (!ctx->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    for (auto& e : ctx->gather_done)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->comm = comm;
+    ctx->comm_ranks = nranks;
+    ctx->comm_rank = rank;
+    return VX_OK;
+}
+
+int vx_comm_destroy(vx_context* ctx) {
+    if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    if (!ctx->comm) return VX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->comm_stream) HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
+    NCCL_TRY(g_rccl.CommDestroy(ctx->comm));
+    ctx->comm = nullptr;
+    ctx->comm_ranks = ctx->comm_rank = 0;
+    return VX_OK;
+}
+
+int vx_comm_info(const vx_context* ctx, int* nranks, int* rank) {
+    if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    if (nranks) *nranks = ctx->comm_ranks;
+    if (rank) *rank = ctx->comm_rank;
+    return VX_OK;
+}
+
+int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank, void* gathered, int root, int* out_ticket) {
+    if (!ctx || !tiles || !bytes_per_rank || (bytes_per_rank & 3)) return fail(VX_ERR_INVALID_ARGUMENT, "gather_tiles: bad argument");
+    if (!ctx->comm) return fail(VX_ERR_STATE, "gather_tiles: no communicator (vx_comm_init)");
+    if (root < 0 || root >= ctx->comm_ranks) return fail(VX_ERR_INVALID_ARGUMENT, "gather_tiles: bad root");
+    if (ctx->comm_rank == root && !gathered) return fail(VX_ERR_INVALID_ARGUMENT, "gather_tiles: the root needs a destination");
+    HIP_TRY(hipSetDevice(ctx->device));
+    // behind the renders issued so far (the list's among them), on the communicator's own stream: the frame streams go on with the
+    // next frames meanwhile
+    if (ctx->render_recorded) HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->render_done, 0));
+    for (int i = 0; i < vx_context::kFrameStreams; ++i)  // (every frame issued so far: a list may hold a group of frames)
+        if (ctx->frame_recorded[i]) HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->frame_done[i], 0));
+    const size_t words = size_t(bytes_per_rank / 4);
+    if (ctx->comm_rank == root) {
+        uint8_t* dst = static_cast<uint8_t*>(gathered);
+        HIP_TRY(hipMemcpyAsync(dst + size_t(root) * bytes_per_rank, tiles, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->comm_stream));  // its own share
+        if (ctx->comm_ranks > 1) {
+            // one receive per peer, grouped: every peer sends over its own xGMI link at the same time
+            NCCL_TRY(g_rccl.GroupStart());
+            for (int r = 0; r < ctx->comm_ranks; ++r)
+                if (r != root) NCCL_TRY(g_rccl.Recv(dst + size_t(r) * bytes_per_rank, words, ncclUint32, r, ctx->comm, ctx->comm_stream));
+            NCCL_TRY(g_rccl.GroupEnd());
+        }
+    } else {
+        NCCL_TRY(g_rccl.Send(tiles, words, ncclUint32, root, ctx->comm, ctx->comm_stream));
+    }
+    const int ticket = int(ctx->gather_index++ % unsigned(vx_context::kGatherEvents));
+    HIP_TRY(hipEventRecord(ctx->gather_done[ticket], ctx->comm_stream));
+    if (out_ticket) *out_ticket = ticket;
+    return VX_OK;
+}
+
+int vx_wait_gather(vx_context* ctx, int ticket) {
+    if (!ctx || ticket < 0 || ticket >= vx_context::kGatherEvents) return fail(VX_ERR_INVALID_ARGUMENT, "wait_gather: bad ticket");
+    if (!ctx->gather_done[ticket]) return fail(VX_ERR_STATE, "wait_gather: no communicator");
+    ctx->pending_gather = ctx->gather_done[ticket];
+    return VX_OK;
+}
+
+void* vx_comm_stream(vx_context* ctx) { return ctx ? static_cast<void*>(ctx->comm_stream) : nullptr; }
 
 uint64_t vx_traversal_image_with_origin(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words,
                                         uint64_t capacity_words, uint32_t* out_origin_words, uint64_t origin_capacity_words) {

@@ -984,7 +984,31 @@ struct RenderParams {
     uint32_t width, height;
     uint32_t tiles_x, tiles_y;
     uint32_t tile_rank, tile_count, n_local_tiles;
+    // screen sharding (tile_count > 1): the image's 32x32 tiles in Morton order of their (x, y) -- this context renders the tiles
+    // tile_order[k * tile_count + tile_rank], k = 0 .. n_local_tiles - 1 (device memory; null when the whole image is rendered)
+    const uint32_t* tile_order;
+    uint32_t rgba8;  // the target holds RGBA8 pixels (vx_target.format): 4 bytes each, and a whole image has its TOP row first
 };
+
+// A pixel's place in the target and its value there. RGBA32F: the image2D of world.glsl:10 (row 0 = bottom). RGBA8: what
+// Framebuffer::as_image makes of it (src/graphics/framebuffer.rs:97-111) -- glReadPixels(RGBA, UNSIGNED_BYTE), i.e. clamp to [0,1]
+// and round to the nearest of 255 steps (NaN -> 0), rows flipped so that the top row comes first; tile lists keep their tile-local
+// order in both formats.
+__device__ __forceinline__ uint32_t image_index(const RenderParams& p, uint32_t x, uint32_t y) { return (p.rgba8 ? p.height - 1u - y : y) * p.width + x; }
+__device__ __forceinline__ uint32_t pack_rgba8(const float c[4]) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float f = c[k];
+        f = f != f ? 0.0f : (f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f));
+        v |= uint32_t(f * 255.0f + 0.5f) << (8 * k);
+    }
+    return v;
+}
+__device__ __forceinline__ void store_pixel(const RenderParams& p, float4* out, size_t index, const float c[4]) {
+    if (p.rgba8) reinterpret_cast<uint32_t*>(out)[index] = pack_rgba8(c);
+    else out[index] = make_float4(c[0], c[1], c[2], c[3]);
+}
 
 __device__ __forceinline__ float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void normalize3(const float v[3], float out[3]) {

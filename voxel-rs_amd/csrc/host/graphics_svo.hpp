@@ -162,7 +162,7 @@ public:
         const float nan = std::nanf("");
         const Vec3 sel = p.selected_voxel.value_or(Vec3{nan, nan, nan});  // svo.rs:211
         u.highlight_pos[0] = sel.x; u.highlight_pos[1] = sel.y; u.highlight_pos[2] = sel.z;
-        vx_target t{target.data(), nullptr, VX_MEM_HOST, 0, 1};
+        vx_target t{target.data(), nullptr, VX_MEM_HOST, 0, 1, VX_FORMAT_RGBA32F};
         check(vx_render(ctx_, &u, uint32_t(target.width()), uint32_t(target.height()), &t));
     }
 

@@ -13,6 +13,8 @@ from .build import lib_path, share_hip_runtime_with_torch
 
 VX_OK = 0
 VX_MEM_HOST, VX_MEM_DEVICE = 0, 1
+VX_FORMAT_RGBA32F, VX_FORMAT_RGBA8 = 0, 1
+VX_COMM_ID_BYTES = 128
 TILE = 32
 
 MATERIAL_DTYPE = np.dtype([("specular_pow", "<f4"), ("specular_strength", "<f4"), ("tex_top", "<i4"), ("tex_side", "<i4"), ("tex_bottom", "<i4"),
@@ -40,7 +42,8 @@ class Range(C.Structure):
 
 
 class Target(C.Structure):
-    _fields_ = [("rgba32f", C.c_void_p), ("hits", C.c_void_p), ("memory", C.c_int32), ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32)]
+    _fields_ = [("rgba32f", C.c_void_p), ("hits", C.c_void_p), ("memory", C.c_int32), ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32),
+                ("format", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -84,6 +87,17 @@ SYMBOLS = {
     "vx_resolve_2x2": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "vx_assemble_tiles": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "vx_assemble_tiles_on": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp]),
+    "vx_assemble_tiles_format": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp, _int, _vp]),
+    "vx_tile_order": (_u32, [_u32, _u32, _vp, _u32]),
+    "vx_present_begin": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, _int, C.POINTER(_int)]),
+    "vx_present_wait": (_int, [_vp, _int, C.POINTER(_vp), C.POINTER(_sz)]),
+    "vx_comm_unique_id": (_int, [_vp, _sz]),
+    "vx_comm_init": (_int, [_vp, _int, _int, _vp]),
+    "vx_comm_destroy": (_int, [_vp]),
+    "vx_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
+    "vx_gather_tiles": (_int, [_vp, _vp, _u64, _vp, _int, C.POINTER(_int)]),
+    "vx_wait_gather": (_int, [_vp, _int]),
+    "vx_comm_stream": (_vp, [_vp]),
     "vx_local_tile_count": (_u32, [_u32, _u32, _u32, _u32]),
     "vx_render_counters": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, _u32, _u32, C.POINTER(Counters)]),
     "vx_excursion_counters": (_int, [_vp, C.POINTER(_u64 * 4), _int]),
@@ -136,6 +150,21 @@ def make_uniforms(view, fovy, aspect, ambient, light_dir, cam_pos, render_shadow
 
 def local_tile_count(width, height, rank, count):
     return lib().vx_local_tile_count(width, height, rank, count)
+
+
+def tile_order(width, height):
+    """vx_tile_order: row-major tile ids in the Morton order the ranks share out."""
+    n = lib().vx_tile_order(width, height, None, 0)
+    out = np.zeros(n, dtype=np.uint32)
+    lib().vx_tile_order(width, height, out.ctypes.data_as(_vp), n)
+    return out
+
+
+def comm_unique_id():
+    """A fresh RCCL unique id (bytes) for vx_comm_init; made on ONE rank and handed to the others by the caller."""
+    buf = C.create_string_buffer(VX_COMM_ID_BYTES)
+    _check(lib().vx_comm_unique_id(buf, VX_COMM_ID_BYTES))
+    return buf.raw
 
 
 def traversal_image(svo_type, world_frame_words, used_bytes, layout=0, with_origin=False):
@@ -211,23 +240,61 @@ class Svo:
         return dict(used_bytes=int(s.used_bytes), capacity_bytes=int(s.capacity_bytes), depth=int(s.depth))
 
     # -- Svo::render (svo.rs:196-229) ---------------------------------------------------------------------
-    def render(self, uniforms, width, height, want_hits=False, tile_rank=0, tile_count=1):
-        """Returns (image float32 [h][w][4] row 0 = bottom, hits or None); tile-sharded calls return compact tile lists."""
+    def render(self, uniforms, width, height, want_hits=False, tile_rank=0, tile_count=1, fmt=VX_FORMAT_RGBA32F):
+        """Returns (image [h][w][4] -- float32, row 0 = bottom; or uint8 (fmt RGBA8), row 0 = top --, hits or None); tile-sharded
+        calls return compact tile lists."""
+        dt = np.uint8 if fmt == VX_FORMAT_RGBA8 else np.float32
         if tile_count > 1:
             n = local_tile_count(width, height, tile_rank, tile_count)
-            img = np.zeros((n, TILE, TILE, 4), dtype=np.float32)
+            img = np.zeros((n, TILE, TILE, 4), dtype=dt)
             hits = np.zeros((n, TILE, TILE), dtype=HIT_DTYPE) if want_hits else None
         else:
-            img = np.zeros((height, width, 4), dtype=np.float32)
+            img = np.zeros((height, width, 4), dtype=dt)
             hits = np.zeros((height, width), dtype=HIT_DTYPE) if want_hits else None
-        t = Target(img.ctypes.data, hits.ctypes.data if want_hits else None, VX_MEM_HOST, tile_rank, tile_count)
+        t = Target(img.ctypes.data, hits.ctypes.data if want_hits else None, VX_MEM_HOST, tile_rank, tile_count, fmt)
         _check(lib().vx_render(self._h, C.byref(uniforms), width, height, C.byref(t)))
         return img, hits
 
-    def render_device(self, uniforms, width, height, out_ptr, hits_ptr=None, tile_rank=0, tile_count=1):
+    def render_device(self, uniforms, width, height, out_ptr, hits_ptr=None, tile_rank=0, tile_count=1, fmt=VX_FORMAT_RGBA32F):
         """Asynchronous render into device memory (e.g. a torch tensor's data_ptr()); pair with sync()."""
-        t = Target(out_ptr, hits_ptr, VX_MEM_DEVICE, tile_rank, tile_count)
+        t = Target(out_ptr, hits_ptr, VX_MEM_DEVICE, tile_rank, tile_count, fmt)
         _check(lib().vx_render(self._h, C.byref(uniforms), width, height, C.byref(t)))
+
+    # -- pipelined presentation -------------------------------------------------------------------------------
+    def present_begin(self, uniforms, width, height, fmt=VX_FORMAT_RGBA8):
+        slot = _int(0)
+        _check(lib().vx_present_begin(self._h, C.byref(uniforms), width, height, fmt, C.byref(slot)))
+        return slot.value
+
+    def present_wait(self, slot, width, height, fmt=VX_FORMAT_RGBA8):
+        """The slot's image as a numpy VIEW of the library's pinned ring (copy it to keep it beyond three more frames)."""
+        ptr, n = _vp(), _sz(0)
+        _check(lib().vx_present_wait(self._h, slot, C.byref(ptr), C.byref(n)))
+        dt = np.uint8 if fmt == VX_FORMAT_RGBA8 else np.float32
+        buf = (C.c_char * n.value).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dt).reshape(height, width, 4)
+
+    # -- multi-GPU ------------------------------------------------------------------------------------------------
+    def comm_init(self, nranks, rank, unique_id):
+        _check(lib().vx_comm_init(self._h, nranks, rank, C.c_char_p(unique_id)))
+
+    def comm_destroy(self):
+        _check(lib().vx_comm_destroy(self._h))
+
+    def gather_tiles(self, tiles_ptr, bytes_per_rank, gathered_ptr, root=0):
+        ticket = _int(-1)
+        _check(lib().vx_gather_tiles(self._h, tiles_ptr, bytes_per_rank, gathered_ptr, root, C.byref(ticket)))
+        return ticket.value
+
+    def wait_gather(self, ticket):
+        _check(lib().vx_wait_gather(self._h, ticket))
+
+    @property
+    def comm_stream(self):
+        return lib().vx_comm_stream(self._h)
+
+    def assemble_tiles_format(self, tiles_ptr, stride_pixels, tile_count, width, height, out_ptr, fmt, stream):
+        _check(lib().vx_assemble_tiles_format(self._h, tiles_ptr, stride_pixels, tile_count, width, height, out_ptr, fmt, _vp(stream or 0)))
 
     def render_counters(self, uniforms, width, height, tile_rank=0, tile_count=1):
         c = Counters()

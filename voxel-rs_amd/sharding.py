@@ -1,8 +1,9 @@
 """Screen-tile sharding of one frame over the GPUs of a node.
 
 Rays are independent and the SVO is replicated, so the only exchange step is the gather of finished tiles:
-32x32-pixel tiles, numbered row-major from the bottom-left, tile t belongs to rank t % world (interleaved, so sky-only
-and silhouette-heavy regions spread evenly). A rank renders its tiles into a COMPACT list (local tile k = global tile
+32x32-pixel tiles taken in Morton order of their (x, y); the tile at place j of that order belongs to rank j % world
+(any run of consecutive places is a compact patch of the screen, so every rank gets an even sample of every region:
+sky, silhouettes, near ground). A rank renders its tiles into a COMPACT list (local tile k = the tile at place
 k*world + rank); rank 0 gathers the lists (RCCL: every peer sends over its own xGMI link) and scatters them into the image.
 
 `FrameSharder` is the one implementation of that step; bench.py runs it on GPUs over NCCL/RCCL, the CPU tests run it with
@@ -17,9 +18,22 @@ def tile_grid(width, height):
     return (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
 
 
-def local_tile_ids(width, height, rank, world):
+def _spread(v):
+    v &= 0xFFFF
+    v = (v | (v << 8)) & 0x00FF00FF
+    v = (v | (v << 4)) & 0x0F0F0F0F
+    v = (v | (v << 2)) & 0x33333333
+    return (v | (v << 1)) & 0x55555555
+
+
+def tile_order(width, height):
+    """Row-major tile ids (ty * tiles_x + tx, from the bottom-left) in Morton order of (tx, ty): vx_tile_order."""
     tx, ty = tile_grid(width, height)
-    return list(range(rank, tx * ty, world))
+    return sorted(range(tx * ty), key=lambda t: (_spread(t % tx) | (_spread(t // tx) << 1), t))
+
+
+def local_tile_ids(width, height, rank, world):
+    return tile_order(width, height)[rank::world]
 
 
 def extract_tiles(image, rank, world):
@@ -61,6 +75,8 @@ class FrameSharder:
     about as long as a small collective does (8 GPUs at 1080p). step() then returns None for the frames that only rendered,
     and flush() exchanges a group that is not full yet (call it before waiting for the last frames).
 
+    `gather(tiles, gathered)` replaces torch.distributed's gather for the exchange (same layout: rank r's lists at gathered[r]).
+
     Stream-ordering hooks (GPU: the renderer has its own streams, the collective runs on torch's; no-ops on CPU):
       before_render(g)  -- the renderer must not overwrite group g's tile lists while the collective that last used them is
                            still sending;
@@ -69,7 +85,7 @@ class FrameSharder:
     """
 
     def __init__(self, width, height, rank, world, dist, device, render_tiles, assemble, before_render=None, after_render=None,
-                 after_exchange=None, buffers=2, group=1):
+                 after_exchange=None, buffers=2, group=1, gather=None):
         import torch
 
         if group < 1 or buffers < group or buffers % group:
@@ -80,6 +96,9 @@ class FrameSharder:
         self.after_render = after_render or (lambda: None)
         self.after_exchange = after_exchange or (lambda g: None)
         self.group = group
+        # gather(tiles, gathered_or_None): the exchange step. Default: torch.distributed's gather (what the CPU tests run, on gloo);
+        # bench.py hands in the library's own (vx_gather_tiles: RCCL send/receive owned by the render context)
+        self.gather = gather
         self.n_local = len(local_tile_ids(width, height, rank, world))
         self.n_max = max(len(local_tile_ids(width, height, r, world)) for r in range(world))
         n_groups = buffers // group
@@ -121,7 +140,10 @@ class FrameSharder:
         g, count = self._g, self._slot
         tiles, gathered = self.tiles[g][:count], self.gathered[g]
         # the one exchange step of the path: finished tiles -> rank 0
-        self.dist.gather(tiles, [gathered[r, :count] for r in range(self.world)] if self.rank == 0 else None, dst=0)
+        if self.gather is not None:
+            self.gather(self.tiles[g], gathered)  # (whole groups: a group that is not full yet travels with its unused lists)
+        else:
+            self.dist.gather(tiles, [gathered[r, :count] for r in range(self.world)] if self.rank == 0 else None, dst=0)
         if self.rank == 0:
             for j in range(count):
                 self.assemble(gathered[:, j], self.images[j])
