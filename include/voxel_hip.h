@@ -253,7 +253,8 @@ uint32_t vx_tile_order(uint32_t width, uint32_t height, uint32_t* out, uint32_t 
  *   vx_comm_init        on every rank, collectively: ncclCommInitRank on this context's device
  *   vx_gather_tiles     the one exchange step of the path: this rank's compact tile list (`bytes_per_rank` bytes of device
  *                       memory, the same on every rank) goes to `root`, which receives rank r's list at gathered + r *
- *                       bytes_per_rank -- grouped ncclSend / ncclRecv, every peer straight to the root over its own xGMI link, on
+ *                       bytes_per_rank (the root's own list is copied there unless it already is there:
+ *                       tiles == gathered + root * bytes_per_rank) -- grouped ncclSend / ncclRecv, every peer straight to the root over its own xGMI link, on
  *                       the communicator's stream and ordered behind every vx_render issued so far (the list's among them). Returns
  *                       after enqueueing; *out_ticket (optional) names the gather for vx_wait_gather
  *   vx_wait_gather      the NEXT vx_render waits (on the device) for that gather: call it before rendering into a tile list a

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void assemble_kernel_rgba8(const uint32_t* __r
     if (x >= width || y >= height) return;
     const uint32_t j = inverse[(y / kTile) * tiles_x + (x / kTile)];
     const uint32_t rank = j % tile_count, local = j / tile_count;
-    out[size_t(y) * width + x] = tiles[rank * stride_px + size_t(local) * (kTile * kTile) + (y % kTile) * kTile + (x % kTile)];
+    out[size_t(height - 1u - y) * width + x] =  /* (an RGBA8 image has its top row first) */ tiles[rank * stride_px + size_t(local) * (kTile * kTile) + (y % kTile) * kTile + (x % kTile)];
 }
 
 }  // namespace
@@ -1708,7 +1708,13 @@ int vx_comm_init(vx_context* ctx, int nranks, int rank, const void* unique_id) {
     std::memcpy(&id, unique_id, sizeof id);
     ncclComm_t comm = nullptr;
     NCCL_TRY(g_rccl.CommInitRank(&comm, nranks, id, rank));
-    if (!ctx->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    if (!ctx->comm_stream) {
+        // highest priority: the gather's and the assembly's few waves get the first compute-unit slots that the frames in flight
+        // (persistent kernels that fill the device) give up, instead of queueing behind the next frame's waves
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        HIP_TRY(hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, prio_greatest));
+    }
     for (auto& e : ctx->gather_done)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->comm = comm;
@@ -1749,7 +1755,9 @@ int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank,
     const size_t words = size_t(bytes_per_rank / 4);
     if (ctx->comm_rank == root) {
         uint8_t* dst = static_cast<uint8_t*>(gathered);
-        HIP_TRY(hipMemcpyAsync(dst + size_t(root) * bytes_per_rank, tiles, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->comm_stream));  // its own share
+        // its own share (nothing to move when the root renders straight into its place in `gathered`)
+        if (tiles != dst + size_t(root) * bytes_per_rank)
+            HIP_TRY(hipMemcpyAsync(dst + size_t(root) * bytes_per_rank, tiles, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->comm_stream));
         if (ctx->comm_ranks > 1) {
             // one receive per peer, grouped: every peer sends over its own xGMI link at the same time
             NCCL_TRY(g_rccl.GroupStart());

@@ -106,6 +106,9 @@ class FrameSharder:
         self.tiles = [torch.zeros((group, self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) for _ in range(n_groups)]
         self.gathered = [torch.zeros((world, group, self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) if rank == 0 else None
                          for _ in range(n_groups)]
+        if gather is not None and rank == 0:
+            # the root renders straight into its own place in the gathered buffer: its share needs no copy (vx_gather_tiles)
+            self.tiles = [self.gathered[i][0] for i in range(n_groups)]
         self.images = [torch.zeros((height, width, 4), dtype=torch.float32, device=device) for _ in range(group)] if rank == 0 else None
         if str(device).startswith("cuda"):
             torch.cuda.synchronize()  # the zero fills ran on torch's stream; a renderer with its own streams must not race them
