@@ -2,6 +2,7 @@
 // Each case restates the expected values of one of the reference's own #[test]s; the case name carries the
 // reference location. Run by tests/test_host_kats.py (one pytest case per KAT).
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -10,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "camera.hpp"
 #include "chunk.hpp"
 #include "chunkloader.hpp"
 #include "csvo.hpp"
@@ -811,8 +813,58 @@ static void chunkloader_changing_lod() {  // chunkloader.rs:217-241
     CHECK_SEQ(lod_scale_on_x_axis(second, 1), change);
 }
 
+static void camera_is_in_frustum() {  // camera.rs:106-140
+    vx::graphics::Camera camera(72.0f, 1.0f, 0.01f, 30.0f);
+    camera.position[0] = camera.position[1] = camera.position[2] = 0.0f;
+    camera.forward[0] = 0.0f; camera.forward[1] = 0.0f; camera.forward[2] = 1.0f;
+    auto in = [&](float x, float y, float z, float r) {
+        const float p[3] = {x, y, z};
+        return camera.is_in_frustum(p, r);
+    };
+    CHECK(!in(0, 0, 0, 0)); CHECK(in(0, 0, 10, 0)); CHECK(in(0, 0, 29, 0)); CHECK(!in(0, 0, 31, 0)); CHECK(in(0, 0, 0, 1)); CHECK(in(0, 0, 31, 1));
+    CHECK(in(0, 0, 3, 0)); CHECK(in(0, 2, 3, 0)); CHECK(!in(0, 3, 3, 0)); CHECK(in(0, -2, 3, 0)); CHECK(!in(0, -3, 3, 0)); CHECK(in(0, 3, 3, 1)); CHECK(in(0, -3, 3, 1));
+    CHECK(in(0, 0, 3, 0)); CHECK(in(2, 0, 3, 0)); CHECK(!in(3, 0, 3, 0)); CHECK(in(-2, 0, 3, 0)); CHECK(!in(-3, 0, 3, 0)); CHECK(in(3, 0, 3, 1)); CHECK(in(-3, 0, 3, 1));
+}
+
+static void sort_chunks_by_view_frustum() {  // world.rs:233-262 (the reference has no test of its own for it)
+    vx::systems::ChunkLoader cl(6, 0, 1);
+    const std::vector<ChunkEvent> events = cl.update(16.0f, 16.0f, 16.0f);  // nearest first around chunk (0,0,0)
+    vx::graphics::Camera camera(72.0f, 16.0f / 9.0f, 0.01f, 1024.0f);
+    camera.position[0] = 16.0f; camera.position[1] = 16.0f; camera.position[2] = 16.0f;
+    camera.forward[0] = 1.0f; camera.forward[1] = 0.0f; camera.forward[2] = 0.0f;
+    const std::vector<ChunkEvent> sorted = vx::systems::sort_chunks_by_view_frustum(events, camera);
+    CHECK(sorted.size() == events.size());
+    // a permutation
+    std::vector<ChunkEvent> a = events, b = sorted;
+    std::sort(a.begin(), a.end());
+    std::sort(b.begin(), b.end());
+    CHECK(a == b);
+    // the visible ones first, in the loader's order; then the rest, front to back
+    size_t n_visible = 0;
+    std::vector<ChunkEvent> visible_in_loader_order;
+    for (const ChunkEvent& e : events) {
+        const float c[3] = {float(e.pos.x * 32 + 16), float(e.pos.y * 32 + 16), float(e.pos.z * 32 + 16)};
+        if (camera.is_in_frustum(c, 32.0f)) visible_in_loader_order.push_back(e);
+    }
+    n_visible = visible_in_loader_order.size();
+    CHECK(n_visible > 10 && n_visible < events.size() - 10);
+    for (size_t i = 0; i < n_visible; ++i) CHECK(sorted[i] == visible_in_loader_order[i]);
+    float last = -2.0f;
+    for (size_t i = n_visible; i < sorted.size(); ++i) {
+        float t[3] = {float(sorted[i].pos.x * 32) - 16.0f, float(sorted[i].pos.y * 32) - 16.0f, float(sorted[i].pos.z * 32) - 16.0f};
+        const float len = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+        const float k = -(t[0] / len);  // -dot(normalize(t), forward)
+        CHECK(k >= last);
+        last = k;
+    }
+    CHECK(sorted.back().pos.x < 0);  // what is behind the camera comes last
+    CHECK(sorted.front().pos == (vx::ChunkPos{0, 0, 0}));  // the chunk the camera is in: its sphere reaches the near plane
+}
+
 int main(int argc, char** argv) {
     const std::map<std::string, std::function<void()>> cases = {
+        {"camera_is_in_frustum", camera_is_in_frustum},
+        {"sort_chunks_by_view_frustum", sort_chunks_by_view_frustum},
         {"octree_add_leaf_single", octree_add_leaf_single},
         {"octree_add_leaf_multiple", octree_add_leaf_multiple},
         {"octree_remove_and_add_leaf", octree_remove_and_add_leaf},

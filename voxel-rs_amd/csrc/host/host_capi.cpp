@@ -290,6 +290,16 @@ uint64_t vxh_stream_move_to(void* sp, float x, float y, float z) {
     return s->svo_type == 1 ? s->esvo.move_to(x, y, z) : s->csvo.move_to(x, y, z);
 }
 
+// the same with the chunk events ordered by the camera's view (frustum first, then front to back: world.rs:233-262);
+// view = forward[3], up[3], fov_y_deg, aspect_ratio, near, far
+uint64_t vxh_stream_move_to_view(void* sp, float x, float y, float z, const float* view) {
+    Streamer* s = static_cast<Streamer*>(sp);
+    graphics::Camera cam(view[6], view[7], view[8], view[9]);
+    cam.position[0] = x; cam.position[1] = y; cam.position[2] = z;
+    for (int k = 0; k < 3; ++k) { cam.forward[k] = view[k]; cam.up[k] = view[3 + k]; }
+    return s->svo_type == 1 ? s->esvo.move_to(x, y, z, &cam) : s->csvo.move_to(x, y, z, &cam);
+}
+
 // out[11] = events, loads, unloads, lod_changes, ranges, bytes, arena_bytes, pending, build_us, apply_us, commit_us;
 // returns 0 or -1 (capacity / HIP error)
 int vxh_stream_pump(void* sp, void* ctx, uint32_t max_events, uint64_t* out) {

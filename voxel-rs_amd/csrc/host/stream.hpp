@@ -19,6 +19,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "camera.hpp"
 #include "chunkloader.hpp"
 #include "scene.hpp"
 #include "voxel_hip.h"
@@ -81,7 +82,8 @@ public:
     std::function<void(WorldT&, const std::vector<vx_range>&)> on_dry_commit;
 
     // returns the number of events the move produced
-    size_t move_to(float x, float y, float z) {
+    // camera (optional): the view the events of this move are ordered by; its position is (x, y, z)
+    size_t move_to(float x, float y, float z, const graphics::Camera* camera = nullptr) {
         const ChunkPos centre = ChunkPos::from_block_pos(int32_t(std::floor(x)), int32_t(std::floor(y)), int32_t(std::floor(z)));
         if (!(centre == cs_.center) || !has_centre_) {
             cs_.center = centre;
@@ -89,7 +91,9 @@ public:
             shift_chunks(cs_, leaf_ids_, world_);  // worldsvo.rs:161-196
             dirty_ = true;
         }
-        const std::vector<ChunkEvent> events = loader_.update(x, y, z);
+        std::vector<ChunkEvent> events = loader_.update(x, y, z);
+        // what the player looks at first, the rest from front to back (src/gamelogic/world.rs:132-137)
+        if (camera) events = sort_chunks_by_view_frustum(events, *camera);
         for (const ChunkEvent& e : events) queue_.push_back(e);
         return events.size();
     }

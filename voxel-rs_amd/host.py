@@ -50,6 +50,7 @@ def lib():
             "vxh_stream_new": (vp, [C.c_int, u32, u32, u32, C.c_int32, C.c_int32]),
             "vxh_stream_free": (None, [vp]),
             "vxh_stream_move_to": (u64, [vp, C.c_float, C.c_float, C.c_float]),
+            "vxh_stream_move_to_view": (u64, [vp, C.c_float, C.c_float, C.c_float, vp]),
             "vxh_stream_pump": (C.c_int, [vp, vp, u32, vp]),
             "vxh_stream_frame": (sz, [vp, vp, sz]),
             "vxh_stream_mirror_image": (C.c_int, [vp, C.c_uint64, C.c_int]),
@@ -233,9 +234,14 @@ class WorldStreamer:
             lib().vxh_stream_free(self._h)
             self._h = None
 
-    def move_to(self, x, y, z):
-        """Queues the chunk events of the target moving to this world position; returns how many."""
-        return int(lib().vxh_stream_move_to(self._h, x, y, z))
+    def move_to(self, x, y, z, forward=None, up=(0.0, 1.0, 0.0), fov_y_deg=72.0, aspect=16.0 / 9.0, near=0.01, far=1024.0):
+        """Queues the chunk events of the target moving to this world position; returns how many. With `forward` (the camera's
+        view direction) the events are ordered like the reference orders them (src/gamelogic/world.rs:233-262): chunks in the
+        view frustum first, the rest from front to back; without, nearest first (the chunk loader's own order)."""
+        if forward is None:
+            return int(lib().vxh_stream_move_to(self._h, x, y, z))
+        view = (C.c_float * 10)(*forward, *up, fov_y_deg, aspect, near, far)
+        return int(lib().vxh_stream_move_to_view(self._h, x, y, z, view))
 
     def pump(self, svo_handle, max_events=400):
         """Applies up to max_events queued events and commits the dirty ranges to the vx context (needs a GPU)."""
