@@ -98,6 +98,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank != 0:
+        os.dup2(2, 1)  # only rank 0 owns stdout (the one JSON line): whatever a library prints on the other ranks goes to stderr
     if world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -272,6 +274,8 @@ def main():
     block_s = sorted(float(t) for t in times)
     elapsed = block_s[len(block_s) // 2]
     if rank != 0:
+        if sharded and args.gather == "library":
+            svo.comm_destroy()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -377,9 +381,17 @@ def main():
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
+    # the JSON line is the LAST thing on stdout: tear the communicators down first (RCCL prints a banner through C stdio, which
+    # is flushed at exit otherwise) and flush C's buffers before Python's
+    if sharded and args.gather == "library":
+        svo.comm_destroy()
     if dist is not None:
         dist.destroy_process_group()
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -302,10 +302,14 @@ uint64_t vxh_stream_move_to_view(void* sp, float x, float y, float z, const floa
 
 // out[11] = events, loads, unloads, lod_changes, ranges, bytes, arena_bytes, pending, build_us, apply_us, commit_us;
 // returns 0 or -1 (capacity / HIP error)
-int vxh_stream_pump(void* sp, void* ctx, uint32_t max_events, uint64_t* out) {
+// wait = 0: only events whose chunks the background workers have finished are applied (a frame loop); 1: the call waits for them
+int vxh_stream_pump_mode(void* sp, void* ctx, uint32_t max_events, int wait, uint64_t* out);
+int vxh_stream_pump(void* sp, void* ctx, uint32_t max_events, uint64_t* out) { return vxh_stream_pump_mode(sp, ctx, max_events, 1, out); }
+int vxh_stream_pump_mode(void* sp, void* ctx, uint32_t max_events, int wait, uint64_t* out) {
     Streamer* s = static_cast<Streamer*>(sp);
     try {
-        const systems::PumpStats st = s->svo_type == 1 ? s->esvo.pump(static_cast<vx_context*>(ctx), max_events) : s->csvo.pump(static_cast<vx_context*>(ctx), max_events);
+        const systems::PumpStats st = s->svo_type == 1 ? s->esvo.pump(static_cast<vx_context*>(ctx), max_events, wait != 0)
+                                                       : s->csvo.pump(static_cast<vx_context*>(ctx), max_events, wait != 0);
         const uint64_t v[11] = {st.events, st.loads, st.unloads, st.lod_changes, st.ranges, st.bytes, st.arena_bytes, st.pending,
                                 uint64_t(st.build_ms * 1000.0), uint64_t(st.apply_ms * 1000.0), uint64_t(st.commit_ms * 1000.0)};
         std::memcpy(out, v, sizeof v);

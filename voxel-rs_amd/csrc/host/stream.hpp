@@ -11,6 +11,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <deque>
 #include <functional>
 #include <optional>
@@ -77,6 +80,16 @@ public:
         cs_.dst = radius;
         threads_ = threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     }
+    ~WorldStreamer() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+        }
+        cv_jobs_.notify_all();
+        for (std::thread& t : pool_) t.join();
+    }
+    WorldStreamer(const WorldStreamer&) = delete;
+    WorldStreamer& operator=(const WorldStreamer&) = delete;
 
     // pump(nullptr, ..) hands the dirty ranges here instead of to vx_commit (tests)
     std::function<void(WorldT&, const std::vector<vx_range>&)> on_dry_commit;
@@ -94,40 +107,54 @@ public:
         std::vector<ChunkEvent> events = loader_.update(x, y, z);
         // what the player looks at first, the rest from front to back (src/gamelogic/world.rs:132-137)
         if (camera) events = sort_chunks_by_view_frustum(events, *camera);
-        for (const ChunkEvent& e : events) queue_.push_back(e);
+        // Every event gets a slot in the queue; chunks are generated and serialized in the background from now on (the reference
+        // hands them to its job system as soon as they are known, worldsvo.rs:90-99) and applied, in event order, by pump().
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            for (const ChunkEvent& e : events) {
+                auto slot = std::make_shared<Slot>();
+                slot->event = e;
+                if (e.kind == ChunkEvent::Unload) slot->ready = true;  // nothing to build
+                else jobs_.push_back(slot);
+                queue_.push_back(std::move(slot));
+            }
+        }
+        if (pool_.empty() && !events.empty())
+            for (uint32_t t = 0; t < threads_; ++t) pool_.emplace_back([this]() { build_loop(); });
+        cv_jobs_.notify_all();
         return events.size();
     }
 
-    PumpStats pump(vx_context* ctx, uint32_t max_events) {
+    // wait = true: the next max_events events are applied, whether their chunks are built yet or not (the call waits for them: what
+    // the tests want, the same events per call whatever the machine). wait = false: only events whose chunks are ready are applied,
+    // in order (what a frame loop wants: a chunk that is not built yet arrives with a later frame, like in the reference, whose
+    // update() takes whatever its job system has finished, worldsvo.rs:139).
+    PumpStats pump(vx_context* ctx, uint32_t max_events, bool wait = true) {
         PumpStats st;
         using clock = std::chrono::steady_clock;
         auto ms_since = [](clock::time_point t0) { return std::chrono::duration<double, std::milli>(clock::now() - t0).count(); };
         clock::time_point t0 = clock::now();
-        // take the batch, build its chunks on worker threads (the reference serializes chunks on its job system,
-        // worldsvo.rs:90-99), then apply the results in event order on this thread
         std::vector<ChunkEvent> batch;
-        while (!queue_.empty() && batch.size() < max_events) {
-            batch.push_back(queue_.front());
-            queue_.pop_front();
+        std::vector<std::optional<SerializedT>> built;
+        {
+            std::unique_lock<std::mutex> lock(m_);
+            while (!queue_.empty() && batch.size() < max_events) {
+                Slot& slot = *queue_.front();
+                if (!slot.ready) {
+                    if (!wait) break;
+                    cv_done_.wait(lock, [&]() { return slot.ready; });
+                }
+                batch.push_back(slot.event);
+                built.push_back(std::move(slot.built));
+                if (slot.event.kind != ChunkEvent::Unload) --built_ahead_;
+                queue_.pop_front();
+            }
         }
+        cv_jobs_.notify_all();  // (room for the workers to build further ahead)
         std::vector<std::optional<Position>> where(batch.size());
-        std::vector<std::optional<SerializedT>> built(batch.size());
         for (size_t i = 0; i < batch.size(); ++i)
             if (batch[i].kind != ChunkEvent::Unload) where[i] = cs_.cnv_chunk_pos(batch[i].pos);  // none: outside the cylinder by now
-        std::atomic<size_t> next{0};
-        auto worker = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < batch.size();) {
-                if (!where[i]) continue;
-                std::optional<Chunk> chunk = generate_heightfield_chunk(scene_depth_, seed_, batch[i].pos, batch[i].lod);
-                if (chunk) built[i].emplace(*chunk);
-            }
-        };
-        const uint32_t n_workers = std::min<uint32_t>(threads_, uint32_t(batch.size() / 8 + 1));
-        std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < n_workers; ++t) pool.emplace_back(worker);
-        worker();
-        for (std::thread& t : pool) t.join();
-        st.build_ms = ms_since(t0);
+        st.build_ms = ms_since(t0);  // (time spent waiting for chunks that were not built yet)
         t0 = clock::now();
 
         for (size_t i = 0; i < batch.size(); ++i) {
@@ -148,7 +175,10 @@ public:
             leaf_ids_[e.pos] = r.first;
             dirty_ = true;
         }
-        st.pending = uint32_t(queue_.size());
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            st.pending = uint32_t(queue_.size());
+        }
         if (dirty_) {
             dirty_ = false;
             world_.serialize();
@@ -179,9 +209,43 @@ public:
     WorldT& world() { return world_; }
     const SvoCoordSpace& coord_space() const { return cs_; }
     size_t resident_chunks() const { return leaf_ids_.size(); }
-    size_t pending_events() const { return queue_.size(); }
+    size_t pending_events() {
+        std::lock_guard<std::mutex> lock(m_);
+        return queue_.size();
+    }
 
 private:
+    // one queued event and, once a worker is through with it, its serialized chunk (none: the chunk holds no voxel)
+    struct Slot {
+        ChunkEvent event;
+        bool ready = false;
+        std::optional<SerializedT> built;
+    };
+
+    void build_loop() {
+        for (;;) {
+            std::shared_ptr<Slot> slot;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                // not too far ahead of pump(): finished chunks wait in memory until they are applied
+                cv_jobs_.wait(lock, [&]() { return stop_ || (!jobs_.empty() && built_ahead_ < kMaxBuiltAhead); });
+                if (stop_) return;
+                slot = std::move(jobs_.front());
+                jobs_.pop_front();
+                ++built_ahead_;
+            }
+            std::optional<SerializedT> built;
+            std::optional<Chunk> chunk = generate_heightfield_chunk(scene_depth_, seed_, slot->event.pos, slot->event.lod);
+            if (chunk) built.emplace(*chunk);
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                slot->built = std::move(built);
+                slot->ready = true;
+            }
+            cv_done_.notify_all();
+        }
+    }
+
     void remove(ChunkPos pos) {
         auto it = leaf_ids_.find(pos);
         if (it == leaf_ids_.end()) return;
@@ -196,7 +260,14 @@ private:
     bool has_centre_ = false, dirty_ = false;
     WorldT world_;
     std::unordered_map<ChunkPos, LeafId, ChunkPosHash> leaf_ids_;
-    std::deque<ChunkEvent> queue_;
+    // events in arrival order; jobs_ = those of them no worker has taken yet
+    std::deque<std::shared_ptr<Slot>> queue_, jobs_;
+    static constexpr size_t kMaxBuiltAhead = 16384;
+    size_t built_ahead_ = 0;  // chunks taken by workers and not applied yet
+    std::mutex m_;
+    std::condition_variable cv_jobs_, cv_done_;
+    std::vector<std::thread> pool_;
+    bool stop_ = false;
 };
 
 }  // namespace systems

@@ -52,6 +52,7 @@ def lib():
             "vxh_stream_move_to": (u64, [vp, C.c_float, C.c_float, C.c_float]),
             "vxh_stream_move_to_view": (u64, [vp, C.c_float, C.c_float, C.c_float, vp]),
             "vxh_stream_pump": (C.c_int, [vp, vp, u32, vp]),
+            "vxh_stream_pump_mode": (C.c_int, [vp, vp, u32, C.c_int, vp]),
             "vxh_stream_frame": (sz, [vp, vp, sz]),
             "vxh_stream_mirror_image": (C.c_int, [vp, C.c_uint64, C.c_int]),
             "vxh_stream_image": (C.c_uint64, [vp, vp, C.c_uint64]),
@@ -243,10 +244,12 @@ class WorldStreamer:
         view = (C.c_float * 10)(*forward, *up, fov_y_deg, aspect, near, far)
         return int(lib().vxh_stream_move_to_view(self._h, x, y, z, view))
 
-    def pump(self, svo_handle, max_events=400):
-        """Applies up to max_events queued events and commits the dirty ranges to the vx context (needs a GPU)."""
+    def pump(self, svo_handle, max_events=400, wait=True):
+        """Applies up to max_events queued events and commits the dirty ranges to the vx context (needs a GPU). Chunks are built
+        by background workers from the moment move_to queues their events; wait=False applies only those that are finished (a
+        frame loop: the rest arrive with later frames), wait=True waits for them (the same events per call on any machine)."""
         out = (C.c_uint64 * 11)()
-        if lib().vxh_stream_pump(self._h, svo_handle, max_events, out) != 0:
+        if lib().vxh_stream_pump_mode(self._h, svo_handle, max_events, int(wait), out) != 0:
             raise RuntimeError("stream pump failed (capacity exceeded or HIP error)")
         return dict(zip(self.PUMP_FIELDS, (int(v) for v in out)))
 
