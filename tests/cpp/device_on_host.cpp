@@ -69,16 +69,17 @@ extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t worl
 // the loop, the hand-over to the full stack below the LDS-resident levels, leaf tests, and -- for the image of a CSVO world --
 // the excursion onto the world's own bytes when the ray is led into a voxel. Returns the reference's OctreeResult and the
 // number of loop iterations.
-template <int IMG, int FOREIGN, bool SHALLOW>
+template <int IMG, int FOREIGN, bool SHALLOW, int LV = kLdsLevels>
 static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float pos[3], const float dir[3], float max_dst, bool cast_translucent,
                        bool restart_in_place, vx_result* out, uint32_t* steps) {
     StackSpill spill;
-    Stack<1, false> st;
-    typedef Stack<1, true, SHALLOW> FastStack;
+    typedef Stack<1, false, false, LV, (LV > kLdsLevels)> FullStack;  // (16 levels: the 16-bit third plane, like the kernel's)
+    typedef Stack<1, true, SHALLOW, LV, (LV > kLdsLevels)> FastStack;
+    FullStack st;
     FastStack fast_st;
     st.init(0, &spill);
     fast_st.init(0, &spill);
-    constexpr int kFastFloor = kLdsBaseScale - 1;
+    constexpr int kFastFloor = FullStack::kBaseScale - 1;
     Trav<IMG> tr;
     tr.init(sc, pos, dir, max_dst);
     Result res;
@@ -92,26 +93,28 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
                 if (s != kTravContinue) tr.sync_idx();
             } else {
                 tr.sync_idx();
-                s = tr.template step<false, false, true, Stack<1, false>, true, FOREIGN != 0>(sc, st, nullptr, nullptr);
+                s = tr.template step<false, false, true, FullStack, true, FOREIGN != 0>(sc, st, nullptr, nullptr);
                 if (s == kTravForeign) --tr.iter;
             }
             continue;
         }
         if (s == kTravDeep) {
-            s = tr.template step<false, false, true, Stack<1, false>, true, FOREIGN != 0>(sc, st, nullptr, nullptr);
+            s = tr.template step<false, false, true, FullStack, true, FOREIGN != 0>(sc, st, nullptr, nullptr);
             if (s == kTravForeign) --tr.iter;
             continue;
         }
         if (s == kTravForeign) {
-            if (restart_in_place) {
-                s = enter_voxel_on_bytes<IMG, Stack<1, false>, true, true>(sc, sc_bytes, tr, st, cast_translucent, res);
+            if (restart_in_place && LV == kLdsLevels) {
+                s = enter_voxel_on_bytes<IMG, FullStack, true, (LV == kLdsLevels)>(sc, sc_bytes, tr, st, cast_translucent, res);
             } else {
                 // what the render kernel does: a ray whose walk inside the voxel overwrote the byte cursor's leaf pointers is given up
                 // here and run whole on the world's own bytes later (its pixel goes on the wave's list)
-                s = enter_voxel_on_bytes<IMG, Stack<1, false>, true, false>(sc, sc_bytes, tr, st, cast_translucent, res);
+                s = enter_voxel_on_bytes<IMG, FullStack, true, false>(sc, sc_bytes, tr, st, cast_translucent, res);
                 if (s == kTravForeign) {
                     uint32_t n = 0;
-                    intersect<VX_SVO_CSVO, false, false, true>(sc_bytes, pos, dir, max_dst, cast_translucent, st, res, n, nullptr, nullptr);
+                    Stack<1, false> st2;  // (the byte cursor's entries are three full words: the plain layout over the same memory)
+                    st2.init(0, &spill);
+                    intersect<VX_SVO_CSVO, false, false, true>(sc_bytes, pos, dir, max_dst, cast_translucent, st2, res, n, nullptr, nullptr);
                     out->t = res.t; out->value = res.value; out->face_id = res.face_id;
                     std::memcpy(out->pos, res.pos, 12); std::memcpy(out->uv, res.uv, 8); std::memcpy(out->color, res.color, 16);
                     out->lod = res.lod; out->inside_voxel = res.inside_voxel ? 1 : 0;
@@ -153,11 +156,17 @@ extern "C" void devhost_image_cast(int svo_type, int layout, int shallow, int re
     }
     sa.image = image; sa.image_bytes = image_bytes; sa.origin = origin;
     const DevScene sc = make_image_scene(sa), sc_bytes = make_scene(sa);
-    std::vector<unsigned char> lds(Stack<1>::kBytes + 64);
+    std::vector<unsigned char> lds(Stack<1, false, false, 16, false>::kBytes + 64);
     vx_smem = lds.data();
     for (uint32_t i = 0; i < n; ++i) {
         const bool ct = cast_translucent != 0;
 #define CAST(IMG, FOREIGN, SHALLOW) image_cast<IMG, FOREIGN, SHALLOW>(sc, sc_bytes, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, ct, restart_in_place != 0, &results[i], &steps[i])
+#define CAST16(IMG, FOREIGN) image_cast<IMG, FOREIGN, true, 16>(sc, sc_bytes, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, ct, false, &results[i], &steps[i])
+        if (shallow == 2) {  // the kernel build with 16 resident stack levels
+            if (svo_type == 1) { if (layout == 1) CAST16(VX_SVO_IMAGE, 0); else CAST16(VX_SVO_IMAGE_WIDE, 0); }
+            else { if (layout == 1) CAST16(VX_SVO_IMAGE, VX_SVO_CSVO); else CAST16(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO); }
+            continue;
+        }
         if (svo_type == 1) {
             if (layout == 1) { if (shallow) CAST(VX_SVO_IMAGE, 0, true); else CAST(VX_SVO_IMAGE, 0, false); }
             else { if (shallow) CAST(VX_SVO_IMAGE_WIDE, 0, true); else CAST(VX_SVO_IMAGE_WIDE, 0, false); }
@@ -166,5 +175,6 @@ extern "C" void devhost_image_cast(int svo_type, int layout, int shallow, int re
             else { if (shallow) CAST(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO, true); else CAST(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO, false); }
         }
 #undef CAST
+#undef CAST16
     }
 }

@@ -207,3 +207,7 @@ def test_image_traversal_in_deep_worlds(devhost, golden, fmt, base, depth):
     if depth <= (13 if fmt == "esvo" else 14):  # what vx_render takes for "no push below the resident levels" (vx_api.hip, launch_render)
         got, gsteps = image_cast(devhost, fmt, world, mats, tex, mips, tasks, 1, 1, shallow=True)
         assert_same_casts(got, gsteps, exp, esteps)
+    # the build with 16 resident stack levels (third plane 16 bits wide): every depth here without the hand-over
+    for layout in (1, 2):
+        got, gsteps = image_cast(devhost, fmt, world, mats, tex, mips, tasks, 1, layout, shallow=2)
+        assert_same_casts(got, gsteps, exp, esteps)

@@ -160,7 +160,9 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
 // bytes and comes back to the image (vx_device.hpp, enter_voxel_on_bytes) -- in the service phase, like every other rare and
 // expensive thing a ray can need. (The image of an ESVO world serves such rays itself.)
 // SHALLOW: no ray can push below the LDS-resident stack levels (the host knows the image's depth): no hand-over test in the loop.
-template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false>
+// LV: stack levels resident in LDS -- 13 (three u32 planes), or 16 with a 16-bit third plane (image cursors: worlds of 14 to 16 levels
+// without the hand-over; the same 10 KB per wave).
+template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false, int LV = kLdsLevels>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
     constexpr bool IMAGE = SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE;
@@ -169,16 +171,18 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     static_assert(!SHALLOW || IMAGE, "only a traversal image bounds how deep a ray can get");
     const DevScene sc = IMAGE ? make_image_scene(sa) : make_scene(sa);
     const uint32_t lane = threadIdx.x;
+    static_assert(LV == kLdsLevels || IMAGE, "only an image cursor's third stack word fits 16 bits");
     StackSpill spill;
-    Stack<64, false> st;       // all 23 levels: LDS, then the per-lane spill array
-    // the same LDS slots, no range checks: what the traversal loop uses. SHALLOW (an image of at most kLdsLevels levels): no ray
+    typedef Stack<64, false, false, LV, (LV > kLdsLevels)> FullStack;
+    FullStack st;       // all 23 levels: LDS, then the per-lane spill array
+    // the same LDS slots, no range checks: what the traversal loop uses. SHALLOW (an image of at most LV levels): no ray
     // ever needs anything else
-    typedef Stack<64, true, SHALLOW> FastStack;
+    typedef Stack<64, true, SHALLOW, LV, (LV > kLdsLevels)> FastStack;
     FastStack fast_st;
     st.init(lane, &spill);
     fast_st.init(lane, &spill);
     // a ray may use fast_st while every level it can pop to is LDS resident
-    constexpr int kFastFloor = kLdsBaseScale - 1;
+    constexpr int kFastFloor = FullStack::kBaseScale - 1;
     // set in Trav::iter while the lane is not traversing, so that "iter < kMaxSteps" alone says "run one more step"
     constexpr uint32_t kParked = 0x80000000u;
 
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             tr.iter &= ~kParked;
             tr.sync_idx();
             for (;;) {
-                const TravStatus s = tr.template step<false, STATS, false, Stack<64, false>, true, FOREIGN != 0>(sc, st, nullptr, STATS ? &ctr : nullptr);
+                const TravStatus s = tr.template step<false, STATS, false, FullStack, true, FOREIGN != 0>(sc, st, nullptr, STATS ? &ctr : nullptr);
                 if (s == kTravContinue && tr.scale < kFastFloor) continue;
                 state = LaneState(s);
                 break;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     const DevScene sc_bytes = make_scene(sa);
                     tr.iter &= ~kParked;
                     const uint32_t before = tr.iter;
-                    const TravStatus s = enter_voxel_on_bytes<SVO, Stack<64, false>, false, false>(sc, sc_bytes, tr, st, true, res);
+                    const TravStatus s = enter_voxel_on_bytes<SVO, FullStack, false, false>(sc, sc_bytes, tr, st, true, res);
                     on_bytes = tr.iter - before;
                     // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there / given up (the pixel's turn comes later)
                     given_up = s == kTravForeign;
@@ -415,6 +419,9 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     // ---- second phase (FOREIGN): the pixels this wave gave up on the image, whole, on the world's own bytes ----
     if (FOREIGN) {
         const DevScene sc_bytes = make_scene(sa);
+        // (the byte cursor's stack entries are three full words: the plain 13-level layout, over the same LDS -- the first phase is over)
+        Stack<64, false> st2;
+        st2.init(lane, &spill);
         for (uint32_t c = my_chunk; c != 0;) {
             const uint32_t* chunk = todo.chunks + size_t(c - 1) * kChunkDwords;
             const uint32_t n = __builtin_amdgcn_readfirstlane(chunk[1]);
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     out_index_to_xy(p, index, x, y);
                     float color[4];
                     vx_hit r;
-                    shade_pixel<FOREIGN ? FOREIGN : VX_SVO_CSVO, false>(sc_bytes, p, x, y, st, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
+                    shade_pixel<FOREIGN ? FOREIGN : VX_SVO_CSVO, false>(sc_bytes, p, x, y, st2, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
                     if (out) store_pixel(p, out, index, color);
                     if (HITS) hits[index] = r;
                 }
@@ -649,6 +656,8 @@ struct vx_context {
     static constexpr int kDeltaSlots = 3;
     DeltaSlot delta[kDeltaSlots];
     unsigned delta_next = 0;
+    bool deep_stack = true;       // VX_DEEP_STACK=0: images of 14 to 16 levels on the 13-level stack with the hand-over (A/B)
+    bool no_excursion = false;    // VX_NO_EXCURSION=1 (MEASUREMENT ONLY, wrong pixels): a CSVO world's image walked by the kernel without the excursion code
     bool big = false;             // an ESVO world buffer of 4 GiB and more: kernels on its own bytes use 64-bit addresses (VX_SVO_ESVO_BIG)
     bool image_enabled = true;  // VX_TRAVERSAL_IMAGE=0: traverse the world's own bytes
     bool image_ok = false;
@@ -784,8 +793,9 @@ int check_ready(vx_context* ctx) {
 // The persistent render kernel for a context's world: on the world's own bytes (ESVO, ESVO beyond 4 GiB, CSVO), or on its
 // traversal image (byte-offset or wide layout; with the excursion onto the bytes for CSVO worlds; without the stack hand-over test
 // where the image's depth rules deep pushes out). The image-only build of the hot variants is held to 128 VGPRs (4 waves per SIMD).
+// levels: the LDS-resident stack levels of an image kernel -- kLdsLevels, or 16 (16-bit third plane) for images of 14 to 16 levels
 template <bool HITS, bool STATS>
-const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow) {
+const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, int levels) {
     const bool esvo = ctx->svo_type == VX_SVO_ESVO;
 #define VX_K(...) reinterpret_cast<const void*>(&render_persistent<__VA_ARGS__>)
     if (!imaged) {
@@ -796,12 +806,11 @@ const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow) 
     }
     constexpr int W = HITS ? 1 : 4;
     const bool wide = ctx->image.layout() == vximg::kOct64Wide;  // an image beyond 4 GiB: octant indices, 64-bit addresses
-    if (esvo) {
-        if (wide) return shallow ? VX_K(VX_SVO_IMAGE_WIDE, HITS, false, W, 0, true) : VX_K(VX_SVO_IMAGE_WIDE, HITS, false, W, 0, false);
-        return shallow ? VX_K(VX_SVO_IMAGE, HITS, false, W, 0, true) : VX_K(VX_SVO_IMAGE, HITS, false, W, 0, false);
-    }
-    if (wide) return shallow ? VX_K(VX_SVO_IMAGE_WIDE, HITS, false, W, VX_SVO_CSVO, true) : VX_K(VX_SVO_IMAGE_WIDE, HITS, false, W, VX_SVO_CSVO, false);
-    return shallow ? VX_K(VX_SVO_IMAGE, HITS, false, W, VX_SVO_CSVO, true) : VX_K(VX_SVO_IMAGE, HITS, false, W, VX_SVO_CSVO, false);
+#define VX_IMG(IMAGE, FOREIGN)                                                                                                       \
+    (levels == 16 ? VX_K(IMAGE, HITS, false, W, FOREIGN, true, 16) : (shallow ? VX_K(IMAGE, HITS, false, W, FOREIGN, true) : VX_K(IMAGE, HITS, false, W, FOREIGN, false)))
+    if (esvo || ctx->no_excursion) return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, 0) : VX_IMG(VX_SVO_IMAGE, 0);
+    return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO) : VX_IMG(VX_SVO_IMAGE, VX_SVO_CSVO);
+#undef VX_IMG
 #undef VX_K
 }
 
@@ -833,7 +842,6 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             hipLaunchKernelGGL((render_kernel<VX_SVO_CSVO, HITS, STATS>), grid, block, lds, stream, sc, p, reinterpret_cast<float4*>(out), hits, counters);
     } else {
         // persistent waves: as many 64-thread workgroups as the device keeps resident, fed from the sub-tile queue
-        const size_t wave_lds = Stack<64>::kBytes;
         // Worlds are rendered from their traversal image; the instrumented variant stays on the world's own bytes so that its
         // counters are the reference's own fetches
         const bool imaged = !STATS && ctx->image_ok;
@@ -842,8 +850,16 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // CSVO world such a ray leaves for its excursion instead, and the deepest PUSH is one level higher. Where that is an LDS
         // resident slot (scales >= kLdsBaseScale) the loop needs no hand-over test.
         const uint32_t depth = ctx->image.depth();
-        const bool shallow = imaged && depth <= uint32_t(kLdsLevels) + (ctx->svo_type == VX_SVO_CSVO ? 1u : 0u);
-        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow);
+        const uint32_t slack = ctx->svo_type == VX_SVO_CSVO ? 1u : 0u;
+        bool shallow = imaged && depth <= uint32_t(kLdsLevels) + slack;
+        // deeper images, up to 16 levels: the kernel build with 16 resident levels (16-bit third stack plane) -- no hand-over either
+        int levels = kLdsLevels;
+        if (imaged && !shallow && depth <= 16u + slack && ctx->deep_stack) {
+            levels = 16;
+            shallow = true;
+        }
+        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels);
+        const size_t wave_lds = levels == 16 ? Stack<64, false, false, 16, true>::kBytes : Stack<64>::kBytes;
         int& per_cu = ctx->persistent_blocks[fn];
         if (per_cu == 0) {
             int n = 0;
@@ -1112,6 +1128,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (c->frames_in_flight < 1) c->frames_in_flight = 1;
         if (c->frames_in_flight > vx_context::kFrameStreams) c->frames_in_flight = vx_context::kFrameStreams;
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_IMAGE_CAP_BYTES")) c->image_cap_bytes = size_t(std::strtoull(e, nullptr, 10));
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)

@@ -112,15 +112,15 @@ struct Counters {  // per-thread, reduced by the instrumented kernel
     uint32_t rays, iterations, pushes, leaf_tests, leaf_tests_trilinear, boundaries, csvo_header_bytes, csvo_pointer_bytes;
 };
 
-// Per-ray traversal stack. The levels an octree of depth <= kLdsLevels - 1 can legitimately reach live in LDS as three
-// u32 planes [plane][level][thread]: every lane's slot for a level sits in its own bank whatever mix of levels the lanes
-// are on, and the planes are a compile-time distance apart, so one address register serves all three accesses (the
-// first two fuse into ds_write2st64_b32 / ds_read2st64_b32). A ray that starts INSIDE a voxel makes the reference
-// descend "below" the leaves, interpreting leaf bytes as nodes (svo.esvo.glsl:183-185 / svo.csvo.glsl:293-295 only
-// treat a leaf as a hit when t_min > 0); its stack arrays hold MAX_SCALE + 1 entries (svo.esvo.glsl:28-30), so those
-// pushes are kept too -- in a per-thread spill array that ordinary rays never touch.
-constexpr int kLdsLevels = 13;
-constexpr int kLdsBaseScale = kMaxScale - kLdsLevels;  // scales [kLdsBaseScale, 22] are LDS resident
+// Per-ray traversal stack. The levels an octree of depth <= LEVELS - 1 can legitimately reach live in LDS as three planes
+// [plane][level][thread]: every lane's slot for a level sits in its own bank whatever mix of levels the lanes are on, and the
+// planes are a compile-time distance apart, so one address register serves the accesses (the first two fuse into
+// ds_write2st64_b32 / ds_read2st64_b32). A ray that starts INSIDE a voxel makes the reference descend "below" the leaves,
+// interpreting leaf bytes as nodes (svo.esvo.glsl:183-185 / svo.csvo.glsl:293-295 only treat a leaf as a hit when t_min > 0);
+// its stack arrays hold MAX_SCALE + 1 entries (svo.esvo.glsl:28-30), so those pushes are kept too -- in a per-thread spill
+// array that ordinary rays never touch.
+constexpr int kLdsLevels = 13;                          // the default: three u32 planes, 9.75 KB per wave, 16 waves per CU
+constexpr int kLdsBaseScale = kMaxScale - kLdsLevels;   // scales [kLdsBaseScale, 22] are LDS resident
 
 // per-thread backing store for the levels below the LDS-resident ones (lives in scratch)
 struct StackSpill {
@@ -129,39 +129,56 @@ struct StackSpill {
     uint32_t aux[kMaxScale];
 };
 
-// What a slot holds -- ESVO: {own-octant pointer, t_max, child masks}; CSVO: {node byte pointer, t_max, depth << 16 | header}.
+// What a slot holds -- ESVO: {own-octant pointer, t_max, child masks}; CSVO: {node byte pointer, t_max, depth << 16 | header};
+// image: {octant offset, t_max, masks (the upper half of a word)}.
 // FAST = the caller guarantees LDS-resident scales only (see Trav::step: a ray that is about to leave them reports
 // kTravDeep instead), so push/pop are the bare LDS accesses.
-// BOUNDED (fast stacks): the caller also guarantees that no PUSH goes below them -- an octree of at most kLdsLevels levels whose
+// BOUNDED (fast stacks): the caller also guarantees that no PUSH goes below them -- an octree of at most LEVELS levels whose
 // rays cannot be led beyond its leaves (a validated traversal image) -- so step() does not even look.
-template <int THREADS, bool FAST = false, bool BOUNDED = false>
+// AUX16 (image cursors only: their third word has its lower half free): the third plane holds 16 bits per slot. Ten bytes per
+// level and lane instead of twelve: 16 levels in the 10 KB a wave can have at 16 waves per CU (LEVELS = 16: worlds of up to 16
+// levels without the deep-push hand-over), at one more address computation per push and pop.
+template <int THREADS, bool FAST = false, bool BOUNDED = false, int LEVELS = kLdsLevels, bool AUX16 = false>
 struct Stack {
     static constexpr bool kFast = FAST;
     static constexpr bool kCanOverflow = FAST && !BOUNDED;
-    static constexpr uint32_t kPlane = uint32_t(kLdsLevels) * THREADS * 4;  // bytes between planes
-    static constexpr uint32_t kBytes = 3 * kPlane;                          // dynamic LDS a block of THREADS threads needs
+    static constexpr bool kAux16 = AUX16;
+    static constexpr int kLevels = LEVELS;
+    static constexpr int kBaseScale = kMaxScale - LEVELS;                   // scales [kBaseScale, 22] are LDS resident
+    static constexpr uint32_t kPlane = uint32_t(LEVELS) * THREADS * 4;      // bytes between the first two planes
+    static constexpr uint32_t kBytes = 2 * kPlane + (AUX16 ? kPlane / 2 : kPlane);  // dynamic LDS a block of THREADS threads needs
     uint32_t slot0;  // byte offset of this thread's slot for scale 0 of a (virtual) full-height plane; may be "negative"
+    // (non-FAST) scales below this one go to the spill array even if they are LDS resident: enter_voxel_on_bytes keeps what the byte
+    // cursor pushes inside a voxel -- 32-bit third words -- out of the image's slots
+    int lds_floor;
     VX_AS_PRIVATE StackSpill* spill;
 
     __device__ __forceinline__ void init(uint32_t tid, StackSpill* sp) {
-        slot0 = tid * 4u - uint32_t(kLdsBaseScale) * THREADS * 4u;
+        slot0 = tid * 4u - uint32_t(kBaseScale) * THREADS * 4u;
+        lds_floor = kBaseScale;
         spill = (VX_AS_PRIVATE StackSpill*)sp;
     }
     __device__ __forceinline__ VX_AS_LDS uint32_t* at(uint32_t byte) const { return (VX_AS_LDS uint32_t*)((VX_AS_LDS unsigned char*)vx_smem + byte); }
+    __device__ __forceinline__ VX_AS_LDS uint16_t* at16(uint32_t byte) const { return (VX_AS_LDS uint16_t*)((VX_AS_LDS unsigned char*)vx_smem + byte); }
+    __device__ __forceinline__ bool resident(int scale) const { return FAST || (scale >= lds_floor && scale < kMaxScale); }
 
     __device__ __forceinline__ void push(int scale, uint32_t p, float t, uint32_t a) const {
-        if (FAST || uint32_t(scale - kLdsBaseScale) < uint32_t(kLdsLevels)) {
+        if (resident(scale)) {
             const uint32_t s = uint32_t(scale) * (THREADS * 4u) + slot0;
-            *at(s) = p; *at(s + kPlane) = __float_as_uint(t); *at(s + 2 * kPlane) = a;
+            *at(s) = p; *at(s + kPlane) = __float_as_uint(t);
+            if (AUX16) *at16(2 * kPlane + (s >> 1)) = uint16_t(a >> 16);
+            else *at(s + 2 * kPlane) = a;
         } else if (uint32_t(scale) < uint32_t(kMaxScale)) {
             spill->ptr[scale] = p; spill->t_max[scale] = t; spill->aux[scale] = a;
         }
     }
     // scale is in [0, kMaxScale) here (the caller has already left the octree otherwise)
     __device__ __forceinline__ void pop(int scale, uint32_t& p, float& t, uint32_t& a) const {
-        if (FAST || uint32_t(scale - kLdsBaseScale) < uint32_t(kLdsLevels)) {
+        if (resident(scale)) {
             const uint32_t s = uint32_t(scale) * (THREADS * 4u) + slot0;
-            p = *at(s); t = __uint_as_float(*at(s + kPlane)); a = *at(s + 2 * kPlane);
+            p = *at(s); t = __uint_as_float(*at(s + kPlane));
+            if (AUX16) a = uint32_t(*at16(2 * kPlane + (s >> 1))) << 16;
+            else a = *at(s + 2 * kPlane);
         } else {
             p = spill->ptr[scale]; t = spill->t_max[scale]; a = spill->aux[scale];
         }
@@ -652,7 +669,7 @@ struct Trav {
         const float tv_max = gmin(t_max, tc_max);
         if (descend && t_min <= tv_max) {
             // ---- PUSH (svo.esvo.glsl:280-311, svo.csvo.glsl:387-426) ----
-            if (ST::kCanOverflow && scale < kLdsBaseScale) {
+            if (ST::kCanOverflow && scale < ST::kBaseScale) {
                 // this PUSH would write a slot below the resident ones: hand over. The iteration is repeated by the caller's
                 // full-stack step, so the CALLER takes `iter` back by one (undoing it here would make the counter's update
                 // path dependent, which costs every iteration a register copy).
@@ -859,6 +876,10 @@ __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, 
     const uint32_t img_ptr = tr.ptr, img_node = tr.node;
     const float parent_t_max = tr.t_max;
 
+    static_assert(!(ST::kAux16 && RESTART), "a 16-bit third plane cannot hold the byte cursor's entries from the root down");
+    // what the byte cursor pushes inside the voxel stays out of the LDS slots (they are the image's; theirs may be 16-bit)
+    ST bst = st;
+    bst.lds_floor = parent_scale > ST::kBaseScale ? parent_scale : ST::kBaseScale;
     // (every field of `tr` is written back from `tb` at the single exit below: nothing of `tr` is live while the byte cursor runs)
     ByteTrav tb;
     tb.rox = tr.rox; tb.roy = tr.roy; tb.roz = tr.roz; tb.rdx = tr.rdx; tb.rdy = tr.rdy; tb.rdz = tr.rdz;
@@ -891,9 +912,9 @@ __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, 
     bool first = true, for_good = false;
     for (;;) {
         // first trip: the iteration the image cursor stopped in, again -- PUSH into the voxel, or ADVANCE if the voxel's span is empty
-        TravStatus s = tb.template step<false, false, LIMIT, ST>(bytes, st, nullptr, nullptr);
+        TravStatus s = tb.template step<false, false, LIMIT, ST>(bytes, bst, nullptr, nullptr);
         if (s == kTravAtLeaf) {
-            const LeafOutcome o = tb.template leaf_test<false, false>(bytes, st, cast_translucent, res, nullptr, nullptr);
+            const LeafOutcome o = tb.template leaf_test<false, false>(bytes, bst, cast_translucent, res, nullptr, nullptr);
             if (o == kLeafHit) {
                 outcome = kTravAtLeaf;
                 break;
@@ -910,7 +931,7 @@ __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, 
         if (tb.scale < parent_scale) {
             // inside the voxel. The PUSH wrote the parent's entry as the byte cursor sees it (where the reference's `tc_max < h` let
             // it): the way back needs the image's (writing it where the reference wrote nothing is harmless: such a slot is never popped)
-            if (was_first) st.push(parent_scale, img_ptr, parent_t_max, img_node);
+            if (was_first) bst.push(parent_scale, img_ptr, parent_t_max, img_node);
             continue;
         }
         // back among real nodes
@@ -928,7 +949,7 @@ __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, 
             tb.node = img_node;
         } else {  // the slot the POP read holds an image entry (the byte cursor misread it): read it as one
             uint32_t a;
-            st.pop(tb.scale, tb.ptr, tb.t_max, a);
+            bst.pop(tb.scale, tb.ptr, tb.t_max, a);
             tb.node = a;
         }
         outcome = kTravContinue;
