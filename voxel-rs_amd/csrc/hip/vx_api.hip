@@ -248,7 +248,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // foreign_min lanes of the wave are there, or until no lane is left that could traverse meanwhile.
         if (FOREIGN) {
             const unsigned long long fm = __ballot(state == kForeign);
-            if (fm && (uint32_t(__popcll(fm)) >= a.foreign_min || __ballot(state == kTrav || state == kLeaf || state == kDone || state == kMissed || state == kDeep) == 0)) {
+            // (unlikely: tells the register allocator that what the walk needs may be spilled around it, not across the phase)
+            if (__builtin_expect(fm && (uint32_t(__popcll(fm)) >= a.foreign_min || __ballot(state == kTrav || state == kLeaf || state == kDone || state == kMissed || state == kDeep) == 0), 0)) {
                 uint32_t on_bytes = 0;
                 bool given_up = false;
                 if (state == kForeign) {
