@@ -124,6 +124,21 @@ struct PersistentArgs {
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
     uint32_t foreign_min;     // images of CSVO worlds: rays led into a voxel wait until this many of a wave's lanes are, and go together
+    // Expensive sub-tiles first. A frame cannot end before its longest rays do (grazing rays take hundreds of iterations against a mean
+    // of about thirty), so the sub-tiles that held such rays in the PREVIOUS frame on this stream are handed out before all others:
+    // tickets [0, hot_cap) belong to last frame's list of them (entries beyond its length are null tickets), tickets [hot_cap,
+    // hot_cap + total_subtiles) to the sub-tiles in order, minus those the first pass took (their cost entry carries prev_tag).
+    // Every ray that ends after more than kHotIterations iterations notes its sub-tile for the next frame (cost_cur / hot_cur).
+    // Order only: which pixel gets which value does not depend on it.
+    uint32_t hot_cap;               // 0 = no list to read (first frame of a view)
+    uint32_t prev_tag, cur_tag;     // frame tags of the entries to read / to write (20 bits, never 0)
+    const uint32_t* hot_prev;       // [hot_cap] sub-tile ids
+    const uint32_t* hot_prev_count; // how many of them (may exceed hot_cap: the surplus was not listed)
+    const uint32_t* cost_prev;      // [total_subtiles] tag << 12 | iterations
+    uint32_t* hot_cur;              // the same, being written (capacity hot_cur_cap); null = do not note anything
+    uint32_t* hot_cur_count;
+    uint32_t* cost_cur;
+    uint32_t hot_cur_cap;
     unsigned long long* excursions;  // [0] rays that made the excursion into a voxel on the world's bytes, [1] of which started over, [2] service phases that ran excursions, [3] loop iterations made on the bytes
 };
 
@@ -152,6 +167,38 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
         x = out_index % p.width;
         y = out_index / p.width;
         if (p.rgba8) y = p.height - 1u - y;
+    }
+}
+
+constexpr uint32_t kHotIterations = 128;  // a ray that needed more makes its sub-tile an expensive one (the mean is about 30)
+
+// the sub-tile (8x8 pixels: the unit of the queue) a pixel's output index lies in
+__device__ __forceinline__ uint32_t subtile_of(const RenderParams& p, uint32_t out_index) {
+    uint32_t local_tile, in_x, in_y;
+    if (p.tile_count > 1) {
+        local_tile = out_index >> 10;
+        in_y = (out_index >> 5) & 31u;
+        in_x = out_index & 31u;
+    } else {
+        uint32_t x, y;
+        out_index_to_xy(p, out_index, x, y);
+        local_tile = (y / kTile) * p.tiles_x + x / kTile;
+        in_x = x & 31u;
+        in_y = y & 31u;
+    }
+    const uint32_t sx = in_x >> 3, sy = in_y >> 3;  // 4x4 sub-tiles in Morton order (see the refill)
+    return local_tile * 16u + ((sx & 1u) | ((sy & 1u) << 1) | ((sx & 2u) << 1) | ((sy & 2u) << 2));
+}
+
+// a ray of this pixel has just ended after `iterations` loop iterations: remember expensive sub-tiles for the next frame
+__device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderParams& p, uint32_t out_index, uint32_t iterations) {
+    if (iterations <= kHotIterations || !a.hot_cur) return;
+    const uint32_t sub = subtile_of(p, out_index);
+    const uint32_t old = atomicMax(&a.cost_cur[sub], (a.cur_tag << 12) | (iterations < 4095u ? iterations : 4095u));
+    if ((old >> 12) != a.cur_tag) {  // the first such ray of this sub-tile in this frame: list it (listed <=> its entry carries the tag)
+        const uint32_t slot = atomicAdd(a.hot_cur_count, 1u);
+        if (slot < a.hot_cur_cap) a.hot_cur[slot] = sub;
+        else atomicExch(&a.cost_cur[sub], 0u);
     }
 }
 
@@ -201,6 +248,11 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
     bool queue_empty = false;
+    uint32_t n_hot = 0;             // wave-uniform: entries of last frame's list of expensive sub-tiles
+    if (a.hot_cap) {
+        n_hot = __builtin_amdgcn_readfirstlane(*a.hot_prev_count);
+        n_hot = n_hot < a.hot_cap ? n_hot : a.hot_cap;
+    }
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
 
     for (;;) {
@@ -313,6 +365,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if (state == kDone) {
             float color[4];
             bool write = true;
+            note_cost(a, p, out_index, tr.iter & ~kParked);
             if (!shadow_ray) {
                 PrimaryOutcome o;
                 shade_primary(sc, p, res, o);
@@ -366,15 +419,26 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             if (STATS) ++refills;
             for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
                 if (cursor >= 64) {
-                    uint32_t t = 0;
-                    if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base;  // unsigned: survives the counter wrapping
-                    t = __builtin_amdgcn_readfirstlane(t);
-                    if (t >= a.total_subtiles) {
-                        queue_empty = true;
+                    for (;;) {
+                        uint32_t t = 0;
+                        if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base;  // unsigned: survives the counter wrapping
+                        t = __builtin_amdgcn_readfirstlane(t);
+                        if (t >= a.hot_cap + a.total_subtiles) {
+                            queue_empty = true;
+                            break;
+                        }
+                        if (t < a.hot_cap) {  // first pass: last frame's expensive sub-tiles
+                            if (t >= n_hot) continue;  // (a null ticket: the list is shorter than its capacity)
+                            sub = __builtin_amdgcn_readfirstlane(a.hot_prev[t]);
+                            if (sub >= a.total_subtiles) continue;  // (never: a list of another view is not read)
+                        } else {              // second pass: everything the first did not take
+                            sub = t - a.hot_cap;
+                            if (a.hot_cap && (uint32_t(__builtin_amdgcn_readfirstlane(a.cost_prev[sub])) >> 12) == a.prev_tag) continue;
+                        }
+                        cursor = 0;
                         break;
                     }
-                    sub = t;
-                    cursor = 0;
+                    if (queue_empty) break;
                 }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
                 const uint32_t k = cursor + rank;
@@ -623,6 +687,19 @@ struct vx_context {
     uint32_t* d_main_todo = nullptr;
     size_t main_todo_chunks = 0;
     uint32_t main_tickets = 0;
+    // expensive-sub-tiles-first (PersistentArgs): per stream two generations of {cost per sub-tile, list, count}, the view they are of
+    struct HotState {
+        uint32_t* cost[2] = {nullptr, nullptr};
+        uint32_t* list[2] = {nullptr, nullptr};
+        uint32_t* count = nullptr;  // [2]
+        size_t subtiles = 0;        // capacity of cost[]
+        uint32_t list_cap = 0;
+        uint32_t tag = 0;           // of the generation written last
+        unsigned parity = 0;        // ... and its index
+        uint32_t width = 0, height = 0, tile_rank = 0, tile_count = 0;  // the view that generation is of (0 = none)
+    };
+    HotState hot[kFrameStreams + 1];  // [slot + 1]
+    bool hot_first = true;            // VX_HOT_FIRST=0: sub-tiles in plain order (A/B)
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
     hipEvent_t pending_gather = nullptr;  // vx_wait_gather: the gather that still reads the tile list the next render overwrites
     int frames_in_flight = 2;           // 1 serialises frames on `stream` again (vx_set_frames_in_flight / VX_FRAMES_IN_FLIGHT)
@@ -875,6 +952,62 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.service_min = ctx->service_min;
         a.foreign_min = ctx->foreign_min;
         a.excursions = ctx->d_excursions;
+        a.hot_cap = 0;
+        a.prev_tag = a.cur_tag = 0xfffffu;
+        a.hot_prev = a.hot_prev_count = a.cost_prev = nullptr;
+        a.hot_cur = a.hot_cur_count = a.cost_cur = nullptr;
+        a.hot_cur_cap = 0;
+        if (ctx->hot_first && !STATS) {
+            vx_context::HotState& hs = ctx->hot[slot + 1];
+            const size_t n_sub = a.total_subtiles;
+            if (hs.subtiles < n_sub) {  // (grow: the stream's earlier frames read the old arrays)
+                HIP_TRY(hipStreamSynchronize(stream));
+                for (int g = 0; g < 2; ++g) {
+                    if (hs.cost[g]) (void)hipFree(hs.cost[g]);
+                    if (hs.list[g]) (void)hipFree(hs.list[g]);
+                    hs.cost[g] = hs.list[g] = nullptr;
+                }
+                if (hs.count) (void)hipFree(hs.count);
+                hs.count = nullptr;
+                hs.subtiles = 0;
+                const size_t cap = n_sub + n_sub / 4 + 1024;
+                const uint32_t list_cap = uint32_t(std::max<size_t>(1024, cap / 4));
+                for (int g = 0; g < 2; ++g) {
+                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hs.cost[g]), cap * 4));
+                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hs.list[g]), size_t(list_cap) * 4));
+                    HIP_TRY(hipMemsetAsync(hs.cost[g], 0, cap * 4, stream));
+                }
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hs.count), 2 * 4));
+                HIP_TRY(hipMemsetAsync(hs.count, 0, 2 * 4, stream));
+                hs.subtiles = cap;
+                hs.list_cap = list_cap;
+                hs.width = 0;  // nothing to read yet
+                hs.tag = 0;
+            }
+            if (hs.tag >= 0xffff0u) {  // (tags are 20 bits: start over once in a million frames)
+                for (int g = 0; g < 2; ++g) HIP_TRY(hipMemsetAsync(hs.cost[g], 0, hs.subtiles * 4, stream));
+                hs.tag = 0;
+                hs.width = 0;
+            }
+            const bool same_view = hs.width == p.width && hs.height == p.height && hs.tile_rank == p.tile_rank && hs.tile_count == p.tile_count;
+            const unsigned prev = hs.parity, cur = hs.parity ^ 1u;
+            a.prev_tag = hs.tag;
+            a.cur_tag = hs.tag + 1;
+            if (same_view) {
+                a.hot_cap = hs.list_cap;
+                a.hot_prev = hs.list[prev];
+                a.hot_prev_count = hs.count + prev;
+                a.cost_prev = hs.cost[prev];
+            }
+            a.hot_cur = hs.list[cur];
+            a.hot_cur_count = hs.count + cur;
+            a.cost_cur = hs.cost[cur];
+            a.hot_cur_cap = hs.list_cap;
+            HIP_TRY(hipMemsetAsync(hs.count + cur, 0, 4, stream));
+            hs.parity = cur;
+            hs.tag += 1;
+            hs.width = p.width; hs.height = p.height; hs.tile_rank = p.tile_rank; hs.tile_count = p.tile_count;
+        }
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
         PixelList todo = {nullptr, nullptr, 0};
@@ -903,7 +1036,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         }
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, &todo};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
-        tickets += a.total_subtiles + waves;
+        tickets += a.hot_cap + a.total_subtiles + waves;
     }
     HIP_TRY(hipGetLastError());
     if (ctx->profile) {
@@ -1131,6 +1264,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_HOT_FIRST")) c->hot_first = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_IMAGE_CAP_BYTES")) c->image_cap_bytes = size_t(std::strtoull(e, nullptr, 10));
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)
@@ -1174,6 +1308,13 @@ void vx_destroy(vx_context* c) {
         if (c->frame_stream[i]) (void)hipStreamDestroy(c->frame_stream[i]);
     }
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    for (auto& hs : c->hot) {
+        for (int g = 0; g < 2; ++g) {
+            if (hs.cost[g]) (void)hipFree(hs.cost[g]);
+            if (hs.list[g]) (void)hipFree(hs.list[g]);
+        }
+        if (hs.count) (void)hipFree(hs.count);
+    }
     for (auto& e : c->gather_done)
         if (e) (void)hipEventDestroy(e);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
