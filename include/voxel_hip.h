@@ -312,6 +312,10 @@ int vx_render_counters(vx_context* ctx, const vx_uniforms* uniforms, uint32_t wi
 int vx_profile_enable(vx_context* ctx, int enabled);
 /* Sum of the bracketed kernel durations (ms) and their count since the last call; synchronises. */
 int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches);
+/* Measurement (contexts created with VX_TIMELINE=1 in the environment; else returns 0): per wave of the most recent render launch
+ * four words -- when it started, when it found the sub-tile queue empty, when it left (all in 10 ns ticks of the device's constant
+ * clock) and how many sub-tiles it took. Returns the number of waves copied. Waits for every frame in flight. */
+uint32_t vx_timeline_read(vx_context* ctx, uint64_t* out, uint32_t capacity_waves);
 /* What vx_render walks after the last commit: [0] 0 = the world's own bytes (no image: switched off, or the world cannot be
  * imaged), 1 = the traversal image with byte offsets, 2 = its layout for more than 4 GiB (32-byte units behind a 64-bit pointer);
  * [1] bytes of the image, [2] bytes of its origin table (CSVO worlds), [3] chunks it holds. */

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Where a frame's time goes, wave by wave: when each persistent wave of one C3 frame started, found the sub-tile queue empty and left
+(VX_TIMELINE=1; vx_timeline_read). One frame at a time.
+
+    VX_TIMELINE=1 python profiles/timeline.py --format esvo [--hot 0|1]
+"""
+import argparse
+import json
+import os
+import sys
+from pathlib import Path
+
+os.environ["VX_TIMELINE"] = "1"
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from _pkg import load_package  # noqa: E402
+
+vra = load_package()
+from voxel_rs_amd import hip, scenes  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--format", default="esvo")
+    ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--hot", default="1")
+    args = ap.parse_args()
+    os.environ["VX_HOT_FIRST"] = args.hot
+    import numpy as np
+    import torch
+
+    fmt = vra.SVO_ESVO if args.format == "esvo" else vra.SVO_CSVO
+    W, H = 1920, 1080
+    world = vra.World(fmt)
+    st = world.build_heightfield(args.depth)
+    svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20))
+    svo.set_materials(scenes.synthetic_materials())
+    svo.set_textures(scenes.asset_textures(), 6)
+    svo.update(world)
+    svo.set_frames_in_flight(1)
+    u = scenes.bench_camera(args.depth, st["h_max"], W, H, shadow_distance=3.0e38, render_shadows=True)
+    image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(6):
+        svo.render_device(u, W, H, image.data_ptr())
+    svo.sync()
+    t = svo.timeline().astype(np.float64)
+    t0 = t[:, 0].min()
+    start, empty, leave = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0  # microseconds
+    q = lambda a: [round(float(np.percentile(a, p)), 1) for p in (0, 10, 50, 90, 99, 100)]
+    print(json.dumps({"format": args.format, "hot_first": args.hot, "waves": int(len(t)), "percentiles": [0, 10, 50, 90, 99, 100],
+                      "start_us": q(start), "queue_empty_us": q(empty[t[:, 1] > 0]), "exit_us": q(leave), "tail_us_per_wave": q((leave - empty)[t[:, 1] > 0]),
+                      "subtiles_taken": q(t[:, 3]), "kernel_us": round(float(leave.max()), 1),
+                      "mean_wave_lifetime_us": round(float((leave - start).mean()), 1)}))
+
+
+if __name__ == "__main__":
+    main()

@@ -124,21 +124,16 @@ struct PersistentArgs {
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
     uint32_t foreign_min;     // images of CSVO worlds: rays led into a voxel wait until this many of a wave's lanes are, and go together
-    // Expensive sub-tiles first. A frame cannot end before its longest rays do (grazing rays take hundreds of iterations against a mean
-    // of about thirty), so the sub-tiles that held such rays in the PREVIOUS frame on this stream are handed out before all others:
-    // tickets [0, hot_cap) belong to last frame's list of them (entries beyond its length are null tickets), tickets [hot_cap,
-    // hot_cap + total_subtiles) to the sub-tiles in order, minus those the first pass took (their cost entry carries prev_tag).
-    // Every ray that ends after more than kHotIterations iterations notes its sub-tile for the next frame (cost_cur / hot_cur).
-    // Order only: which pixel gets which value does not depend on it.
-    uint32_t hot_cap;               // 0 = no list to read (first frame of a view)
-    uint32_t prev_tag, cur_tag;     // frame tags of the entries to read / to write (20 bits, never 0)
-    const uint32_t* hot_prev;       // [hot_cap] sub-tile ids
-    const uint32_t* hot_prev_count; // how many of them (may exceed hot_cap: the surplus was not listed)
-    const uint32_t* cost_prev;      // [total_subtiles] tag << 12 | iterations
-    uint32_t* hot_cur;              // the same, being written (capacity hot_cur_cap); null = do not note anything
-    uint32_t* hot_cur_count;
-    uint32_t* cost_cur;
-    uint32_t hot_cur_cap;
+    // Expensive sub-tiles first. A ray is a chain of dependent steps -- about 0.8 us per iteration on a busy device -- so a frame cannot
+    // end before its longest rays do (up to ~300 iterations against a mean of ~30): handed out in screen order they start in mid-frame
+    // and the frame ends with a long tail of waves that wait for a few of them (profiles/timeline.py). So every ray that ends notes
+    // its iteration count in its sub-tile's entry of `cost_cur` (atomic max), a small kernel behind the frame sorts the sub-tiles into
+    // eight cost classes, most expensive first, screen order within a class (order_kernel), and the NEXT frame of the same view on this
+    // stream draws its tickets through that table: `order` (null: screen order). Order only: no pixel's value depends on it.
+    const uint32_t* order;          // [total_subtiles] sub-tile ids, or null
+    uint32_t* cost_cur;             // [total_subtiles] tag << 12 | iterations of the sub-tile's longest ray this frame; null = do not note
+    uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
+    unsigned long long* timeline;   // measurement (VX_TIMELINE=1), else null: per wave {start, queue found empty, exit} in 10 ns ticks, pixels taken
     unsigned long long* excursions;  // [0] rays that made the excursion into a voxel on the world's bytes, [1] of which started over, [2] service phases that ran excursions, [3] loop iterations made on the bytes
 };
 
@@ -170,7 +165,7 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
     }
 }
 
-constexpr uint32_t kHotIterations = 128;  // a ray that needed more makes its sub-tile an expensive one (the mean is about 30)
+constexpr uint32_t kCostFloor = 32;  // rays that end sooner (the mean is about 30) leave their sub-tile in the cheapest class: no note
 
 // the sub-tile (8x8 pixels: the unit of the queue) a pixel's output index lies in
 __device__ __forceinline__ uint32_t subtile_of(const RenderParams& p, uint32_t out_index) {
@@ -190,16 +185,10 @@ __device__ __forceinline__ uint32_t subtile_of(const RenderParams& p, uint32_t o
     return local_tile * 16u + ((sx & 1u) | ((sy & 1u) << 1) | ((sx & 2u) << 1) | ((sy & 2u) << 2));
 }
 
-// a ray of this pixel has just ended after `iterations` loop iterations: remember expensive sub-tiles for the next frame
+// a ray of this pixel has just ended after `iterations` loop iterations: the sub-tile's entry keeps the maximum
 __device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderParams& p, uint32_t out_index, uint32_t iterations) {
-    if (iterations <= kHotIterations || !a.hot_cur) return;
-    const uint32_t sub = subtile_of(p, out_index);
-    const uint32_t old = atomicMax(&a.cost_cur[sub], (a.cur_tag << 12) | (iterations < 4095u ? iterations : 4095u));
-    if ((old >> 12) != a.cur_tag) {  // the first such ray of this sub-tile in this frame: list it (listed <=> its entry carries the tag)
-        const uint32_t slot = atomicAdd(a.hot_cur_count, 1u);
-        if (slot < a.hot_cur_cap) a.hot_cur[slot] = sub;
-        else atomicExch(&a.cost_cur[sub], 0u);
-    }
+    if (iterations < kCostFloor || !a.cost_cur) return;
+    atomicMax(&a.cost_cur[subtile_of(p, out_index)], (a.cur_tag << 12) | (iterations < 4095u ? iterations : 4095u));
 }
 
 // IMAGE = the rays walk the traversal image of the world (traversal_image.hpp) instead of its own bytes. FOREIGN (an image of a
@@ -248,11 +237,9 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
     bool queue_empty = false;
-    uint32_t n_hot = 0;             // wave-uniform: entries of last frame's list of expensive sub-tiles
-    if (a.hot_cap) {
-        n_hot = __builtin_amdgcn_readfirstlane(*a.hot_prev_count);
-        n_hot = n_hot < a.hot_cap ? n_hot : a.hot_cap;
-    }
+    const unsigned long long t_start = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long t_empty = 0ull;
+    uint32_t taken = 0;
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
 
     for (;;) {
@@ -419,26 +406,18 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             if (STATS) ++refills;
             for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
                 if (cursor >= 64) {
-                    for (;;) {
-                        uint32_t t = 0;
-                        if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base;  // unsigned: survives the counter wrapping
-                        t = __builtin_amdgcn_readfirstlane(t);
-                        if (t >= a.hot_cap + a.total_subtiles) {
-                            queue_empty = true;
-                            break;
-                        }
-                        if (t < a.hot_cap) {  // first pass: last frame's expensive sub-tiles
-                            if (t >= n_hot) continue;  // (a null ticket: the list is shorter than its capacity)
-                            sub = __builtin_amdgcn_readfirstlane(a.hot_prev[t]);
-                            if (sub >= a.total_subtiles) continue;  // (never: a list of another view is not read)
-                        } else {              // second pass: everything the first did not take
-                            sub = t - a.hot_cap;
-                            if (a.hot_cap && (uint32_t(__builtin_amdgcn_readfirstlane(a.cost_prev[sub])) >> 12) == a.prev_tag) continue;
-                        }
-                        cursor = 0;
+                    uint32_t t = 0;
+                    if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base;  // unsigned: survives the counter wrapping
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    if (t >= a.total_subtiles) {
+                        queue_empty = true;
+                        if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
                         break;
                     }
-                    if (queue_empty) break;
+                    sub = a.order ? uint32_t(__builtin_amdgcn_readfirstlane(a.order[t])) : t;  // most expensive first, or screen order
+                    if (sub >= a.total_subtiles) sub = t;  // (never: a table of another view is not used)
+                    cursor = 0;
+                    ++taken;
                 }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
                 const uint32_t k = cursor + rank;
@@ -481,6 +460,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if (__ballot(state != kIdle) == 0 && queue_empty) break;
     }
 
+    if (a.timeline && lane == 0) {
+        unsigned long long* row = a.timeline + size_t(blockIdx.x) * 4;
+        row[0] = t_start; row[1] = t_empty; row[2] = __builtin_amdgcn_s_memrealtime(); row[3] = taken;
+    }
     // ---- second phase (FOREIGN): the pixels this wave gave up on the image, whole, on the world's own bytes ----
     if (FOREIGN) {
         const DevScene sc_bytes = make_scene(sa);
@@ -594,6 +577,53 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneArgs sa, TraceArgs a, vx
     *n_frames = tk.n_frames;
 }
 
+// Sorts a frame's sub-tiles for the next frame's queue (PersistentArgs::order): eight classes by the iteration count of the sub-tile's
+// longest ray (class = min(7, iterations / 32); entries without this frame's tag are class 0), the highest class first, screen
+// order within a class (a stable counting sort: the rays of neighbouring sub-tiles walk the same nodes). Four waves, each with a
+// contiguous quarter of the sub-tiles, 64 at a time: a lane's place inside its class is a ballot and a popcount. Small on purpose --
+// it runs behind a frame whose successor on the other streams fills the device: four wave slots are free long before a whole CU is.
+__global__ __launch_bounds__(256) void order_kernel(const uint32_t* __restrict__ cost, uint32_t tag, uint32_t n, uint32_t* __restrict__ order) {
+    __shared__ uint32_t totals[4][8];  // [wave][slot], slot 0 = the most expensive class
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t blocks = (n + 63u) / 64u, per = (blocks + 3u) / 4u;
+    const uint32_t first = wave * per < blocks ? wave * per : blocks, last = first + per < blocks ? first + per : blocks;
+    auto slot_of = [&](uint32_t i) -> uint32_t {
+        if (i >= n) return 8u;  // (beyond the end: no class)
+        const uint32_t c = cost[i];
+        const uint32_t cls = (c >> 12) == tag ? ((c & 0xfffu) / 32u < 7u ? (c & 0xfffu) / 32u : 7u) : 0u;
+        return 7u - cls;
+    };
+    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform
+    for (uint32_t b = first; b < last; ++b) {
+        const uint32_t slot = slot_of(b * 64u + lane);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) mine[k] += uint32_t(__popcll(__ballot(slot == k)));
+    }
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) totals[wave][k] = mine[k];
+    __syncthreads();
+    // where this wave's members of each class go: behind every more expensive class, and behind the same class of the waves before
+    uint32_t at[8];
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < 8; ++k) {
+        for (uint32_t w = 0; w < 4; ++w) {
+            if (w == wave) at[k] = run;
+            run += totals[w][k];
+        }
+    }
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64u - lane));
+    for (uint32_t b = first; b < last; ++b) {
+        const uint32_t i = b * 64u + lane;
+        const uint32_t slot = slot_of(i);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const unsigned long long m = __ballot(slot == k);
+            if (slot == k) order[at[k] + uint32_t(__popcll(m & below))] = i;
+            at[k] += uint32_t(__popcll(m));
+        }
+    }
+}
+
 // vx_commit's packed uploads: piece b of the table = {device address, offset in the packed payload, bytes}; source and
 // destination agree modulo 16 (the packer pads), so the middle of a piece moves as 16-byte words
 __global__ __launch_bounds__(256) void scatter_kernel(const uint64_t* __restrict__ table, const uint8_t* __restrict__ packed) {
@@ -687,19 +717,22 @@ struct vx_context {
     uint32_t* d_main_todo = nullptr;
     size_t main_todo_chunks = 0;
     uint32_t main_tickets = 0;
-    // expensive-sub-tiles-first (PersistentArgs): per stream two generations of {cost per sub-tile, list, count}, the view they are of
+    // expensive sub-tiles first (PersistentArgs::order): per stream three generations of {cost per sub-tile, order table}. Frame j of a
+    // view on a stream notes costs in generation j % 3; the order kernel for it runs on `order_stream`, behind the frame and beside
+    // the next one; frame j + 2 draws its tickets through that table (every step ordered by events: nothing is read while written).
     struct HotState {
-        uint32_t* cost[2] = {nullptr, nullptr};
-        uint32_t* list[2] = {nullptr, nullptr};
-        uint32_t* count = nullptr;  // [2]
-        size_t subtiles = 0;        // capacity of cost[]
-        uint32_t list_cap = 0;
+        uint32_t* cost[3] = {nullptr, nullptr, nullptr};
+        uint32_t* order[3] = {nullptr, nullptr, nullptr};
+        hipEvent_t order_done[3] = {nullptr, nullptr, nullptr};
+        size_t subtiles = 0;        // capacity of each
         uint32_t tag = 0;           // of the generation written last
-        unsigned parity = 0;        // ... and its index
-        uint32_t width = 0, height = 0, tile_rank = 0, tile_count = 0;  // the view that generation is of (0 = none)
+        uint32_t frames = 0;        // frames of the current view issued on this stream
+        uint32_t width = 0, height = 0, tile_rank = 0, tile_count = 0;  // the view (0 = none)
     };
+    hipStream_t order_stream = nullptr;
     HotState hot[kFrameStreams + 1];  // [slot + 1]
     bool hot_first = true;            // VX_HOT_FIRST=0: sub-tiles in plain order (A/B)
+    bool hot_use = true, hot_note = true, hot_sort = true;  // VX_HOT_FIRST bits (measurement): 1 use the table, 2 note costs, 4 run the order kernel
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
     hipEvent_t pending_gather = nullptr;  // vx_wait_gather: the gather that still reads the tile list the next render overwrites
     int frames_in_flight = 2;           // 1 serialises frames on `stream` again (vx_set_frames_in_flight / VX_FRAMES_IN_FLIGHT)
@@ -722,6 +755,8 @@ struct vx_context {
 
     uint32_t* d_work_counter = nullptr;
     unsigned long long* d_excursions = nullptr;  // [3], see PersistentArgs
+    unsigned long long* d_timeline = nullptr;    // VX_TIMELINE=1: [8192][4], the last launch's waves (PersistentArgs::timeline)
+    uint32_t timeline_waves = 0;
     // the traversal image of the world (traversal_image.hpp), rebuilt for the changed chunks by every commit
     vximg::WorldImage image;
     uint8_t* d_image = nullptr;
@@ -804,6 +839,7 @@ int drain_streams(vx_context* c) {
         if (c->frame_stream[i]) HIP_TRY(hipStreamSynchronize(c->frame_stream[i]));
     if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
     if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    if (c->order_stream) HIP_TRY(hipStreamSynchronize(c->order_stream));
     return VX_OK;
 }
 
@@ -902,6 +938,8 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
     const SceneArgs sc = scene_of(ctx);
 
     uint32_t& tickets = slot >= 0 ? ctx->frame_tickets[slot] : ctx->main_tickets;
+    vx_context::HotState* order_after = nullptr;
+    uint32_t order_subtiles = 0;
     ProfiledLaunch ev{};
     if (ctx->profile) {
         if (!ctx->event_pool.empty()) {
@@ -952,64 +990,62 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.service_min = ctx->service_min;
         a.foreign_min = ctx->foreign_min;
         a.excursions = ctx->d_excursions;
-        a.hot_cap = 0;
-        a.prev_tag = a.cur_tag = 0xfffffu;
-        a.hot_prev = a.hot_prev_count = a.cost_prev = nullptr;
-        a.hot_cur = a.hot_cur_count = a.cost_cur = nullptr;
-        a.hot_cur_cap = 0;
-        if (ctx->hot_first && !STATS) {
-            vx_context::HotState& hs = ctx->hot[slot + 1];
+        a.timeline = ctx->d_timeline;
+        a.order = nullptr;
+        a.cost_cur = nullptr;
+        a.cur_tag = 0xfffffu;
+        vx_context::HotState* hs = nullptr;
+        // One frame at a time only (the context's own stream): with several frames in flight the next frame's waves fill the tail anyway,
+        // and noting costs (+6 %) and sorting them (+7 %: four wave slots for most of a frame) would be all cost (profiles/round2).
+        if (ctx->hot_first && !STATS && slot < 0) {
+            hs = &ctx->hot[slot + 1];
             const size_t n_sub = a.total_subtiles;
-            if (hs.subtiles < n_sub) {  // (grow: the stream's earlier frames read the old arrays)
+            if (!ctx->order_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->order_stream, hipStreamNonBlocking));
+            if (hs->subtiles < n_sub) {  // (grow: earlier frames of this stream and their order kernels use the old arrays)
                 HIP_TRY(hipStreamSynchronize(stream));
-                for (int g = 0; g < 2; ++g) {
-                    if (hs.cost[g]) (void)hipFree(hs.cost[g]);
-                    if (hs.list[g]) (void)hipFree(hs.list[g]);
-                    hs.cost[g] = hs.list[g] = nullptr;
+                HIP_TRY(hipStreamSynchronize(ctx->order_stream));
+                for (int g = 0; g < 3; ++g) {
+                    if (hs->cost[g]) (void)hipFree(hs->cost[g]);
+                    if (hs->order[g]) (void)hipFree(hs->order[g]);
+                    hs->cost[g] = hs->order[g] = nullptr;
                 }
-                if (hs.count) (void)hipFree(hs.count);
-                hs.count = nullptr;
-                hs.subtiles = 0;
+                hs->subtiles = 0;
                 const size_t cap = n_sub + n_sub / 4 + 1024;
-                const uint32_t list_cap = uint32_t(std::max<size_t>(1024, cap / 4));
-                for (int g = 0; g < 2; ++g) {
-                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hs.cost[g]), cap * 4));
-                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hs.list[g]), size_t(list_cap) * 4));
-                    HIP_TRY(hipMemsetAsync(hs.cost[g], 0, cap * 4, stream));
+                for (int g = 0; g < 3; ++g) {
+                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hs->cost[g]), cap * 4));
+                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hs->order[g]), cap * 4));
+                    HIP_TRY(hipMemsetAsync(hs->cost[g], 0, cap * 4, stream));
+                    if (!hs->order_done[g]) HIP_TRY(hipEventCreateWithFlags(&hs->order_done[g], hipEventDisableTiming));
                 }
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hs.count), 2 * 4));
-                HIP_TRY(hipMemsetAsync(hs.count, 0, 2 * 4, stream));
-                hs.subtiles = cap;
-                hs.list_cap = list_cap;
-                hs.width = 0;  // nothing to read yet
-                hs.tag = 0;
+                hs->subtiles = cap;
+                hs->width = 0;
+                hs->tag = 0;
             }
-            if (hs.tag >= 0xffff0u) {  // (tags are 20 bits: start over once in a million frames)
-                for (int g = 0; g < 2; ++g) HIP_TRY(hipMemsetAsync(hs.cost[g], 0, hs.subtiles * 4, stream));
-                hs.tag = 0;
-                hs.width = 0;
+            if (hs->tag >= 0xffff0u) {  // (tags are 20 bits: start over once in a million frames)
+                HIP_TRY(hipStreamSynchronize(ctx->order_stream));
+                for (int g = 0; g < 3; ++g) HIP_TRY(hipMemsetAsync(hs->cost[g], 0, hs->subtiles * 4, stream));
+                hs->tag = 0;
+                hs->width = 0;
             }
-            const bool same_view = hs.width == p.width && hs.height == p.height && hs.tile_rank == p.tile_rank && hs.tile_count == p.tile_count;
-            const unsigned prev = hs.parity, cur = hs.parity ^ 1u;
-            a.prev_tag = hs.tag;
-            a.cur_tag = hs.tag + 1;
-            if (same_view) {
-                a.hot_cap = hs.list_cap;
-                a.hot_prev = hs.list[prev];
-                a.hot_prev_count = hs.count + prev;
-                a.cost_prev = hs.cost[prev];
+            const bool same_view = hs->width == p.width && hs->height == p.height && hs->tile_rank == p.tile_rank && hs->tile_count == p.tile_count;
+            if (!same_view) hs->frames = 0;
+            if (hs->frames >= 2 && ctx->hot_sort) {  // the table made from this view's frame before last on this stream (its kernel had a whole frame's time)
+                const uint32_t g = (hs->frames - 2) % 3;
+                HIP_TRY(hipStreamWaitEvent(stream, hs->order_done[g], 0));
+                if (ctx->hot_use) a.order = hs->order[g];
+            } else if (hs->frames == 0 && hs->order_done[0]) {
+                // a new view starts over in generation 0: what the old view's order kernels still have to write comes first
+                for (int g = 0; g < 3; ++g) HIP_TRY(hipStreamWaitEvent(stream, hs->order_done[g], 0));
             }
-            a.hot_cur = hs.list[cur];
-            a.hot_cur_count = hs.count + cur;
-            a.cost_cur = hs.cost[cur];
-            a.hot_cur_cap = hs.list_cap;
-            HIP_TRY(hipMemsetAsync(hs.count + cur, 0, 4, stream));
-            hs.parity = cur;
-            hs.tag += 1;
-            hs.width = p.width; hs.height = p.height; hs.tile_rank = p.tile_rank; hs.tile_count = p.tile_count;
+            hs->tag += 1;
+            if (ctx->hot_note) a.cost_cur = hs->cost[hs->frames % 3];
+            a.cur_tag = hs->tag;
+            hs->width = p.width; hs->height = p.height; hs->tile_rank = p.tile_rank; hs->tile_count = p.tile_count;
         }
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
+        if (waves > 8192) a.timeline = nullptr;
+        ctx->timeline_waves = a.timeline ? waves : 0;
         PixelList todo = {nullptr, nullptr, 0};
         if (imaged && ctx->svo_type == VX_SVO_CSVO) {
             // per stream: a ring of chunks behind a counter that only ever grows -- nothing to reset between frames. A finished
@@ -1036,7 +1072,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         }
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, &todo};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
-        tickets += a.hot_cap + a.total_subtiles + waves;
+        tickets += a.total_subtiles + waves;
+        order_after = hs;
+        order_subtiles = a.total_subtiles;
     }
     HIP_TRY(hipGetLastError());
     if (ctx->profile) {
@@ -1049,6 +1087,18 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
     } else {
         HIP_TRY(hipEventRecord(ctx->render_done, stream));
         ctx->render_recorded = true;
+    }
+    if (order_after) {
+        // behind this frame but not in its stream's way: the table the frame after next draws its tickets through (PersistentArgs::order)
+        vx_context::HotState* hs = order_after;
+        const uint32_t g = hs->frames % 3;
+        if (ctx->hot_sort) {
+            HIP_TRY(hipStreamWaitEvent(ctx->order_stream, slot >= 0 ? ctx->frame_done[slot] : ctx->render_done, 0));
+            hipLaunchKernelGGL(order_kernel, dim3(1), dim3(256), 0, ctx->order_stream, hs->cost[g], hs->tag, order_subtiles, hs->order[g]);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(hs->order_done[g], ctx->order_stream));
+        }
+        hs->frames += 1;
     }
     ctx->last_frame_slot = slot;
     return VX_OK;
@@ -1264,7 +1314,13 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VX_HOT_FIRST")) c->hot_first = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_HOT_FIRST")) {
+            const int v = std::atoi(e);
+            c->hot_first = v != 0;
+            c->hot_use = (v & 1) != 0; c->hot_note = (v & 2) != 0; c->hot_sort = (v & 4) != 0;
+        }
+        if (const char* e = std::getenv("VX_TIMELINE"))
+            if (std::atoi(e) != 0) CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_timeline), 8192 * 4 * sizeof(unsigned long long)));
         if (const char* e = std::getenv("VX_IMAGE_CAP_BYTES")) c->image_cap_bytes = size_t(std::strtoull(e, nullptr, 10));
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)
@@ -1298,7 +1354,7 @@ void vx_destroy(vx_context* c) {
     for (auto& l : c->event_pool) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     if (c->staging) (void)hipHostFree(c->staging);
     void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_frame, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
-                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin, c->d_excursions, c->d_main_todo};
+                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin, c->d_excursions, c->d_main_todo, c->d_timeline};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
@@ -1309,15 +1365,16 @@ void vx_destroy(vx_context* c) {
     }
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     for (auto& hs : c->hot) {
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < 3; ++g) {
             if (hs.cost[g]) (void)hipFree(hs.cost[g]);
-            if (hs.list[g]) (void)hipFree(hs.list[g]);
+            if (hs.order[g]) (void)hipFree(hs.order[g]);
+            if (hs.order_done[g]) (void)hipEventDestroy(hs.order_done[g]);
         }
-        if (hs.count) (void)hipFree(hs.count);
     }
     for (auto& e : c->gather_done)
         if (e) (void)hipEventDestroy(e);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    if (c->order_stream) (void)hipStreamDestroy(c->order_stream);
     for (auto& ps : c->present) {
         if (ps.dev) (void)hipFree(ps.dev);
         if (ps.host) (void)hipHostFree(ps.host);
@@ -1775,6 +1832,7 @@ int vx_sync(vx_context* ctx) {
     for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
     if (ctx->copy_stream) HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
     if (ctx->comm_stream) HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
+    if (ctx->order_stream) HIP_TRY(hipStreamSynchronize(ctx->order_stream));
     return VX_OK;
 }
 
@@ -1991,6 +2049,14 @@ int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches) 
     *launches = uint32_t(ctx->launches.size());
     ctx->launches.clear();
     return VX_OK;
+}
+
+uint32_t vx_timeline_read(vx_context* ctx, uint64_t* out, uint32_t capacity_waves) {
+    if (!ctx || !ctx->d_timeline || !out) return 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || drain_streams(ctx) != VX_OK) return 0;
+    const uint32_t n = ctx->timeline_waves < capacity_waves ? ctx->timeline_waves : capacity_waves;
+    if (n && hipMemcpy(out, ctx->d_timeline, size_t(n) * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
 }
 
 int vx_image_info(const vx_context* ctx, uint64_t out[4]) {

@@ -102,6 +102,7 @@ SYMBOLS = {
     "vx_render_counters": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, _u32, _u32, C.POINTER(Counters)]),
     "vx_excursion_counters": (_int, [_vp, C.POINTER(_u64 * 4), _int]),
     "vx_image_info": (_int, [_vp, C.POINTER(_u64 * 4)]),
+    "vx_timeline_read": (_u32, [_vp, _vp, _u32]),
     "vx_profile_enable": (_int, [_vp, _int]),
     "vx_profile_read": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32)]),
     "vx_stream": (_vp, [_vp]),
@@ -342,6 +343,12 @@ class Svo:
     def stream_wait_render(self, stream):
         """Makes the raw hipStream_t `stream` wait for the most recently issued render."""
         _check(lib().vx_stream_wait_render(self._h, _vp(stream)))
+
+    def timeline(self):
+        """Per wave of the last launch: [start, queue empty, exit] in 10 ns ticks and sub-tiles taken (needs VX_TIMELINE=1)."""
+        out = np.zeros((8192, 4), dtype=np.uint64)
+        n = lib().vx_timeline_read(self._h, out.ctypes.data_as(_vp), 8192)
+        return out[:n]
 
     def image_info(self):
         out = (_u64 * 4)()
