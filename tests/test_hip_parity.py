@@ -422,8 +422,10 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     results = []
     for env in ({"VX_RENDER_KERNEL": "1"}, {"VX_RENDER_KERNEL": "2"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"},
                 {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "64", "VX_SERVICE_MIN": "64"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"},
-                {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_WIDE_IMAGE": "1", "VX_MIN_WAVES": "1"}):
-        for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_MIN_WAVES"):
+                {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_WIDE_IMAGE": "1", "VX_MIN_WAVES": "1"},
+                {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_MIN": "1"}):
+        for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_MIN_WAVES", "VX_HOT_LEVELS", "VX_HOT_FIRST",
+                  "VX_FOREIGN_MIN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -432,8 +434,9 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
         svo.set_textures(tex, 6)
         svo.update_full(world)  # a fresh buffer each time: the world's dirty ranges were consumed by the first update
         img, hits = svo.render(u, w, h, want_hits=True)
-        img2, _ = svo.render(u, w, h)
-        assert img2.tobytes() == img.tobytes()
+        for _ in range(4):  # (from the third frame of a view on, the queue hands the sub-tiles out by last frame's cost)
+            img2, _ = svo.render(u, w, h)
+            assert img2.tobytes() == img.tobytes()
         # (the occupancy counters describe how a kernel scheduled its lanes, not what the rays did)
         counters = {k: v for k, v in svo.render_counters(u, w, h).items() if k not in OCCUPANCY_COUNTERS}
         results.append((img, hits.tobytes(), counters))

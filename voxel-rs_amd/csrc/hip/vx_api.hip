@@ -198,7 +198,8 @@ __device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderP
 // SHALLOW: no ray can push below the LDS-resident stack levels (the host knows the image's depth): no hand-over test in the loop.
 // LV: stack levels resident in LDS -- 13 (three u32 planes), or 16 with a 16-bit third plane (image cursors: worlds of 14 to 16 levels
 // without the hand-over; the same 10 KB per wave).
-template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false, int LV = kLdsLevels>
+// HOT (experiment X1): the image's root octant and its eight child octants copied into LDS, PUSHes out of them served from there.
+template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false, int LV = kLdsLevels, bool HOT = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
     constexpr bool IMAGE = SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE;
@@ -209,14 +210,16 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     const uint32_t lane = threadIdx.x;
     static_assert(LV == kLdsLevels || IMAGE, "only an image cursor's third stack word fits 16 bits");
     StackSpill spill;
-    typedef Stack<64, false, false, LV, (LV > kLdsLevels)> FullStack;
+    static_assert(!HOT || (SVO == VX_SVO_IMAGE && LV == kLdsLevels), "the LDS copy of the top levels: byte-offset images, 13 stack levels");
+    typedef Stack<64, false, false, LV, (LV > kLdsLevels) || HOT, HOT> FullStack;
     FullStack st;       // all 23 levels: LDS, then the per-lane spill array
     // the same LDS slots, no range checks: what the traversal loop uses. SHALLOW (an image of at most LV levels): no ray
     // ever needs anything else
-    typedef Stack<64, true, SHALLOW, LV, (LV > kLdsLevels)> FastStack;
+    typedef Stack<64, true, SHALLOW, LV, (LV > kLdsLevels) || HOT, HOT> FastStack;
     FastStack fast_st;
     st.init(lane, &spill);
     fast_st.init(lane, &spill);
+    if (HOT) fast_st.load_hot(sc, lane);
     // a ray may use fast_st while every level it can pop to is LDS resident
     constexpr int kFastFloor = FullStack::kBaseScale - 1;
     // set in Trav::iter while the lane is not traversing, so that "iter < kMaxSteps" alone says "run one more step"
@@ -769,6 +772,7 @@ struct vx_context {
     static constexpr int kDeltaSlots = 3;
     DeltaSlot delta[kDeltaSlots];
     unsigned delta_next = 0;
+    bool hot_levels = false;      // VX_HOT_LEVELS=1 (experiment X1): the image's top two levels served from an LDS copy (ESVO worlds, image-only renders)
     bool deep_stack = true;       // VX_DEEP_STACK=0: images of 14 to 16 levels on the 13-level stack with the hand-over (A/B)
     bool no_excursion = false;    // VX_NO_EXCURSION=1 (MEASUREMENT ONLY, wrong pixels): a CSVO world's image walked by the kernel without the excursion code
     bool big = false;             // an ESVO world buffer of 4 GiB and more: kernels on its own bytes use 64-bit addresses (VX_SVO_ESVO_BIG)
@@ -922,6 +926,7 @@ const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, 
     const bool wide = ctx->image.layout() == vximg::kOct64Wide;  // an image beyond 4 GiB: octant indices, 64-bit addresses
 #define VX_IMG(IMAGE, FOREIGN)                                                                                                       \
     (levels == 16 ? VX_K(IMAGE, HITS, false, W, FOREIGN, true, 16) : (shallow ? VX_K(IMAGE, HITS, false, W, FOREIGN, true) : VX_K(IMAGE, HITS, false, W, FOREIGN, false)))
+    if (ctx->hot_levels && !HITS && !wide && shallow && levels == kLdsLevels && (esvo || ctx->no_excursion)) return VX_K(VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true);
     if (esvo || ctx->no_excursion) return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, 0) : VX_IMG(VX_SVO_IMAGE, 0);
     return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO) : VX_IMG(VX_SVO_IMAGE, VX_SVO_CSVO);
 #undef VX_IMG
@@ -975,7 +980,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             shallow = true;
         }
         const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels);
-        const size_t wave_lds = levels == 16 ? Stack<64, false, false, 16, true>::kBytes : Stack<64>::kBytes;
+        size_t wave_lds = levels == 16 ? Stack<64, false, false, 16, true>::kBytes : Stack<64>::kBytes;
+        if (fn == reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true>))
+            wave_lds = Stack<64, false, false, kLdsLevels, true, true>::kBytes;
         int& per_cu = ctx->persistent_blocks[fn];
         if (per_cu == 0) {
             int n = 0;
@@ -1314,6 +1321,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_HOT_LEVELS")) c->hot_levels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_HOT_FIRST")) {
             const int v = std::atoi(e);
             c->hot_first = v != 0;

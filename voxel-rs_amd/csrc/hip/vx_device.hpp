@@ -138,15 +138,21 @@ struct StackSpill {
 // AUX16 (image cursors only: their third word has its lower half free): the third plane holds 16 bits per slot. Ten bytes per
 // level and lane instead of twelve: 16 levels in the 10 KB a wave can have at 16 waves per CU (LEVELS = 16: worlds of up to 16
 // levels without the deep-push hand-over), at one more address computation per push and pop.
-template <int THREADS, bool FAST = false, bool BOUNDED = false, int LEVELS = kLdsLevels, bool AUX16 = false>
+// HOT (experiment X1, "hot upper octree levels staged in LDS"; image cursors, one wave per block): behind the planes the block keeps
+// a copy of the image's root octant and of the root's eight child octants (9 x 64 bytes, Stack::load_hot); a PUSH out of one of
+// those nodes takes its entry from there instead of from memory (Trav::step_with).
+template <int THREADS, bool FAST = false, bool BOUNDED = false, int LEVELS = kLdsLevels, bool AUX16 = false, bool HOT = false>
 struct Stack {
     static constexpr bool kFast = FAST;
+    static constexpr bool kHot = HOT;
     static constexpr bool kCanOverflow = FAST && !BOUNDED;
     static constexpr bool kAux16 = AUX16;
     static constexpr int kLevels = LEVELS;
     static constexpr int kBaseScale = kMaxScale - LEVELS;                   // scales [kBaseScale, 22] are LDS resident
     static constexpr uint32_t kPlane = uint32_t(LEVELS) * THREADS * 4;      // bytes between the first two planes
-    static constexpr uint32_t kBytes = 2 * kPlane + (AUX16 ? kPlane / 2 : kPlane);  // dynamic LDS a block of THREADS threads needs
+    static constexpr uint32_t kStackBytes = 2 * kPlane + (AUX16 ? kPlane / 2 : kPlane);
+    static constexpr uint32_t kHotBytes = HOT ? 9u * 64u : 0u;
+    static constexpr uint32_t kBytes = kStackBytes + kHotBytes;  // dynamic LDS a block of THREADS threads needs
     uint32_t slot0;  // byte offset of this thread's slot for scale 0 of a (virtual) full-height plane; may be "negative"
     // (non-FAST) scales below this one go to the spill array even if they are LDS resident: enter_voxel_on_bytes keeps what the byte
     // cursor pushes inside a voxel -- 32-bit third words -- out of the image's slots
@@ -160,6 +166,26 @@ struct Stack {
     }
     __device__ __forceinline__ VX_AS_LDS uint32_t* at(uint32_t byte) const { return (VX_AS_LDS uint32_t*)((VX_AS_LDS unsigned char*)vx_smem + byte); }
     __device__ __forceinline__ VX_AS_LDS uint16_t* at16(uint32_t byte) const { return (VX_AS_LDS uint16_t*)((VX_AS_LDS unsigned char*)vx_smem + byte); }
+    // HOT: entry `child` (0..7) of hot node `n` (0 = the root, 1 + c = the root's child c)
+    __device__ __forceinline__ uint2 hot_entry(uint32_t n, uint32_t child) const {
+        const VX_AS_LDS uint32_t* e = at(kStackBytes + n * 64u + child * 8u);
+        return make_uint2(e[0], e[1]);
+    }
+    // HOT: fills the copy (one wave; `lane` 0..63). The root's entries first, then entry (lane & 7) of the root's child (lane >> 3)
+    // -- whatever that child is: only octants of inner nodes are ever read back.
+    template <class SCENE>
+    __device__ __forceinline__ void load_hot(const SCENE& sc, uint32_t lane) const {
+        const uint32_t root = buf_u32(sc.world, 8);
+        if (lane < 8) {
+            const uint2 e = buf_u64(sc.world, root + lane * 8u);
+            VX_AS_LDS uint32_t* d = at(kStackBytes + lane * 8u);
+            d[0] = e.x; d[1] = e.y;
+        }
+        const uint32_t child_octant = *at(kStackBytes + (lane >> 3) * 8u);
+        const uint2 e = buf_u64(sc.world, child_octant + (lane & 7u) * 8u);
+        VX_AS_LDS uint32_t* d = at(kStackBytes + 64u + lane * 8u);
+        d[0] = e.x; d[1] = e.y;
+    }
     __device__ __forceinline__ bool resident(int scale) const { return FAST || (scale >= lds_floor && scale < kMaxScale); }
 
     __device__ __forceinline__ void push(int scale, uint32_t p, float t, uint32_t a) const {
@@ -686,7 +712,14 @@ struct Trav {
             uint32_t w0 = 0, w1 = 0, table = 0, offset = 0;
             if (IMG) {
                 // one aligned 8-byte entry: the child's octant and the child's masks (no clamp: image pointers are valid by construction)
-                const uint2 e = WIDE ? wide_entry(sc, ptr, octant_idx) : buf_u64(sc.world, ptr + octant_idx * 8u);
+                uint2 e;
+                if (ST::kHot && scale >= kMaxScale - 2) {
+                    // out of the root (scale 22) or of the root's child the ray is in (scale 21; which one: the position's bit 22)
+                    const uint32_t at_root = uint32_t(bit_at(__float_as_uint(px), 22) | (bit_at(__float_as_uint(py), 22) << 1) | (bit_at(__float_as_uint(pz), 22) << 2)) ^ uint32_t(octant_mask);
+                    e = st.hot_entry(scale == kMaxScale - 1 ? 0u : 1u + at_root, octant_idx);
+                } else {
+                    e = WIDE ? wide_entry(sc, ptr, octant_idx) : buf_u64(sc.world, ptr + octant_idx * 8u);
+                }
                 w0 = e.x;
                 // A ray that starts inside a voxel is led INTO it (the leaf was not accepted above: t_min <= 0). In an ESVO world a voxel's
                 // own masks are zero in everything the serializer writes (esvo.rs:465-485 never ORs a leaf's masks into its parent's
