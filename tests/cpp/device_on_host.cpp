@@ -16,6 +16,7 @@ struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct uint2 { uint32_t x, y; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 static inline uint32_t __popc(uint32_t v) { return uint32_t(__builtin_popcount(v)); }
 static inline int __clz(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }

@@ -557,10 +557,13 @@ struct Trav {
             // just that bit, stepping one whose bit is clear borrows from above it. So "idx & step_mask after the flip"
             // (svo.esvo.glsl:337-343) == "the old and new corners differ above bit `scale`", and the differing bits are the POP's own
             // (svo.esvo.glsl:345-349: per stepped axis bits(pos) ^ bits(pos + scale_exp2), the subtraction being exact).
-            if (tc_max >= tcrx) px -= scale_exp2;
-            if (tc_max >= tcry) py -= scale_exp2;
-            if (tc_max >= tcrz) pz -= scale_exp2;
-            differing_bits = (ox ^ __float_as_uint(px)) | (oy ^ __float_as_uint(py)) | (oz ^ __float_as_uint(pz));
+            // (written so that the stepped corner is the LAST thing computed from the old one: the new value can then live in the old
+            // one's register, and the loop needs no copies where its paths meet. The old coordinate of a stepped axis is the new one
+            // plus the step, exactly.)
+            const float ax = tc_max >= tcrx ? scale_exp2 : 0.0f, ay = tc_max >= tcry ? scale_exp2 : 0.0f, az = tc_max >= tcrz ? scale_exp2 : 0.0f;
+            px -= ax; py -= ay; pz -= az;
+            differing_bits = (__float_as_uint(px + ax) ^ __float_as_uint(px)) | (__float_as_uint(py + ay) ^ __float_as_uint(py)) |
+                             (__float_as_uint(pz + az) ^ __float_as_uint(pz));
             pop = differing_bits >= (2u << scale);
         } else {
             int step_mask = 0;
