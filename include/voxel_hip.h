@@ -200,6 +200,19 @@ size_t vx_arena_capacity(const vx_context* ctx);
 int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes);
 /* Same, treating [0, used_bytes) of the arena as dirty (what the first write_changes_to after write_to does). */
 int vx_commit_all(vx_context* ctx, uint32_t depth, uint64_t used_bytes);
+/* Pipelined commits. VX_COMMIT_INLINE (default): vx_commit does the image update and queues the uploads before it returns, and
+ * every later render sees the new world. VX_COMMIT_PIPELINED: vx_commit only posts the job to a worker thread of the context
+ * (0.01 ms) and returns; the worker updates the image, packs and queues the uploads while the caller goes on -- renders issued
+ * meanwhile show the world as of the commit before, WHOLLY (world bytes, image and origin table change together, ordered on the
+ * device behind the frames in flight and before every later one), so a change becomes visible at most one frame late, like the
+ * reference's own one-frame lag between Svo::update and the next fence (svo.rs:171-189, 196-229). One job at a time: the next
+ * vx_commit, vx_staging_ptr (the worker reads the mirror: ask for the pointer before writing the next changes, as
+ * write_changes_to's callers do), vx_commit_wait and vx_sync wait for the posted one. A pipelined commit's error (VX_ERR_HIP
+ * etc.) is reported by the next vx_commit, vx_commit_wait or vx_sync. The first commit of a context is always done inline. */
+typedef enum vx_commit_mode { VX_COMMIT_INLINE = 0, VX_COMMIT_PIPELINED = 1 } vx_commit_mode;
+int vx_set_commit_mode(vx_context* ctx, int mode);
+/* wait until the posted commit has been queued on the device (not for the device itself: vx_sync), return its error */
+int vx_commit_wait(vx_context* ctx);
 /* Svo::get_stats (svo.rs:191-193) */
 int vx_get_stats(const vx_context* ctx, vx_stats* out);
 

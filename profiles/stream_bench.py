@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--speed", type=float, default=2.0, help="blocks per frame along +x")
     ap.add_argument("--events", type=int, default=400)
     ap.add_argument("--capacity-mb", type=int, default=2000)
+    ap.add_argument("--pipelined", type=int, default=1, help="1 = VX_COMMIT_PIPELINED during the flight (the commit worker), 0 = inline commits")
     args = ap.parse_args()
     import torch
 
@@ -71,6 +72,7 @@ def main():
     # phase 2: fly along +x, one commit of <= args.events events and one frame per step
     rows = []
     svo.profile_enable(True)
+    svo.set_commit_mode(bool(args.pipelined))
     for f in range(args.frames):
         eye[0] += args.speed
         t0 = time.perf_counter()
@@ -80,10 +82,12 @@ def main():
         cam = s.to_svo(eye)
         u = scenes.render_params_to_uniforms(cam, (0.6, -0.35, 0.7), (0.0, 1.0, 0.0), math.radians(72.0), W / H, 0.3, (-1.0, -1.0, -1.0), True, 3.0e38)
         svo.render_device(u, W, H, image.data_ptr())
+        step_ms = (time.perf_counter() - t0) * 1e3  # everything the frame loop's thread did this step
         ms, launches = svo.profile_read()
-        rows.append(dict(st, host_ms=host_ms, kernel_ms=ms / max(launches, 1), frame=f))
+        rows.append(dict(st, host_ms=host_ms, step_ms=step_ms, kernel_ms=ms / max(launches, 1), frame=f))
     # phase 3: stand still until the queue has drained, then a few settled frames
     settled = []
+    svo.set_commit_mode(False)
     while True:
         st = s.pump(svo._h, args.events)
         if st["pending"] == 0:
@@ -110,6 +114,8 @@ def main():
         "commit_ranges_median": int(statistics.median(r["ranges"] for r in commits)) if commits else None,
         # move_to (chunk loader) + pump (apply finished chunks, root, staging write, vx_commit); chunks are built by background workers
         "host_ms_per_step_median": round(statistics.median(r["host_ms"] for r in streaming), 3) if streaming else None,
+        "commit_mode": "pipelined" if args.pipelined else "inline",
+        "host_ms_per_step_with_render_call_median": round(statistics.median(r["step_ms"] for r in streaming), 3) if streaming else None,
         "host_ms_per_step_max": round(max(r["host_ms"] for r in streaming), 3) if streaming else None,
         "build_ms_median": round(statistics.median(r["build_us"] for r in commits) / 1e3, 2) if commits else None,
         "apply_ms_median": round(statistics.median(r["apply_us"] for r in commits) / 1e3, 2) if commits else None,

@@ -358,6 +358,116 @@ def test_incremental_update_ranges(hip, golden, fmt):
 
 
 @pytest.mark.parametrize("fmt", FMTS)
+def test_pipelined_commits_show_whole_versions(hip, fmt):
+    """VX_COMMIT_PIPELINED: vx_commit posts the job and returns; frames rendered meanwhile show the world of the commit before or
+    the new one -- never a mixture of the two (world bytes, image and origin table change together) --, and after vx_commit_wait
+    the new one. Every frame is compared with the oracle's frames of both versions."""
+    from voxel_rs_amd import scenes
+
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    w, h = 192, 128
+    u = scenes.render_params_to_uniforms((30.0, 26.0, -14.0), (0.05, -0.45, 1.0), (0.0, 1.0, 0.0), np.radians(72.0), w / h)
+    ou = orc.Uniforms.from_buffer_copy(bytes(u))
+    world = vra.World(SVO_TYPES[fmt])
+    floor = vra.Chunk(0, 0, 0, 5)
+    floor.apply_blocks([dict(box=[[0, 32], [0, 2], [0, 32]], id=1)])
+    floor.compact()
+    world.set_chunk((0, 0, 0), floor)
+    world.set_chunk((1, 0, 0), floor_at(1))
+    world.serialize()
+    svo = hip.Svo(SVO_TYPES[fmt], 8 << 20)
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)  # the first commit of a context is done inline in either mode
+    svo.set_commit_mode(True)
+
+    def oracle_frame():
+        scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+        return scene.render(ou, w, h)
+
+    old = oracle_frame()
+    img, hits = svo.render(u, w, h, want_hits=True)
+    compare_frames(img, hits, *old)
+    saw_old = 0
+    for step in range(6):
+        # a tower of a different height and block every step: a third of the pixels change
+        c = vra.Chunk(0, 0, 0, 5)
+        c.apply_blocks([dict(box=[[0, 32], [0, 2], [0, 32]], id=1), dict(box=[[4, 28], [2, 6 + 4 * step], [8, 24]], id=2 + step % 3)])
+        c.compact()
+        world.set_chunk((0, 0, 0), c)
+        world.serialize()
+        new = oracle_frame()
+        assert not np.array_equal(new[1]["value"], old[1]["value"])
+        svo.update(world)  # posts the job
+        for _ in range(3):
+            img, hits = svo.render(u, w, h, want_hits=True)
+            if np.array_equal(hits["value"], old[1]["value"]):
+                compare_frames(img, hits, *old)
+                saw_old += 1
+            else:
+                compare_frames(img, hits, *new)
+        svo.commit_wait()
+        img, hits = svo.render(u, w, h, want_hits=True)
+        compare_frames(img, hits, *new)
+        old = new
+    # back to inline commits: the worker is gone, an update is visible at once
+    svo.set_commit_mode(False)
+    world.set_chunk((0, 0, 0), floor)
+    world.serialize()
+    svo.update(world)
+    img, hits = svo.render(u, w, h, want_hits=True)
+    compare_frames(img, hits, *oracle_frame())
+    print("frames that still showed the previous version:", saw_old)
+
+
+def floor_at(cx):
+    c = vra.Chunk(cx, 0, 0, 5)
+    c.apply_blocks([dict(box=[[0, 32], [0, 3], [0, 32]], id=3)])
+    c.compact()
+    return c
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_pipelined_commits_under_frames_in_flight(hip, fmt):
+    """Many pipelined commits while frames are queued on the frame streams without waiting (the streaming loop): no error, and
+    the frame after the last commit is the oracle's."""
+    import torch
+    from voxel_rs_amd import scenes
+
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    w, h = 256, 160
+    u = scenes.render_params_to_uniforms((30.0, 30.0, -10.0), (0.05, -0.5, 1.0), (0.0, 1.0, 0.0), np.radians(72.0), w / h)
+    world = vra.World(SVO_TYPES[fmt])
+    for cx in range(2):
+        world.set_chunk((cx, 0, 0), floor_at(cx))
+    world.serialize()
+    svo = hip.Svo(SVO_TYPES[fmt], 16 << 20)
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+    svo.set_commit_mode(True)
+    svo.set_frames_in_flight(4)
+    out = torch.zeros((4, h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(3)
+    for step in range(40):
+        c = vra.Chunk(int(step % 2), 0, 0, 5)
+        x0, z0 = (int(v) for v in rng.integers(0, 20, 2))
+        c.apply_blocks([dict(box=[[0, 32], [0, 3], [0, 32]], id=3), dict(box=[[x0, x0 + 10], [3, 4 + step % 20], [z0, z0 + 10]], id=1 + step % 4)])
+        c.compact()
+        world.set_chunk((int(step % 2), 0, 0), c)
+        world.serialize()
+        svo.update(world)
+        for k in range(2):
+            svo.render_device(u, w, h, out[(2 * step + k) % 4].data_ptr())
+    svo.commit_wait()
+    img, hits = svo.render(u, w, h, want_hits=True)
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    compare_frames(img, hits, *scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h))
+    svo.sync()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
 def test_tile_sharded_render_matches_full(hip, fmt):
     import ctypes as C
 

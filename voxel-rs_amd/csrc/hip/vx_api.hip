@@ -10,11 +10,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -809,7 +812,32 @@ struct vx_context {
     bool profile = false;
     std::vector<ProfiledLaunch> launches;
     std::vector<ProfiledLaunch> event_pool;
+
+    // Every entry point that queues device work, or reads what a commit publishes, holds `mutex` while it does. A context is still
+    // driven by ONE caller thread; the second party is the context's own commit worker (vx_set_commit_mode), which takes the
+    // mutex for the part of a commit that touches the device and the published state -- so a render is either wholly before a
+    // commit (which then waits for it on the device) or wholly after it (and waits for its uploads).
+    std::recursive_mutex mutex;
+    // what renders need to know of the traversal image, as of the last commit that reached the device (`image` itself belongs to
+    // whoever runs the commit)
+    struct ImagePublished { uint64_t frame_bytes = 0, origin_bytes = 0, chunks = 0; uint32_t depth = 0; vximg::Layout layout = vximg::kOct64; } pub;
+    // pipelined commits: one posted job at a time, run by `worker`
+    int commit_mode = VX_COMMIT_INLINE;
+    struct CommitJob { uint32_t depth = 0; std::vector<vx_range> ranges; uint64_t used_bytes = 0; } job;
+    std::thread worker;
+    std::mutex job_mutex;
+    std::condition_variable job_cv;
+    bool job_posted = false, job_running = false, worker_stop = false;
+    int async_rc = VX_OK;       // of the last pipelined commit, reported by the next vx_commit / vx_commit_wait / vx_sync
+    std::string async_error;
 };
+
+#define VX_LOCK(ctx) std::lock_guard<std::recursive_mutex> vx_lock_((ctx)->mutex)
+
+namespace {
+void wait_commit_idle(vx_context* ctx);
+void stop_commit_worker(vx_context* ctx);
+}  // namespace
 
 namespace {
 
@@ -830,7 +858,7 @@ SceneArgs scene_of(const vx_context* c) {
     s.width = c->tex.width; s.height = c->tex.height; s.layers = c->tex.layers; s.levels = c->tex.levels;
     for (int l = 0; l < 16; ++l) s.level_offset[l] = c->tex.level_offset[l];
     s.image = c->image_ok ? c->d_image : nullptr;
-    s.image_bytes = c->image_ok ? c->image.frame_bytes() + kImagePad : 0u;
+    s.image_bytes = c->image_ok ? c->pub.frame_bytes + kImagePad : 0u;
     s.origin = c->image_ok ? c->d_origin : nullptr;
     return s;
 }
@@ -923,7 +951,7 @@ const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, 
         return esvo ? (ctx->big ? VX_K(VX_SVO_ESVO_BIG, HITS, STATS, W) : VX_K(VX_SVO_ESVO, HITS, STATS, W)) : VX_K(VX_SVO_CSVO, HITS, STATS, W);
     }
     constexpr int W = HITS ? 1 : 4;
-    const bool wide = ctx->image.layout() == vximg::kOct64Wide;  // an image beyond 4 GiB: octant indices, 64-bit addresses
+    const bool wide = ctx->pub.layout == vximg::kOct64Wide;  // an image beyond 4 GiB: octant indices, 64-bit addresses
 #define VX_IMG(IMAGE, FOREIGN)                                                                                                       \
     (levels == 16 ? VX_K(IMAGE, HITS, false, W, FOREIGN, true, 16) : (shallow ? VX_K(IMAGE, HITS, false, W, FOREIGN, true) : VX_K(IMAGE, HITS, false, W, FOREIGN, false)))
     if (ctx->hot_levels && !HITS && !wide && shallow && levels == kLdsLevels && (esvo || ctx->no_excursion)) return VX_K(VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true);
@@ -970,7 +998,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // into a voxel (a ray that started inside it walks it as an empty node), out of a node at scale 23 - depth; on the image of a
         // CSVO world such a ray leaves for its excursion instead, and the deepest PUSH is one level higher. Where that is an LDS
         // resident slot (scales >= kLdsBaseScale) the loop needs no hand-over test.
-        const uint32_t depth = ctx->image.depth();
+        const uint32_t depth = ctx->pub.depth;
         const uint32_t slack = ctx->svo_type == VX_SVO_CSVO ? 1u : 0u;
         bool shallow = imaged && depth <= uint32_t(kLdsLevels) + slack;
         // deeper images, up to 16 levels: the kernel build with 16 resident levels (16-bit third stack plane) -- no hand-over either
@@ -1356,6 +1384,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
 
 void vx_destroy(vx_context* c) {
     if (!c) return;
+    stop_commit_worker(c);
     (void)hipSetDevice(c->device);
     (void)drain_streams(c);  // nothing may still be reading what is freed below
     for (auto& l : c->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
@@ -1407,6 +1436,7 @@ void vx_destroy(vx_context* c) {
 
 int vx_set_materials(vx_context* ctx, const vx_material* rows, uint32_t count) {
     if (!ctx || !rows || count == 0) return fail(VX_ERR_INVALID_ARGUMENT, "materials: null or empty");
+    VX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     // the new table is complete before anything is swapped; the old one is freed once every frame in flight (they hold its address
     // in their kernel arguments, on any of the frame streams) has finished
@@ -1428,6 +1458,7 @@ int vx_set_materials(vx_context* ctx, const vx_material* rows, uint32_t count) {
 
 int vx_set_textures(vx_context* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, uint32_t layers, uint32_t mip_levels) {
     if (!ctx || !rgba8 || !width || !height || !layers) return fail(VX_ERR_INVALID_ARGUMENT, "textures: null or empty");
+    VX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     // mip_levels = min(requested, ilog2(min(w, h))), never below 1 (texture_array.rs:108, :193)
     uint32_t m = width < height ? width : height, lg = 0;
@@ -1482,20 +1513,24 @@ int vx_set_textures(vx_context* ctx, const uint8_t* rgba8, uint32_t width, uint3
     return VX_OK;
 }
 
-uint8_t* vx_staging_ptr(vx_context* ctx) { return ctx ? ctx->staging : nullptr; }
+uint8_t* vx_staging_ptr(vx_context* ctx) {
+    if (!ctx) return nullptr;
+    // a pipelined commit reads the mirror on the worker thread: whoever asks for the pointer (to write the next changes) waits for it
+    if (ctx->worker.joinable()) wait_commit_idle(ctx);
+    return ctx->staging;
+}
 size_t vx_capacity(const vx_context* ctx) { return ctx ? size_t(ctx->stats.capacity_bytes) : 0; }
 size_t vx_arena_capacity(const vx_context* ctx) { return ctx ? size_t(ctx->stats.capacity_bytes) - 4 - header_bytes(ctx) : 0; }
 
-int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes) {
-    if (!ctx || (count && !ranges)) return fail(VX_ERR_INVALID_ARGUMENT, "commit: null argument");
-    if (depth > uint32_t(kMaxScale)) return fail(VX_ERR_INVALID_ARGUMENT, "depth exceeds the traversal's 23-level limit (svo.esvo.glsl:21)");
+}  // extern "C"
+
+namespace {
+
+// The commit proper (arguments already checked): image update and packing on the calling thread -- the caller's, or the
+// context's commit worker --, then, under the context's mutex, everything that touches the device or what renders read.
+int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes) {
     HIP_TRY(hipSetDevice(ctx->device));
     const uint64_t head = 4 + header_bytes(ctx);
-    const uint64_t arena = ctx->stats.capacity_bytes - head;
-    if (used_bytes > arena) return fail(VX_ERR_CAPACITY, "dst is not large enough: used_bytes exceeds the world buffer");
-    for (uint32_t i = 0; i < count; ++i)
-        if (ranges[i].start + ranges[i].length > arena || ranges[i].start + ranges[i].length < ranges[i].start)
-            return fail(VX_ERR_CAPACITY, "dst is not large enough: a dirty range exceeds the world buffer");
 
     // octree_scale = 2^-depth as f32 at byte 0 (svo.rs:173-175)
     const float scale = std::exp2(-float(depth));
@@ -1534,6 +1569,7 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
             image_ok = ctx->image.update(ctx->staging, used_bytes, nullptr, 0, threads);
         }
     }
+    VX_LOCK(ctx);  // from here on: device memory, streams, events and the state renders read
     // The image is an accelerator: whatever goes wrong with it (a world that cannot be imaged, no device memory for it), the
     // context falls back to traversing the world's own bytes -- with nothing of a half-made image left behind.
     auto drop_image = [&]() {
@@ -1623,6 +1659,13 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
         return rc;
     }
     ctx->image_ok = image_ok;
+    if (image_ok) {
+        ctx->pub.frame_bytes = ctx->image.frame_bytes();
+        ctx->pub.origin_bytes = ctx->image.has_origin() ? ctx->image.origin_bytes() : 0u;
+        ctx->pub.chunks = ctx->image.chunk_count();
+        ctx->pub.depth = ctx->image.depth();
+        ctx->pub.layout = ctx->image.layout();
+    }
     HIP_TRY(hipEventRecord(ctx->upload_done, ctx->upload_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_done, 0));
     for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamWaitEvent(ctx->frame_stream[i], ctx->upload_done, 0));
@@ -1633,6 +1676,104 @@ int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t 
     return VX_OK;
 }
 
+// ---- pipelined commits: the context's worker thread ------------------------------------------------------------------------
+
+void wait_commit_idle(vx_context* ctx) {
+    std::unique_lock<std::mutex> lk(ctx->job_mutex);
+    ctx->job_cv.wait(lk, [&] { return !ctx->job_posted && !ctx->job_running; });
+}
+
+// the error of the last pipelined commit, once (VX_OK if there was none)
+int take_async_error(vx_context* ctx) {
+    std::unique_lock<std::mutex> lk(ctx->job_mutex);
+    const int rc = ctx->async_rc;
+    if (rc == VX_OK) return VX_OK;
+    ctx->async_rc = VX_OK;
+    return fail(rc, "pipelined commit failed: " + ctx->async_error);
+}
+
+void commit_worker(vx_context* ctx) {
+    (void)hipSetDevice(ctx->device);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(ctx->job_mutex);
+            ctx->job_cv.wait(lk, [&] { return ctx->job_posted || ctx->worker_stop; });
+            if (!ctx->job_posted) return;
+            ctx->job_posted = false;
+            ctx->job_running = true;
+        }
+        const vx_context::CommitJob& j = ctx->job;  // (not rewritten before job_running is false again)
+        const int rc = commit_now(ctx, j.depth, j.ranges.data(), uint32_t(j.ranges.size()), j.used_bytes);
+        {
+            std::unique_lock<std::mutex> lk(ctx->job_mutex);
+            if (rc != VX_OK && ctx->async_rc == VX_OK) {
+                ctx->async_rc = rc;
+                ctx->async_error = g_last_error;
+            }
+            ctx->job_running = false;
+        }
+        ctx->job_cv.notify_all();
+    }
+}
+
+void stop_commit_worker(vx_context* ctx) {
+    if (!ctx->worker.joinable()) return;
+    wait_commit_idle(ctx);
+    {
+        std::unique_lock<std::mutex> lk(ctx->job_mutex);
+        ctx->worker_stop = true;
+    }
+    ctx->job_cv.notify_all();
+    ctx->worker.join();
+    ctx->worker_stop = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes) {
+    if (!ctx || (count && !ranges)) return fail(VX_ERR_INVALID_ARGUMENT, "commit: null argument");
+    if (depth > uint32_t(kMaxScale)) return fail(VX_ERR_INVALID_ARGUMENT, "depth exceeds the traversal's 23-level limit (svo.esvo.glsl:21)");
+    const uint64_t head = 4 + header_bytes(ctx);
+    const uint64_t arena = ctx->stats.capacity_bytes - head;
+    if (used_bytes > arena) return fail(VX_ERR_CAPACITY, "dst is not large enough: used_bytes exceeds the world buffer");
+    for (uint32_t i = 0; i < count; ++i)
+        if (ranges[i].start + ranges[i].length > arena || ranges[i].start + ranges[i].length < ranges[i].start)
+            return fail(VX_ERR_CAPACITY, "dst is not large enough: a dirty range exceeds the world buffer");
+    if (ctx->commit_mode == VX_COMMIT_PIPELINED && ctx->committed) {
+        // (the first commit of a context is always done here and now: nothing can be rendered before it)
+        wait_commit_idle(ctx);
+        if (int rc = take_async_error(ctx)) return rc;
+        {
+            std::unique_lock<std::mutex> lk(ctx->job_mutex);
+            ctx->job.depth = depth;
+            ctx->job.ranges.assign(ranges, ranges + count);
+            ctx->job.used_bytes = used_bytes;
+            ctx->job_posted = true;
+        }
+        ctx->job_cv.notify_all();
+        return VX_OK;
+    }
+    wait_commit_idle(ctx);
+    return commit_now(ctx, depth, ranges, count, used_bytes);
+}
+
+int vx_set_commit_mode(vx_context* ctx, int mode) {
+    if (!ctx || (mode != VX_COMMIT_INLINE && mode != VX_COMMIT_PIPELINED)) return fail(VX_ERR_INVALID_ARGUMENT, "commit mode: VX_COMMIT_INLINE or VX_COMMIT_PIPELINED");
+    wait_commit_idle(ctx);
+    if (mode == VX_COMMIT_PIPELINED && !ctx->worker.joinable()) ctx->worker = std::thread(commit_worker, ctx);
+    if (mode == VX_COMMIT_INLINE) stop_commit_worker(ctx);
+    ctx->commit_mode = mode;
+    return VX_OK;
+}
+
+int vx_commit_wait(vx_context* ctx) {
+    if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    wait_commit_idle(ctx);
+    return take_async_error(ctx);
+}
+
 int vx_commit_all(vx_context* ctx, uint32_t depth, uint64_t used_bytes) {
     const vx_range all = {0, used_bytes};
     return vx_commit(ctx, depth, &all, 1, used_bytes);
@@ -1640,12 +1781,14 @@ int vx_commit_all(vx_context* ctx, uint32_t depth, uint64_t used_bytes) {
 
 int vx_get_stats(const vx_context* ctx, vx_stats* out) {
     if (!ctx || !out) return fail(VX_ERR_INVALID_ARGUMENT, "stats: null argument");
+    VX_LOCK(const_cast<vx_context*>(ctx));
     *out = ctx->stats;
     return VX_OK;
 }
 
 int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, const vx_target* target) {
     if (int rc = check_ready(ctx)) return rc;
+    VX_LOCK(ctx);
     if (!target || !target->rgba32f) return fail(VX_ERR_INVALID_ARGUMENT, "render: null target");
     RenderParams p;
     if (int rc = fill_params(ctx, uniforms, width, height, target->tile_rank, target->tile_count, target->format, p)) return rc;
@@ -1690,6 +1833,7 @@ int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint
 
 int vx_present_begin(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, int format, int* out_slot) {
     if (int rc = check_ready(ctx)) return rc;
+    VX_LOCK(ctx);
     if (!out_slot) return fail(VX_ERR_INVALID_ARGUMENT, "present: null slot");
     RenderParams p;
     if (int rc = fill_params(ctx, uniforms, width, height, 0, 1, format, p)) return rc;
@@ -1723,6 +1867,7 @@ int vx_present_begin(vx_context* ctx, const vx_uniforms* uniforms, uint32_t widt
 
 int vx_present_wait(vx_context* ctx, int slot, const void** pixels, size_t* bytes) {
     if (!ctx || slot < 0 || slot >= vx_context::kPresentSlots || !pixels) return fail(VX_ERR_INVALID_ARGUMENT, "present_wait: bad argument");
+    VX_LOCK(ctx);
     vx_context::PresentSlot& ps = ctx->present[slot];
     if (!ps.busy) return fail(VX_ERR_STATE, "present_wait: nothing was begun on this slot");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1735,6 +1880,7 @@ int vx_present_wait(vx_context* ctx, int slot, const void** pixels, size_t* byte
 int vx_render_counters(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_count,
                        vx_counters* out) {
     if (int rc = check_ready(ctx)) return rc;
+    VX_LOCK(ctx);
     if (!out) return fail(VX_ERR_INVALID_ARGUMENT, "counters: null output");
     RenderParams p;
     if (int rc = fill_params(ctx, uniforms, width, height, tile_rank, tile_count, VX_FORMAT_RGBA32F, p)) return rc;
@@ -1757,6 +1903,7 @@ int vx_render_counters(vx_context* ctx, const vx_uniforms* uniforms, uint32_t wi
 
 int vx_raycast(vx_context* ctx, const vx_picker_task* tasks, uint32_t count, vx_picker_result* results) {
     if (int rc = check_ready(ctx)) return rc;
+    VX_LOCK(ctx);
     if (count == 0) return VX_OK;
     if (!tasks || !results) return fail(VX_ERR_INVALID_ARGUMENT, "raycast: null argument");
     if (ctx->picker_cap < count) {
@@ -1789,6 +1936,7 @@ int vx_raycast(vx_context* ctx, const vx_picker_task* tasks, uint32_t count, vx_
 int vx_debug_trace(vx_context* ctx, const float pos[3], const float dir[3], float max_dst, int cast_translucent, vx_result* result,
                    vx_frame* frames, uint32_t max_frames, uint32_t* n_frames) {
     if (int rc = check_ready(ctx)) return rc;
+    VX_LOCK(ctx);
     if (!pos || !dir || !result) return fail(VX_ERR_INVALID_ARGUMENT, "debug_trace: null argument");
     if (max_frames > 1024) max_frames = 1024;
     if (!frames) max_frames = 0;
@@ -1834,6 +1982,9 @@ int vx_debug_trace(vx_context* ctx, const float pos[3], const float dir[3], floa
 
 int vx_sync(vx_context* ctx) {
     if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    wait_commit_idle(ctx);
+    if (int rc = take_async_error(ctx)) return rc;
+    VX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->upload_stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1846,6 +1997,7 @@ int vx_sync(vx_context* ctx) {
 
 int vx_set_frames_in_flight(vx_context* ctx, int frames) {
     if (!ctx || frames < 1 || frames > vx_context::kFrameStreams) return fail(VX_ERR_INVALID_ARGUMENT, "frames in flight: 1..8");
+    VX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
     ctx->frames_in_flight = frames;
@@ -1855,12 +2007,14 @@ int vx_set_frames_in_flight(vx_context* ctx, int frames) {
 
 int vx_wait_event(vx_context* ctx, void* hip_event) {
     if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    VX_LOCK(ctx);
     ctx->pending_wait = static_cast<hipEvent_t>(hip_event);
     return VX_OK;
 }
 
 int vx_stream_wait_render(vx_context* ctx, void* stream) {
     if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    VX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     const int slot = ctx->last_frame_slot;
     if (slot >= 0) {
@@ -1889,6 +2043,7 @@ int vx_assemble_tiles_format(vx_context* ctx, const void* tiles, uint64_t stride
                              int format, void* stream) {
     if (!ctx || !tiles || !out || !tile_count || !width || !height || (format != VX_FORMAT_RGBA32F && format != VX_FORMAT_RGBA8))
         return fail(VX_ERR_INVALID_ARGUMENT, "assemble_tiles: bad argument");
+    VX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t tiles_x = (width + kTile - 1) / kTile, tiles_y = (height + kTile - 1) / kTile;
     const vx_context::TileTable* t = nullptr;
@@ -1927,6 +2082,7 @@ int vx_comm_unique_id(void* out_id, size_t bytes) {
 
 int vx_comm_init(vx_context* ctx, int nranks, int rank, const void* unique_id) {
     if (!ctx || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) return fail(VX_ERR_INVALID_ARGUMENT, "comm_init: bad argument");
+    VX_LOCK(ctx);
     if (ctx->comm) return fail(VX_ERR_STATE, "comm_init: this context already has a communicator");
     if (int rc = rccl_open()) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1951,6 +2107,7 @@ int vx_comm_init(vx_context* ctx, int nranks, int rank, const void* unique_id) {
 
 int vx_comm_destroy(vx_context* ctx) {
     if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    VX_LOCK(ctx);
     if (!ctx->comm) return VX_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->comm_stream) HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
@@ -1969,6 +2126,7 @@ int vx_comm_info(const vx_context* ctx, int* nranks, int* rank) {
 
 int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank, void* gathered, int root, int* out_ticket) {
     if (!ctx || !tiles || !bytes_per_rank || (bytes_per_rank & 3)) return fail(VX_ERR_INVALID_ARGUMENT, "gather_tiles: bad argument");
+    VX_LOCK(ctx);
     if (!ctx->comm) return fail(VX_ERR_STATE, "gather_tiles: no communicator (vx_comm_init)");
     if (root < 0 || root >= ctx->comm_ranks) return fail(VX_ERR_INVALID_ARGUMENT, "gather_tiles: bad root");
     if (ctx->comm_rank == root && !gathered) return fail(VX_ERR_INVALID_ARGUMENT, "gather_tiles: the root needs a destination");
@@ -2002,6 +2160,7 @@ int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank,
 
 int vx_wait_gather(vx_context* ctx, int ticket) {
     if (!ctx || ticket < 0 || ticket >= vx_context::kGatherEvents) return fail(VX_ERR_INVALID_ARGUMENT, "wait_gather: bad ticket");
+    VX_LOCK(ctx);
     if (!ctx->gather_done[ticket]) return fail(VX_ERR_STATE, "wait_gather: no communicator");
     ctx->pending_gather = ctx->gather_done[ticket];
     return VX_OK;
@@ -2027,6 +2186,7 @@ uint64_t vx_traversal_image(int svo_type, const uint8_t* world_frame, uint64_t u
 
 int vx_resolve_2x2(vx_context* ctx, const float* src_rgba32f, uint32_t width, uint32_t height, float* dst_rgba32f, void* stream) {
     if (!ctx || !src_rgba32f || !dst_rgba32f || !width || !height) return fail(VX_ERR_INVALID_ARGUMENT, "resolve_2x2: bad argument");
+    VX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     const dim3 grid((width + 15) / 16, (height + 15) / 16), block(256);
     hipLaunchKernelGGL(resolve_2x2_kernel, grid, block, 0, static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(src_rgba32f), width, height,
@@ -2037,12 +2197,14 @@ int vx_resolve_2x2(vx_context* ctx, const float* src_rgba32f, uint32_t width, ui
 
 int vx_profile_enable(vx_context* ctx, int enabled) {
     if (!ctx) return fail(VX_ERR_INVALID_ARGUMENT, "null context");
+    VX_LOCK(ctx);
     ctx->profile = enabled != 0;
     return VX_OK;
 }
 
 int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches) {
     if (!ctx || !kernel_ms_sum || !launches) return fail(VX_ERR_INVALID_ARGUMENT, "profile_read: null argument");
+    VX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < vx_context::kFrameStreams; ++i) HIP_TRY(hipStreamSynchronize(ctx->frame_stream[i]));
@@ -2061,6 +2223,7 @@ int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches) 
 
 uint32_t vx_timeline_read(vx_context* ctx, uint64_t* out, uint32_t capacity_waves) {
     if (!ctx || !ctx->d_timeline || !out) return 0;
+    VX_LOCK(ctx);
     if (hipSetDevice(ctx->device) != hipSuccess || drain_streams(ctx) != VX_OK) return 0;
     const uint32_t n = ctx->timeline_waves < capacity_waves ? ctx->timeline_waves : capacity_waves;
     if (n && hipMemcpy(out, ctx->d_timeline, size_t(n) * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return 0;
@@ -2069,15 +2232,17 @@ uint32_t vx_timeline_read(vx_context* ctx, uint64_t* out, uint32_t capacity_wave
 
 int vx_image_info(const vx_context* ctx, uint64_t out[4]) {
     if (!ctx || !out) return fail(VX_ERR_INVALID_ARGUMENT, "image_info: null argument");
-    out[0] = ctx->image_ok ? (ctx->image.layout() == vximg::kOct64Wide ? 2u : 1u) : 0u;
-    out[1] = ctx->image_ok ? ctx->image.frame_bytes() : 0u;
-    out[2] = ctx->image_ok && ctx->image.has_origin() ? ctx->image.origin_bytes() : 0u;
-    out[3] = ctx->image_ok ? ctx->image.chunk_count() : 0u;
+    VX_LOCK(const_cast<vx_context*>(ctx));
+    out[0] = ctx->image_ok ? (ctx->pub.layout == vximg::kOct64Wide ? 2u : 1u) : 0u;
+    out[1] = ctx->image_ok ? ctx->pub.frame_bytes : 0u;
+    out[2] = ctx->image_ok ? ctx->pub.origin_bytes : 0u;
+    out[3] = ctx->image_ok ? ctx->pub.chunks : 0u;
     return VX_OK;
 }
 
 int vx_excursion_counters(vx_context* ctx, uint64_t out[4], int reset) {
     if (!ctx || !out) return fail(VX_ERR_INVALID_ARGUMENT, "excursion_counters: null argument");
+    VX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     if (int rc = drain_streams(ctx)) return rc;
     unsigned long long h[8] = {};

@@ -73,6 +73,8 @@ SYMBOLS = {
     "vx_capacity": (_sz, [_vp]),
     "vx_commit": (_int, [_vp, _u32, _vp, _u32, _u64]),
     "vx_commit_all": (_int, [_vp, _u32, _u64]),
+    "vx_set_commit_mode": (_int, [_vp, _int]),
+    "vx_commit_wait": (_int, [_vp]),
     "vx_get_stats": (_int, [_vp, C.POINTER(Stats)]),
     "vx_render": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, C.POINTER(Target)]),
     "vx_raycast": (_int, [_vp, _vp, _u32, _vp]),
@@ -234,6 +236,13 @@ class Svo:
         C.memmove(lib().vx_staging_ptr(self._h), raw.ctypes.data, raw.size)
         header = 20 if self.svo_type == 1 else 4
         _check(lib().vx_commit_all(self._h, depth, max(raw.size - 4 - header, 0)))
+
+    def set_commit_mode(self, pipelined):
+        """VX_COMMIT_PIPELINED: update() only posts the commit; a worker thread of the context does the rest."""
+        _check(lib().vx_set_commit_mode(self._h, 1 if pipelined else 0))
+
+    def commit_wait(self):
+        _check(lib().vx_commit_wait(self._h))
 
     def get_stats(self):
         s = Stats()
