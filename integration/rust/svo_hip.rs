@@ -98,6 +98,11 @@ impl Svo {
         let rows = registry.material_rows();
         check(unsafe { vx_set_materials(ctx, rows.as_ptr(), rows.len() as u32) });
 
+        // Svo::update is called from the frame loop (systems/worldsvo.rs:397-409): let the library's worker thread do the image
+        // update and the uploads, so that `update` costs the frame loop what write_changes_to costs. A change shows one frame
+        // late at most -- the original's update() + render_fence pair has the same lag.
+        check(unsafe { vx_set_commit_mode(ctx, 1) });
+
         Self { ctx, stats: Stats { used_bytes: 0, capacity_bytes: size_mb * 1000 * 1000, depth: 0 } }
     }
 

@@ -108,6 +108,9 @@ extern "C" {
     pub fn vx_arena_capacity(ctx: *const vx_context) -> usize;
     pub fn vx_commit(ctx: *mut vx_context, depth: u32, ranges: *const vx_range, count: u32, used_bytes: u64) -> c_int;
     pub fn vx_commit_all(ctx: *mut vx_context, depth: u32, used_bytes: u64) -> c_int;
+    /// VX_COMMIT_INLINE = 0, VX_COMMIT_PIPELINED = 1 (a worker thread of the context does the image update and the uploads)
+    pub fn vx_set_commit_mode(ctx: *mut vx_context, mode: c_int) -> c_int;
+    pub fn vx_commit_wait(ctx: *mut vx_context) -> c_int;
     pub fn vx_get_stats(ctx: *const vx_context, out: *mut vx_stats) -> c_int;
     // ---- the hot path (Svo::render, Svo::raycast) ---------------------------------------------------------------------------
     pub fn vx_render(ctx: *mut vx_context, uniforms: *const vx_uniforms, width: u32, height: u32, target: *const vx_target) -> c_int;
