@@ -199,8 +199,9 @@ __device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderP
 // bytes and comes back to the image (vx_device.hpp, enter_voxel_on_bytes) -- in the service phase, like every other rare and
 // expensive thing a ray can need. (The image of an ESVO world serves such rays itself.)
 // SHALLOW: no ray can push below the LDS-resident stack levels (the host knows the image's depth): no hand-over test in the loop.
-// LV: stack levels resident in LDS -- 13 (three u32 planes), or 16 with a 16-bit third plane (image cursors: worlds of 14 to 16 levels
-// without the hand-over; the same 10 KB per wave).
+// LV: stack levels resident in LDS -- 13 (three u32 planes); 16 with a 16-bit third plane (image cursors: worlds of 14 to 16 levels
+// without the hand-over; the same 10 KB per wave); or 12 with a 16-bit third plane (images of at most 12 levels: 7.5 KB per wave, so
+// that 20 waves fit a CU's LDS -- the build for five waves per SIMD, MINW = 5: 96 VGPRs, the spills stay in the service phases).
 // HOT (experiment X1): the image's root octant and its eight child octants copied into LDS, PUSHes out of them served from there.
 template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false, int LV = kLdsLevels, bool HOT = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
@@ -214,11 +215,11 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     static_assert(LV == kLdsLevels || IMAGE, "only an image cursor's third stack word fits 16 bits");
     StackSpill spill;
     static_assert(!HOT || (SVO == VX_SVO_IMAGE && LV == kLdsLevels), "the LDS copy of the top levels: byte-offset images, 13 stack levels");
-    typedef Stack<64, false, false, LV, (LV > kLdsLevels) || HOT, HOT> FullStack;
+    typedef Stack<64, false, false, LV, (LV != kLdsLevels) || HOT, HOT> FullStack;
     FullStack st;       // all 23 levels: LDS, then the per-lane spill array
     // the same LDS slots, no range checks: what the traversal loop uses. SHALLOW (an image of at most LV levels): no ray
     // ever needs anything else
-    typedef Stack<64, true, SHALLOW, LV, (LV > kLdsLevels) || HOT, HOT> FastStack;
+    typedef Stack<64, true, SHALLOW, LV, (LV != kLdsLevels) || HOT, HOT> FastStack;
     FastStack fast_st;
     st.init(lane, &spill);
     fast_st.init(lane, &spill);
@@ -473,8 +474,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     // ---- second phase (FOREIGN): the pixels this wave gave up on the image, whole, on the world's own bytes ----
     if (FOREIGN) {
         const DevScene sc_bytes = make_scene(sa);
-        // (the byte cursor's stack entries are three full words: the plain 13-level layout, over the same LDS -- the first phase is over)
-        Stack<64, false> st2;
+        // (the byte cursor's stack entries are three full words: the plain layout, as many levels as fit the same LDS -- the first phase is over)
+        Stack<64, false, false, int(FullStack::kStackBytes / (64u * 12u))> st2;
         st2.init(lane, &spill);
         for (uint32_t c = my_chunk; c != 0;) {
             const uint32_t* chunk = todo.chunks + size_t(c - 1) * kChunkDwords;
@@ -776,6 +777,7 @@ struct vx_context {
     DeltaSlot delta[kDeltaSlots];
     unsigned delta_next = 0;
     bool hot_levels = false;      // VX_HOT_LEVELS=1 (experiment X1): the image's top two levels served from an LDS copy (ESVO worlds, image-only renders)
+    bool five_waves = false;      // VX_FIVE_WAVES=1 (experiment, 3 % slower): images of up to 12 levels on a 12-level stack with a 16-bit third plane, five waves per SIMD
     bool deep_stack = true;       // VX_DEEP_STACK=0: images of 14 to 16 levels on the 13-level stack with the hand-over (A/B)
     bool no_excursion = false;    // VX_NO_EXCURSION=1 (MEASUREMENT ONLY, wrong pixels): a CSVO world's image walked by the kernel without the excursion code
     bool big = false;             // an ESVO world buffer of 4 GiB and more: kernels on its own bytes use 64-bit addresses (VX_SVO_ESVO_BIG)
@@ -953,7 +955,8 @@ const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, 
     constexpr int W = HITS ? 1 : 4;
     const bool wide = ctx->pub.layout == vximg::kOct64Wide;  // an image beyond 4 GiB: octant indices, 64-bit addresses
 #define VX_IMG(IMAGE, FOREIGN)                                                                                                       \
-    (levels == 16 ? VX_K(IMAGE, HITS, false, W, FOREIGN, true, 16) : (shallow ? VX_K(IMAGE, HITS, false, W, FOREIGN, true) : VX_K(IMAGE, HITS, false, W, FOREIGN, false)))
+    (levels == 12 ? VX_K(IMAGE, false, false, 5, FOREIGN, true, 12)                                                                 \
+                  : (levels == 16 ? VX_K(IMAGE, HITS, false, W, FOREIGN, true, 16) : (shallow ? VX_K(IMAGE, HITS, false, W, FOREIGN, true) : VX_K(IMAGE, HITS, false, W, FOREIGN, false))))
     if (ctx->hot_levels && !HITS && !wide && shallow && levels == kLdsLevels && (esvo || ctx->no_excursion)) return VX_K(VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true);
     if (esvo || ctx->no_excursion) return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, 0) : VX_IMG(VX_SVO_IMAGE, 0);
     return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO) : VX_IMG(VX_SVO_IMAGE, VX_SVO_CSVO);
@@ -1007,8 +1010,10 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             levels = 16;
             shallow = true;
         }
+        // shallower images, up to 12 levels, image-only renders: 12 resident levels in 7.5 KB, five waves per SIMD
+        if (!HITS && shallow && levels == kLdsLevels && depth <= 12u + slack && ctx->five_waves && !ctx->hot_levels) levels = 12;
         const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels);
-        size_t wave_lds = levels == 16 ? Stack<64, false, false, 16, true>::kBytes : Stack<64>::kBytes;
+        size_t wave_lds = levels == 16 ? Stack<64, false, false, 16, true>::kBytes : (levels == 12 ? Stack<64, false, false, 12, true>::kBytes : Stack<64>::kBytes);
         if (fn == reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true>))
             wave_lds = Stack<64, false, false, kLdsLevels, true, true>::kBytes;
         int& per_cu = ctx->persistent_blocks[fn];
@@ -1349,6 +1354,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_FIVE_WAVES")) c->five_waves = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_HOT_LEVELS")) c->hot_levels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_HOT_FIRST")) {
             const int v = std::atoi(e);
