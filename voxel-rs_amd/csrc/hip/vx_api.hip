@@ -137,6 +137,8 @@ struct PersistentArgs {
     uint32_t* cost_cur;             // [total_subtiles] tag << 12 | iterations of the sub-tile's longest ray this frame; null = do not note
     uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
     unsigned long long* timeline;   // measurement (VX_TIMELINE=1), else null: per wave {start, queue found empty, exit} in 10 ns ticks, pixels taken
+    // BATCH kernels: per wave a ring of ray records and a ring of result records (kWaveBatchBytes each wave), see render_persistent
+    uint8_t* batch;
     unsigned long long* excursions;  // [0] rays that made the excursion into a voxel on the world's bytes, [1] of which started over, [2] service phases that ran excursions, [3] loop iterations made on the bytes
 };
 
@@ -194,6 +196,13 @@ __device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderP
     atomicMax(&a.cost_cur[subtile_of(p, out_index)], (a.cur_tag << 12) | (iterations < 4095u ? iterations : 4095u));
 }
 
+// BATCH kernels: a record is four 16-byte words; per wave 256 ray records and 128 result records
+constexpr uint32_t kRayRing = 256, kHitRing = 128;
+constexpr size_t kWaveBatchBytes = size_t(kRayRing + kHitRing) * 64;
+__device__ __forceinline__ uint32_t rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)); }
+__device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); }
+
 // IMAGE = the rays walk the traversal image of the world (traversal_image.hpp) instead of its own bytes. FOREIGN (an image of a
 // CSVO world; = VX_SVO_CSVO): a ray that is about to be led into the voxel it started in makes that excursion on the world's own
 // bytes and comes back to the image (vx_device.hpp, enter_voxel_on_bytes) -- in the service phase, like every other rare and
@@ -203,13 +212,21 @@ __device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderP
 // without the hand-over; the same 10 KB per wave); or 12 with a 16-bit third plane (images of at most 12 levels: 7.5 KB per wave, so
 // that 20 waves fit a CU's LDS -- the build for five waves per SIMD, MINW = 5: 96 VGPRs, the spills stay in the service phases).
 // HOT (experiment X1): the image's root octant and its eight child octants copied into LDS, PUSHes out of them served from there.
-template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false, int LV = kLdsLevels, bool HOT = false>
+// BATCH (image-only renders): what does not need the lane's own traversal state is not done by the few lanes that happen to need it
+// in a service phase (about 30 % of the wave), but 64 at a time, by all lanes, from records in two rings of the wave's own (global
+// memory; no other wave touches them, so there is nothing to wait for and nothing to synchronise): a finished ray leaves a result
+// record and its lane takes the next ray record at once; 64 result records are shaded together (primary hits: material, normal
+// map, light -> the pixel, or a shadow-ray record; misses: the sky; shadow results: the lit pixel); primary rays are generated for
+// a whole sub-tile at a time. Leaf tests (they continue the traversal) and ray set-up stay with the lane. Same arithmetic per
+// pixel, same pixels.
+template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false, int LV = kLdsLevels, bool HOT = false, bool BATCH = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
     constexpr bool IMAGE = SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE;
     static_assert(!(IMAGE && STATS), "the instrumented kernel counts the reference's own fetches: it walks the world's own bytes");
     static_assert(FOREIGN == 0 || (IMAGE && FOREIGN == VX_SVO_CSVO), "FOREIGN: the image of a CSVO world");
     static_assert(!SHALLOW || IMAGE, "only a traversal image bounds how deep a ray can get");
+    static_assert(!BATCH || (!HITS && !STATS), "batched service phases: image-only renders");
     const DevScene sc = IMAGE ? make_image_scene(sa) : make_scene(sa);
     const uint32_t lane = threadIdx.x;
     static_assert(LV == kLdsLevels || IMAGE, "only an image cursor's third stack word fits 16 bits");
@@ -248,6 +265,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     unsigned long long t_empty = 0ull;
     uint32_t taken = 0;
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
+    // BATCH, wave-uniform: the wave's two rings
+    uint4* const ring_r = BATCH ? reinterpret_cast<uint4*>(a.batch + size_t(blockIdx.x) * kWaveBatchBytes) : nullptr;
+    uint4* const ring_h = BATCH ? ring_r + size_t(kRayRing) * 4 : nullptr;
+    uint32_t r_head = 0, r_count = 0, h_head = 0, h_count = 0;
 
     for (;;) {
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
@@ -354,6 +375,156 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // freshly assigned pixel -- only records origin and direction; one Trav::init below serves both kinds together.
         float new_ro[3] = {0, 0, 0}, new_rd[3] = {0, 0, 0};
         bool new_ray = false;
+
+        if constexpr (BATCH) {
+            // ---- finished rays leave their result in the wave's ring; the lane is free ----
+            {
+                const bool done = state == kDone;
+                const unsigned long long dm = __ballot(done);
+                if (done) {
+                    note_cost(a, p, out_index, tr.iter & ~kParked);
+                    uint4* r = ring_h + size_t((h_head + h_count + rank_in(dm)) & (kHitRing - 1u)) * 4;
+                    if (!shadow_ray) {
+                        // (a miss needs the ray's direction for the sky and nothing of the hit: it travels in the position's place)
+                        const bool sky = res.t == -1.0f;
+                        r[0] = make_uint4(out_index, fbits(res.t), res.value, uint32_t(res.face_id));
+                        r[1] = make_uint4(fbits(sky ? primary_rd[0] : res.pos[0]), fbits(sky ? primary_rd[1] : res.pos[1]), fbits(sky ? primary_rd[2] : res.pos[2]), fbits(res.uv[0]));
+                        r[2] = make_uint4(fbits(res.uv[1]), fbits(res.lod), fbits(res.color[0]), fbits(res.color[1]));
+                        r[3] = make_uint4(fbits(res.color[2]), fbits(res.color[3]), 0u, 0u);
+                    } else {
+                        r[0] = make_uint4(out_index | 0x80000000u, fbits(res.t), fbits(keep_color[0]), fbits(keep_color[1]));
+                        r[1] = make_uint4(fbits(keep_color[2]), fbits(keep_color[3]), fbits(keep_ds), 0u);
+                    }
+                    state = kIdle;
+                }
+                h_count += uint32_t(__popcll(dm));
+            }
+            // ---- 64 results at a time, all lanes: shading, sky, light -> pixels and shadow-ray records. (Fewer only when nothing
+            // else could feed the idle lanes: the queue and the ray ring are empty.) ----
+            while (h_count >= 64u || (h_count != 0u && queue_empty && r_count == 0u)) {
+                const uint32_t n = h_count < 64u ? h_count : 64u;
+                bool cast = false;
+                uint32_t pixel = 0;
+                float so[3] = {0, 0, 0}, kc[4] = {0, 0, 0, 0}, kds = 0.0f;
+                if (lane < n) {
+                    const uint4* r = ring_h + size_t((h_head + lane) & (kHitRing - 1u)) * 4;
+                    const uint4 w0 = r[0], w1 = r[1];
+                    pixel = w0.x & 0x7fffffffu;
+                    float color[4];
+                    bool write = true;
+                    if (!(w0.x >> 31)) {
+                        const uint4 w2 = r[2], w3 = r[3];
+                        Result rs;
+                        rs.t = bitsf(w0.y); rs.value = w0.z; rs.face_id = int(w0.w);
+                        rs.pos[0] = bitsf(w1.x); rs.pos[1] = bitsf(w1.y); rs.pos[2] = bitsf(w1.z);
+                        rs.uv[0] = bitsf(w1.w); rs.uv[1] = bitsf(w2.x); rs.lod = bitsf(w2.y);
+                        rs.color[0] = bitsf(w2.z); rs.color[1] = bitsf(w2.w); rs.color[2] = bitsf(w3.x); rs.color[3] = bitsf(w3.y);
+                        rs.inside_voxel = false;
+                        PrimaryOutcome o;
+                        shade_primary(sc, p, rs, o);
+                        if (rs.t == -1.0f) {  // no hit: sky (world.glsl:135-138)
+                            const float rd[3] = {rs.pos[0], rs.pos[1], rs.pos[2]};
+                            float sky[3];
+                            sky_color(rd, sky);
+                            color[0] = sky[0]; color[1] = sky[1]; color[2] = sky[2]; color[3] = 1.0f;
+                        } else {
+                            color[0] = o.color[0]; color[1] = o.color[1]; color[2] = o.color[2]; color[3] = o.color[3];
+                            if (!o.final_color) {
+                                cast = true;
+                                write = false;
+                                so[0] = o.shadow_origin[0]; so[1] = o.shadow_origin[1]; so[2] = o.shadow_origin[2];
+                                kc[0] = o.color[0]; kc[1] = o.color[1]; kc[2] = o.color[2]; kc[3] = o.color[3];
+                                kds = o.ds;
+                            }
+                        }
+                    } else {
+                        color[0] = bitsf(w0.z); color[1] = bitsf(w0.w); color[2] = bitsf(w1.x); color[3] = bitsf(w1.y);
+                        apply_light(p, color, bitsf(w1.z), bitsf(w0.y) < 0.0f ? 1.0f : 0.0f);
+                    }
+                    if (write && out) store_pixel(p, out, pixel, color);
+                }
+                h_head += n;
+                h_count -= n;
+                const unsigned long long cm = __ballot(cast);
+                if (cast) {
+                    uint4* r = ring_r + size_t((r_head + r_count + rank_in(cm)) & (kRayRing - 1u)) * 4;
+                    r[0] = make_uint4(pixel | 0x80000000u, fbits(so[0]), fbits(so[1]), fbits(so[2]));
+                    r[1] = make_uint4(fbits(kc[0]), fbits(kc[1]), fbits(kc[2]), fbits(kc[3]));
+                    r[2] = make_uint4(fbits(kds), 0u, 0u, 0u);
+                }
+                r_count += uint32_t(__popcll(cm));
+            }
+            // ---- idle lanes take the oldest ray records; primary rays are made a sub-tile at a time, by all lanes ----
+            const unsigned long long idle_mask = __ballot(state == kIdle);
+            const uint32_t n_idle = uint32_t(__popcll(idle_mask));
+            if (idle_mask && (n_idle >= a.refill_min || idle_mask == ~0ull || queue_empty)) {
+                while (r_count < n_idle && !queue_empty) {
+                    uint32_t t = 0;
+                    if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base;  // unsigned: survives the counter wrapping
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    if (t >= a.total_subtiles) {
+                        queue_empty = true;
+                        if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
+                        break;
+                    }
+                    sub = a.order ? uint32_t(__builtin_amdgcn_readfirstlane(a.order[t])) : t;  // most expensive first, or screen order
+                    if (sub >= a.total_subtiles) sub = t;  // (never: a table of another view is not used)
+                    ++taken;
+                    // sub-tile -> pixel: 32x32 tile (sharding unit), 4x4 sub-tiles in Morton order, 8x8 pixels in Morton order
+                    const uint32_t local_tile = sub >> 4, sq = sub & 15u;
+                    const uint32_t tile = p.tile_count > 1 ? p.tile_order[local_tile * p.tile_count + p.tile_rank] : local_tile;
+                    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+                    const uint32_t sx = (sq & 1u) | ((sq >> 1) & 2u), sy = ((sq >> 1) & 1u) | ((sq >> 2) & 2u);
+                    uint32_t lx, ly;
+                    lane_to_xy(lane, lx, ly);
+                    const uint32_t in_x = sx * 8 + lx, in_y = sy * 8 + ly;
+                    const uint32_t px_x = tx * kTile + in_x, px_y = ty * kTile + in_y;
+                    const uint32_t index = p.tile_count > 1 ? local_tile * (kTile * kTile) + in_y * kTile + in_x : image_index(p, px_x, px_y);
+                    const bool inside = px_x < p.width && px_y < p.height;
+                    const unsigned long long im = __ballot(inside);
+                    if (inside) {
+                        float ro[3], rd[3];
+                        primary_ray(p, px_x, px_y, ro, rd);
+                        uint4* r = ring_r + size_t((r_head + r_count + rank_in(im)) & (kRayRing - 1u)) * 4;
+                        r[0] = make_uint4(index, fbits(rd[0]), fbits(rd[1]), fbits(rd[2]));
+                    } else if (p.tile_count > 1) {
+                        // padding pixel of an edge tile: keep the compact tile list fully defined
+                        const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (out) store_pixel(p, out, index, zero);
+                    }
+                    r_count += uint32_t(__popcll(im));
+                }
+                const uint32_t take = n_idle < r_count ? n_idle : r_count;
+                const uint32_t rk = rank_in(idle_mask);
+                if (state == kIdle && rk < take) {
+                    const uint4* r = ring_r + size_t((r_head + rk) & (kRayRing - 1u)) * 4;
+                    const uint4 w0 = r[0];
+                    out_index = w0.x & 0x7fffffffu;
+                    shadow_ray = (w0.x >> 31) != 0u;
+                    if (shadow_ray) {
+                        const uint4 w1 = r[1];
+                        const uint32_t w2 = r[2].x;
+                        new_ro[0] = bitsf(w0.y); new_ro[1] = bitsf(w0.z); new_ro[2] = bitsf(w0.w);
+                        new_rd[0] = -p.u.light_dir[0]; new_rd[1] = -p.u.light_dir[1]; new_rd[2] = -p.u.light_dir[2];
+                        keep_color[0] = bitsf(w1.x); keep_color[1] = bitsf(w1.y); keep_color[2] = bitsf(w1.z); keep_color[3] = bitsf(w1.w);
+                        keep_ds = bitsf(w2);
+                    } else {
+                        new_ro[0] = p.ray_origin[0]; new_ro[1] = p.ray_origin[1]; new_ro[2] = p.ray_origin[2];
+                        new_rd[0] = bitsf(w0.y); new_rd[1] = bitsf(w0.z); new_rd[2] = bitsf(w0.w);
+                        primary_rd[0] = new_rd[0]; primary_rd[1] = new_rd[1]; primary_rd[2] = new_rd[2];
+                    }
+                    new_ray = true;
+                }
+                r_head += take;
+                r_count -= take;
+            }
+            if (new_ray) {
+                tr.init(sc, new_ro, new_rd, -1.0f);  // iter = 0: not parked
+                state = kTrav;
+            }
+            if (__ballot(state != kIdle) == 0 && queue_empty && r_count == 0u && h_count == 0u) break;
+            continue;
+        }
 
         // ---- finished rays ----
         if (state == kDone) {
@@ -777,6 +948,9 @@ struct vx_context {
     DeltaSlot delta[kDeltaSlots];
     unsigned delta_next = 0;
     bool hot_levels = false;      // VX_HOT_LEVELS=1 (experiment X1): the image's top two levels served from an LDS copy (ESVO worlds, image-only renders)
+    bool batch_service = false;   // VX_BATCH=1 (experiment): image-only renders by the build that shades, lights and generates rays 64 records at a time
+    uint8_t* d_batch[kFrameStreams + 1] = {};  // [slot + 1]: the waves' record rings of a BATCH kernel (PersistentArgs::batch)
+    size_t batch_waves[kFrameStreams + 1] = {};
     bool five_waves = false;      // VX_FIVE_WAVES=1 (experiment, 3 % slower): images of up to 12 levels on a 12-level stack with a 16-bit third plane, five waves per SIMD
     bool deep_stack = true;       // VX_DEEP_STACK=0: images of 14 to 16 levels on the 13-level stack with the hand-over (A/B)
     bool no_excursion = false;    // VX_NO_EXCURSION=1 (MEASUREMENT ONLY, wrong pixels): a CSVO world's image walked by the kernel without the excursion code
@@ -943,7 +1117,7 @@ int check_ready(vx_context* ctx) {
 // where the image's depth rules deep pushes out). The image-only build of the hot variants is held to 128 VGPRs (4 waves per SIMD).
 // levels: the LDS-resident stack levels of an image kernel -- kLdsLevels, or 16 (16-bit third plane) for images of 14 to 16 levels
 template <bool HITS, bool STATS>
-const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, int levels) {
+const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, int levels, bool batch) {
     const bool esvo = ctx->svo_type == VX_SVO_ESVO;
 #define VX_K(...) reinterpret_cast<const void*>(&render_persistent<__VA_ARGS__>)
     if (!imaged) {
@@ -955,8 +1129,10 @@ const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, 
     constexpr int W = HITS ? 1 : 4;
     const bool wide = ctx->pub.layout == vximg::kOct64Wide;  // an image beyond 4 GiB: octant indices, 64-bit addresses
 #define VX_IMG(IMAGE, FOREIGN)                                                                                                       \
-    (levels == 12 ? VX_K(IMAGE, false, false, 5, FOREIGN, true, 12)                                                                 \
-                  : (levels == 16 ? VX_K(IMAGE, HITS, false, W, FOREIGN, true, 16) : (shallow ? VX_K(IMAGE, HITS, false, W, FOREIGN, true) : VX_K(IMAGE, HITS, false, W, FOREIGN, false))))
+    (batch ? (levels == 16 ? VX_K(IMAGE, false, false, 4, FOREIGN, true, 16, false, true)                                           \
+                           : (shallow ? VX_K(IMAGE, false, false, 4, FOREIGN, true, kLdsLevels, false, true) : VX_K(IMAGE, false, false, 4, FOREIGN, false, kLdsLevels, false, true))) \
+           : (levels == 12 ? VX_K(IMAGE, false, false, 5, FOREIGN, true, 12)                                                        \
+                           : (levels == 16 ? VX_K(IMAGE, HITS, false, W, FOREIGN, true, 16) : (shallow ? VX_K(IMAGE, HITS, false, W, FOREIGN, true) : VX_K(IMAGE, HITS, false, W, FOREIGN, false)))))
     if (ctx->hot_levels && !HITS && !wide && shallow && levels == kLdsLevels && (esvo || ctx->no_excursion)) return VX_K(VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true);
     if (esvo || ctx->no_excursion) return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, 0) : VX_IMG(VX_SVO_IMAGE, 0);
     return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO) : VX_IMG(VX_SVO_IMAGE, VX_SVO_CSVO);
@@ -1012,7 +1188,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         }
         // shallower images, up to 12 levels, image-only renders: 12 resident levels in 7.5 KB, five waves per SIMD
         if (!HITS && shallow && levels == kLdsLevels && depth <= 12u + slack && ctx->five_waves && !ctx->hot_levels) levels = 12;
-        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels);
+        // image-only renders: the build with batched service phases (render_persistent, BATCH)
+        const bool batch = imaged && !HITS && ctx->batch_service && levels != 12 && !ctx->hot_levels;
+        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels, batch);
         size_t wave_lds = levels == 16 ? Stack<64, false, false, 16, true>::kBytes : (levels == 12 ? Stack<64, false, false, 12, true>::kBytes : Stack<64>::kBytes);
         if (fn == reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true>))
             wave_lds = Stack<64, false, false, kLdsLevels, true, true>::kBytes;
@@ -1109,6 +1287,24 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             todo.next_chunk = ring;
             todo.chunks = ring + 32;
             todo.mask = uint32_t(have - 1);
+        }
+        a.batch = nullptr;
+        if (batch) {
+            uint8_t*& rings = ctx->d_batch[slot + 1];
+            size_t& have = ctx->batch_waves[slot + 1];
+            if (have < waves) {
+                if (rings) {
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    (void)hipFree(rings);
+                    rings = nullptr;
+                    have = 0;
+                }
+                const size_t all = size_t(ctx->cu_count) * size_t(per_cu);  // (the most a launch of this kernel ever has)
+                const size_t n = all > waves ? all : waves;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rings), n * kWaveBatchBytes));
+                have = n;
+            }
+            a.batch = rings;
         }
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, &todo};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
@@ -1355,6 +1551,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FIVE_WAVES")) c->five_waves = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_BATCH")) c->batch_service = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_HOT_LEVELS")) c->hot_levels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_HOT_FIRST")) {
             const int v = std::atoi(e);
@@ -1400,6 +1597,8 @@ void vx_destroy(vx_context* c) {
                    c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin, c->d_excursions, c->d_main_todo, c->d_timeline};
     for (void* p : dev)
         if (p) (void)hipFree(p);
+    for (int i = 0; i <= vx_context::kFrameStreams; ++i)
+        if (c->d_batch[i]) (void)hipFree(c->d_batch[i]);
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
         if (c->d_frame_counter[i]) (void)hipFree(c->d_frame_counter[i]);
         if (c->d_frame_todo[i]) (void)hipFree(c->d_frame_todo[i]);
