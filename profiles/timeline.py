@@ -24,13 +24,15 @@ def main():
     ap.add_argument("--format", default="esvo")
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--hot", default="1")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
     args = ap.parse_args()
     os.environ["VX_HOT_FIRST"] = args.hot
     import numpy as np
     import torch
 
     fmt = vra.SVO_ESVO if args.format == "esvo" else vra.SVO_CSVO
-    W, H = 1920, 1080
+    W, H = args.width, args.height
     world = vra.World(fmt)
     st = world.build_heightfield(args.depth)
     svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20))
@@ -41,9 +43,12 @@ def main():
     u = scenes.bench_camera(args.depth, st["h_max"], W, H, shadow_distance=3.0e38, render_shadows=True)
     image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
+    svo.profile_enable(True)
     for _ in range(6):
         svo.render_device(u, W, H, image.data_ptr())
     svo.sync()
+    ms, launches = svo.profile_read()
+    svo.profile_enable(False)
     t = svo.timeline().astype(np.float64)
     t0 = t[:, 0].min()
     start, empty, leave = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0  # microseconds
@@ -51,6 +56,7 @@ def main():
     print(json.dumps({"format": args.format, "hot_first": args.hot, "waves": int(len(t)), "percentiles": [0, 10, 50, 90, 99, 100],
                       "start_us": q(start), "queue_empty_us": q(empty[t[:, 1] > 0]), "exit_us": q(leave), "tail_us_per_wave": q((leave - empty)[t[:, 1] > 0]),
                       "subtiles_taken": q(t[:, 3]), "kernel_us": round(float(leave.max()), 1),
+                      "kernel_us_by_events_mean_of_launches": round(ms / max(launches, 1) * 1e3, 1),
                       "mean_wave_lifetime_us": round(float((leave - start).mean()), 1)}))
 
 

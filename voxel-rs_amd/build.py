@@ -5,7 +5,8 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-LIB = PKG / "lib"
+# VX_LIB_DIR (measurements: A/B of two builds of the libraries in one gpurun call) overrides the in-tree lib directory
+LIB = Path(os.environ["VX_LIB_DIR"]).resolve() if os.environ.get("VX_LIB_DIR") else PKG / "lib"
 
 
 def _run(cmd, cwd):

@@ -274,6 +274,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
         // idle lanes are not waiting for anything; lanes that wait for company before their excursion (FOREIGN) are not waiting for service
         const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle || (FOREIGN && state == kForeign))));
+        // the loop goes on while more than this many lanes traverse (64 - popcount(trav) < park_limit, and trav != 0)
+        const uint32_t keep_going = park_limit >= 64u ? 0u : 64u - park_limit;
         for (;;) {
             if (tr.iter < uint32_t(kMaxSteps)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
                 tr.template step_with<false, STATS, false, FastStack, false, FOREIGN != 0>(sc, fast_st, nullptr, STATS ? &ctr : nullptr, [&](TravStatus s) {
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 ++wave_steps;
                 if (queue_empty) { ++tail_wave_steps; tail_iterations += uint32_t(__popcll(trav)); }
             }
-            if (trav == 0 || 64u - uint32_t(__popcll(trav)) >= park_limit) break;
+            if (uint32_t(__popcll(trav)) <= keep_going) break;
         }
         if (STATS) ++services;
         // what a ray found: produced (leaf test, miss) and consumed (shading) within this service phase, never carried into the loop

@@ -648,6 +648,18 @@ struct Trav {
         const float tc_max = gmin3(tcrx, tcry, tcrz);
         const uint32_t octant_idx = uint32_t(cur_idx ^ octant_mask);
 
+        // Image cursors (byte-offset layout): the entry a PUSH out of this node into this child would read is requested NOW, for every
+        // lane, whether the lane turns out to descend or not -- the address is known, and everything the iteration does (the tests
+        // below, the stack access, the other lanes' ADVANCE and POP) runs while it is in flight; it is looked at once, at the very end.
+        // Requested for nothing by the lanes that do not descend: the same one load instruction per trip of a wave, and any address
+        // is harmless (an octant of eight values is read beyond its 32 bytes, into the next one or the padding; a byte-offset image is
+        // read through a buffer resource with its range check; the wide layout's 64-bit addresses are kept valid: see `ptr` below).
+        constexpr bool kAhead = IMG && !ST::kHot;
+        uint2 ahead = make_uint2(0u, 0u);
+        if (kAhead) ahead = WIDE ? wide_entry(sc, ptr, octant_idx) : buf_u64(sc.world, ptr + octant_idx * 8u);
+        bool pushed = false;
+        const float cell_before = scale_exp2;
+
         bool is_child, is_leaf;
         uint32_t tag = 0;  // CSVO: the child's 2-bit pointer-width tag (01 for every present child of the 1-bit levels)
         if (IMG) {
@@ -715,21 +727,23 @@ struct Trav {
             uint32_t w0 = 0, w1 = 0, table = 0, offset = 0;
             if (IMG) {
                 // one aligned 8-byte entry: the child's octant and the child's masks (no clamp: image pointers are valid by construction)
-                uint2 e;
-                if (ST::kHot && scale >= kMaxScale - 2) {
+                uint2 e = ahead;
+                if (kAhead) {
+                    // (requested at the top of the iteration)
+                } else if (ST::kHot && scale >= kMaxScale - 2) {
                     // out of the root (scale 22) or of the root's child the ray is in (scale 21; which one: the position's bit 22)
                     const uint32_t at_root = uint32_t(bit_at(__float_as_uint(px), 22) | (bit_at(__float_as_uint(py), 22) << 1) | (bit_at(__float_as_uint(pz), 22) << 2)) ^ uint32_t(octant_mask);
                     e = st.hot_entry(scale == kMaxScale - 1 ? 0u : 1u + at_root, octant_idx);
                 } else {
                     e = WIDE ? wide_entry(sc, ptr, octant_idx) : buf_u64(sc.world, ptr + octant_idx * 8u);
                 }
-                w0 = e.x;
+                if (!kAhead) w0 = e.x;
                 // A ray that starts inside a voxel is led INTO it (the leaf was not accepted above: t_min <= 0). In an ESVO world a voxel's
                 // own masks are zero in everything the serializer writes (esvo.rs:465-485 never ORs a leaf's masks into its parent's
                 // header; the transcoder refuses worlds where that is not so), so the reference walks the voxel as an empty node: so
                 // do we, whatever the entry holds (an octant of voxels has values where others have entries). The pointer is never used.
                 // The image of a CSVO world never gets here (FOREIGN: Trav::enter_voxel_on_bytes).
-                w1 = (!FOREIGN && is_leaf) ? 0u : e.y;
+                if (!kAhead) w1 = (!FOREIGN && is_leaf) ? 0u : e.y;
             } else if (!CSVO) {
                 // the child's pointer word and the header word with its masks, both in the octant at `ptr`
                 w0 = word(sc, ptr + 4 + octant_idx);
@@ -762,7 +776,9 @@ struct Trav {
             if (!ST::kFast) idx = int(upper_x) | (int(upper_y) << 1) | (int(upper_z) << 2);
             t_max = tv_max;
             sched_fence();
-            if (IMG) {
+            if (kAhead) {
+                pushed = true;  // (pointer and masks: below, where the other lanes' ADVANCE has been done too)
+            } else if (IMG) {
                 ptr = w0;
                 node = w1;
             } else if (!CSVO) {
@@ -792,9 +808,22 @@ struct Trav {
                 node = csvo_header(sc);
                 if (depth == 2) pre_leaf_pointer = ptr;
             }
+            if (!kAhead) return;
+        }
+        if (!kAhead) {
+            if (!advance<TRACE>(sc, st, tcrx, tcry, tcrz, tc_max, tk)) on_exit(kTravFinished);
             return;
         }
-        if (!advance<TRACE>(sc, st, tcrx, tcry, tcrz, tc_max, tk)) on_exit(kTravFinished);
+        if (!pushed && !advance<TRACE>(sc, st, tcrx, tcry, tcrz, tc_max, tk)) return on_exit(kTravFinished);
+        // The entry requested at the top: the child's octant and the child's masks (a voxel's: none -- see the PUSH above). "This lane
+        // descended" is read off the cell size (PUSH halves it, POP grows it) rather than off the path taken: a condition the compiler
+        // cannot trace back to the branch keeps these two selects -- and with them the wait for the entry -- here, behind both paths,
+        // instead of inside the PUSH path in front of the other lanes' ADVANCE.
+        const bool descended = scale_exp2 < cell_before;
+        // (wide layout: what a voxel's place in an octant of values holds is no pointer, and the next iteration requests an entry behind
+        // whatever `ptr` is -- the image's first octant will do; the byte-offset layout's range check makes any value harmless)
+        ptr = descended ? ((WIDE && !FOREIGN && is_leaf) ? 0u : ahead.x) : ptr;
+        node = descended ? ((!FOREIGN && is_leaf) ? 0u : ahead.y) : node;
     }
 
     // image octants: bytes between the children's values -- an octant all of whose children are leaves (child bits 31..24 == leaf
