@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Dumps the traversal loop (the innermost loop around the image's 8-byte entry load) of one render_persistent variant from the
-compiler's assembly, with source lines, and counts its instructions. Usage: python profiles/tools/hot_loop.py [mangled-substring] [--asm]"""
+compiler's assembly, with source lines, and counts its instructions. (Counted: the instructions between the loop's head and its back
+edge. A path of the loop that the compiler lays out behind it -- since the load-ahead change the PUSH path, 16 VALU -- is not.) Usage: python profiles/tools/hot_loop.py [mangled-substring] [--asm]"""
 import re
 import subprocess
 import sys
