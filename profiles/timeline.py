@@ -55,7 +55,9 @@ def main():
     q = lambda a: [round(float(np.percentile(a, p)), 1) for p in (0, 10, 50, 90, 99, 100)]
     print(json.dumps({"format": args.format, "hot_first": args.hot, "waves": int(len(t)), "percentiles": [0, 10, 50, 90, 99, 100],
                       "start_us": q(start), "queue_empty_us": q(empty[t[:, 1] > 0]), "exit_us": q(leave), "tail_us_per_wave": q((leave - empty)[t[:, 1] > 0]),
-                      "subtiles_taken": q(t[:, 3]), "kernel_us": round(float(leave.max()), 1),
+                      "subtiles_taken": q(t[:, 3].astype(np.uint64) & np.uint64(0xfffff)),
+                      "service_phases_per_wave": q((t[:, 3].astype(np.uint64) >> np.uint64(20)) & np.uint64(0xfff)),
+                      "us_in_service_phases_per_wave": q((t[:, 3].astype(np.uint64) >> np.uint64(32)).astype(np.float64) / 100.0), "kernel_us": round(float(leave.max()), 1),
                       "kernel_us_by_events_mean_of_launches": round(ms / max(launches, 1) * 1e3, 1),
                       "mean_wave_lifetime_us": round(float((leave - start).mean()), 1)}))
 

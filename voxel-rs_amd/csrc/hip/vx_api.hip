@@ -136,6 +136,8 @@ struct PersistentArgs {
     const uint32_t* order;          // [total_subtiles] sub-tile ids, or null
     uint32_t* cost_cur;             // [total_subtiles] tag << 12 | iterations of the sub-tile's longest ray this frame; null = do not note
     uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
+    uint32_t ticket_ahead;          // 1 = waves draw their next sub-tile's ticket when they start on one (its round trip runs under the traversal)
+    uint32_t timeline_part;         // measurement: which part of the service phases the timeline's tick count covers (0 all, 1 leaf tests, 2 finished rays, 3 refill, 4 ray set-up)
     unsigned long long* timeline;   // measurement (VX_TIMELINE=1), else null: per wave {start, queue found empty, exit} in 10 ns ticks, pixels taken
     // BATCH kernels: per wave a ring of ray records and a ring of result records (kWaveBatchBytes each wave), see render_persistent
     uint8_t* batch;
@@ -264,6 +266,15 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     const unsigned long long t_start = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long t_empty = 0ull;
     uint32_t taken = 0;
+    uint32_t in_service = 0, service_phases = 0;  // timeline only, wave-uniform
+    // the sub-tile queue: a ticket is this launch's sub-tile number (lane 0's value counts)
+    auto draw_ticket = [&]() -> uint32_t {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base;  // unsigned: survives the counter wrapping
+        return t;
+    };
+    uint32_t ticket = 0;        // drawn ahead, not looked at yet
+    bool ticket_ahead = false;  // wave-uniform
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
     // BATCH, wave-uniform: the wave's two rings
     uint4* const ring_r = BATCH ? reinterpret_cast<uint4*>(a.batch + size_t(blockIdx.x) * kWaveBatchBytes) : nullptr;
@@ -291,6 +302,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             if (uint32_t(__popcll(trav)) <= keep_going) break;
         }
         if (STATS) ++services;
+        const unsigned long long t_service = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        unsigned long long t_part = 0ull;
+#define VX_PART_BEGIN(n) if (a.timeline && a.timeline_part == (n)) t_part = __builtin_amdgcn_s_memrealtime()
+#define VX_PART_END(n) if (a.timeline && a.timeline_part == (n)) in_service += uint32_t(__builtin_amdgcn_s_memrealtime() - t_part)
         // what a ray found: produced (leaf test, miss) and consumed (shading) within this service phase, never carried into the loop
         Result res;
         if (state == kTrav && tr.iter >= uint32_t(kMaxSteps)) {  // the cap ended this ray
@@ -361,6 +376,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         }
 
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
+        VX_PART_BEGIN(1);
         if (state == kLeaf) {
             tr.iter &= ~kParked;
             tr.sync_idx();
@@ -372,6 +388,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             result_miss(res, tr.inside_voxel());
             state = kDone;
         }
+        VX_PART_END(1);
 
         // A lane that gets a new ray in this service phase -- the shadow ray of a shaded pixel, or the primary ray of a
         // freshly assigned pixel -- only records origin and direction; one Trav::init below serves both kinds together.
@@ -529,6 +546,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         }
 
         // ---- finished rays ----
+        VX_PART_BEGIN(2);
         if (state == kDone) {
             float color[4];
             bool write = true;
@@ -580,15 +598,19 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             }
         }
 
+        VX_PART_END(2);
         // ---- refill idle lanes from the sub-tile queue ----
+        VX_PART_BEGIN(3);
         unsigned long long idle_mask = __ballot(state == kIdle);
         if (!queue_empty && idle_mask && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
             if (STATS) ++refills;
             for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
                 if (cursor >= 64) {
-                    uint32_t t = 0;
-                    if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base;  // unsigned: survives the counter wrapping
+                    // the ticket drawn ahead, if there is one (its round trip -- an atomic is carried out at the memory side -- ran under the
+                    // traversal since)
+                    uint32_t t = ticket_ahead ? ticket : draw_ticket();
                     t = __builtin_amdgcn_readfirstlane(t);
+                    ticket_ahead = false;
                     if (t >= a.total_subtiles) {
                         queue_empty = true;
                         if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
@@ -598,6 +620,11 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     if (sub >= a.total_subtiles) sub = t;  // (never: a table of another view is not used)
                     cursor = 0;
                     ++taken;
+                    // one ahead -- but not in the frame's last stretch, where a sub-tile reserved by a busy wave is one an idle wave cannot take
+                    if (a.ticket_ahead && t + 2u * gridDim.x < a.total_subtiles) {
+                        ticket = draw_ticket();
+                        ticket_ahead = true;
+                    }
                 }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
                 const uint32_t k = cursor + rank;
@@ -632,17 +659,24 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             }
         }
 
+        VX_PART_END(3);
         // ---- ray set-up (svo.esvo.glsl:50-150) for every lane that got a ray above ----
+        VX_PART_BEGIN(4);
         if (new_ray) {
             tr.init(sc, new_ro, new_rd, -1.0f);  // iter = 0: not parked
             state = kTrav;
         }
+        VX_PART_END(4);
+#undef VX_PART_BEGIN
+#undef VX_PART_END
+        if (a.timeline) { if (a.timeline_part == 0) in_service += uint32_t(__builtin_amdgcn_s_memrealtime() - t_service); ++service_phases; }
         if (__ballot(state != kIdle) == 0 && queue_empty) break;
     }
 
     if (a.timeline && lane == 0) {
         unsigned long long* row = a.timeline + size_t(blockIdx.x) * 4;
-        row[0] = t_start; row[1] = t_empty; row[2] = __builtin_amdgcn_s_memrealtime(); row[3] = taken;
+        row[0] = t_start; row[1] = t_empty; row[2] = __builtin_amdgcn_s_memrealtime();
+        row[3] = taken | ((unsigned long long)(service_phases & 0xfffu) << 20) | ((unsigned long long)in_service << 32);  // sub-tiles, service phases, ticks spent in them
     }
     // ---- second phase (FOREIGN): the pixels this wave gave up on the image, whole, on the world's own bytes ----
     if (FOREIGN) {
@@ -937,6 +971,9 @@ struct vx_context {
     unsigned long long* d_excursions = nullptr;  // [3], see PersistentArgs
     unsigned long long* d_timeline = nullptr;    // VX_TIMELINE=1: [8192][4], the last launch's waves (PersistentArgs::timeline)
     uint32_t timeline_waves = 0;
+    uint32_t timeline_part = 0;   // VX_TIMELINE_PART
+    int ticket_ahead = -1;        // VX_TICKET_AHEAD: 1/0 = always/never; default (-1): for frames on the frame streams (several in flight: the next frame fills
+                                  // this one's tail), not for one frame at a time on the context's stream (a reserved sub-tile lengthens the tail)
     // the traversal image of the world (traversal_image.hpp), rebuilt for the changed chunks by every commit
     vximg::WorldImage image;
     uint8_t* d_image = nullptr;
@@ -1211,6 +1248,8 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.foreign_min = ctx->foreign_min;
         a.excursions = ctx->d_excursions;
         a.timeline = ctx->d_timeline;
+        a.timeline_part = ctx->timeline_part;
+        a.ticket_ahead = ctx->ticket_ahead >= 0 ? uint32_t(ctx->ticket_ahead) : (slot >= 0 ? 1u : 0u);
         a.order = nullptr;
         a.cost_cur = nullptr;
         a.cur_tag = 0xfffffu;
@@ -1562,6 +1601,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         }
         if (const char* e = std::getenv("VX_TIMELINE"))
             if (std::atoi(e) != 0) CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_timeline), 8192 * 4 * sizeof(unsigned long long)));
+        if (const char* e = std::getenv("VX_TIMELINE_PART")) c->timeline_part = uint32_t(std::atoi(e));
+        if (const char* e = std::getenv("VX_TICKET_AHEAD")) c->ticket_ahead = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VX_IMAGE_CAP_BYTES")) c->image_cap_bytes = size_t(std::strtoull(e, nullptr, 10));
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)
