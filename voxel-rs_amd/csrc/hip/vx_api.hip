@@ -122,7 +122,7 @@ static_assert(int(kTrav) == int(vxd::kTravContinue) && int(kLeaf) == int(vxd::kT
               "a TravStatus is stored as the lane's state");
 
 struct PersistentArgs {
-    uint32_t* work_counter;   // ticket dispenser, never reset: this launch's sub-tile t is ticket ticket_base + t
+    uint32_t* work_counter;   // ticket dispenser, never reset: this launch's sub-tile waves + t is ticket ticket_base + t (wave w starts on sub-tile w)
     uint32_t ticket_base;
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
@@ -268,13 +268,15 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     uint32_t taken = 0;
     uint32_t in_service = 0, service_phases = 0;  // timeline only, wave-uniform
     // the sub-tile queue: a ticket is this launch's sub-tile number (lane 0's value counts)
+    // Wave w starts on sub-tile w without asking (a launch never has more waves than sub-tiles): 4096 waves do not open the frame by
+    // queueing at one counter. The counter hands out the sub-tiles from gridDim.x on.
     auto draw_ticket = [&]() -> uint32_t {
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base;  // unsigned: survives the counter wrapping
+        if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base + gridDim.x;  // unsigned: survives the counter wrapping
         return t;
     };
-    uint32_t ticket = 0;        // drawn ahead, not looked at yet
-    bool ticket_ahead = false;  // wave-uniform
+    uint32_t ticket = blockIdx.x;                    // drawn ahead, not looked at yet
+    bool ticket_ahead = !BATCH;                      // wave-uniform
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
     // BATCH, wave-uniform: the wave's two rings
     uint4* const ring_r = BATCH ? reinterpret_cast<uint4*>(a.batch + size_t(blockIdx.x) * kWaveBatchBytes) : nullptr;
@@ -923,8 +925,9 @@ struct vx_context {
     hipEvent_t frame_done[kFrameStreams] = {};
     bool frame_recorded[kFrameStreams] = {};
     uint32_t* d_frame_counter[kFrameStreams] = {};
-    // Tickets drawn from each dispenser so far. A launch draws exactly total_subtiles + waves tickets (every wave draws one
-    // ticket past the end before it stops), so the next launch on the same stream starts there and no reset is needed.
+    // Tickets drawn from each dispenser so far. A launch draws exactly total_subtiles tickets (the sub-tiles beyond the waves' first
+    // ones, plus one past the end by every wave before it stops), so the next launch on the same stream starts there and no reset
+    // is needed.
     uint32_t frame_tickets[kFrameStreams] = {};
     uint32_t* d_frame_todo[kFrameStreams] = {};  // images of CSVO worlds: [chunk counter][ring of 128-dword chunks] per stream (PixelList)
     size_t frame_todo_chunks[kFrameStreams] = {};
@@ -1349,7 +1352,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         }
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, &todo};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
-        tickets += a.total_subtiles + waves;
+        // tickets drawn by this launch: the sub-tiles beyond the waves' first ones, and one past the end by every wave before it stops
+        // (BATCH kernels draw every sub-tile)
+        tickets += a.total_subtiles + (batch ? waves : 0u);
         order_after = hs;
         order_subtiles = a.total_subtiles;
     }
