@@ -975,8 +975,7 @@ struct vx_context {
     unsigned long long* d_timeline = nullptr;    // VX_TIMELINE=1: [8192][4], the last launch's waves (PersistentArgs::timeline)
     uint32_t timeline_waves = 0;
     uint32_t timeline_part = 0;   // VX_TIMELINE_PART
-    int ticket_ahead = -1;        // VX_TICKET_AHEAD: 1/0 = always/never; default (-1): for frames on the frame streams (several in flight: the next frame fills
-                                  // this one's tail), not for one frame at a time on the context's stream (a reserved sub-tile lengthens the tail)
+    int ticket_ahead = 1;         // VX_TICKET_AHEAD=0: waves draw a sub-tile's ticket when they need it (A/B)
     // the traversal image of the world (traversal_image.hpp), rebuilt for the changed chunks by every commit
     vximg::WorldImage image;
     uint8_t* d_image = nullptr;
@@ -1252,7 +1251,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.excursions = ctx->d_excursions;
         a.timeline = ctx->d_timeline;
         a.timeline_part = ctx->timeline_part;
-        a.ticket_ahead = ctx->ticket_ahead >= 0 ? uint32_t(ctx->ticket_ahead) : (slot >= 0 ? 1u : 0u);
+        a.ticket_ahead = ctx->ticket_ahead != 0 ? 1u : 0u;
         a.order = nullptr;
         a.cost_cur = nullptr;
         a.cur_tag = 0xfffffu;
