@@ -999,7 +999,7 @@ struct vx_context {
     bool image_enabled = true;  // VX_TRAVERSAL_IMAGE=0: traverse the world's own bytes
     bool image_ok = false;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
-    uint32_t refill_min = 4, service_min = 28, foreign_min = 32;
+    uint32_t refill_min = 4, service_min = 32, foreign_min = 32;
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int cu_count = 256;
