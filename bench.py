@@ -168,7 +168,7 @@ def main():
         # in flight: a render only has to wait for the collective that last read its buffer.
         # frames in flight: the smaller a rank's share of the frame, the longer its tail relative to its body (a frame cannot
         # finish before its longest ray) and the more frames it takes to keep the device full
-        FRAMES = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else min(8, max(3, world_size))
+        FRAMES = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else min(8, max(2, world_size))
         # frames per collective (1: every frame is gathered as soon as it is rendered; more: fewer, larger messages)
         GROUP = args.gather_group if args.gather_group else 1
         GROUP = max(1, min(GROUP, FRAMES))

@@ -9,6 +9,10 @@ for i in 1 2 3; do for f in esvo csvo; do
   VX_LIB_DIR=voxel-rs_amd/lib_ab/$BASE timeout 300 python bench.py --format $f --no-cpu-baseline --repeats 11 2>/dev/null | tail -n 1 > $O/base_${f}_$i.json
   timeout 300 python bench.py --format $f --no-cpu-baseline --repeats 11 2>/dev/null | tail -n 1 > $O/new_${f}_$i.json
 done; done
+for i in 1 2; do
+  VX_LIB_DIR=voxel-rs_amd/lib_ab/$BASE timeout 300 python bench.py --format csvo --force-sharded --no-cpu-baseline --repeats 11 2>/dev/null | grep '^{' | tail -n 1 > $O/base_sharded_$i.json
+  timeout 300 python bench.py --format csvo --force-sharded --no-cpu-baseline --repeats 11 2>/dev/null | grep '^{' | tail -n 1 > $O/new_sharded_$i.json
+done
 for part in 0 1 2 3 4; do VX_TIMELINE_PART=$part VX_TIMELINE=1 timeout 200 python profiles/timeline.py --format esvo --hot 7 2>/dev/null | tail -n 1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('part', $part, 'us per wave p10/p50/p90:', d['us_in_service_phases_per_wave'][1:4], 'phases', d['service_phases_per_wave'][2], 'lifetime', d['mean_wave_lifetime_us'], 'kernel', d['kernel_us'])" >> $O/parts_esvo.txt; done
 tail -n 3 $O/pytest.log
 python3 - <<'PY'
