@@ -122,8 +122,13 @@ static_assert(int(kTrav) == int(vxd::kTravContinue) && int(kLeaf) == int(vxd::kT
               "a TravStatus is stored as the lane's state");
 
 struct PersistentArgs {
-    uint32_t* work_counter;   // ticket dispenser, never reset: this launch's sub-tile waves + t is ticket ticket_base + t (wave w starts on sub-tile w)
-    uint32_t ticket_base;
+    // The sub-tile queue: eight dispensers (kQueueStride words apart: one memory-side atomic unit each), dispenser c hands out the sub-tiles
+    // c, c + 8, c + 16, ... beyond the waves' first ones (wave w starts on sub-tile w without asking). A wave draws from dispenser
+    // (w & 7) and, when that one is empty, from the next. One dispenser for 4096 waves is 70 M atomic adds per second on one address:
+    // more than the memory side carries out there -- a ticket took tens of microseconds. A stream has two sets: a launch uses one and
+    // clears the other for its successor (which does not start before this one has ended).
+    uint32_t* work_counter;   // this launch's set
+    uint32_t* next_counter;   // the set to clear
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
     uint32_t foreign_min;     // images of CSVO worlds: rays led into a voxel wait until this many of a wave's lanes are, and go together
@@ -172,6 +177,7 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
     }
 }
 
+constexpr uint32_t kQueues = 8, kQueueStride = 64;  // dispensers of the sub-tile queue, words between them
 constexpr uint32_t kCostFloor = 32;  // rays that end sooner (the mean is about 30) leave their sub-tile in the cheapest class: no note
 
 // the sub-tile (8x8 pixels: the unit of the queue) a pixel's output index lies in
@@ -270,13 +276,25 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     // the sub-tile queue: a ticket is this launch's sub-tile number (lane 0's value counts)
     // Wave w starts on sub-tile w without asking (a launch never has more waves than sub-tiles): 4096 waves do not open the frame by
     // queueing at one counter. The counter hands out the sub-tiles from gridDim.x on.
+    uint32_t my_queue = blockIdx.x & (kQueues - 1u);  // wave-uniform: the dispenser this wave draws from
     auto draw_ticket = [&]() -> uint32_t {
+        // the n-th ticket of dispenser c is sub-tile (first_c + n) * 8 + c, first_c = how many of the waves' own first sub-tiles are c's
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base + gridDim.x;  // unsigned: survives the counter wrapping
+        if (lane == 0) t = (((gridDim.x + kQueues - 1u - my_queue) >> 3) + atomicAdd(a.work_counter + my_queue * kQueueStride, 1u)) * kQueues + my_queue;
         return t;
     };
+    // the ticket as the wave's value; a dispenser that has run dry sends the wave on to the next one (the frame's last stretch only)
+    auto settle_ticket = [&](uint32_t t) -> uint32_t {
+        t = __builtin_amdgcn_readfirstlane(t);
+        for (uint32_t tried = 1; t >= a.total_subtiles && tried < kQueues; ++tried) {
+            my_queue = (my_queue + 1u) & (kQueues - 1u);
+            t = __builtin_amdgcn_readfirstlane(draw_ticket());
+        }
+        return t;
+    };
+    if (blockIdx.x == 0 && lane < kQueues) a.next_counter[lane * kQueueStride] = 0u;
     uint32_t ticket = blockIdx.x;                    // drawn ahead, not looked at yet
-    bool ticket_ahead = !BATCH;                      // wave-uniform
+    bool ticket_ahead = true;                        // wave-uniform
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
     // BATCH, wave-uniform: the wave's two rings
     uint4* const ring_r = BATCH ? reinterpret_cast<uint4*>(a.batch + size_t(blockIdx.x) * kWaveBatchBytes) : nullptr;
@@ -480,9 +498,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             const uint32_t n_idle = uint32_t(__popcll(idle_mask));
             if (idle_mask && (n_idle >= a.refill_min || idle_mask == ~0ull || queue_empty)) {
                 while (r_count < n_idle && !queue_empty) {
-                    uint32_t t = 0;
-                    if (lane == 0) t = atomicAdd(a.work_counter, 1u) - a.ticket_base;  // unsigned: survives the counter wrapping
-                    t = __builtin_amdgcn_readfirstlane(t);
+                    const uint32_t t = settle_ticket(ticket_ahead ? ticket : draw_ticket());
+                    ticket_ahead = false;
                     if (t >= a.total_subtiles) {
                         queue_empty = true;
                         if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
@@ -610,8 +627,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 if (cursor >= 64) {
                     // the ticket drawn ahead, if there is one (its round trip -- an atomic is carried out at the memory side -- ran under the
                     // traversal since)
-                    uint32_t t = ticket_ahead ? ticket : draw_ticket();
-                    t = __builtin_amdgcn_readfirstlane(t);
+                    const uint32_t t = settle_ticket(ticket_ahead ? ticket : draw_ticket());
                     ticket_ahead = false;
                     if (t >= a.total_subtiles) {
                         queue_empty = true;
@@ -925,9 +941,7 @@ struct vx_context {
     hipEvent_t frame_done[kFrameStreams] = {};
     bool frame_recorded[kFrameStreams] = {};
     uint32_t* d_frame_counter[kFrameStreams] = {};
-    // Tickets drawn from each dispenser so far. A launch draws exactly total_subtiles tickets (the sub-tiles beyond the waves' first
-    // ones, plus one past the end by every wave before it stops), so the next launch on the same stream starts there and no reset
-    // is needed.
+    // Launches on each stream so far: a stream's two sets of ticket dispensers take turns (PersistentArgs::work_counter).
     uint32_t frame_tickets[kFrameStreams] = {};
     uint32_t* d_frame_todo[kFrameStreams] = {};  // images of CSVO worlds: [chunk counter][ring of 128-dword chunks] per stream (PixelList)
     size_t frame_todo_chunks[kFrameStreams] = {};
@@ -1242,8 +1256,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             per_cu = n;
         }
         PersistentArgs a;
-        a.work_counter = work_counter;
-        a.ticket_base = tickets;
+        // (`tickets` counts this stream's launches: its sets of dispensers take turns)
+        a.work_counter = work_counter + size_t(tickets & 1u) * (kQueues * kQueueStride);
+        a.next_counter = work_counter + size_t((tickets & 1u) ^ 1u) * (kQueues * kQueueStride);
         a.total_subtiles = p.n_local_tiles * 16;
         a.refill_min = ctx->refill_min;
         a.service_min = ctx->service_min;
@@ -1351,9 +1366,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         }
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, &todo};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
-        // tickets drawn by this launch: the sub-tiles beyond the waves' first ones, and one past the end by every wave before it stops
-        // (BATCH kernels draw every sub-tile)
-        tickets += a.total_subtiles + (batch ? waves : 0u);
+        tickets += 1u;
         order_after = hs;
         order_subtiles = a.total_subtiles;
     }
@@ -1575,12 +1588,12 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         const int prio = (i & 1) ? prio_greatest : prio_least;
         CREATE_TRY(hipStreamCreateWithPriority(&c->frame_stream[i], hipStreamNonBlocking, prio));
         CREATE_TRY(hipEventCreateWithFlags(&c->frame_done[i], hipEventDisableTiming));
-        CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_frame_counter[i]), sizeof(uint32_t)));
-        CREATE_TRY(hipMemset(c->d_frame_counter[i], 0, sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_frame_counter[i]), 2 * kQueues * kQueueStride * sizeof(uint32_t)));
+        CREATE_TRY(hipMemset(c->d_frame_counter[i], 0, 2 * kQueues * kQueueStride * sizeof(uint32_t)));
     }
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
-    CREATE_TRY(hipMemset(c->d_work_counter, 0, sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), 2 * kQueues * kQueueStride * sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(c->d_work_counter, 0, 2 * kQueues * kQueueStride * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_excursions), 8 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(c->d_excursions, 0, 8 * sizeof(unsigned long long)));
     {
