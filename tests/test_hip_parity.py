@@ -533,9 +533,9 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     for env in ({"VX_RENDER_KERNEL": "1"}, {"VX_RENDER_KERNEL": "2"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"},
                 {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "64", "VX_SERVICE_MIN": "64"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"},
                 {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_WIDE_IMAGE": "1", "VX_MIN_WAVES": "1"},
-                {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_MIN": "1"}, {"VX_FIVE_WAVES": "1"}, {"VX_BATCH": "1"}, {"VX_TICKET_AHEAD": "1"}, {"VX_TICKET_AHEAD": "0", "VX_FRAMES_IN_FLIGHT": "3"}):
+                {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_MIN": "1"}, {"VX_FIVE_WAVES": "1"}, {"VX_BATCH": "1"}, {"VX_TICKET_AHEAD": "1"}, {"VX_TICKET_AHEAD": "0", "VX_FRAMES_IN_FLIGHT": "3"}, {"VX_FOREIGN_RERUN": "0"}):
         for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_MIN_WAVES", "VX_HOT_LEVELS", "VX_HOT_FIRST",
-                  "VX_FOREIGN_MIN", "VX_FIVE_WAVES", "VX_BATCH", "VX_TICKET_AHEAD", "VX_FRAMES_IN_FLIGHT"):
+                  "VX_FOREIGN_MIN", "VX_FIVE_WAVES", "VX_BATCH", "VX_TICKET_AHEAD", "VX_FRAMES_IN_FLIGHT", "VX_FOREIGN_RERUN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -162,6 +162,10 @@ struct PixelList {
     uint32_t mask;
 };
 constexpr uint32_t kChunkDwords = 128, kChunkEntries = 126;
+// FOREIGN = kForeignRerun: the list holds RAYS instead (below): chunks of 1024 dwords, [0] previous chunk + 1, [1] records, from dword 16 on up to
+// 64 records of 12 dwords {pixel | shadow << 31, origin in octree space, colour to be lit, diffuse + specular}
+constexpr int kForeignRerun = 3;
+constexpr uint32_t kRayChunkDwords = 1024, kRayChunkRecords = 64, kRayRecordDwords = 12, kRayChunkHeader = 16;
 
 // compact / row-major output index -> pixel coordinates (the inverse of the index computation in the refill)
 __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t out_index, uint32_t& x, uint32_t& y) {
@@ -232,7 +236,15 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
     constexpr bool IMAGE = SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE;
     static_assert(!(IMAGE && STATS), "the instrumented kernel counts the reference's own fetches: it walks the world's own bytes");
-    static_assert(FOREIGN == 0 || (IMAGE && FOREIGN == VX_SVO_CSVO), "FOREIGN: the image of a CSVO world");
+    // FOREIGN = kForeignRerun (image-only renders): a ray that is about to be led into the voxel it started in is not walked here at all. Its
+    // lane takes it down -- pixel, origin, and for a shadow ray what the pixel's colour still needs -- in a list of the wave's own and is
+    // free; when the wave's queue is empty and its rays are done, the wave runs the listed rays, 64 at a time, from their origins on the
+    // world's own bytes with the reference's own cursor (a primary ray: the whole pixel) -- the same iterations the image cursor made,
+    // then the walk inside the voxel, then the rest: the same ray. The render loop carries no code for the walk (whose registers its
+    // service phases used to spill around: 11 % of a C3 frame), no lane waits for company, nothing stalls a wave in mid-frame, and the
+    // listed rays run with every lane busy.
+    static_assert(FOREIGN == 0 || (IMAGE && (FOREIGN == VX_SVO_CSVO || FOREIGN == kForeignRerun)), "FOREIGN: the image of a CSVO world");
+    static_assert(FOREIGN != kForeignRerun || (!HITS && !STATS), "rays for the world's bytes are listed by image-only renders");
     static_assert(!SHALLOW || IMAGE, "only a traversal image bounds how deep a ray can get");
     static_assert(!BATCH || (!HITS && !STATS), "batched service phases: image-only renders");
     const DevScene sc = IMAGE ? make_image_scene(sa) : make_scene(sa);
@@ -304,7 +316,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     for (;;) {
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
         // idle lanes are not waiting for anything; lanes that wait for company before their excursion (FOREIGN) are not waiting for service
-        const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle || (FOREIGN && state == kForeign))));
+        const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle || (FOREIGN == VX_SVO_CSVO && state == kForeign))));
         // the loop goes on while more than this many lanes traverse (64 - popcount(trav) < park_limit, and trav != 0)
         const uint32_t keep_going = park_limit >= 64u ? 0u : 64u - park_limit;
         for (;;) {
@@ -347,10 +359,47 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             if (state != kTrav) tr.iter |= kParked;
         }
 
-        // ---- rays that are led into a voxel (they started inside it), image of a CSVO world: the excursion on the world's own bytes ----
+        // ---- rays that are led into a voxel (they started inside it), image of a CSVO world: listed for the world's own bytes ----
+        if (FOREIGN == kForeignRerun) {
+            const bool listed = state == kForeign;
+            const unsigned long long fm = __ballot(listed);
+            if (fm) {
+                const uint32_t k = uint32_t(__popcll(fm)), r = rank_in(fm);
+                const uint32_t room = my_chunk ? kRayChunkRecords - my_fill : 0u;
+                uint32_t* cur = todo.chunks + size_t(my_chunk ? my_chunk - 1 : 0u) * kRayChunkDwords;
+                uint32_t* dst = cur + kRayChunkHeader + (my_fill + r) * kRayRecordDwords;
+                if (k > room) {  // (the records beyond the chunk's 64 start the next one)
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(todo.next_chunk, 1u);
+                    c = __builtin_amdgcn_readfirstlane(c) & todo.mask;
+                    uint32_t* fresh = todo.chunks + size_t(c) * kRayChunkDwords;
+                    if (lane == 0) {
+                        fresh[0] = my_chunk;
+                        fresh[1] = k - room;
+                        if (my_chunk) cur[1] = kRayChunkRecords;
+                    }
+                    if (r >= room) dst = fresh + kRayChunkHeader + (r - room) * kRayRecordDwords;
+                    my_chunk = c + 1;
+                    my_fill = k - room;
+                } else {
+                    my_fill += k;
+                    if (lane == 0) cur[1] = my_fill;
+                }
+                if (listed) {
+                    uint4* w = reinterpret_cast<uint4*>(dst);
+                    w[0] = make_uint4(out_index | (shadow_ray ? 0x80000000u : 0u), fbits(tr.rox), fbits(tr.roy), fbits(tr.roz));
+                    w[1] = make_uint4(fbits(keep_color[0]), fbits(keep_color[1]), fbits(keep_color[2]), fbits(keep_color[3]));
+                    w[2] = make_uint4(fbits(keep_ds), 0u, 0u, 0u);
+                    state = kIdle;
+                }
+                if (lane == 0) atomicAdd(&a.excursions[0], (unsigned long long)k);
+            }
+        }
+
+        // ---- ... or (FOREIGN = VX_SVO_CSVO) the excursion on the world's own bytes ----
         // The walk runs with only these lanes active, so they go together: a lane waits (parked, at no cost to the loop) until
         // foreign_min lanes of the wave are there, or until no lane is left that could traverse meanwhile.
-        if (FOREIGN) {
+        if (FOREIGN == VX_SVO_CSVO) {
             const unsigned long long fm = __ballot(state == kForeign);
             // (unlikely: tells the register allocator that what the walk needs may be spilled around it, not across the phase)
             if (__builtin_expect(fm && (uint32_t(__popcll(fm)) >= a.foreign_min || __ballot(state == kTrav || state == kLeaf || state == kDone || state == kMissed || state == kDeep) == 0), 0)) {
@@ -696,8 +745,53 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         row[0] = t_start; row[1] = t_empty; row[2] = __builtin_amdgcn_s_memrealtime();
         row[3] = taken | ((unsigned long long)(service_phases & 0xfffu) << 20) | ((unsigned long long)in_service << 32);  // sub-tiles, service phases, ticks spent in them
     }
-    // ---- second phase (FOREIGN): the pixels this wave gave up on the image, whole, on the world's own bytes ----
-    if (FOREIGN) {
+    // ---- second phase (FOREIGN = kForeignRerun): the rays this wave listed, on the world's own bytes ----
+    if (FOREIGN == kForeignRerun) {
+        const DevScene sc_bytes = make_scene(sa);
+        Stack<64, false, false, int(FullStack::kStackBytes / (64u * 12u))> st2;  // (three full words per slot, over the same LDS: the first phase is over)
+        st2.init(lane, &spill);
+        const float to_light[3] = {-p.u.light_dir[0], -p.u.light_dir[1], -p.u.light_dir[2]};
+        for (uint32_t c = my_chunk; c != 0;) {
+            const uint32_t* chunk = todo.chunks + size_t(c - 1) * kRayChunkDwords;
+            const uint32_t n = __builtin_amdgcn_readfirstlane(chunk[1]);
+            c = __builtin_amdgcn_readfirstlane(chunk[0]);
+            if (lane < n) {
+                const uint4* w = reinterpret_cast<const uint4*>(chunk + kRayChunkHeader + lane * kRayRecordDwords);
+                const uint4 w0 = w[0];
+                const uint32_t index = w0.x & 0x7fffffffu;
+                float color[4];
+                if (w0.x >> 31) {
+                    const uint4 w1 = w[1];
+                    const float ds = bitsf(w[2].x);
+                    // a shadow ray: from its origin on the world's bytes, with the reference's own cursor
+                    Trav<VX_SVO_CSVO> tb;
+                    tb.init_in_octree_space(sc_bytes, bitsf(w0.y), bitsf(w0.z), bitsf(w0.w), to_light, -1.0f);
+                    Result rs;
+                    for (;;) {
+                        TravStatus s2 = tb.template step<false, false, false>(sc_bytes, st2, nullptr, nullptr);
+                        if (s2 == kTravAtLeaf) {
+                            const LeafOutcome o = tb.template leaf_test<false, false>(sc_bytes, st2, true, rs, nullptr, nullptr);
+                            if (o == kLeafHit) break;
+                            s2 = o == kLeafPassed ? kTravContinue : kTravFinished;
+                        }
+                        if (s2 == kTravFinished) {
+                            result_miss(rs, tb.inside_voxel());
+                            break;
+                        }
+                    }
+                    color[0] = bitsf(w1.x); color[1] = bitsf(w1.y); color[2] = bitsf(w1.z); color[3] = bitsf(w1.w);
+                    apply_light(p, color, ds, rs.t < 0.0f ? 1.0f : 0.0f);
+                } else {
+                    uint32_t x, y;
+                    out_index_to_xy(p, index, x, y);
+                    shade_pixel<VX_SVO_CSVO, false>(sc_bytes, p, x, y, st2, color, nullptr, nullptr, nullptr, nullptr);
+                }
+                if (out) store_pixel(p, out, index, color);
+            }
+        }
+    }
+    // ---- second phase (FOREIGN = VX_SVO_CSVO): the pixels this wave gave up on the image, whole, on the world's own bytes ----
+    if (FOREIGN == VX_SVO_CSVO) {
         const DevScene sc_bytes = make_scene(sa);
         // (the byte cursor's stack entries are three full words: the plain layout, as many levels as fit the same LDS -- the first phase is over)
         Stack<64, false, false, int(FullStack::kStackBytes / (64u * 12u))> st2;
@@ -713,7 +807,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     out_index_to_xy(p, index, x, y);
                     float color[4];
                     vx_hit r;
-                    shade_pixel<FOREIGN ? FOREIGN : VX_SVO_CSVO, false>(sc_bytes, p, x, y, st2, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
+                    shade_pixel<VX_SVO_CSVO, false>(sc_bytes, p, x, y, st2, color, HITS ? &r : nullptr, nullptr, nullptr, nullptr);
                     if (out) store_pixel(p, out, index, color);
                     if (HITS) hits[index] = r;
                 }
@@ -1003,6 +1097,8 @@ struct vx_context {
     DeltaSlot delta[kDeltaSlots];
     unsigned delta_next = 0;
     bool hot_levels = false;      // VX_HOT_LEVELS=1 (experiment X1): the image's top two levels served from an LDS copy (ESVO worlds, image-only renders)
+    int foreign_rerun = -1;       // VX_FOREIGN_RERUN: 1 / 0 = image-only renders of a CSVO world always / never list their inside-voxel rays for the bytes
+                                  // (kForeignRerun) instead of making the excursion in the render loop; default: worlds of at most 12 levels do
     bool batch_service = false;   // VX_BATCH=1 (experiment): image-only renders by the build that shades, lights and generates rays 64 records at a time
     uint8_t* d_batch[kFrameStreams + 1] = {};  // [slot + 1]: the waves' record rings of a BATCH kernel (PersistentArgs::batch)
     size_t batch_waves[kFrameStreams + 1] = {};
@@ -1172,7 +1268,7 @@ int check_ready(vx_context* ctx) {
 // where the image's depth rules deep pushes out). The image-only build of the hot variants is held to 128 VGPRs (4 waves per SIMD).
 // levels: the LDS-resident stack levels of an image kernel -- kLdsLevels, or 16 (16-bit third plane) for images of 14 to 16 levels
 template <bool HITS, bool STATS>
-const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, int levels, bool batch) {
+const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, int levels, bool batch, bool rerun) {
     const bool esvo = ctx->svo_type == VX_SVO_ESVO;
 #define VX_K(...) reinterpret_cast<const void*>(&render_persistent<__VA_ARGS__>)
     if (!imaged) {
@@ -1190,6 +1286,10 @@ const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, 
                            : (levels == 16 ? VX_K(IMAGE, HITS, false, W, FOREIGN, true, 16) : (shallow ? VX_K(IMAGE, HITS, false, W, FOREIGN, true) : VX_K(IMAGE, HITS, false, W, FOREIGN, false)))))
     if (ctx->hot_levels && !HITS && !wide && shallow && levels == kLdsLevels && (esvo || ctx->no_excursion)) return VX_K(VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true);
     if (esvo || ctx->no_excursion) return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, 0) : VX_IMG(VX_SVO_IMAGE, 0);
+    if constexpr (!HITS && !STATS) {
+        // image-only renders of a CSVO world: rays that start inside a voxel are listed and run on the world's bytes afterwards (kForeignRerun)
+        if (rerun && shallow && levels == kLdsLevels) return wide ? VX_K(VX_SVO_IMAGE_WIDE, false, false, 4, kForeignRerun, true) : VX_K(VX_SVO_IMAGE, false, false, 4, kForeignRerun, true);
+    }
     return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO) : VX_IMG(VX_SVO_IMAGE, VX_SVO_CSVO);
 #undef VX_IMG
 #undef VX_K
@@ -1245,7 +1345,14 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         if (!HITS && shallow && levels == kLdsLevels && depth <= 12u + slack && ctx->five_waves && !ctx->hot_levels) levels = 12;
         // image-only renders: the build with batched service phases (render_persistent, BATCH)
         const bool batch = imaged && !HITS && ctx->batch_service && levels != 12 && !ctx->hot_levels;
-        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels, batch);
+        // Which way a CSVO world's inside-voxel rays go is a matter of how many there are, and that of the world's size: below 4096 the
+        // reference's 0.001 shadow offset survives rounding and they are a few dozen per frame -- listed, and run on the bytes when
+        // the wave is done (kForeignRerun: +8 % at C3, for a render loop without the walk's code). From 8192 on every second shadow ray
+        // is one (2 M per 4K frame): there the excursion inside the render loop, batched, is a fifth faster than running them whole on
+        // the bytes (profiles/round2/foreign_rerun/).
+        const bool rerun = imaged && ctx->svo_type == VX_SVO_CSVO && !HITS && !STATS && !batch && shallow && levels == kLdsLevels && !ctx->no_excursion &&
+                           (ctx->foreign_rerun == 1 || (ctx->foreign_rerun < 0 && depth <= 12u));
+        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels, batch, rerun);
         size_t wave_lds = levels == 16 ? Stack<64, false, false, 16, true>::kBytes : (levels == 12 ? Stack<64, false, false, 12, true>::kBytes : Stack<64>::kBytes);
         if (fn == reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true>))
             wave_lds = Stack<64, false, false, kLdsLevels, true, true>::kBytes;
@@ -1328,7 +1435,10 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             // chunk holds at least 63 pixels, every wave can have one unfinished one: pixels / 63 + waves chunks per launch at most.
             uint32_t*& ring = slot >= 0 ? ctx->d_frame_todo[slot] : ctx->d_main_todo;
             size_t& have = slot >= 0 ? ctx->frame_todo_chunks[slot] : ctx->main_todo_chunks;
-            const size_t need = size_t(p.n_local_tiles) * kTile * kTile / 63 + waves + 1;
+            // (kForeignRerun: chunks of 64 rays, eight times the size: every pixel can list one ray; a chunk is full before the wave starts
+            // the next)
+            const size_t need = rerun ? (size_t(p.n_local_tiles) * kTile * kTile / kRayChunkRecords + waves + 1) * (kRayChunkDwords / kChunkDwords)
+                                      : size_t(p.n_local_tiles) * kTile * kTile / 63 + waves + 1;
             if (have < need) {
                 if (ring) {
                     HIP_TRY(hipStreamSynchronize(stream));
@@ -1344,7 +1454,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             }
             todo.next_chunk = ring;
             todo.chunks = ring + 32;
-            todo.mask = uint32_t(have - 1);
+            todo.mask = uint32_t((rerun ? have / (kRayChunkDwords / kChunkDwords) : have) - 1);
         }
         a.batch = nullptr;
         if (batch) {
@@ -1610,6 +1720,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FIVE_WAVES")) c->five_waves = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_BATCH")) c->batch_service = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_FOREIGN_RERUN")) c->foreign_rerun = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VX_HOT_LEVELS")) c->hot_levels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_HOT_FIRST")) {
             const int v = std::atoi(e);

@@ -485,7 +485,20 @@ struct Trav {
         rox = ro_in[0] * octree_scale; roy = ro_in[1] * octree_scale; roz = ro_in[2] * octree_scale;
         max_dst = max_dst_in * octree_scale;
         rox += 1.0f; roy += 1.0f; roz += 1.0f;
+        aim<TRACE>(sc, rd_in, tk);
+    }
 
+    // A ray whose origin is already where init() puts it (octree space, [1, 2)^3): what a cursor on another encoding of the same
+    // world took down for it (render_persistent's list of rays for the world's own bytes). max_dst as for init().
+    __device__ __forceinline__ void init_in_octree_space(const DevScene& sc, float ox, float oy, float oz, const float rd_in[3], float max_dst_in) {
+        rox = ox; roy = oy; roz = oz;
+        max_dst = max_dst_in * sc.octree_scale;
+        aim<false>(sc, rd_in, nullptr);
+    }
+
+    // the direction-dependent half of the set-up (svo.esvo.glsl:60-125) and the cursor at the root
+    template <bool TRACE = false>
+    __device__ __forceinline__ void aim(const DevScene& sc, const float rd_in[3], TracePtr tk = nullptr) {
         rdx = rd_in[0]; rdy = rd_in[1]; rdz = rd_in[2];
         const uint32_t eps_bits = __float_as_uint(kEps) & 0x7fffffffu;
         if (fabsf(rdx) < kEps) rdx = __uint_as_float(eps_bits | (__float_as_uint(rdx) & 0x80000000u));
