@@ -18,7 +18,7 @@ vra = load_package()
 from voxel_rs_amd import hip, scenes  # noqa: E402
 
 KEYS = {"k": "VX_RENDER_KERNEL", "r": "VX_REFILL_MIN", "s": "VX_SERVICE_MIN", "m": "VX_MIN_WAVES", "w": "VX_WAVES_PER_CU", "f": "VX_FRAMES_IN_FLIGHT",
-        "e": "VX_FOREIGN_MIN", "x": "VX_NO_EXCURSION", "d": "VX_DEEP_STACK", "h": "VX_HOT_FIRST", "X": "VX_HOT_LEVELS", "L": "VX_HIP_LIB", "v": "VX_VARIANT", "W": "VX_FIVE_WAVES", "B": "VX_BATCH", "T": "VX_TICKET_AHEAD", "R": "VX_FOREIGN_RERUN"}
+        "e": "VX_FOREIGN_MIN", "x": "VX_NO_EXCURSION", "d": "VX_DEEP_STACK", "h": "VX_HOT_FIRST", "X": "VX_HOT_LEVELS", "L": "VX_HIP_LIB", "v": "VX_VARIANT", "W": "VX_FIVE_WAVES", "B": "VX_BATCH", "T": "VX_TICKET_AHEAD", "R": "VX_FOREIGN_RERUN", "G": "VX_AHEAD_GUARD"}
 
 
 def main():

@@ -141,7 +141,8 @@ struct PersistentArgs {
     const uint32_t* order;          // [total_subtiles] sub-tile ids, or null
     uint32_t* cost_cur;             // [total_subtiles] tag << 12 | iterations of the sub-tile's longest ray this frame; null = do not note
     uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
-    uint32_t ticket_ahead;          // 1 = waves draw their next sub-tile's ticket when they start on one (its round trip runs under the traversal)
+    uint32_t ticket_ahead;          // 0 = no; 1 + g = waves draw their next sub-tile's ticket when they start on one (its round trip runs under the traversal),
+                                    // except for the frame's last g quarter-grids of tickets
     uint32_t timeline_part;         // measurement: which part of the service phases the timeline's tick count covers (0 all, 1 leaf tests, 2 finished rays, 3 refill, 4 ray set-up)
     unsigned long long* timeline;   // measurement (VX_TIMELINE=1), else null: per wave {start, queue found empty, exit} in 10 ns ticks, pixels taken
     // BATCH kernels: per wave a ring of ray records and a ring of result records (kWaveBatchBytes each wave), see render_persistent
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     cursor = 0;
                     ++taken;
                     // one ahead -- but not in the frame's last stretch, where a sub-tile reserved by a busy wave is one an idle wave cannot take
-                    if (a.ticket_ahead && t + 2u * gridDim.x < a.total_subtiles) {
+                    if (a.ticket_ahead && t + ((a.ticket_ahead - 1u) * gridDim.x >> 2) < a.total_subtiles) {
                         ticket = draw_ticket();
                         ticket_ahead = true;
                     }
@@ -1083,6 +1084,7 @@ struct vx_context {
     unsigned long long* d_timeline = nullptr;    // VX_TIMELINE=1: [8192][4], the last launch's waves (PersistentArgs::timeline)
     uint32_t timeline_waves = 0;
     uint32_t timeline_part = 0;   // VX_TIMELINE_PART
+    uint32_t ahead_guard = 2;     // VX_AHEAD_GUARD: quarter-grids of tickets at the end of a frame that are not drawn ahead
     int ticket_ahead = 1;         // VX_TICKET_AHEAD=0: waves draw a sub-tile's ticket when they need it (A/B)
     // the traversal image of the world (traversal_image.hpp), rebuilt for the changed chunks by every commit
     vximg::WorldImage image;
@@ -1373,7 +1375,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.excursions = ctx->d_excursions;
         a.timeline = ctx->d_timeline;
         a.timeline_part = ctx->timeline_part;
-        a.ticket_ahead = ctx->ticket_ahead != 0 ? 1u : 0u;
+        a.ticket_ahead = ctx->ticket_ahead != 0 ? 1u + ctx->ahead_guard : 0u;
         a.order = nullptr;
         a.cost_cur = nullptr;
         a.cur_tag = 0xfffffu;
@@ -1731,6 +1733,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
             if (std::atoi(e) != 0) CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_timeline), 8192 * 4 * sizeof(unsigned long long)));
         if (const char* e = std::getenv("VX_TIMELINE_PART")) c->timeline_part = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_TICKET_AHEAD")) c->ticket_ahead = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("VX_AHEAD_GUARD")) c->ahead_guard = uint32_t(std::max(0, std::min(64, std::atoi(e))));
         if (const char* e = std::getenv("VX_IMAGE_CAP_BYTES")) c->image_cap_bytes = size_t(std::strtoull(e, nullptr, 10));
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)
