@@ -27,6 +27,7 @@ extern unsigned char* vx_smem;
 
 inline uint32_t bit_at(uint32_t v, int pos) { return (v >> pos) & 1u; }
 inline void sched_fence() {}
+inline float sky_acos(float x) { return acosf(x); }
 inline float gmin3(float x, float y, float z) { float m = y < x ? y : x; return z < m ? z : m; }
 inline float gmax3(float x, float y, float z) { float m = x < y ? y : x; return m < z ? z : m; }
 inline float glsl_pow(float x, float y) { return powf(x, y); }

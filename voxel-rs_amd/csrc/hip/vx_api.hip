@@ -320,14 +320,16 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle || (FOREIGN == VX_SVO_CSVO && state == kForeign))));
         // the loop goes on while more than this many lanes traverse (64 - popcount(trav) < park_limit, and trav != 0)
         const uint32_t keep_going = park_limit >= 64u ? 0u : 64u - park_limit;
+        // (the lanes that traverse, as the wave's mask: one compare per trip serves the loop's exit test and the next trip's execution mask)
+        unsigned long long trav = __ballot(tr.iter < uint32_t(kMaxSteps));
         for (;;) {
-            if (tr.iter < uint32_t(kMaxSteps)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
+            if (__builtin_amdgcn_inverse_ballot_w64(trav)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
                 tr.template step_with<false, STATS, false, FastStack, false, FOREIGN != 0>(sc, fast_st, nullptr, STATS ? &ctr : nullptr, [&](TravStatus s) {
                     state = LaneState(s);
                     tr.iter = (s == kTravDeep || s == kTravForeign ? tr.iter - 1 : tr.iter) | kParked;  // a handed-over iteration is counted by the step that repeats it
                 });
             }
-            const unsigned long long trav = __ballot(tr.iter < uint32_t(kMaxSteps));
+            trav = __ballot(tr.iter < uint32_t(kMaxSteps));
             if (STATS) {
                 ++wave_steps;
                 if (queue_empty) { ++tail_wave_steps; tail_iterations += uint32_t(__popcll(trav)); }

@@ -1157,7 +1157,7 @@ __device__ __forceinline__ void sky_color(const float rd[3], float out[3]) {
     float p[3];
     normalize3(flat, p);
     // argument clamped like the oracle does: the reference's expected image has no undefined (acos(1+)) horizon pixels
-    const float a = acosf(gclamp(dot3(rd, p) / fabsf(sqrtf(dot3(rd, rd))) * fabsf(sqrtf(dot3(p, p))), -1.0f, 1.0f));
+    const float a = sky_acos(gclamp(dot3(rd, p) / fabsf(sqrtf(dot3(rd, rd))) * fabsf(sqrtf(dot3(p, p))), -1.0f, 1.0f));
     float grad = a / 1.570796f;
     const float g1 = 1.0f - grad;
     grad = 1.0f - g1 * g1 * g1;  // pow(x, 3.0): two multiplications are within an ulp of any pow() and an order of magnitude cheaper

@@ -66,4 +66,21 @@ __device__ __forceinline__ float gmax3(float x, float y, float z) {
 // of the ~170 of a correctly rounded powf. Colour only (the specular term), inside the stated colour tolerance.
 __device__ __forceinline__ float glsl_pow(float x, float y) { return y == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 
+// acos() for the sky's gradient (colour only): Abramowitz & Stegun 4.4.46, sqrt(1 - |x|) times a degree-7 polynomial, absolute error below
+// 2e-8 + rounding (measured against a double-precision acos on 16 M points of [-1, 1]: 4.3e-7 rad, i.e. below 5e-7 in the colour), a quarter of the instructions of the library's
+// correctly rounded acosf. x in [-1, 1].
+__device__ __forceinline__ float sky_acos(float x) {
+    const float a = __builtin_fabsf(x);
+    float p = -0.0012624911f;
+    p = __builtin_fmaf(p, a, 0.0066700901f);
+    p = __builtin_fmaf(p, a, -0.0170881256f);
+    p = __builtin_fmaf(p, a, 0.0308918810f);
+    p = __builtin_fmaf(p, a, -0.0501743046f);
+    p = __builtin_fmaf(p, a, 0.0889789874f);
+    p = __builtin_fmaf(p, a, -0.2145988016f);
+    p = __builtin_fmaf(p, a, 1.5707963050f);
+    const float r = __builtin_sqrtf(1.0f - a) * p;
+    return x < 0.0f ? 3.14159265358979f - r : r;
+}
+
 }  // namespace vxd
