@@ -240,7 +240,7 @@ int vx_sync(vx_context* ctx);
  * vx_sync waits for everything; vx_commit orders uploads after every frame in flight (Svo::update's fence, svo.rs:178). */
 /* 1 = every render on the context's stream again; 2 (default) .. 8 = that many frame streams in rotation. More frames in
  * flight hide more of each frame's tail, which matters when a context renders only a share of the tiles (multi-GPU:
- * an eighth of a 1080p frame takes 0.41 ms per frame with 1, 0.17 ms with 3, 0.11 ms with 8 frames in flight). */
+ * an eighth of a 1080p frame takes 0.24 ms per frame with 1, 0.085 ms with 3, 0.068 ms with 4 or more frames in flight). */
 int vx_set_frames_in_flight(vx_context* ctx, int frames);
 int vx_wait_event(vx_context* ctx, void* hip_event);
 int vx_stream_wait_render(vx_context* ctx, void* stream);
