@@ -136,7 +136,7 @@ struct PersistentArgs {
     // end before its longest rays do (up to ~300 iterations against a mean of ~30): handed out in screen order they start in mid-frame
     // and the frame ends with a long tail of waves that wait for a few of them (profiles/timeline.py). So every ray that ends notes
     // its iteration count in its sub-tile's entry of `cost_cur` (atomic max), a small kernel behind the frame sorts the sub-tiles into
-    // eight cost classes, most expensive first, screen order within a class (order_kernel), and the NEXT frame of the same view on this
+    // sixteen cost classes, most expensive first, screen order within a class (order_kernel), and the NEXT frame of the same view on this
     // stream draws its tickets through that table: `order` (null: screen order). Order only: no pixel's value depends on it.
     const uint32_t* order;          // [total_subtiles] sub-tile ids, or null
     uint32_t* cost_cur;             // [total_subtiles] tag << 12 | iterations of the sub-tile's longest ray this frame; null = do not note
@@ -906,35 +906,36 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneArgs sa, TraceArgs a, vx
     *n_frames = tk.n_frames;
 }
 
-// Sorts a frame's sub-tiles for the next frame's queue (PersistentArgs::order): eight classes by the iteration count of the sub-tile's
-// longest ray (class = min(7, iterations / 32); entries without this frame's tag are class 0), the highest class first, screen
+// Sorts a frame's sub-tiles for the next frame's queue (PersistentArgs::order): sixteen classes by the iteration count of the sub-tile's
+// longest ray (class = min(15, iterations / 16); entries without this frame's tag are class 0), the highest class first, screen
 // order within a class (a stable counting sort: the rays of neighbouring sub-tiles walk the same nodes). Four waves, each with a
 // contiguous quarter of the sub-tiles, 64 at a time: a lane's place inside its class is a ballot and a popcount. Small on purpose --
 // it runs behind a frame whose successor on the other streams fills the device: four wave slots are free long before a whole CU is.
+constexpr uint32_t kCostClasses = 16, kCostStep = 16;  // classes of the order table: iterations / kCostStep, capped
 __global__ __launch_bounds__(256) void order_kernel(const uint32_t* __restrict__ cost, uint32_t tag, uint32_t n, uint32_t* __restrict__ order) {
-    __shared__ uint32_t totals[4][8];  // [wave][slot], slot 0 = the most expensive class
+    __shared__ uint32_t totals[4][kCostClasses];  // [wave][slot], slot 0 = the most expensive class
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t blocks = (n + 63u) / 64u, per = (blocks + 3u) / 4u;
     const uint32_t first = wave * per < blocks ? wave * per : blocks, last = first + per < blocks ? first + per : blocks;
     auto slot_of = [&](uint32_t i) -> uint32_t {
-        if (i >= n) return 8u;  // (beyond the end: no class)
+        if (i >= n) return kCostClasses;  // (beyond the end: no class)
         const uint32_t c = cost[i];
-        const uint32_t cls = (c >> 12) == tag ? ((c & 0xfffu) / 32u < 7u ? (c & 0xfffu) / 32u : 7u) : 0u;
-        return 7u - cls;
+        const uint32_t cls = (c >> 12) == tag ? ((c & 0xfffu) / kCostStep < kCostClasses - 1u ? (c & 0xfffu) / kCostStep : kCostClasses - 1u) : 0u;
+        return kCostClasses - 1u - cls;
     };
-    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform
+    uint32_t mine[kCostClasses] = {};  // wave-uniform
     for (uint32_t b = first; b < last; ++b) {
         const uint32_t slot = slot_of(b * 64u + lane);
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) mine[k] += uint32_t(__popcll(__ballot(slot == k)));
+        for (uint32_t k = 0; k < kCostClasses; ++k) mine[k] += uint32_t(__popcll(__ballot(slot == k)));
     }
     if (lane == 0)
-        for (int k = 0; k < 8; ++k) totals[wave][k] = mine[k];
+        for (uint32_t k = 0; k < kCostClasses; ++k) totals[wave][k] = mine[k];
     __syncthreads();
     // where this wave's members of each class go: behind every more expensive class, and behind the same class of the waves before
-    uint32_t at[8];
+    uint32_t at[kCostClasses];
     uint32_t run = 0;
-    for (uint32_t k = 0; k < 8; ++k) {
+    for (uint32_t k = 0; k < kCostClasses; ++k) {
         for (uint32_t w = 0; w < 4; ++w) {
             if (w == wave) at[k] = run;
             run += totals[w][k];
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(256) void order_kernel(const uint32_t* __restrict__
         const uint32_t i = b * 64u + lane;
         const uint32_t slot = slot_of(i);
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
+        for (uint32_t k = 0; k < kCostClasses; ++k) {
             const unsigned long long m = __ballot(slot == k);
             if (slot == k) order[at[k] + uint32_t(__popcll(m & below))] = i;
             at[k] += uint32_t(__popcll(m));
