@@ -468,6 +468,38 @@ def test_pipelined_commits_under_frames_in_flight(hip, fmt):
 
 
 @pytest.mark.parametrize("fmt", FMTS)
+def test_image_sizes_around_the_queue_edges(hip, fmt):
+    """The sub-tile queue at its edges: images of one pixel, of less than a sub-tile, of exactly one tile, a pixel more than a tile, fewer
+    sub-tiles than waves and more, rendered one after the other on the same context (its two sets of ticket dispensers take turns
+    and clear each other), image-only and with hit records, one frame at a time and on the frame streams -- against the oracle."""
+    import torch
+    from voxel_rs_amd import scenes
+
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(7, threads=4)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+    for w, h in ((1, 1), (7, 3), (8, 8), (32, 32), (33, 33), (64, 8), (300, 260), (8, 200), (1, 1)):
+        u = scenes.bench_camera(7, st["h_max"], w, h)
+        cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
+        img, hits = svo.render(u, w, h, want_hits=True)
+        compare_frames(img, hits, cimg, chits)
+        img2, _ = svo.render(u, w, h)  # image-only kernel, the context's own stream
+        assert img2.tobytes() == img.tobytes()
+        out = torch.zeros((3, h, w, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        for k in range(3):  # frame streams, frames in flight
+            svo.render_device(u, w, h, out[k].data_ptr())
+        svo.sync()
+        for k in range(3):
+            assert out[k].cpu().numpy().tobytes() == img.tobytes(), (w, h, k)
+
+
+@pytest.mark.parametrize("fmt", FMTS)
 def test_tile_sharded_render_matches_full(hip, fmt):
     import ctypes as C
 
