@@ -183,7 +183,7 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
 }
 
 constexpr uint32_t kQueues = 8, kQueueStride = 64;  // dispensers of the sub-tile queue, words between them
-constexpr uint32_t kCostFloor = 32;  // rays that end sooner (the mean is about 30) leave their sub-tile in the cheapest class: no note
+constexpr uint32_t kCostFloor = 64;  // rays that end sooner (the mean is about 30; one in eight gets here) leave their sub-tile in the cheapest class: no note
 
 // the sub-tile (8x8 pixels: the unit of the queue) a pixel's output index lies in
 __device__ __forceinline__ uint32_t subtile_of(const RenderParams& p, uint32_t out_index) {
