@@ -11,9 +11,9 @@ out = {"_comment": "HBM-side traffic of the render kernel per launch (C3 workloa
                    "rocprofv3 --pmc passes (profiles/round2/profile_r2.sh; summaries next to this file). FETCH_SIZE/WRITE_SIZE are in KB (x 1024); no gfx950 "
                    "doubling applied: the reads are scattered 8-byte gathers (TCC_EA0_RDREQ x 64 B agrees with FETCH_SIZE within 3 %), an access width "
                    "MI355X_MICROARCH.md calls uncalibrated. WRITE_SIZE against 33.2 MB of RGBA32F pixels, image of an ESVO world: 48.6 MB from the pixel "
-                   "stores (16-byte stores of lanes that finish at different times write partial lines) + 46 MB from the cost notes of 'expensive "
-                   "sub-tiles first' (one atomic max per ray of 32 iterations and more: atomics are carried out at the memory side, 32 bytes each; "
-                   "profiles/round2/run_p.sh: VX_HOT_FIRST=0 48.6 MB, =2 95.1 MB); the kernel for the image of a CSVO world (the build that lists its "
+                   "stores (16-byte stores of lanes that finish at different times write partial lines) + 12 MB from the cost notes of 'expensive "
+                   "sub-tiles first' (one atomic max per ray of 64 iterations and more: atomics are carried out at the memory side, 32 bytes each; "
+                   "with the floor at 32 iterations they were 46 MB -- profiles/round2/run_p.sh: VX_HOT_FIRST=0 48.6 MB, =2 95.1 MB); the kernel for the image of a CSVO world (the build that lists its "
                    "inside-voxel rays) keeps a few registers in scratch in its service phases: the rest of its reads and writes.",
        "commit": sys.argv[1] if len(sys.argv) > 1 else "?"}
 for fmt in ("csvo", "esvo"):
