@@ -1117,6 +1117,7 @@ struct vx_context {
     uint32_t refill_min = 4, service_min = 32, foreign_min = 32;
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
+    int comm_headroom = 4;                // VX_COMM_HEADROOM: wave slots per CU a context with a communicator of more than one rank leaves free (LDS for RCCL's kernels)
     int cu_count = 256;
     std::unordered_map<const void*, int> persistent_blocks;  // kernel -> resident 64-thread workgroups per CU, queried once
 
@@ -1430,7 +1431,14 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             a.cur_tag = hs->tag;
             hs->width = p.width; hs->height = p.height; hs->tile_rank = p.tile_rank; hs->tile_count = p.tile_count;
         }
-        uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu ? ctx->waves_per_cu_cap : per_cu);
+        // Persistent waves per CU: all that fit -- the stacks fill a CU's LDS to the last hundred bytes. A context that gathers its tiles over
+        // RCCL leaves `comm_headroom` (4) of them out: 40 KB of every CU's LDS stay free, in one piece, for the communication kernels'
+        // workgroups, which otherwise find room only when a whole frame has drained (measured cost of twelve waves instead of sixteen: 8 %
+        // of a rank's render rate; the gather itself could not be measured here -- one GPU per box).
+        int per_cu_used = per_cu;
+        if (ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu) per_cu_used = ctx->waves_per_cu_cap;
+        else if (ctx->comm_ranks > 1 && ctx->comm_headroom > 0 && per_cu > ctx->comm_headroom + 4) per_cu_used = per_cu - ctx->comm_headroom;
+        uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(per_cu_used);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
         if (waves > 8192) a.timeline = nullptr;
         ctx->timeline_waves = a.timeline ? waves : 0;
@@ -1744,6 +1752,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_WIDE_IMAGE")) wide_image = std::atoi(e);
         c->image = vximg::WorldImage(svo_type, wide_image ? vximg::kOct64Wide : vximg::kOct64, wide_image == 2 ? (uint64_t(5) << 30) / 4 : 0);
         if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
+        if (const char* e = std::getenv("VX_COMM_HEADROOM")) c->comm_headroom = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_FOREIGN_MIN")) c->foreign_min = uint32_t(std::max(1, std::min(64, std::atoi(e))));
