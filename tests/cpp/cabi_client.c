@@ -120,6 +120,18 @@ int main(void) {
     const uint8_t* same_pixel = px + (size_t)(H - 1) * W * 4; /* RGBA8 image: row H-1 = bottom */
     for (int c = 0; c < 4; ++c) CHECK(same_pixel[c] == (uint8_t)(fminf(fmaxf(bottom_left[c], 0.0f), 1.0f) * 255.0f + 0.5f));
 
+    /* pipelined commits (what svo_hip.rs switches on): the same world committed again through the worker thread; the frame is the same */
+    CHECK(vx_set_commit_mode(ctx, 7) == VX_ERR_INVALID_ARGUMENT);
+    CHECK(vx_set_commit_mode(ctx, VX_COMMIT_PIPELINED) == VX_OK);
+    CHECK(vx_staging_ptr(ctx) != NULL);
+    CHECK(vx_commit_all(ctx, 2, frame_bytes - 20) == VX_OK); /* posted */
+    CHECK(vx_commit_wait(ctx) == VX_OK);                     /* queued on the device */
+    static float image2[W * H * 4];
+    vx_target target2 = {image2, NULL, VX_MEM_HOST, 0, 1, VX_FORMAT_RGBA32F};
+    CHECK(vx_render(ctx, &u, W, H, &target2) == VX_OK);
+    CHECK(memcmp(image, image2, sizeof image) == 0);
+    CHECK(vx_set_commit_mode(ctx, VX_COMMIT_INLINE) == VX_OK);
+
     CHECK(vx_sync(ctx) == VX_OK);
     vx_destroy(ctx);
     printf("cabi_client: ok (%zu of %d pixels hit the voxel)\n", hit_pixels, W * H);
