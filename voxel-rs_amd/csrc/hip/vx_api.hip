@@ -1953,6 +1953,11 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         std::vector<vximg::Range> changed(count);
         for (uint32_t i = 0; i < count; ++i) changed[i] = vximg::Range{ranges[i].start, ranges[i].length};
         const unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        // A world whose image will not fit 32-bit byte offsets starts in the wide layout instead of finding that out at the end of a whole
+        // build (an image is about 0.84 x the bytes of an ESVO world, 3.9 x those of a CSVO world; the wide layout serves any size)
+        if (ctx->image.chunk_count() == 0 && ctx->image.layout() == vximg::kOct64 &&
+            double(used_bytes) * (ctx->svo_type == VX_SVO_ESVO ? 0.95 : 4.4) >= 3.5 * double(1ull << 30))
+            ctx->image = vximg::WorldImage(ctx->svo_type, vximg::kOct64Wide);
         image_ok = ctx->image.update(ctx->staging, used_bytes, changed.data(), changed.size(), threads);
         if (!image_ok && ctx->image.too_big() && ctx->image.layout() == vximg::kOct64) {
             // past what 32-bit byte offsets reach: from here on octant indices (the image is rebuilt once, whole)
