@@ -28,12 +28,74 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <new>
+#include <sys/mman.h>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
 namespace vximg {
+
+// The image's words on the host: a growing array whose new part reads as zero WITHOUT being written -- anonymous pages, extended with
+// mremap. (A std::vector zero-fills what it grows by on the calling thread: 7 GB for the depth-14 terrain, two seconds of a whole-world
+// commit; here the kernel zeroes a page when one of the encoding threads first touches it.)
+class ZeroedWords {
+public:
+    ZeroedWords() = default;
+    ZeroedWords(const ZeroedWords& o) { *this = o; }
+    ZeroedWords(ZeroedWords&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+    ZeroedWords& operator=(const ZeroedWords& o) {
+        if (this != &o) {
+            clear();
+            resize(o.n_, 0u);
+            if (o.n_) std::memcpy(p_, o.p_, o.n_ * 4);
+        }
+        return *this;
+    }
+    ZeroedWords& operator=(ZeroedWords&& o) noexcept {
+        if (this != &o) {
+            clear();
+            p_ = o.p_; n_ = o.n_; cap_ = o.cap_;
+            o.p_ = nullptr; o.n_ = o.cap_ = 0;
+        }
+        return *this;
+    }
+    ~ZeroedWords() { clear(); }
+    const uint32_t* data() const { return p_; }
+    uint32_t* data() { return p_; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    uint32_t& operator[](size_t i) { return p_[i]; }
+    const uint32_t& operator[](size_t i) const { return p_[i]; }
+    void clear() {
+        if (p_) ::munmap(p_, cap_ * 4);
+        p_ = nullptr;
+        n_ = cap_ = 0;
+    }
+    void assign(size_t n, uint32_t /*zero*/) {
+        clear();
+        resize(n, 0u);
+    }
+    // grows only (the image never shrinks between clear()s); the value is always zero
+    void resize(size_t n, uint32_t /*zero*/) {
+        if (n <= n_) return;
+        if (n > cap_) {
+            size_t want = std::max(n, cap_ + cap_ / 2);
+            want = (want * 4 + 4095) / 4096 * 4096 / 4;  // whole pages
+            void* q = p_ ? ::mremap(p_, cap_ * 4, want * 4, MREMAP_MAYMOVE) : ::mmap(nullptr, want * 4, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q == MAP_FAILED) throw std::bad_alloc();
+            p_ = static_cast<uint32_t*>(q);
+            cap_ = want;
+        }
+        n_ = n;
+    }
+
+private:
+    uint32_t* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;  // words
+};
+
 
 enum Layout : int { kEsvo48 = 0, kOct64 = 1, kOct64Wide = 2 };
 
@@ -360,7 +422,7 @@ public:
         : esvo_(svo_type == 1), layout_(layout), first_word_(first_word) {}
 
     // host mirror of the image frame, as 32-bit words
-    const std::vector<uint32_t>& frame() const { return frame_; }
+    const ZeroedWords& frame() const { return frame_; }
     uint64_t frame_bytes() const { return frame_.size() * 4; }
     // byte ranges of frame() changed by the last update(), sorted and merged
     std::vector<Range> dirty_bytes() const {
@@ -379,7 +441,7 @@ public:
     // CSVO worlds in the kOct64 layouts: the origin table, two words per 32-byte unit of the frame (a quarter of its size). For
     // the unit a voxel-parent octant starts at: where that leaf-mask byte is in the world's own bytes (Octant::origin). The
     // renderer reads it when a ray is led into a voxel (vx_device.hpp, enter_voxel_on_bytes). Its dirty ranges are the frame's / 4.
-    const std::vector<uint32_t>& origin() const { return origin_; }
+    const ZeroedWords& origin() const { return origin_; }
     uint64_t origin_bytes() const { return origin_.size() * 4; }
     bool has_origin() const { return !esvo_ && layout_ != kEsvo48; }
     size_t chunk_count() const { return chunks_.size(); }
@@ -652,8 +714,8 @@ private:
     bool esvo_;
     Layout layout_;
     uint64_t first_word_;
-    std::vector<uint32_t> frame_;
-    std::vector<uint32_t> origin_;
+    ZeroedWords frame_;
+    ZeroedWords origin_;
     std::vector<Range> dirty_;
     WordAllocator alloc_;
     std::unordered_map<uint32_t, Placed> chunks_;

@@ -2569,9 +2569,9 @@ uint64_t vx_traversal_image_with_origin(int svo_type, const uint8_t* world_frame
     if (!world_frame || layout < 0 || layout > 2 || (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO)) return 0;
     vximg::WorldImage img(svo_type, layout == 0 ? vximg::kEsvo48 : (layout == 1 ? vximg::kOct64 : vximg::kOct64Wide));
     if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(16u, std::thread::hardware_concurrency())))) return 0;
-    const std::vector<uint32_t>& f = img.frame();
+    const vximg::ZeroedWords& f = img.frame();
     if (out_words && capacity_words >= f.size()) std::memcpy(out_words, f.data(), f.size() * 4);
-    const std::vector<uint32_t>& o = img.origin();
+    const vximg::ZeroedWords& o = img.origin();
     if (out_origin_words && origin_capacity_words >= o.size() && !o.empty()) std::memcpy(out_origin_words, o.data(), o.size() * 4);
     return f.size();
 }

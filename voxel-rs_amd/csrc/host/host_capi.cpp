@@ -348,7 +348,7 @@ int vxh_stream_mirror_image(void* sp, uint64_t capacity, int layout) {
 uint64_t vxh_stream_image(void* sp, uint32_t* dst, uint64_t cap_words) {
     Streamer* s = static_cast<Streamer*>(sp);
     if (!s->image || !s->image_ok) return 0;
-    const std::vector<uint32_t>& f = s->image->frame();
+    const vximg::ZeroedWords& f = s->image->frame();
     if (dst && cap_words >= f.size()) std::memcpy(dst, f.data(), f.size() * 4);
     return f.size();
 }
