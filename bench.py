@@ -127,7 +127,7 @@ def main():
     world = vra.World(fmt)
     st = world.build_heightfield(args.depth)
     build_s = time.time() - t0
-    tex = scenes.asset_textures() if args.textures == "assets" else scenes.synthetic_textures()
+    tex = scenes.asset_textures(ROOT / "tests" / "golden" / "textures") if args.textures == "assets" else scenes.synthetic_textures()
     mats = scenes.synthetic_materials()
     svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20), device=local_rank)
     svo.set_materials(mats)

@@ -326,8 +326,10 @@ int vx_profile_enable(vx_context* ctx, int enabled);
 /* Sum of the bracketed kernel durations (ms) and their count since the last call; synchronises. */
 int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches);
 /* Measurement (contexts created with VX_TIMELINE=1 in the environment; else returns 0): per wave of the most recent render launch
- * four words -- when it started, when it found the sub-tile queue empty, when it left (all in 10 ns ticks of the device's constant
- * clock) and how many sub-tiles it took. Returns the number of waves copied. Waits for every frame in flight. */
+ * EIGHT words -- [0] when it started, [1] when it found the sub-tile queue empty, [2] when it left (all in 10 ns ticks of the device's
+ * constant clock), [3] sub-tiles taken | service phases << 20 | ticks spent in them << 32, [4] its life in shader-clock cycles
+ * (s_memtime: [4] / ([2] - [0]) x 100 MHz is the clock the kernel ran at), [5] the cycles of it spent in the traversal loop, [6] the
+ * loop's trips, [7] 0. `out` holds capacity_waves x 8 words. Returns the number of waves copied. Waits for every frame in flight. */
 uint32_t vx_timeline_read(vx_context* ctx, uint64_t* out, uint32_t capacity_waves);
 /* What vx_render walks after the last commit: [0] 0 = the world's own bytes (no image: switched off, or the world cannot be
  * imaged), 1 = the traversal image with byte offsets, 2 = its layout for more than 4 GiB (32-byte units behind a 64-bit pointer);

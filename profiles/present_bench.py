@@ -32,7 +32,7 @@ def main():
     st = world.build_heightfield(depth)
     svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20))
     svo.set_materials(scenes.synthetic_materials())
-    svo.set_textures(scenes.asset_textures(), 6)
+    svo.set_textures(scenes.asset_textures(ROOT / "tests" / "golden" / "textures"), 6)
     svo.update(world)
     u = scenes.bench_camera(depth, st["h_max"], W, H, shadow_distance=3.0e38, render_shadows=True)
     out = {"workload": f"C3 frame to host memory every frame, {args.format.upper()}", "frames": args.frames}

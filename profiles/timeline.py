@@ -37,7 +37,7 @@ def main():
     st = world.build_heightfield(args.depth)
     svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20))
     svo.set_materials(scenes.synthetic_materials())
-    svo.set_textures(scenes.asset_textures(), 6)
+    svo.set_textures(scenes.asset_textures(ROOT / "tests" / "golden" / "textures"), 6)
     svo.update(world)
     svo.set_frames_in_flight(1)
     u = scenes.bench_camera(args.depth, st["h_max"], W, H, shadow_distance=3.0e38, render_shadows=True)
@@ -59,7 +59,14 @@ def main():
                       "service_phases_per_wave": q((t[:, 3].astype(np.uint64) >> np.uint64(20)) & np.uint64(0xfff)),
                       "us_in_service_phases_per_wave": q((t[:, 3].astype(np.uint64) >> np.uint64(32)).astype(np.float64) / 100.0), "kernel_us": round(float(leave.max()), 1),
                       "kernel_us_by_events_mean_of_launches": round(ms / max(launches, 1) * 1e3, 1),
-                      "mean_wave_lifetime_us": round(float((leave - start).mean()), 1)}))
+                      "mean_wave_lifetime_us": round(float((leave - start).mean()), 1),
+                      # shader-clock stamps: the clock the kernel ran at, and what a trip of the traversal loop costs the wave that makes it
+                      "clock_mhz": q(t[:, 4] / np.maximum(t[:, 2] - t[:, 0], 1.0) * 100.0),
+                      "loop_share_of_wave_life": q(t[:, 5] / np.maximum(t[:, 4], 1.0)),
+                      "loop_trips_per_wave": q(t[:, 6]),
+                      "cycles_per_trip_as_a_wave_sees_it": q(t[:, 5] / np.maximum(t[:, 6], 1.0)),
+                      "cycles_per_trip_mean": round(float(t[:, 5].sum() / max(t[:, 6].sum(), 1.0)), 1),
+                      "simd_cycles_per_trip_at_4_waves": round(float(t[:, 5].sum() / max(t[:, 6].sum(), 1.0)) / 4.0, 1)}))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,266 @@
+// What does a wave64 VALU instruction cost on gfx950 when 1, 2, 3 or 4 waves share a SIMD?  (DESIGN.md priced one at
+// 4 cycles; MI355X_MICROARCH.md says 2 per SIMD, 4 only for one wave alone.)
+//
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue profiles/tools/valu_issue.hip && /tmp/valu_issue
+//
+// Every CU gets W x 4 single-wave workgroups (dynamic LDS sized so that no more fit), each wave runs `iters` trips of an unrolled body
+// and stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around the loop. Reported per body and W:
+//   cycles per wave-instruction as one wave sees it (its own latency), the same divided by the waves that share the SIMD (what the
+//   SIMD pays per instruction = the issue cost), and the clock the loop ran at.
+// Bodies:  fma_indep  32 v_fma_f32 on 8 independent accumulators        fma_chain  32 dependent v_fma_f32
+//          cmp_sel    v_cmp_*_e64 -> SGPR pair -> v_cndmask_e64 pairs   pk_fma     16 v_pk_fma_f32 (independent)
+//          hot_mix    one trip of render_persistent's traversal loop as the compiler lays it out (profiles/tools/hot_loop.py): 81 VALU
+//                     (compares into SGPR pairs, selects, bit-field extracts, fma / pk_fma, min3, moves), 43 SALU (mask algebra,
+//                     saveexec / restore, not-taken forward branches, one taken back edge) -- without its load and LDS accesses
+//          hot_mix_ld the same with the trip's one 8-byte buffer load (L1/L2 resident, requested at the top, waited for at the end) and
+//                     its LDS read pair
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+extern __shared__ unsigned char smem[];
+
+#define R4(x) x x x x
+#define R8(x) R4(x) R4(x)
+
+// one trip of the traversal loop, instruction kinds and dependences as in the compiler's layout (v20-v47 / s[40:55] are scratch)
+#define HOT_TRIP_HEAD                                                                   \
+    "v_cmp_gt_u32_e64 s[40:41], s56, v23\n"                                             \
+    "s_bcnt1_i32_b64 s42, s[40:41]\n"                                                   \
+    "s_cmp_lt_u32 s57, s42\n"                                                           \
+    "s_cbranch_scc0 1f\n"                                                               \
+    "s_and_saveexec_b64 s[44:45], exec\n"                                               \
+    "s_cbranch_execz 1f\n"                                                              \
+    "v_bfe_u32 v20, v30, v31, 1\n"                                                      \
+    "v_bfe_u32 v21, v32, v31, 1\n"
+#define HOT_TRIP_LOAD "v_lshl_add_u32 v28, v22, 3, v29\n buffer_load_dwordx2 v[48:49], v28, %[rsrc], 0 offen\n"
+#define HOT_TRIP_BODY                                                                   \
+    "v_lshlrev_b32_e32 v22, 1, v20\n"                                                   \
+    "v_bfe_u32 v20, v33, v31, 1\n"                                                      \
+    "v_lshl_or_b32 v21, v20, 2, v21\n"                                                  \
+    "v_xor_b32_e32 v22, v21, v22\n"                                                     \
+    "v_and_b32_e32 v22, 7, v22\n"                                                       \
+    "v_lshlrev_b32_e32 v21, v22, v34\n"                                                 \
+    "v_cmp_gt_i32_e32 vcc, 0, v21\n"                                                    \
+    "v_and_b32_e32 v21, 0x800000, v21\n"                                                \
+    "v_cmp_le_f32_e64 s[46:47], v35, v36\n"                                             \
+    "v_cmp_ne_u32_e64 s[48:49], 0, v21\n"                                               \
+    "s_and_b64 vcc, vcc, s[46:47]\n"                                                    \
+    "s_and_b64 s[46:47], s[48:49], vcc\n"                                               \
+    "s_xor_b64 s[50:51], s[46:47], -1\n"                                                \
+    "v_cmp_nlt_f32_e64 s[46:47], 0, v35\n"                                              \
+    "v_add_u32_e32 v23, 1, v23\n"                                                       \
+    "v_fma_f32 v24, v30, v37, -v38\n"                                                   \
+    "v_pk_fma_f32 v[26:27], v[32:33], v[40:41], v[42:43] neg_lo:[0,0,1] neg_hi:[0,0,1]\n" \
+    "s_or_b64 s[46:47], s[50:51], s[46:47]\n"                                           \
+    "v_min3_f32 v25, v24, v26, v27\n"                                                   \
+    "s_and_saveexec_b64 s[50:51], exec\n"                                               \
+    "s_xor_b64 s[50:51], exec, s[50:51]\n"                                              \
+    "s_cbranch_execz 1f\n"                                                              \
+    "v_cmp_lt_f32_e64 s[46:47], v25, v36\n"                                             \
+    "s_xor_b64 s[52:53], vcc, -1\n"                                                     \
+    "s_mov_b64 s[54:55], 0\n"                                                           \
+    "v_cndmask_b32_e64 v44, v36, v25, s[46:47]\n"                                       \
+    "v_cmp_nle_f32_e64 s[46:47], v35, v44\n"                                            \
+    "s_or_b64 s[46:47], s[52:53], s[46:47]\n"                                           \
+    "s_and_saveexec_b64 s[52:53], exec\n"                                               \
+    "s_xor_b64 s[52:53], exec, s[52:53]\n"                                              \
+    "s_cbranch_execz 1f\n"                                                              \
+    /* ADVANCE */                                                                       \
+    "v_cmp_ge_f32_e64 s[46:47], v25, v24\n"                                             \
+    "s_mov_b64 s[54:55], -1\n"                                                          \
+    "v_mov_b32_e32 v45, v29\n"                                                          \
+    "v_cndmask_b32_e64 v20, 0, v39, s[46:47]\n"                                         \
+    "v_cmp_ge_f32_e64 s[46:47], v25, v27\n"                                             \
+    "v_sub_f32_e32 v30, v30, v20\n"                                                     \
+    "v_add_f32_e32 v20, v20, v30\n"                                                     \
+    "v_cndmask_b32_e64 v27, 0, v39, s[46:47]\n"                                         \
+    "v_cmp_ge_f32_e64 s[46:47], v25, v26\n"                                             \
+    "v_xor_b32_e32 v20, v20, v30\n"                                                     \
+    "v_mov_b32_e32 v46, v34\n"                                                          \
+    "v_cndmask_b32_e64 v26, 0, v39, s[46:47]\n"                                         \
+    "v_pk_add_f32 v[32:33], v[32:33], v[26:27] neg_lo:[0,1] neg_hi:[0,1]\n"             \
+    "s_nop 0\n"                                                                         \
+    "v_pk_add_f32 v[26:27], v[26:27], v[32:33]\n"                                       \
+    "s_nop 0\n"                                                                         \
+    "v_xor_b32_e32 v27, v27, v33\n"                                                     \
+    "v_xor_b32_e32 v26, v26, v32\n"                                                     \
+    "v_or3_b32 v26, v20, v26, v27\n"                                                    \
+    "v_lshlrev_b32_e64 v20, v31, 2\n"                                                   \
+    "v_cmp_ge_u32_e64 s[46:47], v26, v20\n"                                             \
+    "v_mov_b32_e32 v20, v39\n"                                                          \
+    "s_and_saveexec_b64 s[46:47], exec\n"                                               \
+    "s_cbranch_execz 1f\n"                                                              \
+    /* POP */                                                                           \
+    "v_ffbh_u32_e32 v26, v26\n"                                                         \
+    "v_xor_b32_e32 v47, 31, v26\n"                                                      \
+    "v_cmp_lt_u32_e64 s[48:49], 22, v47\n"                                              \
+    "s_and_saveexec_b64 s[48:49], exec\n"                                               \
+    "s_xor_b64 s[48:49], exec, s[48:49]\n"                                              \
+    "v_or_b32_e32 v44, 0x80000000, v23\n"                                               \
+    "s_or_saveexec_b64 s[48:49], s[48:49]\n"                                            \
+    "s_mov_b64 s[48:49], 0\n"                                                           \
+    "v_mov_b32_e32 v20, v39\n"                                                          \
+    "s_or_b64 exec, exec, s[48:49]\n"                                                   \
+    "s_cbranch_execz 1f\n"                                                              \
+    "v_lshlrev_b32_e32 v20, 23, v26\n"                                                  \
+    "v_lshl_add_u32 v26, v47, 8, v28\n"
+#define HOT_TRIP_LDS "ds_read2st64_b32 v[50:51], v52 offset1:13\n ds_read_b32 v53, v52 offset:6656\n"
+#define HOT_TRIP_TAIL                                                                   \
+    "v_lshlrev_b32_e64 v26, v47, -1\n"                                                  \
+    "s_mov_b64 s[48:49], exec\n"                                                        \
+    "v_sub_u32_e32 v20, 0x43800000, v20\n"                                              \
+    "v_and_b32_e32 v30, v26, v30\n"                                                     \
+    "v_and_b32_e32 v33, v26, v33\n"                                                     \
+    "v_and_b32_e32 v32, v26, v32\n"                                                     \
+    "v_mov_b32_e32 v44, 0\n"                                                            \
+    "v_or_b32_e32 v30, 0x3f800000, v30\n v_or_b32_e32 v32, 0x3f800000, v32\n v_or_b32_e32 v33, 0x3f800000, v33\n" /* (keeps the model's floats in [1, 2)) */ \
+    "s_orn2_b64 s[48:49], s[48:49], exec\n"                                             \
+    "s_or_b64 exec, exec, s[46:47]\n"                                                   \
+    "s_and_b64 s[46:47], s[48:49], exec\n"                                              \
+    "s_or_saveexec_b64 s[52:53], s[52:53]\n"                                            \
+    "v_mov_b32_e32 v45, v25\n"                                                          \
+    "s_or_b64 exec, exec, s[52:53]\n"                                                   \
+    /* PUSH (laid out behind the loop by the compiler; 16 VALU) */                      \
+    "v_mul_f32_e32 v20, 0.5, v39\n"                                                     \
+    "v_fma_f32 v21, v20, v37, v24\n"                                                    \
+    "v_pk_fma_f32 v[26:27], v[20:21], v[40:41], v[26:27]\n"                             \
+    "v_cmp_lt_f32_e64 s[46:47], v35, v21\n"                                             \
+    "v_cndmask_b32_e64 v21, 0, v20, s[46:47]\n"                                         \
+    "v_cmp_lt_f32_e64 s[46:47], v35, v26\n"                                             \
+    "v_cndmask_b32_e64 v26, 0, v20, s[46:47]\n"                                         \
+    "v_cmp_lt_f32_e64 s[46:47], v35, v27\n"                                             \
+    "v_cndmask_b32_e64 v27, 0, v20, s[46:47]\n"                                         \
+    "v_mov_b32_e32 v46, v25\n"                                                          \
+    "v_add_u32_e32 v47, -1, v31\n"                                                      \
+    "v_mov_b32_e32 v36, v44\n"                                                          \
+    "v_cmp_lt_f32_e64 s[46:47], v25, v45\n"                                             \
+    "s_and_saveexec_b64 s[46:47], exec\n"                                               \
+    "s_or_b64 exec, exec, s[46:47]\n"                                                   \
+    "v_mov_b32_e32 v20, 4\n"                                                            \
+    "s_and_saveexec_b64 s[52:53], exec\n"                                               \
+    "s_cbranch_execz 1f\n"                                                              \
+    "v_cmp_lt_f32_e64 s[46:47], v20, v39\n"
+#define HOT_TRIP_WAIT "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+#define HOT_TRIP_END                                                                    \
+    "v_cndmask_b32_e64 v44, v49, 0, s[40:41]\n"                                         \
+    "v_mov_b32_e32 v20, v45\n"                                                          \
+    "v_cndmask_b32_e64 v29, v45, v48, s[46:47]\n"                                       \
+    "v_cndmask_b32_e64 v34, v46, v44, s[46:47]\n"                                       \
+    "v_and_b32_e32 v29, 0xff8, v29\n v_or_b32_e32 v34, 0x80808080, v34\n v_and_b32_e32 v31, 15, v47\n" /* (model: addresses stay inside the buffer) */ \
+    "v_mov_b32_e32 v23, v44\n v_mov_b32_e32 v23, 0\n"                                   \
+    "s_or_b64 exec, exec, s[52:53]\n"                                                   \
+    "s_or_b64 exec, exec, s[50:51]\n"                                                   \
+    "s_or_b64 exec, exec, s[44:45]\n"                                                   \
+    "1:\n"
+
+#define HOT_CLOBBERS "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", \
+                     "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "s40", "s41", "s42", "s43", "s44", \
+                     "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "vcc", "scc", "memory"
+
+enum { kFmaIndep, kFmaChain, kCmpSel, kPkFma, kHotMix, kHotMixLd, kModes };
+static const char* kNames[kModes] = {"fma_indep", "fma_chain", "cmp_sel", "pk_fma", "hot_mix", "hot_mix_ld"};
+// wave-instructions per trip of the body: VALU, all (VALU + SALU + memory; waits and nops not counted)
+// (hot_mix: counted in the compiler's output of this file -- 81 VALU, 40 SALU + the loop's own 3; hot_mix_ld: one more VALU for the address, 3 memory instructions)
+static const int kValu[kModes] = {32, 32, 32, 16, 81, 82};
+static const int kAll[kModes] = {32, 32, 32, 16, 81 + 43, 82 + 43 + 3};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void body(unsigned long long* out, const uint32_t* buf, uint32_t buf_bytes, int iters) {
+    float a0 = threadIdx.x * 1e-3f + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const float c = 0.999f, d = 1e-3f;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(buf), 0, int(buf_bytes), 0x00020000);
+    if (MODE == kHotMix || MODE == kHotMixLd) {
+        // the model's registers: positions in [1, 2), a scale, masks, ray constants
+        asm volatile("v_mov_b32 v30, 0x3fc00000\n v_mov_b32 v32, 0x3fa00000\n v_mov_b32 v33, 0x3f900000\n v_mov_b32 v31, 12\n v_mov_b32 v34, 0x80808080\n"
+                     "v_mov_b32 v35, 0.5\n v_mov_b32 v36, 2.0\n v_mov_b32 v37, -1.0\n v_mov_b32 v38, -4.0\n v_mov_b32 v39, 0x39800000\n"
+                     "v_mov_b32 v40, -1.0\n v_mov_b32 v41, -1.0\n v_mov_b32 v42, -4.0\n v_mov_b32 v43, -4.0\n v_mov_b32 v23, 0\n v_mov_b32 v29, 64\n"
+                     "v_lshlrev_b32 v52, 2, %0\n v_mov_b32 v48, 0\n v_mov_b32 v49, 0\n v_mov_b32 v22, 0\n v_mov_b32 v28, 0\n s_mov_b32 s56, 1000\n s_mov_b32 s57, 0\n"
+                     : : "v"(threadIdx.x) : HOT_CLOBBERS);
+    }
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+        if (MODE == kFmaIndep) {
+            asm volatile(R4("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                            "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));
+        } else if (MODE == kFmaChain) {
+            asm volatile(R8(R4("v_fma_f32 %0, %0, %1, %2\n")) : "+v"(a0) : "v"(c), "v"(d));
+        } else if (MODE == kCmpSel) {
+            asm volatile(R4("v_cmp_lt_f32_e64 s[40:41], %0, %8\n v_cndmask_b32_e64 %1, %1, %9, s[40:41]\n v_cmp_lt_f32_e64 s[42:43], %2, %8\n v_cndmask_b32_e64 %3, %3, %9, s[42:43]\n"
+                            "v_cmp_lt_f32_e64 s[44:45], %4, %8\n v_cndmask_b32_e64 %5, %5, %9, s[44:45]\n v_cmp_lt_f32_e64 s[46:47], %6, %8\n v_cndmask_b32_e64 %7, %7, %9, s[46:47]\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d)
+                         : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");
+        } else if (MODE == kPkFma) {
+            asm volatile(R4("v_pk_fma_f32 v[20:21], v[20:21], v[28:29], v[30:31]\n v_pk_fma_f32 v[22:23], v[22:23], v[28:29], v[30:31]\n"
+                            "v_pk_fma_f32 v[24:25], v[24:25], v[28:29], v[30:31]\n v_pk_fma_f32 v[26:27], v[26:27], v[28:29], v[30:31]\n")
+                         : : : "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
+        } else if (MODE == kHotMix) {
+            asm volatile(HOT_TRIP_HEAD HOT_TRIP_BODY HOT_TRIP_TAIL HOT_TRIP_END : : : HOT_CLOBBERS);
+        } else {
+            asm volatile(HOT_TRIP_HEAD HOT_TRIP_LOAD HOT_TRIP_BODY HOT_TRIP_LDS HOT_TRIP_TAIL HOT_TRIP_WAIT HOT_TRIP_END : : [rsrc] "s"(rsrc) : HOT_CLOBBERS);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    float keep = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 2] = t1 - t0;
+        out[blockIdx.x * 2 + 1] = r1 - r0;
+    }
+    if (keep == 123.456f) out[0] = 0;  // (keeps the accumulators alive)
+    (void)smem;
+}
+
+template <int MODE>
+int run(int cus, unsigned long long* d_out, const uint32_t* d_buf, uint32_t buf_bytes) {
+    for (int w = 1; w <= 4; ++w) {
+        const int per_cu = 4 * w, grid = cus * per_cu, iters = MODE >= kHotMix ? 4000 : 20000;
+        const size_t lds = (160 * 1024 / per_cu - 512) & ~size_t(255);  // so that exactly per_cu single-wave workgroups fit a CU
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&body<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        std::vector<unsigned long long> h(size_t(grid) * 2);
+        for (int rep = 0; rep < 3; ++rep) {  // (the last repetition counts: clocks have settled)
+            hipLaunchKernelGGL(body<MODE>, dim3(grid), dim3(64), lds, 0, d_out, d_buf, buf_bytes, iters);
+            CHECK(hipDeviceSynchronize());
+        }
+        CHECK(hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> cyc(grid), clk(grid);
+        for (int i = 0; i < grid; ++i) {
+            cyc[i] = double(h[size_t(i) * 2]);
+            clk[i] = double(h[size_t(i) * 2]) / double(h[size_t(i) * 2 + 1]) * 100.0;  // MHz
+        }
+        std::sort(cyc.begin(), cyc.end());
+        std::sort(clk.begin(), clk.end());
+        const double med = cyc[grid / 2], per_valu = med / (double(iters) * kValu[MODE]), per_any = med / (double(iters) * kAll[MODE]);
+        std::printf("{\"body\": \"%s\", \"waves_per_simd\": %d, \"valu_per_trip\": %d, \"instr_per_trip\": %d, \"cycles_per_trip_per_wave\": %.1f, "
+                    "\"cycles_per_valu_as_a_wave_sees_it\": %.2f, \"simd_cycles_per_valu\": %.2f, \"simd_cycles_per_instruction\": %.2f, \"clock_mhz\": %.0f}\n",
+                    kNames[MODE], w, kValu[MODE], kAll[MODE], med / iters, per_valu, per_valu / w, per_any / w, clk[grid / 2]);
+    }
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    unsigned long long* d_out;
+    uint32_t* d_buf;
+    const uint32_t buf_bytes = 1 << 16;
+    CHECK(hipMalloc(reinterpret_cast<void**>(&d_out), size_t(cus) * 16 * 2 * 8));
+    CHECK(hipMalloc(reinterpret_cast<void**>(&d_buf), buf_bytes));
+    CHECK(hipMemset(d_buf, 0, buf_bytes));
+    std::printf("{\"device\": \"%s\", \"cus\": %d}\n", prop.gcnArchName, cus);
+    if (run<kFmaIndep>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kFmaChain>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kCmpSel>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kPkFma>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kHotMix>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kHotMixLd>(cus, d_out, d_buf, buf_bytes)) return 1;
+    return 0;
+}

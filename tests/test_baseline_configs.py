@@ -3,6 +3,7 @@ C1 256x256 rays against one 32^3 chunk through the picker path; C2 1920x1080 pri
 C3 1920x1080 primary + shadow, textured and normal-mapped, on the depth-12 SVO the benchmark uses. Every hit record is
 compared exactly (t, position, uv, value, face, flags, shadow distance, step count); colours to 5e-6."""
 import math
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -69,20 +70,29 @@ def test_c1_picker_rays_against_one_chunk(hip, fmt):
     assert (exp["dst"] > 0).mean() > 0.3
 
 
+TEXTURE_DIR = Path(__file__).resolve().parent / "golden" / "textures"
+
+# (config, textures, shadow distance): C3 with the reference's textures and an unlimited shadow distance is the frame bench.py times
+# (`--textures assets`, every primary hit casts its shadow ray); 500 blocks is the game's own cut-off (src/gamelogic/world.rs:105-108),
+# bench.py's second line
+FRAMES = [("C2", "synthetic", 3.0e38), ("C3", "synthetic", 3.0e38), ("C3", "assets", 3.0e38), ("C3", "assets", 500.0)]
+
+
 @pytest.mark.parametrize("fmt", FMTS)
-@pytest.mark.parametrize("config", ["C2", "C3"])
-def test_full_size_frames(hip, fmt, config):
+@pytest.mark.parametrize("config,textures,shadow_distance", FRAMES, ids=[f"{c}-{t}-{'inf' if d > 1e30 else int(d)}" for c, t, d in FRAMES])
+def test_full_size_frames(hip, fmt, config, textures, shadow_distance):
     depth, shadows = (10, False) if config == "C2" else (12, True)
     world = vra.World(FMTS[fmt])
     st = world.build_heightfield(depth)
-    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    tex = scenes.asset_textures(TEXTURE_DIR) if textures == "assets" else scenes.synthetic_textures()
+    mats = scenes.synthetic_materials()
     scene = orc.OracleScene(FMTS[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
     svo = hip.Svo(FMTS[fmt], world.size_in_bytes + (16 << 20))
     svo.set_materials(mats)
     svo.set_textures(tex, 6)
     svo.update(world)
     w, h = 1920, 1080
-    u = scenes.bench_camera(depth, st["h_max"], w, h, shadow_distance=3.0e38, render_shadows=shadows)
+    u = scenes.bench_camera(depth, st["h_max"], w, h, shadow_distance=shadow_distance, render_shadows=shadows)
     img, hits = svo.render(u, w, h, want_hits=True)
     cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
     assert hits.tobytes() == chits.tobytes()
@@ -91,10 +101,18 @@ def test_full_size_frames(hip, fmt, config):
     primary_hits = int((chits["flags"] & 1).sum())
     shadow_rays = int(((chits["flags"] >> 1) & 1).sum())
     assert primary_hits > 0.4 * w * h
-    assert shadow_rays == (primary_hits if shadows else 0)
-    # the image-only kernel (no hit records; what the benchmark times) and two frames in flight write the same pixels
+    if not shadows:
+        assert shadow_rays == 0
+    elif shadow_distance > 1e30:
+        assert shadow_rays == primary_hits
+    else:
+        # world.glsl:80: only hits nearer than the cut-off cast one (from this altitude: few or none -- the frame is then primary rays only)
+        assert shadow_rays == int((((chits["flags"] & 1) != 0) & (chits["t"] < shadow_distance)).sum()) < primary_hits
+    # The image-only kernel (no hit records) with the library's default of two frames in flight -- exactly what bench.py times --
+    # against the ORACLE's frame (not only against the hit-record kernel's), and identical to the hit-record kernel's pixels.
     import torch
 
+    svo.set_frames_in_flight(2)  # (bench.py's call; also the library's default)
     a = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     b = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()  # torch zero-fills on ITS stream; the renderer's streams do not wait for it
@@ -104,6 +122,7 @@ def test_full_size_frames(hip, fmt, config):
     svo.sync()
     for t in (a, b):
         got = t.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(cimg)) and np.nanmax(np.abs(got - cimg)) <= 5e-6
         assert np.array_equal(np.isnan(got), np.isnan(img)) and np.nanmax(np.abs(got - img)) == 0.0
 
 

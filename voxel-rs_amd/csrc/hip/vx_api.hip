@@ -286,6 +286,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     unsigned long long t_empty = 0ull;
     uint32_t taken = 0;
     uint32_t in_service = 0, service_phases = 0;  // timeline only, wave-uniform
+    // timeline only: shader-clock stamps (s_memtime) -- the wave's whole life and the part of it spent in the traversal loop -- and the loop's trips
+    const unsigned long long c_start = a.timeline ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long loop_cycles = 0ull;
+    uint32_t loop_trips = 0;
     // the sub-tile queue: a ticket is this launch's sub-tile number (lane 0's value counts)
     // Wave w starts on sub-tile w without asking (a launch never has more waves than sub-tiles): 4096 waves do not open the frame by
     // queueing at one counter. The counter hands out the sub-tiles from gridDim.x on.
@@ -322,7 +326,9 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         const uint32_t keep_going = park_limit >= 64u ? 0u : 64u - park_limit;
         // (the lanes that traverse, as the wave's mask: one compare per trip serves the loop's exit test and the next trip's execution mask)
         unsigned long long trav = __ballot(tr.iter < uint32_t(kMaxSteps));
+        const unsigned long long c_loop = a.timeline ? __builtin_amdgcn_s_memtime() : 0ull;
         for (;;) {
+            ++loop_trips;  // (one scalar add, unconditionally: a test of a.timeline here would cost the loop more than the count does)
             if (__builtin_amdgcn_inverse_ballot_w64(trav)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)
                 tr.template step_with<false, STATS, false, FastStack, false, FOREIGN != 0>(sc, fast_st, nullptr, STATS ? &ctr : nullptr, [&](TravStatus s) {
                     state = LaneState(s);
@@ -336,6 +342,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             }
             if (uint32_t(__popcll(trav)) <= keep_going) break;
         }
+        if (a.timeline) loop_cycles += __builtin_amdgcn_s_memtime() - c_loop;
         if (STATS) ++services;
         const unsigned long long t_service = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;
         unsigned long long t_part = 0ull;
@@ -744,9 +751,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     }
 
     if (a.timeline && lane == 0) {
-        unsigned long long* row = a.timeline + size_t(blockIdx.x) * 4;
+        unsigned long long* row = a.timeline + size_t(blockIdx.x) * 8;
         row[0] = t_start; row[1] = t_empty; row[2] = __builtin_amdgcn_s_memrealtime();
         row[3] = taken | ((unsigned long long)(service_phases & 0xfffu) << 20) | ((unsigned long long)in_service << 32);  // sub-tiles, service phases, ticks spent in them
+        row[4] = __builtin_amdgcn_s_memtime() - c_start; row[5] = loop_cycles; row[6] = loop_trips; row[7] = 0;
     }
     // ---- second phase (FOREIGN = kForeignRerun): the rays this wave listed, on the world's own bytes ----
     if (FOREIGN == kForeignRerun) {
@@ -1084,7 +1092,7 @@ struct vx_context {
 
     uint32_t* d_work_counter = nullptr;
     unsigned long long* d_excursions = nullptr;  // [3], see PersistentArgs
-    unsigned long long* d_timeline = nullptr;    // VX_TIMELINE=1: [8192][4], the last launch's waves (PersistentArgs::timeline)
+    unsigned long long* d_timeline = nullptr;    // VX_TIMELINE=1: [8192][8], the last launch's waves (PersistentArgs::timeline)
     uint32_t timeline_waves = 0;
     uint32_t timeline_part = 0;   // VX_TIMELINE_PART
     uint32_t ahead_guard = 2;     // VX_AHEAD_GUARD: quarter-grids of tickets at the end of a frame that are not drawn ahead
@@ -1741,7 +1749,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
             c->hot_use = (v & 1) != 0; c->hot_note = (v & 2) != 0; c->hot_sort = (v & 4) != 0;
         }
         if (const char* e = std::getenv("VX_TIMELINE"))
-            if (std::atoi(e) != 0) CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_timeline), 8192 * 4 * sizeof(unsigned long long)));
+            if (std::atoi(e) != 0) CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_timeline), 8192 * 8 * sizeof(unsigned long long)));
         if (const char* e = std::getenv("VX_TIMELINE_PART")) c->timeline_part = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_TICKET_AHEAD")) c->ticket_ahead = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VX_AHEAD_GUARD")) c->ahead_guard = uint32_t(std::max(0, std::min(64, std::atoi(e))));
@@ -2622,7 +2630,7 @@ uint32_t vx_timeline_read(vx_context* ctx, uint64_t* out, uint32_t capacity_wave
     VX_LOCK(ctx);
     if (hipSetDevice(ctx->device) != hipSuccess || drain_streams(ctx) != VX_OK) return 0;
     const uint32_t n = ctx->timeline_waves < capacity_waves ? ctx->timeline_waves : capacity_waves;
-    if (n && hipMemcpy(out, ctx->d_timeline, size_t(n) * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (n && hipMemcpy(out, ctx->d_timeline, size_t(n) * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
 }
 

@@ -354,8 +354,9 @@ class Svo:
         _check(lib().vx_stream_wait_render(self._h, _vp(stream)))
 
     def timeline(self):
-        """Per wave of the last launch: [start, queue empty, exit] in 10 ns ticks and sub-tiles taken (needs VX_TIMELINE=1)."""
-        out = np.zeros((8192, 4), dtype=np.uint64)
+        """Per wave of the last launch: [start, queue empty, exit] in 10 ns ticks, sub-tiles taken | phases | ticks in them, then the
+        wave's life and its traversal loop in shader cycles and the loop's trips (voxel_hip.h: vx_timeline_read; needs VX_TIMELINE=1)."""
+        out = np.zeros((8192, 8), dtype=np.uint64)
         n = lib().vx_timeline_read(self._h, out.ctypes.data_as(_vp), 8192)
         return out[:n]
 

@@ -63,17 +63,18 @@ def synthetic_textures(seed=1, size=64):
     return layers
 
 
-def asset_textures(directory=None, seed=1, size=64):
-    """The 25-layer table with the reference's own 64x64 textures where the repository carries them as test fixtures
-    (tests/golden/textures: dirt, grass_side, grass_top, stone and their normal maps -- byte-identical copies of
-    assets/textures/*.png, the eight the reference's render test loads, src/graphics/svo.rs:347-360) and the procedural stand-ins
-    for the rest. Flipped vertically like TextureArrayBuilder does (texture_array.rs:92,126): row 0 = bottom. The benchmark's
+def asset_textures(directory, seed=1, size=64):
+    """The 25-layer table with the 64x64 PNGs found in `directory` (the caller's: bench.py and the tests pass the repository's
+    fixtures -- dirt, grass_side, grass_top, stone and their normal maps, byte-identical copies of assets/textures/*.png, the eight
+    the reference's render test loads, src/graphics/svo.rs:347-360) and the procedural stand-ins for the rest. Flipped vertically like TextureArrayBuilder does (texture_array.rs:92,126): row 0 = bottom. The benchmark's
     terrain only uses grass, dirt and stone, i.e. only real textures."""
     from pathlib import Path
 
     from PIL import Image
 
-    directory = Path(directory) if directory else Path(__file__).resolve().parent.parent / "tests" / "golden" / "textures"
+    directory = Path(directory)
+    if not directory.is_dir():
+        raise FileNotFoundError(f"texture directory {directory} does not exist")
     layers = synthetic_textures(seed, size)
     for li, name in enumerate(TEXTURE_NAMES):
         f = directory / (name[:-7] + "_n.png" if name.endswith("_normal") else name + ".png")
