@@ -9,6 +9,7 @@
 //   SIMD pays per instruction = the issue cost), and the clock the loop ran at.
 // Bodies:  fma_indep  32 v_fma_f32 on 8 independent accumulators        fma_chain  32 dependent v_fma_f32
 //          cmp_sel    v_cmp_*_e64 -> SGPR pair -> v_cndmask_e64 pairs   pk_fma     16 v_pk_fma_f32 (independent)
+//          salu / valu_salu_1to1 / cmp_vcc_sel / cmp_only / sel_only / mov / int_ops / branches: what the other kinds of instruction of the loop cost
 //          hot_mix    one trip of render_persistent's traversal loop as the compiler lays it out (profiles/tools/hot_loop.py): 81 VALU
 //                     (compares into SGPR pairs, selects, bit-field extracts, fma / pk_fma, min3, moves), 43 SALU (mask algebra,
 //                     saveexec / restore, not-taken forward branches, one taken back edge) -- without its load and LDS accesses
@@ -163,12 +164,13 @@ extern __shared__ unsigned char smem[];
                      "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "s40", "s41", "s42", "s43", "s44", \
                      "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "vcc", "scc", "memory"
 
-enum { kFmaIndep, kFmaChain, kCmpSel, kPkFma, kHotMix, kHotMixLd, kModes };
-static const char* kNames[kModes] = {"fma_indep", "fma_chain", "cmp_sel", "pk_fma", "hot_mix", "hot_mix_ld"};
+enum { kFmaIndep, kFmaChain, kCmpSel, kPkFma, kHotMix, kHotMixLd, kSalu, kValuSalu, kCmpVccSel, kCmpOnly, kSelOnly, kMov, kIntOps, kBranchNotTaken, kSaveexec, kBranchTaken, kModes };
+static const char* kNames[kModes] = {"fma_indep", "fma_chain", "cmp_sel", "pk_fma", "hot_mix", "hot_mix_ld", "salu", "valu_salu_1to1", "cmp_vcc_sel", "cmp_only", "sel_only", "mov", "int_ops",
+                                     "fma_plus_branch_not_taken", "saveexec_fma_restore", "fma_plus_branch_taken"};
 // wave-instructions per trip of the body: VALU, all (VALU + SALU + memory; waits and nops not counted)
 // (hot_mix: counted in the compiler's output of this file -- 81 VALU, 40 SALU + the loop's own 3; hot_mix_ld: one more VALU for the address, 3 memory instructions)
-static const int kValu[kModes] = {32, 32, 32, 16, 81, 82};
-static const int kAll[kModes] = {32, 32, 32, 16, 81 + 43, 82 + 43 + 3};
+static const int kValu[kModes] = {32, 32, 32, 16, 81, 82, 0, 16, 32, 32, 32, 32, 32, 16, 16, 16};
+static const int kAll[kModes] = {32, 32, 32, 16, 81 + 43, 82 + 43 + 3, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32};
 
 template <int MODE>
 __global__ __launch_bounds__(64) void body(unsigned long long* out, const uint32_t* buf, uint32_t buf_bytes, int iters) {
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(64) void body(unsigned long long* out, const uint32
                      "v_lshlrev_b32 v52, 2, %0\n v_mov_b32 v48, 0\n v_mov_b32 v49, 0\n v_mov_b32 v22, 0\n v_mov_b32 v28, 0\n s_mov_b32 s56, 1000\n s_mov_b32 s57, 0\n"
                      : : "v"(threadIdx.x) : HOT_CLOBBERS);
     }
+    if (MODE == kSalu || MODE == kValuSalu || MODE == kSelOnly) asm volatile("s_mov_b64 s[56:57], -1\n s_mov_b64 s[58:59], 0x5555\n" : : : "s56", "s57", "s58", "s59");
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
@@ -201,6 +204,51 @@ __global__ __launch_bounds__(64) void body(unsigned long long* out, const uint32
             asm volatile(R4("v_pk_fma_f32 v[20:21], v[20:21], v[28:29], v[30:31]\n v_pk_fma_f32 v[22:23], v[22:23], v[28:29], v[30:31]\n"
                             "v_pk_fma_f32 v[24:25], v[24:25], v[28:29], v[30:31]\n v_pk_fma_f32 v[26:27], v[26:27], v[28:29], v[30:31]\n")
                          : : : "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
+        } else if (MODE == kSalu) {
+            asm volatile(R4("s_and_b64 s[40:41], s[40:41], s[56:57]\n s_or_b64 s[42:43], s[42:43], s[56:57]\n s_and_b64 s[44:45], s[44:45], s[56:57]\n s_or_b64 s[46:47], s[46:47], s[56:57]\n"
+                            "s_and_b64 s[48:49], s[48:49], s[56:57]\n s_or_b64 s[50:51], s[50:51], s[56:57]\n s_and_b64 s[52:53], s[52:53], s[56:57]\n s_or_b64 s[54:55], s[54:55], s[56:57]\n")
+                         : : : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "scc");
+        } else if (MODE == kValuSalu) {
+            asm volatile(R4("v_fma_f32 %0, %0, %4, %5\n s_and_b64 s[40:41], s[40:41], s[56:57]\n v_fma_f32 %1, %1, %4, %5\n s_or_b64 s[42:43], s[42:43], s[56:57]\n"
+                            "v_fma_f32 %2, %2, %4, %5\n s_and_b64 s[44:45], s[44:45], s[56:57]\n v_fma_f32 %3, %3, %4, %5\n s_or_b64 s[46:47], s[46:47], s[56:57]\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s56", "s57", "scc");
+        } else if (MODE == kCmpVccSel) {
+            asm volatile(R4("v_cmp_lt_f32_e32 vcc, %0, %8\n v_cndmask_b32_e32 %1, %1, %9, vcc\n v_cmp_lt_f32_e32 vcc, %2, %8\n v_cndmask_b32_e32 %3, %3, %9, vcc\n"
+                            "v_cmp_lt_f32_e32 vcc, %4, %8\n v_cndmask_b32_e32 %5, %5, %9, vcc\n v_cmp_lt_f32_e32 vcc, %6, %8\n v_cndmask_b32_e32 %7, %7, %9, vcc\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d) : "vcc");
+        } else if (MODE == kCmpOnly) {
+            asm volatile(R4("v_cmp_lt_f32_e64 s[40:41], %0, %8\n v_cmp_lt_f32_e64 s[42:43], %1, %8\n v_cmp_lt_f32_e64 s[44:45], %2, %8\n v_cmp_lt_f32_e64 s[46:47], %3, %8\n"
+                            "v_cmp_lt_f32_e64 s[48:49], %4, %8\n v_cmp_lt_f32_e64 s[50:51], %5, %8\n v_cmp_lt_f32_e64 s[52:53], %6, %8\n v_cmp_lt_f32_e64 s[54:55], %7, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d)
+                         : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55");
+        } else if (MODE == kSelOnly) {
+            asm volatile(R4("v_cndmask_b32_e64 %0, %0, %8, s[56:57]\n v_cndmask_b32_e64 %1, %1, %8, s[58:59]\n v_cndmask_b32_e64 %2, %2, %8, s[56:57]\n v_cndmask_b32_e64 %3, %3, %8, s[58:59]\n"
+                            "v_cndmask_b32_e64 %4, %4, %8, s[56:57]\n v_cndmask_b32_e64 %5, %5, %8, s[58:59]\n v_cndmask_b32_e64 %6, %6, %8, s[56:57]\n v_cndmask_b32_e64 %7, %7, %8, s[58:59]\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d) : "s56", "s57", "s58", "s59");
+        } else if (MODE == kMov) {
+            asm volatile(R4("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (MODE == kIntOps) {
+            asm volatile(R4("v_bfe_u32 %0, %1, 3, 1\n v_lshl_or_b32 %1, %2, 2, %3\n v_and_b32 %2, 0xff, %3\n v_xor_b32 %3, %4, %5\n v_lshl_add_u32 %4, %5, 3, %6\n v_or3_b32 %5, %6, %7, %0\n"
+                            "v_lshlrev_b32 %6, 1, %7\n v_add_u32 %7, 1, %0\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (MODE == kBranchNotTaken) {
+            asm volatile("s_cmp_eq_u32 0, 0\n"  // scc = 1: s_cbranch_scc0 falls through
+                         R4("v_fma_f32 %0, %0, %4, %5\n s_cbranch_scc0 1f\n v_fma_f32 %1, %1, %4, %5\n s_cbranch_scc0 1f\n v_fma_f32 %2, %2, %4, %5\n s_cbranch_scc0 1f\n"
+                            "v_fma_f32 %3, %3, %4, %5\n s_cbranch_scc0 1f\n") "1:\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "scc");
+        } else if (MODE == kSaveexec) {
+            asm volatile(R4("s_and_saveexec_b64 s[40:41], exec\n s_cbranch_execz 1f\n v_fma_f32 %0, %0, %4, %5\n s_or_b64 exec, exec, s[40:41]\n"
+                            "s_and_saveexec_b64 s[42:43], exec\n s_cbranch_execz 1f\n v_fma_f32 %1, %1, %4, %5\n s_or_b64 exec, exec, s[42:43]\n"
+                            "s_and_saveexec_b64 s[44:45], exec\n s_cbranch_execz 1f\n v_fma_f32 %2, %2, %4, %5\n s_or_b64 exec, exec, s[44:45]\n"
+                            "s_and_saveexec_b64 s[46:47], exec\n s_cbranch_execz 1f\n v_fma_f32 %3, %3, %4, %5\n s_or_b64 exec, exec, s[46:47]\n") "1:\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "scc");
+        } else if (MODE == kBranchTaken) {
+            asm volatile("v_fma_f32 %0, %0, %4, %5\n s_branch 2f\n 2: v_fma_f32 %1, %1, %4, %5\n s_branch 3f\n 3: v_fma_f32 %2, %2, %4, %5\n s_branch 4f\n 4: v_fma_f32 %3, %3, %4, %5\n s_branch 5f\n 5:\n"
+                         "v_fma_f32 %0, %0, %4, %5\n s_branch 6f\n 6: v_fma_f32 %1, %1, %4, %5\n s_branch 7f\n 7: v_fma_f32 %2, %2, %4, %5\n s_branch 8f\n 8: v_fma_f32 %3, %3, %4, %5\n s_branch 9f\n 9:\n"
+                         "v_fma_f32 %0, %0, %4, %5\n s_branch 12f\n 12: v_fma_f32 %1, %1, %4, %5\n s_branch 13f\n 13: v_fma_f32 %2, %2, %4, %5\n s_branch 14f\n 14: v_fma_f32 %3, %3, %4, %5\n s_branch 15f\n 15:\n"
+                         "v_fma_f32 %0, %0, %4, %5\n s_branch 16f\n 16: v_fma_f32 %1, %1, %4, %5\n s_branch 17f\n 17: v_fma_f32 %2, %2, %4, %5\n s_branch 18f\n 18: v_fma_f32 %3, %3, %4, %5\n s_branch 19f\n 19:\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d));
         } else if (MODE == kHotMix) {
             asm volatile(HOT_TRIP_HEAD HOT_TRIP_BODY HOT_TRIP_TAIL HOT_TRIP_END : : : HOT_CLOBBERS);
         } else {
@@ -221,7 +269,7 @@ __global__ __launch_bounds__(64) void body(unsigned long long* out, const uint32
 template <int MODE>
 int run(int cus, unsigned long long* d_out, const uint32_t* d_buf, uint32_t buf_bytes) {
     for (int w = 1; w <= 4; ++w) {
-        const int per_cu = 4 * w, grid = cus * per_cu, iters = MODE >= kHotMix ? 4000 : 20000;
+        const int per_cu = 4 * w, grid = cus * per_cu, iters = (MODE == kHotMix || MODE == kHotMixLd) ? 4000 : 20000;
         const size_t lds = (160 * 1024 / per_cu - 512) & ~size_t(255);  // so that exactly per_cu single-wave workgroups fit a CU
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&body<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         std::vector<unsigned long long> h(size_t(grid) * 2);
@@ -262,5 +310,15 @@ int main() {
     if (run<kPkFma>(cus, d_out, d_buf, buf_bytes)) return 1;
     if (run<kHotMix>(cus, d_out, d_buf, buf_bytes)) return 1;
     if (run<kHotMixLd>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kSalu>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kValuSalu>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kCmpVccSel>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kCmpOnly>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kSelOnly>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kMov>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kIntOps>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kBranchNotTaken>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kSaveexec>(cus, d_out, d_buf, buf_bytes)) return 1;
+    if (run<kBranchTaken>(cus, d_out, d_buf, buf_bytes)) return 1;
     return 0;
 }

@@ -24,6 +24,13 @@
 #include "traversal_image.hpp"
 #include "voxel_hip.h"
 #include "vx_device.hpp"
+#include "vx_loop_gfx950.hpp"
+
+// 1 = render_persistent's traversal loop on a byte-offset image whose depth the LDS-resident stack covers is the hand-scheduled one
+// (vx_loop_gfx950.hpp); 0 = the compiler's loop everywhere (A/B builds)
+#ifndef VX_ASM_LOOP
+#define VX_ASM_LOOP 1
+#endif
 
 using namespace vxd;
 
@@ -327,6 +334,24 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // (the lanes that traverse, as the wave's mask: one compare per trip serves the loop's exit test and the next trip's execution mask)
         unsigned long long trav = __ballot(tr.iter < uint32_t(kMaxSteps));
         const unsigned long long c_loop = a.timeline ? __builtin_amdgcn_s_memtime() : 0ull;
+        // The hand-scheduled loop (vx_loop_gfx950.hpp) for cursors on a byte-offset image that the resident stack levels cover. It does not
+        // clear kHasAdjacentLeaf: a wave with a traversing ray that has just passed a translucent voxel takes the compiler's loop this time.
+        constexpr bool kAsmLoop = VX_ASM_LOOP != 0 && SVO == VX_SVO_IMAGE && SHALLOW && LV == kLdsLevels && !HOT && !STATS;
+        bool by_hand = false;
+        if constexpr (kAsmLoop) by_hand = __ballot((tr.flags & Trav<SVO>::kHasAdjacentLeaf) != 0 && tr.iter < uint32_t(kMaxSteps)) == 0;
+        if (kAsmLoop && by_hand) {
+            if constexpr (kAsmLoop) {
+                const uint32_t lds_slot0 = uint32_t(reinterpret_cast<uintptr_t>(fast_st.at(fast_st.slot0)));
+                if (a.timeline) traverse_loop_gfx950<FOREIGN != 0, true>(tr, sc.world, lds_slot0, keep_going, loop_trips);
+                else traverse_loop_gfx950<FOREIGN != 0, false>(tr, sc.world, lds_slot0, keep_going, loop_trips);
+                // a lane the loop parked says why in bits 28..30 of its iteration count
+                const uint32_t why = (tr.iter >> 28) & 7u;
+                if (why) {
+                    state = LaneState(why);
+                    tr.iter &= 0x8fffffffu;
+                }
+            }
+        } else
         for (;;) {
             ++loop_trips;  // (one scalar add, unconditionally: a test of a.timeline here would cost the loop more than the count does)
             if (__builtin_amdgcn_inverse_ballot_w64(trav)) {  // traversing and below the iteration cap (svo.esvo.glsl:152)

@@ -17,6 +17,12 @@
 
 #include "voxel_hip.h"
 
+// 1 = the render loop's step on a traversal image is Trav::step_image (PUSH and ADVANCE merged into one instruction stream); 0 = step_with's
+// own paths (the round-2 loop, kept for A/B builds)
+#ifndef VX_MERGED_STEP
+#define VX_MERGED_STEP 1
+#endif
+
 namespace vxd {
 
 constexpr int kMaxSteps = 1000;       // svo.esvo.glsl:18
@@ -646,6 +652,9 @@ struct Trav {
     // there, which keeps the common paths free of a status value to merge.
     template <bool TRACE, bool STATS, bool LIMIT, class ST, bool CAPPED, bool FOREIGN, class EXIT>
     __device__ __forceinline__ void step_with(const DevScene& sc, const ST& st, TracePtr tk, Counters* ctr, EXIT&& on_exit) {
+#if VX_MERGED_STEP
+        if constexpr (IMG && ST::kFast && !ST::kHot && !TRACE && !STATS) return step_image<LIMIT, ST, CAPPED, FOREIGN>(sc, st, on_exit);
+#endif
         bool live = !CAPPED || iter < uint32_t(kMaxSteps);
         if (LIMIT) live = live && !(max_dst >= 0.0f && t_min > max_dst);
         if (!live) return on_exit(kTravFinished);
@@ -837,6 +846,85 @@ struct Trav {
         // whatever `ptr` is -- the image's first octant will do; the byte-offset layout's range check makes any value harmless)
         ptr = descended ? ((WIDE && !FOREIGN && is_leaf) ? 0u : ahead.x) : ptr;
         node = descended ? ((!FOREIGN && is_leaf) ? 0u : ahead.y) : node;
+    }
+
+    // The same iteration for a cursor on a traversal image with a fast stack -- the render loop's step -- as ONE instruction stream for
+    // the lanes that PUSH and the lanes that ADVANCE. Measured on gfx950 (profiles/tools/valu_issue.hip, profiles/round3/): a SIMD
+    // issues one instruction of a wave every ~2 cycles whatever its kind -- a scalar mask operation or a branch costs as much as a
+    // vector instruction, a compare into a scalar pair and a select out of one half as much again -- and the loop as the compiler lays
+    // out step_with (81 vector + 50 scalar instructions: the PUSH, ADVANCE and POP paths one after the other, each behind its own
+    // execution-mask bookkeeping) runs at 91 % of what that costs. So the two paths are merged, not branched around:
+    //   PUSH     corner += (t_min  <  t(centre plane)) ? half a cell : 0      per axis
+    //   ADVANCE  corner -= (tc_max >= t(corner plane)) ? a cell      : 0      per axis
+    // are the same compare-and-select with the operands chosen per lane: t(centre) = fma(half, t_coef, t(corner)), so with `hm` = half a
+    // cell for a PUSH lane and 0 for an ADVANCE lane one fma gives either plane's distance (fma(0, c, x) == x exactly), L < R is the
+    // PUSH's condition and the negation of the ADVANCE's, and the select's two values (hm : other) = (half : 0) or (0 : -cell) are per-lane
+    // constants. Every float is produced by the operation the reference uses on the operands the reference uses: results are bit for
+    // bit those of step_with (tests/test_device_on_host.py steps this very code against the oracle; test_kernel_versions_agree
+    // compares the builds on the GPU).
+    template <bool LIMIT, class ST, bool CAPPED, bool FOREIGN, class EXIT>
+    __device__ __forceinline__ void step_image(const DevScene& sc, const ST& st, EXIT&& on_exit) {
+        static_assert(IMG && ST::kFast && !ST::kHot, "image cursors on the loop's stack");
+        bool live = !CAPPED || iter < uint32_t(kMaxSteps);
+        if (LIMIT) live = live && !(max_dst >= 0.0f && t_min > max_dst);
+        if (!live) return on_exit(kTravFinished);
+        ++iter;
+        const uint32_t bx = __float_as_uint(px), by = __float_as_uint(py), bz = __float_as_uint(pz);
+        const uint32_t octant_idx = (bit_at(bx, scale) | (bit_at(by, scale) << 1) | (bit_at(bz, scale) << 2)) ^ uint32_t(octant_mask);
+        // the entry a PUSH into this child reads, requested for every lane (see step_with): looked at last
+        const uint2 ahead = WIDE ? wide_entry(sc, ptr, octant_idx) : buf_u64(sc.world, ptr + octant_idx * 8u);
+        const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
+        const float tc_max = gmin3(tcrx, tcry, tcrz);
+        const uint32_t m = node << octant_idx;
+        const bool is_child = int32_t(m) < 0, is_leaf = (m & 0x00800000u) != 0;
+        const bool descend = is_child && t_min <= t_max;
+        flags = descend ? flags : (flags & ~kHasAdjacentLeaf);
+        if (descend && is_leaf) {
+            if (t_min > 0.0f) return on_exit(kTravAtLeaf);
+            if (FOREIGN) return on_exit(kTravForeign);
+            if (t_min == 0.0f) flags |= kInsideVoxel;
+        }
+        const float tv_max = gmin(t_max, tc_max);
+        const bool push = descend && t_min <= tv_max;
+        if (ST::kCanOverflow && push && scale < ST::kBaseScale) return on_exit(kTravDeep);  // (the caller takes `iter` back by one)
+
+        const float half = scale_exp2 * 0.5f;
+        const float hm = push ? half : 0.0f, other = push ? 0.0f : -scale_exp2;
+        const float lhs = push ? t_min : tc_max;
+        const float rx = __builtin_fmaf(hm, tcx, tcrx), ry = __builtin_fmaf(hm, tcy, tcry), rz = __builtin_fmaf(hm, tcz, tcrz);
+        if (push && tc_max < h) st.push(scale, ptr, t_max, node);
+        px += lhs < rx ? hm : other;
+        py += lhs < ry ? hm : other;
+        pz += lhs < rz ? hm : other;
+        // ADVANCE lanes: the stepped corner differs from the old one above bit `scale` exactly when the step left the parent (see advance())
+        const uint32_t differing_bits = (bx ^ __float_as_uint(px)) | (by ^ __float_as_uint(py)) | (bz ^ __float_as_uint(pz));
+        const bool pop = !push && differing_bits >= (2u << scale);
+        t_min = push ? t_min : tc_max;
+        h = push ? tc_max : h;
+        t_max = push ? tv_max : t_max;
+        scale_exp2 = push ? half : scale_exp2;
+        scale = push ? scale - 1 : scale;
+        bool inside = true;
+        if (pop) {
+            scale = 31 - __builtin_clz(differing_bits);  // (pop implies bits above the old scale: never 0)
+            inside = uint32_t(scale) < uint32_t(kMaxScale);
+            if (inside) {
+                scale_exp2 = pow2i(scale - kMaxScale);
+                uint32_t a;
+                st.pop(scale, ptr, t_max, a);
+                node = a;
+                const uint32_t keep = 0xffffffffu << scale;
+                px = __uint_as_float(__float_as_uint(px) & keep);
+                py = __uint_as_float(__float_as_uint(py) & keep);
+                pz = __uint_as_float(__float_as_uint(pz) & keep);
+                h = 0.0f;
+            }
+        }
+        // the child's octant and masks. (A ray led into a voxel of an ESVO world walks it as an empty node whatever the entry holds, and
+        // the wide layout's next request needs a valid octant: see step_with.)
+        ptr = push ? ((WIDE && !FOREIGN && is_leaf) ? 0u : ahead.x) : ptr;
+        node = push ? ((!FOREIGN && is_leaf) ? 0u : ahead.y) : node;
+        if (!inside) return on_exit(kTravFinished);
     }
 
     // image octants: bytes between the children's values -- an octant all of whose children are leaves (child bits 31..24 == leaf

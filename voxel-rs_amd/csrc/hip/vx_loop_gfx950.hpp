@@ -1,0 +1,187 @@
+// render_persistent's traversal loop for cursors on a byte-offset traversal image, hand-scheduled for gfx950.
+//
+// What it computes is Trav<VX_SVO_IMAGE>::step_image (vx_device.hpp) for every traversing lane, trip after trip, until at most `keep_going`
+// lanes of the wave still traverse -- the loop `for (;;) { step; trav = ballot(iter < kMaxSteps); if (popc(trav) <= keep_going) break; }` of
+// vx_api.hip -- bit for bit: every float comes out of the operation step_image uses, on the same operands (the parity tests run both
+// builds: VX_ASM_LOOP=0 keeps the compiler's loop).
+//
+// Why by hand. Measured (profiles/tools/valu_issue.hip, profiles/round3/pass_a): with four waves on a SIMD an instruction of ANY kind
+// costs the SIMD about 2 cycles -- a scalar mask operation 3.4, a taken branch 8, a compare into a scalar pair 3.4, a select out of
+// one 3.0 -- and the traversal loop as the compiler lays it out (78-81 vector + 41-50 scalar instructions per trip, most of the scalar
+// ones execution-mask bookkeeping around its PUSH / ADVANCE / POP regions, compares parked in scalar pairs) runs at 91 % of what
+// that mix costs: the loop is issue bound, and the way to a faster frame is fewer and cheaper instructions per trip. Here a trip is
+// 72 vector + 13 scalar + 6 memory instructions:
+//   * compares go to VCC and are consumed by the next instruction (v_cndmask_e32, v_cmpx), one mask (`push`) lives in a scalar pair;
+//   * "is a child AND ..." is folded into the compared value (t_min or +inf) instead of and-ing masks;
+//   * lanes that stop traversing (at a leaf / led into a voxel / out of the octree) are marked in `iter` itself -- bit 31 = parked,
+//     bits 28..30 = the TravStatus -- by one v_add under a narrowed execution mask; the caller decodes it once per service phase;
+//   * the cell size is derived from the scale (one shift-add) instead of being carried and selected;
+//   * PUSH's five register updates and POP's run under their lanes' execution masks as plain moves / loads into the state registers.
+// Hazards (no hazard recognizer looks inside an asm block): no DPP / SDWA / packed / transcendental / lane-access instructions, no SGPR
+// written by a VALU is read by a memory instruction, s_cbranch_execz only behind a SALU write of EXEC.
+#pragma once
+
+#include "vx_device.hpp"
+
+namespace vxd {
+
+// bits 28..31 of Trav::iter as the loop leaves them on a lane it parked
+constexpr uint32_t kLoopParked = 0x80000000u;
+__device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { return kLoopParked | (uint32_t(s) << 28); }
+
+// the trip, as one string: LEAF_EXITS / TAKE_MASKS differ by the world's format, COUNT is empty or the trip counter
+#define VX_LEAF_EXITS_ESVO                                                                                                         \
+    "v_cmpx_lt_f32_e32 vcc, 0, %[tmin]\n"                        /* exec = at a leaf with t_min > 0: leaf_test() decides */       \
+    "v_add_u32_e32 %[iter], 0xa0000000, %[iter]\n"               /* parked | kTravAtLeaf << 28 */                                  \
+    "s_andn2_b64 exec, %[s_trav], exec\n"                        /* the others go on (into the voxel, if that is where they are led) */
+#define VX_LEAF_EXITS_CSVO                                                                                                         \
+    "s_mov_b64 %[s_save], exec\n"                                                                                                  \
+    "v_add_u32_e32 %[iter], 0xdfffffff, %[iter]\n"               /* parked | kTravForeign << 28, and the iteration taken back */   \
+    "v_cmpx_lt_f32_e32 vcc, 0, %[tmin]\n"                                                                                          \
+    "v_add_u32_e32 %[iter], 0xc0000001, %[iter]\n"               /* t_min > 0 after all: parked | kTravAtLeaf << 28, the iteration counted (sum: + 0xa0000000) */ \
+    "s_andn2_b64 exec, %[s_trav], %[s_save]\n"
+// (an ESVO world's voxel is walked as an empty node whatever its place in the octant holds: vx_device.hpp, step_image)
+#define VX_TAKE_MASKS_ESVO "v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[node], 0, v125, vcc\n"
+#define VX_TAKE_MASKS_CSVO "v_mov_b32_e32 %[node], v125\n"
+#define VX_COUNT_TRIP "s_add_u32 %[trips], %[trips], 1\n"
+#define VX_LOOP_ASM(LEAF_EXITS, TAKE_MASKS, COUNT)                                                                                 \
+        "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
+        "s_cmp_eq_u64 vcc, 0\n"                                                                                                    \
+        "s_cbranch_scc1 9f\n"                                                                                                      \
+        "1:\n"                                                                                                                     \
+        "s_mov_b64 exec, vcc\n"                                                                                                    \
+        "s_mov_b64 %[s_trav], vcc\n"                                                                                               \
+        /* ---- the child the ray is in, its entry requested, the planes' distances ---- */                                       \
+        "v_add_u32_e32 %[iter], 1, %[iter]\n"                                                                                      \
+        "v_bfe_u32 %[t0], %[px], %[sc], 1\n"                                                                                       \
+        "v_bfe_u32 %[t1], %[py], %[sc], 1\n"                                                                                       \
+        "v_bfe_u32 %[t2], %[pz], %[sc], 1\n"                                                                                       \
+        "v_lshlrev_b32_e32 %[t1], 1, %[t1]\n"                                                                                      \
+        "v_lshl_or_b32 %[t0], %[t2], 2, %[t0]\n"                                                                                   \
+        "v_bitop3_b32 %[oct], %[t0], %[om], %[t1] bitop3:0x36\n" /* (t0 | t1) ^ octant_mask */                                     \
+        "v_lshl_add_u32 %[t1], %[oct], 3, %[ptr]\n"                                                                                \
+        "buffer_load_dwordx2 v[124:125], %[t1], %[rsrc], 0 offen\n"                                                                \
+        "v_fma_f32 %[crx], %[px], %[tcx], -%[tbx]\n"                                                                               \
+        "v_fma_f32 %[cry], %[py], %[tcy], -%[tby]\n"                                                                               \
+        "v_fma_f32 %[crz], %[pz], %[tcz], -%[tbz]\n"                                                                               \
+        "v_min3_f32 %[tcm], %[crx], %[cry], %[crz]\n"                                                                              \
+        "v_lshlrev_b32_e32 %[m], %[oct], %[node]\n"              /* the child's "exists" bit in the sign, its "is a leaf" bit at 23 */ \
+        "v_min_f32_e32 %[tvm], %[tmax], %[tcm]\n"                                                                                  \
+        "v_lshl_add_u32 %[sx], %[sc], 23, %[k_cell]\n"                                                                             \
+        "v_lshl_add_u32 %[hf], %[sc], 23, %[k_half]\n"                                                                             \
+        /* ---- a leaf the ray reaches (is a leaf, t_min <= t_max): the lane stops here ---- */                                    \
+        "v_and_b32_e32 %[t2], 0x800000, %[m]\n"                                                                                    \
+        "v_cmpx_ne_u32_e32 vcc, 0, %[t2]\n"                      /* exec: ... whose child is a leaf (a leaf is a child) */         \
+        "v_cmpx_le_f32_e32 vcc, %[tmin], %[tmax]\n"              /* ... and is reached */                                          \
+        LEAF_EXITS                                                                                                                 \
+        /* ---- PUSH or ADVANCE ---- */                                                                                            \
+        "v_cmp_gt_i32_e32 vcc, 0, %[m]\n"                                                                                          \
+        "v_cndmask_b32_e32 %[tq], %[inf], %[tmin], vcc\n"        /* t_min, or +inf where there is no child */                      \
+        "v_cmp_le_f32_e64 %[s_push], %[tq], %[tvm]\n"            /* PUSH: a child, and t_min <= min(t_max, tc_max) */              \
+        "v_cndmask_b32_e64 %[hm], 0, %[hf], %[s_push]\n"         /* half a cell | 0 */                                             \
+        "v_cndmask_b32_e64 %[ot], -%[sx], 0, %[s_push]\n"        /* 0 | minus a cell */                                            \
+        "v_cndmask_b32_e64 %[tmin], %[tcm], %[tmin], %[s_push]\n" /* ADVANCE: t_min = tc_max */                                    \
+        "v_fmac_f32_e32 %[crx], %[hm], %[tcx]\n"                 /* a PUSH lane's centre planes, the others' corner planes still */ \
+        "v_fmac_f32_e32 %[cry], %[hm], %[tcy]\n"                                                                                   \
+        "v_fmac_f32_e32 %[crz], %[hm], %[tcz]\n"                                                                                   \
+        /* the parent's entry goes on the stack if the ray leaves the child before it leaves the parent (tc_max < h) */            \
+        "v_lshl_add_u32 %[t0], %[sc], 8, %[lds]\n"                                                                                 \
+        "s_and_saveexec_b64 %[s_save], %[s_push]\n"                                                                                \
+        "v_cmpx_lt_f32_e32 vcc, %[tcm], %[h]\n"                                                                                    \
+        "ds_write2st64_b32 %[t0], %[ptr], %[tmax] offset1:13\n"                                                                    \
+        "ds_write_b32 %[t0], %[node] offset:6656\n"                                                                                \
+        "s_mov_b64 exec, %[s_save]\n"                                                                                              \
+        /* the corner: += half a cell where t_min < t(centre) | -= a cell where tc_max >= t(corner) */                             \
+        "v_cmp_lt_f32_e32 vcc, %[tmin], %[crx]\n"                                                                                  \
+        "v_cndmask_b32_e32 %[t1], %[ot], %[hm], vcc\n"                                                                             \
+        "v_add_f32_e32 %[nx], %[px], %[t1]\n"                                                                                      \
+        "v_cmp_lt_f32_e32 vcc, %[tmin], %[cry]\n"                                                                                  \
+        "v_cndmask_b32_e32 %[t1], %[ot], %[hm], vcc\n"                                                                             \
+        "v_add_f32_e32 %[ny], %[py], %[t1]\n"                                                                                      \
+        "v_cmp_lt_f32_e32 vcc, %[tmin], %[crz]\n"                                                                                  \
+        "v_cndmask_b32_e32 %[t1], %[ot], %[hm], vcc\n"                                                                             \
+        "v_add_f32_e32 %[nz], %[pz], %[t1]\n"                                                                                      \
+        /* the bits in which the corner changed: above bit `scale` exactly when an ADVANCE left the parent (a PUSH changes bit scale - 1) */ \
+        "v_xor_b32_e32 %[t0], %[px], %[nx]\n"                                                                                      \
+        "v_bitop3_b32 %[t0], %[t0], %[py], %[ny] bitop3:0xf6\n"  /* a | (b ^ c) */                                                 \
+        "v_bitop3_b32 %[t0], %[t0], %[pz], %[nz] bitop3:0xf6\n"                                                                    \
+        "v_mov_b32_e32 %[px], %[nx]\n"                                                                                             \
+        "v_mov_b32_e32 %[py], %[ny]\n"                                                                                             \
+        "v_mov_b32_e32 %[pz], %[nz]\n"                                                                                             \
+        "v_lshlrev_b32_e64 %[t1], %[sc], 2\n"                                                                                      \
+        "v_cmp_ge_u32_e32 vcc, %[t0], %[t1]\n"                                                                                     \
+        /* ---- POP ---- */                                                                                                        \
+        "s_and_saveexec_b64 %[s_save], vcc\n"                                                                                      \
+        "s_cbranch_execz 2f\n"                                                                                                     \
+        "v_ffbh_u32_e32 %[t1], %[t0]\n"                                                                                            \
+        "v_sub_u32_e32 %[sc], 31, %[t1]\n"                       /* the highest differing bit */                                   \
+        "v_lshl_add_u32 %[oct], %[sc], 8, %[lds]\n"                                                                                \
+        "ds_read_b32 %[ptr], %[oct]\n"                                                                                             \
+        "ds_read_b32 %[tmax], %[oct] offset:3328\n"                                                                                \
+        "ds_read_b32 %[node], %[oct] offset:6656\n"                                                                                \
+        "v_lshlrev_b32_e64 %[t1], %[sc], -1\n"                                                                                     \
+        "v_and_b32_e32 %[px], %[t1], %[px]\n"                                                                                      \
+        "v_and_b32_e32 %[py], %[t1], %[py]\n"                                                                                      \
+        "v_and_b32_e32 %[pz], %[t1], %[pz]\n"                                                                                      \
+        "v_mov_b32_e32 %[h], 0\n"                                                                                                  \
+        "v_cmpx_lt_u32_e32 vcc, 22, %[sc]\n"                     /* out of the octree */                                           \
+        "v_add_u32_e32 %[iter], 0xc0000000, %[iter]\n"           /* parked | kTravFinished << 28 */                                \
+        "2:\n"                                                                                                                     \
+        /* ---- PUSH: the child becomes the node ---- */                                                                           \
+        "s_and_b64 exec, %[s_save], %[s_push]\n"                                                                                   \
+        "v_add_u32_e32 %[sc], -1, %[sc]\n"                                                                                         \
+        "v_mov_b32_e32 %[h], %[tcm]\n"                                                                                             \
+        "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
+        "s_waitcnt vmcnt(0)\n"                                                                                                     \
+        "v_mov_b32_e32 %[ptr], v124\n"                                                                                             \
+        TAKE_MASKS                                                                                                                 \
+        /* ---- who still traverses ---- */                                                                                        \
+        "s_mov_b64 exec, %[s_trav]\n"                                                                                              \
+        COUNT                                                                                                                      \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                                   \
+        "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
+        "s_bcnt1_i32_b64 %[s_n], vcc\n"                                                                                            \
+        "s_cmp_gt_u32 %[s_n], %[keep]\n"                                                                                           \
+        "s_cbranch_scc1 1b\n"                                                                                                      \
+        "9:\n"                                                                                                                     \
+        "s_mov_b64 exec, %[entry_exec]\n"
+
+// FOREIGN: the image of a CSVO world -- a ray about to be led into a voxel leaves the loop (kTravForeign, its iteration not counted);
+// otherwise (ESVO world) it walks the voxel as an empty node. COUNT: count the trips in `trips` (measurement).
+// The caller guarantees that no traversing lane has kHasAdjacentLeaf set (the loop does not clear it; such rays -- they have just
+// passed a translucent voxel -- are rare and take the compiler's loop); kInsideVoxel is not maintained (nothing in a render reads it).
+template <bool FOREIGN, bool COUNT>
+__device__ __forceinline__ void traverse_loop_gfx950(Trav<VX_SVO_IMAGE>& tr, buf_t image, uint32_t lds_slot0, uint32_t keep_going, uint32_t& trips) {
+    static_assert(kLdsLevels == 13, "the stack planes are 13 x 256 bytes apart (offset1:13, offset:3328 / 6656)");
+    uint32_t t0, t1, t2, oct, m, nx, ny, nz;
+    float crx, cry, crz, tcm, tvm, tq, hf, hm, ot, sx;
+    unsigned long long s_trav, s_push, s_save;
+    uint32_t s_n;
+    uint32_t px = __float_as_uint(tr.px), py = __float_as_uint(tr.py), pz = __float_as_uint(tr.pz);
+    uint32_t scale = uint32_t(tr.scale);
+    const uint32_t k_cell = 0x34000000u, k_half = 0x33800000u;  // 2^(scale - 23) = (scale + 104) << 23, half of it = (scale + 103) << 23
+    const unsigned long long entry_exec = __builtin_amdgcn_read_exec();
+    // (wave-uniform by construction; the compiler is told so)
+    keep_going = uint32_t(__builtin_amdgcn_readfirstlane(int(keep_going)));
+    uint32_t n_trips = 0;
+#define VX_LOOP_OPERANDS                                                                                                                                   \
+        : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tmin] "+v"(tr.t_min), [tmax] "+v"(tr.t_max), [h] "+v"(tr.h), [sc] "+v"(scale), [ptr] "+v"(tr.ptr),  \
+          [node] "+v"(tr.node), [iter] "+v"(tr.iter), [trips] "+s"(n_trips), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [oct] "=&v"(oct), [m] "=&v"(m), \
+          [nx] "=&v"(nx), [ny] "=&v"(ny), [nz] "=&v"(nz), [crx] "=&v"(crx), [cry] "=&v"(cry), [crz] "=&v"(crz), [tcm] "=&v"(tcm), [tvm] "=&v"(tvm),         \
+          [tq] "=&v"(tq), [hf] "=&v"(hf), [hm] "=&v"(hm), [ot] "=&v"(ot), [sx] "=&v"(sx), [s_trav] "=&s"(s_trav), [s_push] "=&s"(s_push),                  \
+          [s_save] "=&s"(s_save), [s_n] "=&s"(s_n)                                                                                                         \
+        : [tcx] "v"(tr.tcx), [tcy] "v"(tr.tcy), [tcz] "v"(tr.tcz), [tbx] "v"(tr.tbx), [tby] "v"(tr.tby), [tbz] "v"(tr.tbz), [om] "v"(uint32_t(tr.octant_mask)), \
+          [lds] "v"(lds_slot0), [inf] "v"(0x7f800000u), [rsrc] "s"(image), [keep] "s"(keep_going), [k_cell] "s"(k_cell), [k_half] "s"(k_half), [entry_exec] "s"(entry_exec)        \
+        : "v124", "v125", "vcc", "scc", "memory"
+    if constexpr (FOREIGN && COUNT) asm volatile(VX_LOOP_ASM(VX_LEAF_EXITS_CSVO, VX_TAKE_MASKS_CSVO, VX_COUNT_TRIP) VX_LOOP_OPERANDS);
+    else if constexpr (FOREIGN) asm volatile(VX_LOOP_ASM(VX_LEAF_EXITS_CSVO, VX_TAKE_MASKS_CSVO, "") VX_LOOP_OPERANDS);
+    else if constexpr (COUNT) asm volatile(VX_LOOP_ASM(VX_LEAF_EXITS_ESVO, VX_TAKE_MASKS_ESVO, VX_COUNT_TRIP) VX_LOOP_OPERANDS);
+    else asm volatile(VX_LOOP_ASM(VX_LEAF_EXITS_ESVO, VX_TAKE_MASKS_ESVO, "") VX_LOOP_OPERANDS);
+#undef VX_LOOP_OPERANDS
+    trips += n_trips;
+    tr.px = __uint_as_float(px); tr.py = __uint_as_float(py); tr.pz = __uint_as_float(pz);
+    tr.scale = int(scale);
+    tr.scale_exp2 = pow2i(tr.scale - kMaxScale);  // (the loop derives the cell size from the scale; the service phases read the member)
+}
+
+}  // namespace vxd
