@@ -481,11 +481,28 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
         VX_PART_BEGIN(1);
+        // A voxel of a block whose textures are opaque throughout is a hit whatever the sample says (RenderParams::opaque_*): its leaf test
+        // is the value and arithmetic. The hit's colour is sampled when the hit is shaded (a shadow ray's never is).
+        constexpr bool kOpaqueFastPath = !STATS && !BATCH;
+        bool color_pending = false;
         if (state == kLeaf) {
             tr.iter &= ~kParked;
             tr.sync_idx();
-            const LeafOutcome o = tr.template leaf_test<false, STATS>(sc, st, true, res, nullptr, STATS ? &ctr : nullptr);
-            state = o == kLeafHit ? kDone : (o == kLeafPassed ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep) : kMissed);
+            bool tested = false;
+            if constexpr (kOpaqueFastPath) {
+                const uint32_t value = tr.leaf_value(sc);
+                const uint32_t set = value < 32u ? p.opaque_lo : p.opaque_hi;
+                if (value < 64u && ((set >> (value & 31u)) & 1u) != 0u && !(tr.flags & Trav<SVO>::kHasAdjacentLeaf)) {
+                    tr.leaf_hit_opaque(sc, value, res);
+                    color_pending = true;
+                    tested = true;
+                    state = kDone;
+                }
+            }
+            if (!tested) {
+                const LeafOutcome o = tr.template leaf_test<false, STATS>(sc, st, true, res, nullptr, STATS ? &ctr : nullptr);
+                state = o == kLeafHit ? kDone : (o == kLeafPassed ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep) : kMissed);
+            }
             if (state != kTrav) tr.iter |= kParked;
         }
         if (state == kMissed) {
@@ -656,7 +673,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             note_cost(a, p, out_index, tr.iter & ~kParked);
             if (!shadow_ray) {
                 PrimaryOutcome o;
-                shade_primary(sc, p, res, o);
+                shade_primary<kOpaqueFastPath>(sc, p, res, o, color_pending);
                 if (HITS) {
                     rec.t = res.t; rec.value = res.value; rec.face_id = res.face_id; rec.flags = o.flags;
                     rec.pos[0] = res.pos[0]; rec.pos[1] = res.pos[1]; rec.pos[2] = res.pos[2];
@@ -1147,7 +1164,14 @@ struct vx_context {
     bool image_enabled = true;  // VX_TRAVERSAL_IMAGE=0: traverse the world's own bytes
     bool image_ok = false;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
-    uint32_t refill_min = 4, service_min = 32, foreign_min = 32;
+    // (service_min: 32 until round 3; with the hand-scheduled loop a trip costs a third less and fewer, fuller service phases win:
+    // profiles/round3/pass_d/sweep_csvo.txt)
+    uint32_t refill_min = 4, service_min = 56, foreign_min = 32;
+    // Block ids 0..63 all of whose textures are opaque throughout (RenderParams::opaque_*): from host copies of what vx_set_materials and
+    // vx_set_textures were given. opaque_layer[l] = every texel of layer l, on every mip level, has alpha > 0.
+    std::vector<vx_material> host_materials;
+    std::vector<uint8_t> opaque_layer;
+    uint64_t opaque_blocks = 0;
     int min_waves = 4;                    // 4 = the image-only kernel is the build for 4 waves per SIMD (<= 128 VGPRs); 1 = compiler's choice
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int comm_headroom = 4;                // VX_COMM_HEADROOM: wave slots per CU a context with a communicator of more than one rank leaves free (LDS for RCCL's kernels)
@@ -1574,6 +1598,8 @@ int fill_params(vx_context* ctx, const vx_uniforms* u, uint32_t w, uint32_t h, u
     p.n_local_tiles = vx_local_tile_count(w, h, tile_rank, tile_count);
     p.tile_order = nullptr;
     p.rgba8 = format == VX_FORMAT_RGBA8 ? 1u : 0u;
+    p.opaque_lo = uint32_t(ctx->opaque_blocks);
+    p.opaque_hi = uint32_t(ctx->opaque_blocks >> 32);
     if (tile_count > 1) {
         const vx_context::TileTable* t = nullptr;
         if (int rc = tile_table(ctx, p.tiles_x, p.tiles_y, &t)) return rc;
@@ -1858,6 +1884,32 @@ void vx_destroy(vx_context* c) {
     delete c;
 }
 
+}  // extern "C"
+
+namespace {
+// Which block ids (< 64) are opaque throughout: all three face textures of the block's material row -- the layers texture_lod() picks for
+// them (round to nearest, clamped to the array) -- have alpha > 0 in every texel of every mip level. Then every sample's alpha is > 0
+// too (NEAREST: a texel; LINEAR_MIPMAP_LINEAR: a blend of texels with non-negative weights that sum to 1, of which one is >= 1/4 on
+// each level), i.e. a voxel of the block is a hit for any ray that reaches it (svo.esvo.glsl:241: `tex_color.a > 0`).
+void update_opaque_blocks(vx_context* ctx) {
+    uint64_t set = 0;
+    const uint32_t layers = uint32_t(ctx->opaque_layer.size());
+    if (layers != 0 && ctx->tex.levels != 0) {
+        auto layer_of = [&](int32_t id) -> uint32_t {  // texture_lod(): floor(float(id) + 0.5), clamped
+            const float lf = std::floor(float(id) + 0.5f);
+            return lf <= 0.0f ? 0u : (lf >= float(layers - 1) ? layers - 1 : uint32_t(lf));
+        };
+        for (size_t v = 0; v < ctx->host_materials.size() && v < 64; ++v) {
+            const vx_material& m = ctx->host_materials[v];
+            if (ctx->opaque_layer[layer_of(m.tex_top)] && ctx->opaque_layer[layer_of(m.tex_side)] && ctx->opaque_layer[layer_of(m.tex_bottom)]) set |= uint64_t(1) << v;
+        }
+    }
+    ctx->opaque_blocks = std::getenv("VX_NO_OPAQUE_SET") ? 0 : set;  // (measurement: every leaf test samples its texture, as before round 3)
+}
+}  // namespace
+
+extern "C" {
+
 int vx_set_materials(vx_context* ctx, const vx_material* rows, uint32_t count) {
     if (!ctx || !rows || count == 0) return fail(VX_ERR_INVALID_ARGUMENT, "materials: null or empty");
     VX_LOCK(ctx);
@@ -1877,6 +1929,8 @@ int vx_set_materials(vx_context* ctx, const vx_material* rows, uint32_t count) {
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     ctx->d_materials = fresh;
     ctx->n_materials = count;
+    ctx->host_materials.assign(rows, rows + count);
+    update_opaque_blocks(ctx);
     return VX_OK;
 }
 
@@ -1934,6 +1988,16 @@ int vx_set_textures(vx_context* ctx, const uint8_t* rgba8, uint32_t width, uint3
     ctx->d_tex = fresh;
     ctx->tex_bytes = uint32_t(total);
     ctx->tex = t;
+    ctx->opaque_layer.assign(layers, 1);
+    for (uint32_t l = 0; l < levels; ++l) {
+        const uint32_t w = (width >> l) ? (width >> l) : 1, h = (height >> l) ? (height >> l) : 1;
+        for (uint32_t layer = 0; layer < layers; ++layer) {
+            const uint8_t* texels = chain.data() + t.level_offset[l] + size_t(layer) * w * h * 4;
+            for (size_t i = 0; i < size_t(w) * h && ctx->opaque_layer[layer]; ++i)
+                if (texels[i * 4 + 3] == 0) ctx->opaque_layer[layer] = 0;
+        }
+    }
+    update_opaque_blocks(ctx);
     return VX_OK;
 }
 

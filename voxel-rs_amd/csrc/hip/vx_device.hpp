@@ -937,6 +937,81 @@ struct Trav {
     }
     __device__ __forceinline__ void sync_idx() { idx = idx_from_position(); }
 
+    // The voxel's value (block id) for a ray whose step() returned kTravAtLeaf.
+    __device__ __forceinline__ uint32_t leaf_value(const DevScene& sc) const {
+        const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
+        return CSVO  ? csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx)
+               : WIDE ? wide_u32(sc, ptr, octant_idx * image_value_stride())
+               : IMG  ? buf_u32(sc.world, ptr + octant_idx * image_value_stride())
+                     : word(sc, ptr + 4 + octant_idx);
+    }
+
+    // Which face of the voxel the ray enters through and where on it (svo.esvo.glsl:196-233): arithmetic on the cursor only.
+    struct LeafSurface {
+        int face_id;
+        float uvx, uvy;
+        float qx, qy, qz;  // the voxel's un-mirrored corner
+    };
+    __device__ __forceinline__ LeafSurface leaf_surface() const {
+        LeafSurface f;
+        const float ex = __builtin_fmaf(px + scale_exp2, tcx, -tbx);
+        const float ey = __builtin_fmaf(py + scale_exp2, tcy, -tby);
+        const float ez = __builtin_fmaf(pz + scale_exp2, tcz, -tbz);
+        const float tc_min = gmax(gmax(ex, ey), ez);
+
+        f.qx = px; f.qy = py; f.qz = pz;
+        if (octant_mask & 1) f.qx = 3.0f - scale_exp2 - f.qx;
+        if (octant_mask & 2) f.qy = 3.0f - scale_exp2 - f.qy;
+        if (octant_mask & 4) f.qz = 3.0f - scale_exp2 - f.qz;
+
+        const float inv_s = __uint_as_float(0x7f000000u - __float_as_uint(scale_exp2));  // exact 1/scale_exp2
+        if (tc_min == ex) {
+            f.face_id = int((__float_as_uint(rdx) >> 31) & 1u);
+            f.uvx = (__builtin_fmaf(rdz, ex, roz) - f.qz) * inv_s;
+            f.uvy = (__builtin_fmaf(rdy, ex, roy) - f.qy) * inv_s;
+            if (rdx > 0.0f) f.uvx = 1.0f - f.uvx;
+        } else if (tc_min == ey) {
+            f.face_id = 2 | int((__float_as_uint(rdy) >> 31) & 1u);
+            f.uvx = (__builtin_fmaf(rdx, ey, rox) - f.qx) * inv_s;
+            f.uvy = (__builtin_fmaf(rdz, ey, roz) - f.qz) * inv_s;
+            if (rdy > 0.0f) f.uvy = 1.0f - f.uvy;
+        } else {
+            f.face_id = 4 | int((__float_as_uint(rdz) >> 31) & 1u);
+            f.uvx = (__builtin_fmaf(rdx, ez, rox) - f.qx) * inv_s;
+            f.uvy = (__builtin_fmaf(rdy, ez, roy) - f.qy) * inv_s;
+            if (rdz < 0.0f) f.uvx = 1.0f - f.uvx;
+        }
+        return f;
+    }
+    // the texture level of detail at the hit (svo.esvo.glsl:238-239) and the hit record minus its colour (svo.esvo.glsl:246-262)
+    __device__ __forceinline__ static float leaf_lod(float dst) { return smoothstepf(15.0f, 25.0f, dst) * (dst - 15.0f) * 0.05f; }
+    __device__ __forceinline__ void leaf_record(const DevScene& sc, const LeafSurface& f, uint32_t value, float dst, float tex_lod, Result& res) const {
+        const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(sc.octree_scale));  // 2^depth, exact
+        res.t = dst;
+        res.face_id = f.face_id;
+        res.uv[0] = f.uvx; res.uv[1] = f.uvy;
+        res.value = value;
+        res.lod = tex_lod;
+        const float hx = gmin(gmax(__builtin_fmaf(t_min, rdx, rox), f.qx + kEps), f.qx + scale_exp2 - kEps);
+        const float hy = gmin(gmax(__builtin_fmaf(t_min, rdy, roy), f.qy + kEps), f.qy + scale_exp2 - kEps);
+        const float hz = gmin(gmax(__builtin_fmaf(t_min, rdz, roz), f.qz + kEps), f.qz + scale_exp2 - kEps);
+        res.pos[0] = (hx - 1.0f) * inv_scale;
+        res.pos[1] = (hy - 1.0f) * inv_scale;
+        res.pos[2] = (hz - 1.0f) * inv_scale;
+        res.inside_voxel = inside_voxel();
+    }
+
+    // A voxel whose every texel of every face and mip level has alpha > 0 (the host's `opaque` set of block ids: vx_api.hip, opaque_blocks)
+    // is a hit whatever the sample: the HIT phase is then the value and arithmetic -- no material row, no texels. The record is
+    // leaf_test()'s except for its colour, which the caller samples when (and if: a shadow ray's is never looked at) it shades the hit,
+    // with the same function on the same arguments (hit_color()).
+    __device__ __forceinline__ void leaf_hit_opaque(const DevScene& sc, uint32_t value, Result& res) const {
+        const LeafSurface f = leaf_surface();
+        const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(sc.octree_scale));
+        const float dst = t_min * inv_scale;
+        leaf_record(sc, f, value, dst, leaf_lod(dst), res);
+    }
+
     // HIT phase (svo.esvo.glsl:185-265) for a ray whose step() returned kTravAtLeaf. kLeafHit: the leaf is the result
     // (res filled in). Otherwise the translucent leaf is recorded and the ADVANCE half of the iteration is run.
     template <bool TRACE, bool STATS, class ST>
@@ -945,69 +1020,25 @@ struct Trav {
         if (STATS) ctr->leaf_tests++;
         const float octree_scale = sc.octree_scale;
         const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 2^depth, exact
-        const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
-        const uint32_t value = CSVO  ? csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx)
-                               : WIDE ? wide_u32(sc, ptr, octant_idx * image_value_stride())
-                               : IMG  ? buf_u32(sc.world, ptr + octant_idx * image_value_stride())
-                                     : word(sc, ptr + 4 + octant_idx);
-
-        const float ex = __builtin_fmaf(px + scale_exp2, tcx, -tbx);
-        const float ey = __builtin_fmaf(py + scale_exp2, tcy, -tby);
-        const float ez = __builtin_fmaf(pz + scale_exp2, tcz, -tbz);
-        const float tc_min = gmax(gmax(ex, ey), ez);
-
-        float qx = px, qy = py, qz = pz;  // un-mirrored voxel corner
-        if (octant_mask & 1) qx = 3.0f - scale_exp2 - qx;
-        if (octant_mask & 2) qy = 3.0f - scale_exp2 - qy;
-        if (octant_mask & 4) qz = 3.0f - scale_exp2 - qz;
-
-        const float inv_s = __uint_as_float(0x7f000000u - __float_as_uint(scale_exp2));  // exact 1/scale_exp2
-        int face_id;
-        float uvx, uvy;
-        if (tc_min == ex) {
-            face_id = int((__float_as_uint(rdx) >> 31) & 1u);
-            uvx = (__builtin_fmaf(rdz, ex, roz) - qz) * inv_s;
-            uvy = (__builtin_fmaf(rdy, ex, roy) - qy) * inv_s;
-            if (rdx > 0.0f) uvx = 1.0f - uvx;
-        } else if (tc_min == ey) {
-            face_id = 2 | int((__float_as_uint(rdy) >> 31) & 1u);
-            uvx = (__builtin_fmaf(rdx, ey, rox) - qx) * inv_s;
-            uvy = (__builtin_fmaf(rdz, ey, roz) - qz) * inv_s;
-            if (rdy > 0.0f) uvy = 1.0f - uvy;
-        } else {
-            face_id = 4 | int((__float_as_uint(rdz) >> 31) & 1u);
-            uvx = (__builtin_fmaf(rdx, ez, rox) - qx) * inv_s;
-            uvy = (__builtin_fmaf(rdy, ez, roy) - qy) * inv_s;
-            if (rdz < 0.0f) uvx = 1.0f - uvx;
-        }
+        const uint32_t value = leaf_value(sc);
+        const LeafSurface f = leaf_surface();
 
         const vx_material mat = material_at(sc, value);
         int tex_id = mat.tex_side;
-        if (face_id == 3) tex_id = mat.tex_top;
-        else if (face_id == 2) tex_id = mat.tex_bottom;
+        if (f.face_id == 3) tex_id = mat.tex_top;
+        else if (f.face_id == 2) tex_id = mat.tex_bottom;
 
         const float dst = t_min * inv_scale;
-        const float tex_lod = smoothstepf(15.0f, 25.0f, dst) * (dst - 15.0f) * 0.05f;
+        const float tex_lod = leaf_lod(dst);
         if (STATS && tex_lod > 0.0f) ctr->leaf_tests_trilinear++;
 
         float tex_color[4];
-        texture_lod(sc.tex, uvx, uvy, float(tex_id), tex_lod, tex_color);
+        texture_lod(sc.tex, f.uvx, f.uvy, float(tex_id), tex_lod, tex_color);
 
         const bool first_of_kind = !(flags & kHasAdjacentLeaf) || value != last_leaf_value;
         if ((tex_color[3] > 0.0f || !cast_translucent) && first_of_kind) {
-            res.t = dst;
-            res.face_id = face_id;
-            res.uv[0] = uvx; res.uv[1] = uvy;
-            res.value = value;
+            leaf_record(sc, f, value, dst, tex_lod, res);
             res.color[0] = tex_color[0]; res.color[1] = tex_color[1]; res.color[2] = tex_color[2]; res.color[3] = tex_color[3];
-            res.lod = tex_lod;
-            const float hx = gmin(gmax(__builtin_fmaf(t_min, rdx, rox), qx + kEps), qx + scale_exp2 - kEps);
-            const float hy = gmin(gmax(__builtin_fmaf(t_min, rdy, roy), qy + kEps), qy + scale_exp2 - kEps);
-            const float hz = gmin(gmax(__builtin_fmaf(t_min, rdz, roz), qz + kEps), qz + scale_exp2 - kEps);
-            res.pos[0] = (hx - 1.0f) * inv_scale;
-            res.pos[1] = (hy - 1.0f) * inv_scale;
-            res.pos[2] = (hz - 1.0f) * inv_scale;
-            res.inside_voxel = inside_voxel();
             return kLeafHit;
         }
         flags |= kHasAdjacentLeaf;
@@ -1175,6 +1206,9 @@ struct RenderParams {
     // tile_order[k * tile_count + tile_rank], k = 0 .. n_local_tiles - 1 (device memory; null when the whole image is rendered)
     const uint32_t* tile_order;
     uint32_t rgba8;  // the target holds RGBA8 pixels (vx_target.format): 4 bytes each, and a whole image has its TOP row first
+    // block ids 0..63 whose textures -- all three faces, every texel of every mip level -- have alpha > 0: a voxel of such a block is a hit
+    // whatever the sample (Trav::leaf_hit_opaque). The host derives it from the material rows and the mip chain (vx_api.hip).
+    uint32_t opaque_lo, opaque_hi;
 };
 
 // A pixel's place in the target and its value there. RGBA32F: the image2D of world.glsl:10 (row 0 = bottom). RGBA8: what
@@ -1277,7 +1311,10 @@ struct PrimaryOutcome {
     uint32_t flags;       // vx_hit flags accumulated so far
 };
 
-__device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderParams& p, const Result& res, PrimaryOutcome& o) {
+// COLOR_PENDING (a hit accepted by Trav::leaf_hit_opaque): res.color is not there yet -- it is sampled here, where the hit's material row is
+// at hand anyway, with leaf_test()'s own arguments: the face's texture at (uv, lod).
+template <bool COLOR_PENDING = false>
+__device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderParams& p, const Result& res, PrimaryOutcome& o, bool color_pending = false) {
     o.flags = res.t != -1.0f ? 1u : 0u;
     o.final_color = true;
     o.ds = 0.0f;
@@ -1325,6 +1362,12 @@ __device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderPa
 
     o.ds = diffuse + specular;
     o.color[0] = res.color[0]; o.color[1] = res.color[1]; o.color[2] = res.color[2]; o.color[3] = res.color[3];
+    if (COLOR_PENDING && color_pending) {
+        int tex_id = mat.tex_side;
+        if (res.face_id == 3) tex_id = mat.tex_top;
+        else if (res.face_id == 2) tex_id = mat.tex_bottom;
+        texture_lod(sc.tex, res.uv[0], res.uv[1], float(tex_id), res.lod, o.color);
+    }
     if (p.u.render_shadows && res.t < p.u.shadow_distance) {
         o.final_color = false;
         o.flags |= 2u;
