@@ -75,10 +75,16 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--format", choices=["esvo", "csvo"], default="csvo", help="node format; csvo is the reference's default build feature")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames the renderer keeps in flight (1..8); default: the library's own (2) on one GPU, max(3, N) when the frame is sharded over N")
+                    help="frames the renderer keeps in flight (1..8); default: the library's own (2) on one GPU, max(3, N) when the frame is sharded over N "
+                         "(a sharded frame's next render waits for the exchange and rank 0's assembly of the frame before last on its stream)")
     ap.add_argument("--gather-group", type=int, default=0, help="sharded: frames per gather (default 1)")
-    ap.add_argument("--gather", choices=["library", "torch"], default="library",
-                    help="sharded: the exchange step -- library: vx_gather_tiles (RCCL send/receive owned by the render context); torch: torch.distributed.gather")
+    ap.add_argument("--gather", choices=["auto", "library", "torch"], default="auto",
+                    help="sharded: the exchange step -- library: vx_gather_tiles (RCCL send/receive owned by the render context); torch: torch.distributed.gather; "
+                         "auto: the library's, checked on its first frames (watchdog + the assembled frame against the whole render), torch's if that fails")
+    ap.add_argument("--gather-format", choices=["rgba8", "rgba32f"], default="rgba8",
+                    help="sharded: pixel format of the tile lists that travel and of rank 0's image (rgba8 = Framebuffer::as_image's bytes: a quarter of the link time)")
+    ap.add_argument("--gather-timeout", type=float, default=30.0, help="sharded: seconds the first exchange may take before it is declared hung")
+    ap.add_argument("--simulate-gather-failure", action="store_true", help="testing: make the library's exchange fail, to exercise the fall-back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (tile lists, RCCL gather, assembly) even with one rank; needs a torch.distributed.run launch")
@@ -144,63 +150,174 @@ def main():
     my_rays = counters["rays"]
     my_bytes = algorithmic_bytes(args.format, counters)
 
+    gather_used, gather_note, comm_hung = None, None, False
     if sharded:
         from voxel_rs_amd.sharding import FrameSharder
 
-        def render_tiles(tiles):
-            svo.render_device(uniforms, W, H, tiles.data_ptr(), tile_rank=rank, tile_count=world_size)
-
-        library_gather = args.gather == "library"
-        if library_gather:
-            # the render context owns the RCCL communicator the tiles travel over (vx_comm_init); torch.distributed only carries the
-            # id to the ranks and the barriers / statistics of this script
-            uid = [hip.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            svo.comm_init(world_size, rank, uid[0])
-        exchange_stream = svo.comm_stream if library_gather else torch.cuda.current_stream().cuda_stream
-
-        def assemble(gathered, image):
-            # on the exchange's stream: ordered after the gather by construction, and the render streams stay free for the
-            # next frame's tiles. `gathered` is [rank][tile]... with the ranks a whole group of frames apart.
-            svo.assemble_tiles(gathered.data_ptr(), gathered.stride(0), world_size, W, H, image.data_ptr(), stream=exchange_stream)
-
-        # The renderer runs frames on its own streams; the gather and the assembly run on the communicator's. One tile buffer per frame
-        # in flight: a render only has to wait for the collective that last read its buffer.
+        # What travels: the tiles as RGBA8 (Framebuffer::as_image's bytes, vx_format) by default. The exchange is bound by the links
+        # into rank 0 -- (N - 1) / N of every frame, one xGMI link per peer: a 1080p RGBA32F frame is 33 MB, i.e. 16.6 / 8.3 / 4.2 MB
+        # per link at N = 2 / 4 / 8, which at ~77 GB/s a direction is 1.3 x the time the ranks take to RENDER their shares; RGBA8 is
+        # a quarter of that, and a quarter of rank 0's assembly pass.
+        vx_fmt = hip.VX_FORMAT_RGBA8 if args.gather_format == "rgba8" else hip.VX_FORMAT_RGBA32F
         # frames in flight: the smaller a rank's share of the frame, the longer its tail relative to its body (a frame cannot
         # finish before its longest ray) and the more frames it takes to keep the device full
-        FRAMES = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else min(8, max(2, world_size))
+        FRAMES = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else min(8, max(3, world_size))
         # frames per collective (1: every frame is gathered as soon as it is rendered; more: fewer, larger messages)
         GROUP = args.gather_group if args.gather_group else 1
         GROUP = max(1, min(GROUP, FRAMES))
         FRAMES -= FRAMES % GROUP
         svo.set_frames_in_flight(FRAMES)
-        exchange_done = [torch.cuda.Event() for _ in range(FRAMES // GROUP)]
-        recorded = [False] * (FRAMES // GROUP)
-        tickets = {}
+        gather_events = []  # torch path: (start, stop) event pairs around the collective, on torch's stream
 
-        def before_render(g):
-            if library_gather:
-                if g in tickets:
-                    svo.wait_gather(tickets[g])
-            elif recorded[g]:
-                svo.wait_event(exchange_done[g].cuda_event)
+        def render_tiles(tiles):
+            svo.render_device(uniforms, W, H, tiles.data_ptr(), tile_rank=rank, tile_count=world_size, fmt=vx_fmt)
 
-        def after_render():
+        def build_sharder(library_gather):
+            """The whole N > 1 path with one of the two exchanges: the library's own (vx_gather_tiles: grouped ncclSend / ncclRecv on the
+            render context's communicator and stream) or torch.distributed.gather (nccl backend = RCCL as well)."""
+            exchange_stream = svo.comm_stream if library_gather else torch.cuda.current_stream().cuda_stream
+            exchange_done = [torch.cuda.Event() for _ in range(FRAMES // GROUP)]
+            recorded = [False] * (FRAMES // GROUP)
+            tickets = {}
+
+            def assemble(gathered, image):
+                # on the exchange's stream: ordered after the gather by construction, and the render streams stay free for the
+                # next frame's tiles. `gathered` is [rank][tile]... with the ranks a whole group of frames apart.
+                svo.assemble_tiles_format(gathered.data_ptr(), gathered.stride(0) // 4, world_size, W, H, image.data_ptr(), vx_fmt, exchange_stream)
+
+            def before_render(g):
+                # a render into a tile list waits for whatever still reads it: the gather AND rank 0's assembly (the ticket covers both)
+                if library_gather:
+                    if g in tickets:
+                        svo.wait_gather(tickets[g])
+                elif recorded[g]:
+                    svo.wait_event(exchange_done[g].cuda_event)
+
+            def after_render():
+                if not library_gather:
+                    svo.stream_wait_render(torch.cuda.current_stream().cuda_stream)
+
+            def after_exchange(g):
+                if library_gather:
+                    if rank == 0:
+                        tickets[g] = state["last_ticket"]  # (re-recorded behind the assembly by vx_assemble_tiles_format)
+                else:
+                    exchange_done[g].record(torch.cuda.current_stream())
+                    recorded[g] = True
+
+            state = {"last_ticket": None}
+
+            def gather(tiles, gathered):
+                g = sh._g  # (the group being exchanged)
+                if library_gather:
+                    if args.simulate_gather_failure:
+                        raise RuntimeError("simulated failure of the library's gather (--simulate-gather-failure)")
+                    state["last_ticket"] = tickets[g] = svo.gather_tiles(tiles.data_ptr(), tiles.numel() * tiles.element_size(),
+                                                                        gathered.data_ptr() if rank == 0 else None, root=0)
+                else:
+                    timed = svo_profile["on"]
+                    if timed:
+                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev[0].record()
+                    dist.gather(tiles, [gathered[r] for r in range(world_size)] if rank == 0 else None, dst=0)
+                    if timed:
+                        ev[1].record()
+                        gather_events.append(ev)
+
+            sh = FrameSharder(W, H, rank, world_size, dist, "cuda", render_tiles, assemble, before_render=before_render, after_render=after_render,
+                              after_exchange=after_exchange, buffers=FRAMES, group=GROUP, gather=gather, pixel_format=args.gather_format)
             if not library_gather:
-                svo.stream_wait_render(torch.cuda.current_stream().cuda_stream)
+                # (torch's gather wants its own send buffer: the root's list is not rendered in place)
+                sh.tiles = [torch.zeros((GROUP, sh.n_max, 32, 32, 4), dtype=sh.dtype, device="cuda") for _ in range(FRAMES // GROUP)]
+                torch.cuda.synchronize()
+            sh.query = (lambda: svo.gather_query(state["last_ticket"]) if state["last_ticket"] is not None else 1) if library_gather else None
+            return sh
 
-        def after_exchange(g):
-            if not library_gather:
-                exchange_done[g].record(torch.cuda.current_stream())
-                recorded[g] = True
+        svo_profile = {"on": False}
 
-        def gather(tiles, gathered):
-            g = sharder._g  # (the group being exchanged; a later render into its lists waits for this gather to have read them)
-            tickets[g] = svo.gather_tiles(tiles.data_ptr(), tiles.numel() * 4, gathered.data_ptr() if rank == 0 else None, root=0)
+        def whole_frame():
+            img = torch.zeros((H, W, 4), dtype=torch.uint8 if vx_fmt == hip.VX_FORMAT_RGBA8 else torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            svo.render_device(uniforms, W, H, img.data_ptr(), fmt=vx_fmt)
+            svo.sync()
+            return img
 
-        sharder = FrameSharder(W, H, rank, world_size, dist, "cuda", render_tiles, assemble, before_render=before_render,
-                               after_render=after_render, after_exchange=after_exchange, buffers=FRAMES, group=GROUP,
-                               gather=gather if library_gather else None)
+        def frame_is_whole(sh):
+            """rank 0: what the path delivered, against the same frame rendered whole on this GPU"""
+            whole = whole_frame()
+            if world_size > 1:
+                got = sh.image
+            else:
+                # one rank (--force-sharded): tile_count 1 means "the whole frame, row-major" to vx_render, so this rank's "tile list" is the
+                # frame itself and the assembly kernel (which runs for its cost) scatters something that is no tile list -- the check is
+                # on what the gather delivered. (An RGBA8 frame is stored top row first, a tile list bottom row first: same here, the
+                # "list" IS the frame.)
+                got = sh.last_gathered[0].reshape(-1)[:H * W * 4].view(H, W, 4)
+            a, b = whole.contiguous().view(torch.uint8), got.contiguous().view(torch.uint8)
+            return bool(torch.equal(a, b))
+
+        def first_frames_ok(sh, seconds):
+            """GROUP frames through the whole path, watched: the exchange must come back within `seconds` on every rank (a collective a
+            peer never joins would otherwise hang the benchmark) and rank 0's assembled frame must be the whole render's."""
+            ok = 1
+            try:
+                for _ in range(GROUP):
+                    sh.step()
+                sh.flush()
+                if sh.query is not None:
+                    deadline = time.time() + seconds
+                    while True:
+                        q = sh.query()
+                        if q != 0:
+                            ok = 1 if q == 1 else 0
+                            break
+                        if time.time() > deadline:
+                            ok = 0
+                            break
+                        time.sleep(0.002)
+                if ok:
+                    svo.sync()
+                    torch.cuda.synchronize()
+                    if rank == 0:
+                        ok = 1 if frame_is_whole(sh) else 0
+            except Exception as e:  # an error code from the library (VX_ERR_HIP with RCCL's message), or the simulated one
+                print(f"[bench rank {rank}] exchange failed: {e}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(int(flag.item()))
+
+        want_library = args.gather in ("auto", "library")
+        sharder = None
+        if want_library:
+            try:
+                # the render context owns the RCCL communicator the tiles travel over (vx_comm_init); torch.distributed only carries the
+                # id to the ranks and the barriers / statistics of this script
+                uid = [hip.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                svo.comm_init(world_size, rank, uid[0])
+                sharder = build_sharder(True)
+                init_ok = 1
+            except Exception as e:
+                print(f"[bench rank {rank}] vx_comm_init failed: {e}", file=sys.stderr)
+                init_ok = 0
+            flag = torch.tensor([init_ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) and first_frames_ok(sharder, args.gather_timeout):
+                gather_used = "library"
+            elif args.gather == "library":
+                raise SystemExit("--gather library: the library's exchange failed its first frames (see stderr); --gather auto falls back to torch.distributed")
+            else:
+                # never re-exec a process that has touched the GPU: the other exchange, in this process. The library's communicator is left
+                # alone (destroying one with a collective in flight can block).
+                gather_note = "the library's vx_gather_tiles failed its first frames on this node; fell back in-process"
+                comm_hung = True
+                sharder = None
+        if sharder is None:
+            sharder = build_sharder(False)
+            gather_used = "torch"
+            if not first_frames_ok(sharder, args.gather_timeout):
+                gather_note = (gather_note + "; " if gather_note else "") + "torch.distributed.gather's first frames did not reproduce the whole render"
         step = sharder.step
         flush = sharder.flush
     else:
@@ -232,6 +349,8 @@ def main():
     # The timed block -- exactly --steps frames between two barriers -- is run --repeats times back to back and the MEDIAN block is
     # what is reported: 50 frames are 25 ms of GPU time, too little for one sample to stand on.
     svo.profile_enable(True)
+    if sharded:
+        svo_profile["on"] = True
     blocks, enqueue = [], []
     for _ in range(max(args.repeats, 1)):
         barrier()
@@ -242,59 +361,104 @@ def main():
         barrier()
         blocks.append(time.perf_counter() - t0)
     kernel_ms, launches = svo.profile_read()
+    # the exchanges of the timed region: time on the exchange's stream from the first send / receive to the last (the wait for the
+    # slowest peer included)
+    gather_ms, gathers = 0.0, 0
+    if sharded:
+        svo_profile["on"] = False
+        if gather_used == "library":
+            gather_ms, gathers = svo.comm_profile_read()
+        else:
+            torch.cuda.synchronize()
+            gather_ms, gathers = sum(a.elapsed_time(b) for a, b in gather_events), len(gather_events)
+            gather_events.clear()
     svo.profile_enable(False)
     enqueue_s = sorted(enqueue)[len(enqueue) // 2]
 
     # One frame at a time (outside the timed region): with several frames in flight a kernel's HIP-event span includes the time it
     # shares the device with its neighbours, so the kernel's OWN duration -- what the roofline fraction is defined on -- is measured
-    # with the frames serialised on one stream.
-    svo.sync()
-    svo.set_frames_in_flight(1)
-    for _ in range(3):
-        step()
+    # with the device to itself, twice:
+    #  (a) the timed region's own launch policy: the frame streams, every frame waited for before the next is issued;
+    #  (b) the library's one-frame-at-a-time mode (set_frames_in_flight(1): the context's own stream, where it hands out a view's
+    #      sub-tiles most expensive first -- the table is made from the frame before last -- so that the longest rays start early):
+    #      what a consumer that presents every frame runs, and the same command rocprofv3 is run on for profiles/ (VX_FRAMES_IN_FLIGHT=1).
     barrier()
     svo.profile_enable(True)
     for _ in range(20):
         step()
+        flush()
+        svo.sync()
     barrier()
     exclusive_ms, exclusive_launches = svo.profile_read()
+    if sharded and gather_used == "library":
+        svo.comm_profile_read()
     svo.profile_enable(False)
-    svo.set_frames_in_flight(FRAMES)
-    kernel_exclusive_ms = exclusive_ms / max(exclusive_launches, 1)
+    kernel_exclusive_frame_stream_ms = exclusive_ms / max(exclusive_launches, 1)
+    kernel_exclusive_ms = kernel_exclusive_frame_stream_ms
+    if not sharded:
+        svo.set_frames_in_flight(1)
+        for _ in range(4):
+            step()
+        barrier()
+        svo.profile_enable(True)
+        for _ in range(20):
+            step()
+        barrier()
+        exclusive_ms, exclusive_launches = svo.profile_read()
+        svo.profile_enable(False)
+        svo.set_frames_in_flight(FRAMES)
+        kernel_exclusive_ms = exclusive_ms / max(exclusive_launches, 1)
+
+    # The game's own shadow cut-off (500 blocks, src/gamelogic/world.rs:105-108; SURVEY.md 8d asks for both): the same frame with
+    # shadow_distance = 500 -- from this altitude few or no hits are that near, so it is close to a primary-rays-only frame. One GPU only.
+    sd500 = None
+    if not sharded:
+        u500 = scenes.bench_camera(args.depth, st["h_max"], W, H, shadow_distance=500.0, render_shadows=True)
+        rays500 = svo.render_counters(u500, W, H, 0, 1)["rays"]
+        for _ in range(args.warmup):
+            svo.render_device(u500, W, H, images[0].data_ptr())
+        svo.sync()
+        t500 = []
+        for _ in range(5):
+            svo.sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                svo.render_device(u500, W, H, images[i % FRAMES].data_ptr())
+            svo.sync()
+            t500.append(time.perf_counter() - t0)
+        ms500 = sorted(t500)[2] / args.steps * 1e3
+        sd500 = {"shadow_distance": 500.0, "rays_per_frame": int(rays500), "ms_per_step": round(ms500, 4), "value": round(rays500 / (ms500 * 1e-3) / 1e6, 3),
+                 "unit": "Mrays/s", "note": "the timed frame casts a shadow ray from every primary hit (shadow_distance = inf); this is the game's default cut-off"}
 
     times = torch.tensor(blocks, dtype=torch.float64, device="cuda")
-    stats = torch.tensor([float(my_rays), float(my_bytes), kernel_ms / max(launches, 1), kernel_exclusive_ms], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([float(my_rays), float(my_bytes), kernel_ms / max(launches, 1), kernel_exclusive_ms, gather_ms / max(gathers, 1)],
+                         dtype=torch.float64, device="cuda")
+    per_rank = None
     if dist is not None:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)  # per block: the slowest rank
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         total_rays = float(sm[0])
+        every = [torch.zeros_like(stats) for _ in range(world_size)]
+        dist.all_gather(every, stats)
+        per_rank = [{"rank": r, "rays": int(e[0]), "kernel_span_ms_in_flight": round(float(e[2]), 4), "kernel_exclusive_ms": round(float(e[3]), 4),
+                     "exchange_ms": round(float(e[4]), 4)} for r, e in enumerate(every)]
     else:
         total_rays = float(my_rays)
     block_s = sorted(float(t) for t in times)
     elapsed = block_s[len(block_s) // 2]
+    # sharded: the frame rank 0 assembled last against the same frame rendered whole on this GPU (outside the timed region)
+    sharded_frame_identical = None
+    if sharded and rank == 0:
+        sharded_frame_identical = frame_is_whole(sharder)
     if rank != 0:
-        if sharded and args.gather == "library":
+        if sharded and gather_used == "library":
             svo.comm_destroy()
         if dist is not None:
             dist.destroy_process_group()
+        if comm_hung:
+            os._exit(0)  # (a communicator with a collective that never completed: its teardown can block)
         return
-
-    # sharded: the frame rank 0 assembled last against the same frame rendered whole on this GPU (outside the timed region)
-    sharded_frame_identical = None
-    if sharded:
-        whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-        torch.cuda.synchronize()
-        svo.render_device(uniforms, W, H, whole.data_ptr())
-        svo.sync()
-        if world_size > 1:
-            got = sharder.image
-        else:
-            # one rank (--force-sharded): tile_count 1 means "the whole frame, row-major" to vx_render, so this rank's "tile
-            # list" is the frame itself and the assembly kernel (which runs for its cost) scatters something that is no tile
-            # list -- the check is on what the gather delivered
-            got = sharder.last_gathered[0].reshape(-1)[:H * W * 4].view(H, W, 4)
-        sharded_frame_identical = bool(torch.equal(whole.view(torch.int32), got.contiguous().view(torch.int32)))
 
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (ms_per_step * 1e-3) / 1e6  # Mrays/s, whole job
@@ -312,6 +476,11 @@ def main():
                 "byte_model": "the reference's own fetches (SURVEY.md 8d), counted by the instrumented kernel on the world's own bytes",
                 "image_model_bytes_per_launch": int(image_model_bytes(counters)),
                 "frames_in_flight": FRAMES, **({"frames_per_gather": GROUP} if sharded else {}),
+                "kernel_exclusive_mode": ("one frame at a time on the context's own stream (set_frames_in_flight(1)): sub-tiles handed out most expensive first"
+                                          if not sharded else "every frame waited for before the next is issued; the timed region's streams and launch policy"),
+                # the same with the timed region's own launch policy (frame streams, screen order), every frame waited for
+                "kernel_exclusive_ms_timed_policy": round(kernel_exclusive_frame_stream_ms, 4),
+                "timed_region_mode": f"{FRAMES} frames in flight (ms_per_step); kernel_span_ms_in_flight is a launch's own event span there",
                 # what the device sustains over the median timed block: bytes x frames / elapsed
                 "sustained_GBps": round(my_bytes * args.steps / max(elapsed, 1e-9) / 1e9, 3)}
 
@@ -375,16 +544,18 @@ def main():
                                f"({args.format.upper()} nodes), 1 frame per step", "svo_format": args.format, "svo_bytes": world.size_in_bytes,
                    "leaves": st["leaves"], "chunks": st["chunks"], "textures": args.textures, "rays_per_frame": int(total_rays), "primary_rays": W * H,
                    "parallelism": f"screen tiles (32x32, Morton order, round-robin) over {world_size} GPU(s), SVO replicated, RCCL gather to rank 0",
-                   **({"rccl_ranks": world_size, "gather": "vx_gather_tiles (grouped ncclSend/ncclRecv on the render context's own communicator)" if args.gather == "library"
-                       else "torch.distributed.gather (nccl backend)"} if sharded else {}),
+                   **({"rccl_ranks": world_size, "gather": "vx_gather_tiles (grouped ncclSend/ncclRecv on the render context's own communicator)" if gather_used == "library"
+                       else "torch.distributed.gather (nccl backend)", "gather_requested": args.gather, **({"gather_note": gather_note} if gather_note else {}),
+                       "gather_format": args.gather_format, "bytes_gathered_per_frame": int((world_size - 1) * sharder.n_max * 1024 * (4 if args.gather_format == "rgba8" else 16)),
+                       "exchange_ms_per_gather_rank0": round(gather_ms / max(gathers, 1), 4), "per_rank": per_rank} if sharded else {}),
                    **({"sharded_frame_identical_to_whole_render": sharded_frame_identical} if sharded else {}),
                    "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 3),
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4)},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, **({"shadow_distance_500": sd500} if sd500 else {}),
     }
     # the JSON line is the LAST thing on stdout: tear the communicators down first (RCCL prints a banner through C stdio, which
     # is flushed at exit otherwise) and flush C's buffers before Python's
-    if sharded and args.gather == "library":
+    if sharded and gather_used == "library":
         svo.comm_destroy()
     if dist is not None:
         dist.destroy_process_group()
@@ -393,6 +564,8 @@ def main():
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
     print(json.dumps(out), flush=True)
+    if comm_hung:
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -281,8 +281,14 @@ int vx_comm_destroy(vx_context* ctx);
 int vx_comm_info(const vx_context* ctx, int* nranks, int* rank);
 int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank, void* gathered, int root, int* out_ticket);
 int vx_wait_gather(vx_context* ctx, int ticket);
+/* Has that gather (and an assembly issued behind it on the communicator's stream: see vx_assemble_tiles_format) finished? 1 = yes,
+ * 0 = not yet, -1 = bad ticket or a device error. Never blocks: a caller that must not hang on a collective a peer never joins polls
+ * this against a deadline instead of calling vx_sync. */
+int vx_gather_query(vx_context* ctx, int ticket);
 void* vx_comm_stream(vx_context* ctx);
-/* vx_assemble_tiles for either pixel format: stride in PIXELS between the ranks' lists; an RGBA8 image comes out top row first. */
+/* vx_assemble_tiles for either pixel format: stride in PIXELS between the ranks' lists; an RGBA8 image comes out top row first.
+ * Issued on vx_comm_stream(ctx), it extends the newest gather's ticket: vx_wait_gather(ticket) then also waits for this kernel,
+ * which reads every rank's list -- the root's own included, which the root renders into in place. */
 int vx_assemble_tiles_format(vx_context* ctx, const void* tiles, uint64_t stride_pixels, uint32_t tile_count, uint32_t width, uint32_t height, void* out,
                              int format, void* stream);
 
@@ -325,6 +331,9 @@ int vx_render_counters(vx_context* ctx, const vx_uniforms* uniforms, uint32_t wi
 int vx_profile_enable(vx_context* ctx, int enabled);
 /* Sum of the bracketed kernel durations (ms) and their count since the last call; synchronises. */
 int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches);
+/* The same for the exchanges (vx_gather_tiles calls made while profiling was enabled): time on the communicator's stream from the
+ * first send / receive to the last, i.e. including the wait for the slowest peer. Synchronises the communicator's stream. */
+int vx_comm_profile_read(vx_context* ctx, double* gather_ms_sum, uint32_t* gathers);
 /* Measurement (contexts created with VX_TIMELINE=1 in the environment; else returns 0): per wave of the most recent render launch
  * EIGHT words -- [0] when it started, [1] when it found the sub-tile queue empty, [2] when it left (all in 10 ns ticks of the device's
  * constant clock), [3] sub-tiles taken | service phases << 20 | ticks spent in them << 32, [4] its life in shader-clock cycles

@@ -131,6 +131,7 @@ extern "C" {
     pub fn vx_comm_info(ctx: *const vx_context, nranks: *mut c_int, rank: *mut c_int) -> c_int;
     pub fn vx_gather_tiles(ctx: *mut vx_context, tiles: *const c_void, bytes_per_rank: u64, gathered: *mut c_void, root: c_int, out_ticket: *mut c_int) -> c_int;
     pub fn vx_wait_gather(ctx: *mut vx_context, ticket: c_int) -> c_int;
+    pub fn vx_gather_query(ctx: *mut vx_context, ticket: c_int) -> c_int;
     pub fn vx_comm_stream(ctx: *mut vx_context) -> *mut c_void;
     pub fn vx_assemble_tiles(ctx: *mut vx_context, tiles: *const f32, stride_floats: u64, tile_count: u32, width: u32, height: u32, out_rgba32f: *mut f32) -> c_int;
     pub fn vx_assemble_tiles_format(ctx: *mut vx_context, tiles: *const c_void, stride_pixels: u64, tile_count: u32, width: u32, height: u32, out: *mut c_void,

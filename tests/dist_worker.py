@@ -24,6 +24,14 @@ def main():
     scene = orc.OracleScene(SVO_TYPES["esvo"], w_.frame(), scenes.synthetic_materials().view(orc.MATERIAL_DTYPE), scenes.synthetic_textures(), 6)
     u = orc.Uniforms.from_buffer_copy(bytes(scenes.bench_camera(7, st["h_max"], w, h)))
 
+    pixel_format = sys.argv[6] if len(sys.argv) > 6 else "rgba32f"
+
+    def to_format(img):
+        """rgba8: Framebuffer::as_image's bytes (clamp to [0,1], round to 255 steps, NaN -> 0), rows left in place"""
+        if pixel_format == "rgba32f":
+            return img
+        return (np.clip(np.nan_to_num(img, nan=0.0), 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+
     def render_tiles(tiles):
         # render only this rank's tiles (rect by rect) into the compact list, like a sharded vx_render does
         tx, _ = sharding.tile_grid(w, h)
@@ -31,7 +39,7 @@ def main():
         for k, t in enumerate(sharding.local_tile_ids(w, h, rank, world)):
             x0, y0 = (t % tx) * 32, (t // tx) * 32
             img, _ = scene.render(u, w, h, rect=(x0, y0, min(x0 + 32, w), min(y0 + 32, h)), want_hits=False, threads=1)
-            blk = img[y0:y0 + 32, x0:x0 + 32]
+            blk = to_format(img[y0:y0 + 32, x0:x0 + 32])
             tiles[k, :blk.shape[0], :blk.shape[1]] = torch.from_numpy(np.ascontiguousarray(blk))
 
     def assemble(gathered, image):
@@ -43,7 +51,8 @@ def main():
     n_frames = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     calls = {"before": [], "exchange": []}
     fs = sharding.FrameSharder(w, h, rank, world, dist, "cpu", render_tiles, assemble, buffers=2 * group, group=group,
-                               before_render=lambda g: calls["before"].append(g), after_exchange=lambda g: calls["exchange"].append(g))
+                               before_render=lambda g: calls["before"].append(g), after_exchange=lambda g: calls["exchange"].append(g),
+                               pixel_format=pixel_format)
     delivered = []
     for f in range(n_frames):
         u.ambient = 0.3 + 0.05 * f
@@ -62,8 +71,13 @@ def main():
         for f in range(n_frames):
             u.ambient = 0.3 + 0.05 * f
             full, _ = scene.render(u, w, h, want_hits=False, threads=2)
-            same = same and np.array_equal(np.nan_to_num(delivered[f], nan=-7.0), np.nan_to_num(full, nan=-7.0))
-        same = same and np.array_equal(np.nan_to_num(image.numpy(), nan=-7.0), np.nan_to_num(delivered[-1], nan=-7.0))
+            if pixel_format == "rgba8":
+                same = same and delivered[f].dtype == np.uint8 and np.array_equal(delivered[f], to_format(full))
+            else:
+                same = same and np.array_equal(np.nan_to_num(delivered[f], nan=-7.0), np.nan_to_num(full, nan=-7.0))
+        last = image.numpy()
+        same = same and (np.array_equal(last, delivered[-1]) if pixel_format == "rgba8" else
+                         np.array_equal(np.nan_to_num(last, nan=-7.0), np.nan_to_num(delivered[-1], nan=-7.0)))
         Path(out_path).write_text(f"{int(same)} {world} {fs.n_max} {int(np.isfinite(full).all())}\n")
     dist.destroy_process_group()
 

@@ -36,12 +36,12 @@ def test_extract_then_assemble_is_identity():
         assert np.array_equal(sharding.assemble_tiles(gathered, w, h), img)
 
 
-@pytest.mark.parametrize("world,group,frames", [(2, 1, 1), (3, 1, 2), (2, 2, 5)])
-def test_frame_sharder_with_gloo(tmp_path, world, group, frames):
+@pytest.mark.parametrize("world,group,frames,pixel_format", [(2, 1, 1, "rgba32f"), (3, 1, 2, "rgba32f"), (2, 2, 5, "rgba32f"), (2, 1, 3, "rgba8")])
+def test_frame_sharder_with_gloo(tmp_path, world, group, frames, pixel_format):
     out = tmp_path / "result.txt"
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + world + os.getpid() % 200), str(ROOT / "tests" / "dist_worker.py"), str(out), "200", "120", str(group), str(frames)]
+           "--master-port", str(29500 + world + os.getpid() % 200), str(ROOT / "tests" / "dist_worker.py"), str(out), "200", "120", str(group), str(frames), pixel_format]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     same, w_, n_max, _ = out.read_text().split()

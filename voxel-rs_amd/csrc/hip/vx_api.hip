@@ -1190,6 +1190,7 @@ struct vx_context {
     static constexpr int kGatherEvents = 16;
     hipEvent_t gather_done[kGatherEvents] = {};
     unsigned gather_index = 0;
+    std::vector<ProfiledLaunch> gathers;  // vx_profile_enable: the exchanges' event pairs (vx_comm_profile_read)
 
     // pipelined presentation (vx_present_begin / vx_present_wait): per slot a device frame and its pinned host twin; the read-back
     // runs on its own stream behind the frame's kernel, beside the next frame's
@@ -1575,6 +1576,15 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         hs->frames += 1;
     }
     ctx->last_frame_slot = slot;
+    return VX_OK;
+}
+
+// vx_wait_event / vx_wait_gather order the NEXT frame, whichever entry point issues it (vx_render, vx_present_begin): one-shot
+int apply_pending_waits(vx_context* ctx, hipStream_t stream) {
+    if (ctx->pending_wait) HIP_TRY(hipStreamWaitEvent(stream, ctx->pending_wait, 0));
+    if (ctx->pending_gather) HIP_TRY(hipStreamWaitEvent(stream, ctx->pending_gather, 0));
+    ctx->pending_wait = nullptr;
+    ctx->pending_gather = nullptr;
     return VX_OK;
 }
 
@@ -2304,14 +2314,8 @@ int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint
         slot = int(ctx->frame_index++ % unsigned(ctx->frames_in_flight));
         // ordered after whatever the caller put on `stream` before the PREVIOUS frame on this slot was issued is implied by
         // stream order; explicit cross-stream dependencies come in through vx_wait_event
-        if (ctx->pending_wait) HIP_TRY(hipStreamWaitEvent(ctx->frame_stream[slot], ctx->pending_wait, 0));
-        if (ctx->pending_gather) HIP_TRY(hipStreamWaitEvent(ctx->frame_stream[slot], ctx->pending_gather, 0));
-    } else {
-        if (ctx->pending_wait) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->pending_wait, 0));
-        if (ctx->pending_gather) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->pending_gather, 0));
     }
-    ctx->pending_wait = nullptr;
-    ctx->pending_gather = nullptr;
+    if (int rc = apply_pending_waits(ctx, slot >= 0 ? ctx->frame_stream[slot] : ctx->stream)) return rc;
     const int rc = hits ? launch_render<true, false>(ctx, p, out, hits, nullptr) : launch_render<false, false>(ctx, p, out, nullptr, nullptr, slot);
     if (rc) return rc;
     if (target->memory == VX_MEM_HOST) {
@@ -2348,6 +2352,7 @@ int vx_present_begin(vx_context* ctx, const vx_uniforms* uniforms, uint32_t widt
     if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     // the frame on a frame stream (in rotation with the other frames in flight), its read-back on the copy stream behind it
     const int slot = ctx->frames_in_flight > 1 ? int(ctx->frame_index++ % unsigned(ctx->frames_in_flight)) : -1;
+    if (int rc = apply_pending_waits(ctx, slot >= 0 ? ctx->frame_stream[slot] : ctx->stream)) return rc;
     if (int rc = launch_render<false, false>(ctx, p, static_cast<float*>(ps.dev), nullptr, nullptr, slot)) return rc;
     HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, slot >= 0 ? ctx->frame_done[slot] : ctx->render_done, 0));
     HIP_TRY(hipMemcpyAsync(ps.host, ps.dev, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
@@ -2529,6 +2534,7 @@ int vx_assemble_tiles(vx_context* ctx, const float* tiles, uint64_t stride_float
 
 int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_floats, uint32_t tile_count, uint32_t width, uint32_t height,
                          float* out_rgba32f, void* stream) {
+    if (stride_floats & 3) return fail(VX_ERR_INVALID_ARGUMENT, "assemble_tiles: the stride between the ranks' lists must be whole pixels (a multiple of 4 floats)");
     return vx_assemble_tiles_format(ctx, tiles, stride_floats / 4, tile_count, width, height, out_rgba32f, VX_FORMAT_RGBA32F, stream);
 }
 
@@ -2549,6 +2555,13 @@ int vx_assemble_tiles_format(vx_context* ctx, const void* tiles, uint64_t stride
         hipLaunchKernelGGL(assemble_kernel, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const float4*>(tiles), stride_pixels, tile_count, width,
                            height, tiles_x, t->d_inverse, static_cast<float4*>(out));
     HIP_TRY(hipGetLastError());
+    // On the communicator's stream the assembly reads the gathered lists -- the root's own among them, which the root renders straight
+    // into (vx_gather_tiles). The newest gather's ticket therefore covers the assembly too: whoever waits for the ticket before
+    // rendering into a list again (vx_wait_gather) waits for the kernel that still reads it.
+    if (stream && static_cast<hipStream_t>(stream) == ctx->comm_stream && ctx->gather_index > 0) {
+        const int ticket = int((ctx->gather_index - 1) % unsigned(vx_context::kGatherEvents));
+        HIP_TRY(hipEventRecord(ctx->gather_done[ticket], ctx->comm_stream));
+    }
     return VX_OK;
 }
 
@@ -2630,6 +2643,17 @@ int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank,
     for (int i = 0; i < vx_context::kFrameStreams; ++i)  // (every frame issued so far: a list may hold a group of frames)
         if (ctx->frame_recorded[i]) HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->frame_done[i], 0));
     const size_t words = size_t(bytes_per_rank / 4);
+    ProfiledLaunch ev{};
+    if (ctx->profile) {  // (vx_profile_enable: the exchange bracketed by events on the communicator's stream, vx_comm_profile_read)
+        if (!ctx->event_pool.empty()) {
+            ev = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(&ev.start));
+            HIP_TRY(hipEventCreate(&ev.stop));
+        }
+        HIP_TRY(hipEventRecord(ev.start, ctx->comm_stream));
+    }
     if (ctx->comm_rank == root) {
         uint8_t* dst = static_cast<uint8_t*>(gathered);
         // its own share (nothing to move when the root renders straight into its place in `gathered`)
@@ -2645,9 +2669,40 @@ int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank,
     } else {
         NCCL_TRY(g_rccl.Send(tiles, words, ncclUint32, root, ctx->comm, ctx->comm_stream));
     }
+    if (ctx->profile) {
+        HIP_TRY(hipEventRecord(ev.stop, ctx->comm_stream));
+        ctx->gathers.push_back(ev);
+    }
     const int ticket = int(ctx->gather_index++ % unsigned(vx_context::kGatherEvents));
     HIP_TRY(hipEventRecord(ctx->gather_done[ticket], ctx->comm_stream));
     if (out_ticket) *out_ticket = ticket;
+    return VX_OK;
+}
+
+int vx_gather_query(vx_context* ctx, int ticket) {
+    if (!ctx || ticket < 0 || ticket >= vx_context::kGatherEvents || !ctx->gather_done[ticket]) return -1;
+    VX_LOCK(ctx);
+    const hipError_t e = hipEventQuery(ctx->gather_done[ticket]);
+    if (e == hipSuccess) return 1;
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+    return e == hipErrorNotReady ? 0 : -1;
+}
+
+int vx_comm_profile_read(vx_context* ctx, double* gather_ms_sum, uint32_t* gathers) {
+    if (!ctx || !gather_ms_sum || !gathers) return fail(VX_ERR_INVALID_ARGUMENT, "comm_profile_read: null argument");
+    VX_LOCK(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->comm_stream) HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
+    double sum = 0.0;
+    for (const ProfiledLaunch& l : ctx->gathers) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, l.start, l.stop));
+        sum += ms;
+        ctx->event_pool.push_back(l);
+    }
+    *gather_ms_sum = sum;
+    *gathers = uint32_t(ctx->gathers.size());
+    ctx->gathers.clear();
     return VX_OK;
 }
 

@@ -105,6 +105,8 @@ SYMBOLS = {
     "vx_excursion_counters": (_int, [_vp, C.POINTER(_u64 * 4), _int]),
     "vx_image_info": (_int, [_vp, C.POINTER(_u64 * 4)]),
     "vx_timeline_read": (_u32, [_vp, _vp, _u32]),
+    "vx_gather_query": (_int, [_vp, _int]),
+    "vx_comm_profile_read": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32)]),
     "vx_profile_enable": (_int, [_vp, _int]),
     "vx_profile_read": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32)]),
     "vx_stream": (_vp, [_vp]),
@@ -298,6 +300,15 @@ class Svo:
 
     def wait_gather(self, ticket):
         _check(lib().vx_wait_gather(self._h, ticket))
+
+    def gather_query(self, ticket):
+        """1 = that gather (and an assembly issued behind it on the communicator's stream) has finished, 0 = not yet, -1 = error. Never blocks."""
+        return int(lib().vx_gather_query(self._h, ticket))
+
+    def comm_profile_read(self):
+        ms, n = C.c_double(0), _u32(0)
+        _check(lib().vx_comm_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     @property
     def comm_stream(self):

@@ -85,8 +85,15 @@ class FrameSharder:
     """
 
     def __init__(self, width, height, rank, world, dist, device, render_tiles, assemble, before_render=None, after_render=None,
-                 after_exchange=None, buffers=2, group=1, gather=None):
+                 after_exchange=None, buffers=2, group=1, gather=None, pixel_format="rgba32f"):
         import torch
+
+        # rgba32f: the reference's framebuffer; rgba8: what Framebuffer::as_image reads back from it (vx_format) -- a quarter of the
+        # bytes on the links, which is what the exchange is bound by: rank 0 takes in (world - 1) / world of every frame
+        if pixel_format not in ("rgba32f", "rgba8"):
+            raise ValueError("pixel_format must be rgba32f or rgba8")
+        dtype = torch.float32 if pixel_format == "rgba32f" else torch.uint8
+        self.pixel_format, self.dtype = pixel_format, dtype
 
         if group < 1 or buffers < group or buffers % group:
             raise ValueError("buffers must be a multiple of group")
@@ -103,13 +110,13 @@ class FrameSharder:
         self.n_max = max(len(local_tile_ids(width, height, r, world)) for r in range(world))
         n_groups = buffers // group
         # [group][frame in group][tile]...: the lists of one group are one contiguous message
-        self.tiles = [torch.zeros((group, self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) for _ in range(n_groups)]
-        self.gathered = [torch.zeros((world, group, self.n_max, TILE, TILE, 4), dtype=torch.float32, device=device) if rank == 0 else None
+        self.tiles = [torch.zeros((group, self.n_max, TILE, TILE, 4), dtype=dtype, device=device) for _ in range(n_groups)]
+        self.gathered = [torch.zeros((world, group, self.n_max, TILE, TILE, 4), dtype=dtype, device=device) if rank == 0 else None
                          for _ in range(n_groups)]
         if gather is not None and rank == 0:
             # the root renders straight into its own place in the gathered buffer: its share needs no copy (vx_gather_tiles)
             self.tiles = [self.gathered[i][0] for i in range(n_groups)]
-        self.images = [torch.zeros((height, width, 4), dtype=torch.float32, device=device) for _ in range(group)] if rank == 0 else None
+        self.images = [torch.zeros((height, width, 4), dtype=dtype, device=device) for _ in range(group)] if rank == 0 else None
         if str(device).startswith("cuda"):
             torch.cuda.synchronize()  # the zero fills ran on torch's stream; a renderer with its own streams must not race them
         self.frame = 0  # frames rendered
