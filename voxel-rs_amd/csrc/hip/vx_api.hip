@@ -150,7 +150,7 @@ struct PersistentArgs {
     uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
     uint32_t ticket_ahead;          // 0 = no; 1 + g = waves draw their next sub-tile's ticket when they start on one (its round trip runs under the traversal),
                                     // except for the frame's last g quarter-grids of tickets
-    uint32_t timeline_part;         // measurement: which part of the service phases the timeline's tick count covers (0 all, 1 leaf tests, 2 finished rays, 3 refill, 4 ray set-up)
+    uint32_t timeline_part;         // measurement: which part of the service phases the timeline's tick count covers (0 all, 1 leaf tests, 2 finished rays, 3 refill, 4 ray set-up, 5 excursions into voxels)
     unsigned long long* timeline;   // measurement (VX_TIMELINE=1), else null: per wave {start, queue found empty, exit} in 10 ns ticks, pixels taken
     // BATCH kernels: per wave a ring of ray records and a ring of result records (kWaveBatchBytes each wave), see render_persistent
     uint8_t* batch;
@@ -336,14 +336,21 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         const unsigned long long c_loop = a.timeline ? __builtin_amdgcn_s_memtime() : 0ull;
         // The hand-scheduled loop (vx_loop_gfx950.hpp) for cursors on a byte-offset image that the resident stack levels cover. It does not
         // clear kHasAdjacentLeaf: a wave with a traversing ray that has just passed a translucent voxel takes the compiler's loop this time.
-        constexpr bool kAsmLoop = VX_ASM_LOOP != 0 && SVO == VX_SVO_IMAGE && SHALLOW && LV == kLdsLevels && !HOT && !STATS;
+        constexpr bool kAsmLoop = VX_ASM_LOOP != 0 && IMAGE && SHALLOW && (LV == kLdsLevels || LV == 16) && !HOT && !STATS;
         bool by_hand = false;
-        if constexpr (kAsmLoop) by_hand = __ballot((tr.flags & Trav<SVO>::kHasAdjacentLeaf) != 0 && tr.iter < uint32_t(kMaxSteps)) == 0;
+        if constexpr (kAsmLoop) {
+            by_hand = __ballot((tr.flags & Trav<SVO>::kHasAdjacentLeaf) != 0 && tr.iter < uint32_t(kMaxSteps)) == 0;
+            // (the wide layout's entry index -- 4 x the octant index + the child -- is formed in 32 bits)
+            if (SVO == VX_SVO_IMAGE_WIDE && sc.wide_bytes >= (uint64_t(1) << 35)) by_hand = false;
+        }
         if (kAsmLoop && by_hand) {
             if constexpr (kAsmLoop) {
-                const uint32_t lds_slot0 = uint32_t(reinterpret_cast<uintptr_t>(fast_st.at(fast_st.slot0)));
-                if (a.timeline) traverse_loop_gfx950<FOREIGN != 0, true>(tr, sc.world, lds_slot0, keep_going, loop_trips);
-                else traverse_loop_gfx950<FOREIGN != 0, false>(tr, sc.world, lds_slot0, keep_going, loop_trips);
+                const uint32_t lds_base = uint32_t(reinterpret_cast<uintptr_t>(fast_st.at(0)));
+                const uint32_t lds_slot0 = lds_base + fast_st.slot0;
+                // the 16-bit third plane: 2 * kPlane + (slot >> 1), the slot's offset being even and, for the resident scales, not negative
+                const uint32_t lds_aux0 = lds_base + 2u * FastStack::kPlane + uint32_t(int32_t(fast_st.slot0) >> 1);
+                if (a.timeline) traverse_loop_gfx950<SVO, FOREIGN != 0, true, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, loop_trips);
+                else traverse_loop_gfx950<SVO, FOREIGN != 0, false, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, loop_trips);
                 // a lane the loop parked says why in bits 28..30 of its iteration count
                 const uint32_t why = (tr.iter >> 28) & 7u;
                 if (why) {
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // ---- ... or (FOREIGN = VX_SVO_CSVO) the excursion on the world's own bytes ----
         // The walk runs with only these lanes active, so they go together: a lane waits (parked, at no cost to the loop) until
         // foreign_min lanes of the wave are there, or until no lane is left that could traverse meanwhile.
+        VX_PART_BEGIN(5);
         if (FOREIGN == VX_SVO_CSVO) {
             const unsigned long long fm = __ballot(state == kForeign);
             // (unlikely: tells the register allocator that what the walk needs may be spilled around it, not across the phase)
@@ -441,9 +449,12 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 uint32_t on_bytes = 0;
                 bool given_up = false;
                 if (state == kForeign) {
-                    const DevScene sc_bytes = make_scene(sa);
                     tr.iter &= ~kParked;
                     const uint32_t before = tr.iter;
+                    // (as a real call -- a register allocation of its own for the walk, the cursor handed over through scratch -- the walk takes 198
+                    // VGPRs and the kernel's occupancy with it: clang accepts a register bound only on kernels. Inlined, it costs the kernel's
+                    // service phases some forty spilled registers: profiles/round3/README.md)
+                    const DevScene sc_bytes = make_scene(sa);
                     const TravStatus s = enter_voxel_on_bytes<SVO, FullStack, false, false>(sc, sc_bytes, tr, st, true, res);
                     on_bytes = tr.iter - before;
                     // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there / given up (the pixel's turn comes later)
@@ -479,6 +490,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             }
         }
 
+        VX_PART_END(5);
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
         VX_PART_BEGIN(1);
         // A voxel of a block whose textures are opaque throughout is a hit whatever the sample says (RenderParams::opaque_*): its leaf test

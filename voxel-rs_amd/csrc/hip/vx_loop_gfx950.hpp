@@ -17,6 +17,8 @@
 //     bits 28..30 = the TravStatus -- by one v_add under a narrowed execution mask; the caller decodes it once per service phase;
 //   * the cell size is derived from the scale (one shift-add) instead of being carried and selected;
 //   * PUSH's five register updates and POP's run under their lanes' execution masks as plain moves / loads into the state registers.
+// Variants: the image's pointers as byte offsets or (beyond 4 GiB) 32-byte units; a stack of 13 three-word levels or of 16 levels with
+// a 16-bit third plane; worlds in ESVO or CSVO (what happens to a ray that is led into a voxel); with or without a trip counter.
 // Hazards (no hazard recognizer looks inside an asm block): no DPP / SDWA / packed / transcendental / lane-access instructions, no SGPR
 // written by a VALU is read by a memory instruction, s_cbranch_execz only behind a SALU write of EXEC.
 #pragma once
@@ -41,10 +43,25 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
     "v_add_u32_e32 %[iter], 0xc0000001, %[iter]\n"               /* t_min > 0 after all: parked | kTravAtLeaf << 28, the iteration counted (sum: + 0xa0000000) */ \
     "s_andn2_b64 exec, %[s_trav], %[s_save]\n"
 // (an ESVO world's voxel is walked as an empty node whatever its place in the octant holds: vx_device.hpp, step_image)
-#define VX_TAKE_MASKS_ESVO "v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[node], 0, v125, vcc\n"
-#define VX_TAKE_MASKS_CSVO "v_mov_b32_e32 %[node], v125\n"
+// (... and in the wide layout, where `ptr` is dereferenced unchecked, the image's first octant for its pointer)
+#define VX_TAKE_ENTRY_ESVO_BYTES "v_mov_b32_e32 %[ptr], v124\n v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[node], 0, v125, vcc\n"
+#define VX_TAKE_ENTRY_ESVO_UNITS "v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[ptr], 0, v124, vcc\n v_cndmask_b32_e32 %[node], 0, v125, vcc\n"
+#define VX_TAKE_ENTRY_CSVO "v_mov_b32_e32 %[ptr], v124\n v_mov_b32_e32 %[node], v125\n"
 #define VX_COUNT_TRIP "s_add_u32 %[trips], %[trips], 1\n"
-#define VX_LOOP_ASM(LEAF_EXITS, TAKE_MASKS, COUNT)                                                                                 \
+// the entry of child `oct` of the octant at `ptr`: a byte offset through a raw buffer resource (out of range reads 0: any `ptr` is
+// harmless) | (images beyond 4 GiB, which no buffer resource reaches -- a structured one wraps at 4 GiB too, measured) an octant index in
+// 32-byte units: entry 4 * ptr + oct (the image is smaller than 32 GiB) behind a 64-bit base, so `ptr` has to stay a valid octant
+#define VX_LOAD_ENTRY_BYTES "v_lshl_add_u32 %[t1], %[oct], 3, %[ptr]\n buffer_load_dwordx2 v[124:125], %[t1], %[rsrc], 0 offen\n"
+#define VX_LOAD_ENTRY_UNITS                                                                                                        \
+    "v_lshl_add_u32 v122, %[ptr], 2, %[oct]\n v_mov_b32_e32 v123, 0\n v_lshl_add_u64 v[122:123], v[122:123], 3, %[base]\n"         \
+    "global_load_dwordx2 v[124:125], v[122:123], off\n"
+// the stack: 13 levels of three words (planes 13 x 256 bytes apart) | 16 levels with a 16-bit third plane (the masks' upper half: all a
+// cursor on an image needs), planes 16 x 256 bytes apart, the third at half the slot's offset behind them
+#define VX_STACK_WRITE_13 "ds_write2st64_b32 %[t0], %[ptr], %[tmax] offset1:13\n ds_write_b32 %[t0], %[node] offset:6656\n"
+#define VX_STACK_WRITE_16 "v_lshl_add_u32 %[t1], %[sc], 7, %[lds16]\n ds_write2st64_b32 %[t0], %[ptr], %[tmax] offset1:16\n ds_write_b16_d16_hi %[t1], %[node]\n"
+#define VX_STACK_READ_13 "ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:3328\n ds_read_b32 %[node], %[oct] offset:6656\n"
+#define VX_STACK_READ_16 "v_lshl_add_u32 %[m], %[sc], 7, %[lds16]\n ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:4096\n ds_read_u16_d16_hi %[node], %[m]\n"
+#define VX_LOOP_ASM(LEAF_EXITS, TAKE_MASKS, COUNT, LOAD_ENTRY, STACK_WRITE, STACK_READ)                                                                                 \
         "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
         "s_cmp_eq_u64 vcc, 0\n"                                                                                                    \
         "s_cbranch_scc1 9f\n"                                                                                                      \
@@ -59,8 +76,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_lshlrev_b32_e32 %[t1], 1, %[t1]\n"                                                                                      \
         "v_lshl_or_b32 %[t0], %[t2], 2, %[t0]\n"                                                                                   \
         "v_bitop3_b32 %[oct], %[t0], %[om], %[t1] bitop3:0x36\n" /* (t0 | t1) ^ octant_mask */                                     \
-        "v_lshl_add_u32 %[t1], %[oct], 3, %[ptr]\n"                                                                                \
-        "buffer_load_dwordx2 v[124:125], %[t1], %[rsrc], 0 offen\n"                                                                \
+        LOAD_ENTRY                                                                                                                 \
         "v_fma_f32 %[crx], %[px], %[tcx], -%[tbx]\n"                                                                               \
         "v_fma_f32 %[cry], %[py], %[tcy], -%[tby]\n"                                                                               \
         "v_fma_f32 %[crz], %[pz], %[tcz], -%[tbz]\n"                                                                               \
@@ -88,8 +104,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_lshl_add_u32 %[t0], %[sc], 8, %[lds]\n"                                                                                 \
         "s_and_saveexec_b64 %[s_save], %[s_push]\n"                                                                                \
         "v_cmpx_lt_f32_e32 vcc, %[tcm], %[h]\n"                                                                                    \
-        "ds_write2st64_b32 %[t0], %[ptr], %[tmax] offset1:13\n"                                                                    \
-        "ds_write_b32 %[t0], %[node] offset:6656\n"                                                                                \
+        STACK_WRITE                                                                                                                \
         "s_mov_b64 exec, %[s_save]\n"                                                                                              \
         /* the corner: += half a cell where t_min < t(centre) | -= a cell where tc_max >= t(corner) */                             \
         "v_cmp_lt_f32_e32 vcc, %[tmin], %[crx]\n"                                                                                  \
@@ -116,9 +131,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_ffbh_u32_e32 %[t1], %[t0]\n"                                                                                            \
         "v_sub_u32_e32 %[sc], 31, %[t1]\n"                       /* the highest differing bit */                                   \
         "v_lshl_add_u32 %[oct], %[sc], 8, %[lds]\n"                                                                                \
-        "ds_read_b32 %[ptr], %[oct]\n"                                                                                             \
-        "ds_read_b32 %[tmax], %[oct] offset:3328\n"                                                                                \
-        "ds_read_b32 %[node], %[oct] offset:6656\n"                                                                                \
+        STACK_READ                                                                                                                 \
         "v_lshlrev_b32_e64 %[t1], %[sc], -1\n"                                                                                     \
         "v_and_b32_e32 %[px], %[t1], %[px]\n"                                                                                      \
         "v_and_b32_e32 %[py], %[t1], %[py]\n"                                                                                      \
@@ -133,7 +146,6 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_mov_b32_e32 %[h], %[tcm]\n"                                                                                             \
         "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
-        "v_mov_b32_e32 %[ptr], v124\n"                                                                                             \
         TAKE_MASKS                                                                                                                 \
         /* ---- who still traverses ---- */                                                                                        \
         "s_mov_b64 exec, %[s_trav]\n"                                                                                              \
@@ -148,11 +160,17 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 
 // FOREIGN: the image of a CSVO world -- a ray about to be led into a voxel leaves the loop (kTravForeign, its iteration not counted);
 // otherwise (ESVO world) it walks the voxel as an empty node. COUNT: count the trips in `trips` (measurement).
+// SVO: VX_SVO_IMAGE (byte offsets; `image` = a raw resource over the image) or VX_SVO_IMAGE_WIDE (32-byte units behind `image_base`; the image
+// must be smaller than 32 GiB). LEVELS: 13 (three-word slots) or 16 (the
+// 16-bit third plane); lds_slot0 / lds_aux0 = the LDS addresses of this lane's slot for scale 0 in the first and in the third plane.
 // The caller guarantees that no traversing lane has kHasAdjacentLeaf set (the loop does not clear it; such rays -- they have just
 // passed a translucent voxel -- are rare and take the compiler's loop); kInsideVoxel is not maintained (nothing in a render reads it).
-template <bool FOREIGN, bool COUNT>
-__device__ __forceinline__ void traverse_loop_gfx950(Trav<VX_SVO_IMAGE>& tr, buf_t image, uint32_t lds_slot0, uint32_t keep_going, uint32_t& trips) {
-    static_assert(kLdsLevels == 13, "the stack planes are 13 x 256 bytes apart (offset1:13, offset:3328 / 6656)");
+template <int SVO, bool FOREIGN, bool COUNT, int LEVELS>
+__device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image, const uint8_t* image_base, uint32_t lds_slot0, uint32_t lds_aux0, uint32_t keep_going,
+                                                     uint32_t& trips) {
+    static_assert(SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE, "cursors on a traversal image");
+    static_assert(LEVELS == 13 || LEVELS == 16, "stack layouts: Stack<64, true, true, 13> and Stack<64, true, true, 16, true>");
+    constexpr bool UNITS = SVO == VX_SVO_IMAGE_WIDE;
     uint32_t t0, t1, t2, oct, m, nx, ny, nz;
     float crx, cry, crz, tcm, tvm, tq, hf, hm, ot, sx;
     unsigned long long s_trav, s_push, s_save;
@@ -171,12 +189,23 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<VX_SVO_IMAGE>& tr, buf
           [tq] "=&v"(tq), [hf] "=&v"(hf), [hm] "=&v"(hm), [ot] "=&v"(ot), [sx] "=&v"(sx), [s_trav] "=&s"(s_trav), [s_push] "=&s"(s_push),                  \
           [s_save] "=&s"(s_save), [s_n] "=&s"(s_n)                                                                                                         \
         : [tcx] "v"(tr.tcx), [tcy] "v"(tr.tcy), [tcz] "v"(tr.tcz), [tbx] "v"(tr.tbx), [tby] "v"(tr.tby), [tbz] "v"(tr.tbz), [om] "v"(uint32_t(tr.octant_mask)), \
-          [lds] "v"(lds_slot0), [inf] "v"(0x7f800000u), [rsrc] "s"(image), [keep] "s"(keep_going), [k_cell] "s"(k_cell), [k_half] "s"(k_half), [entry_exec] "s"(entry_exec)        \
-        : "v124", "v125", "vcc", "scc", "memory"
-    if constexpr (FOREIGN && COUNT) asm volatile(VX_LOOP_ASM(VX_LEAF_EXITS_CSVO, VX_TAKE_MASKS_CSVO, VX_COUNT_TRIP) VX_LOOP_OPERANDS);
-    else if constexpr (FOREIGN) asm volatile(VX_LOOP_ASM(VX_LEAF_EXITS_CSVO, VX_TAKE_MASKS_CSVO, "") VX_LOOP_OPERANDS);
-    else if constexpr (COUNT) asm volatile(VX_LOOP_ASM(VX_LEAF_EXITS_ESVO, VX_TAKE_MASKS_ESVO, VX_COUNT_TRIP) VX_LOOP_OPERANDS);
-    else asm volatile(VX_LOOP_ASM(VX_LEAF_EXITS_ESVO, VX_TAKE_MASKS_ESVO, "") VX_LOOP_OPERANDS);
+          [lds] "v"(lds_slot0), [lds16] "v"(lds_aux0), [inf] "v"(0x7f800000u), [rsrc] "s"(image), [base] "s"(image_base), [keep] "s"(keep_going), [k_cell] "s"(k_cell),           \
+          [k_half] "s"(k_half), [entry_exec] "s"(entry_exec)                                                                                               \
+        : "v122", "v123", "v124", "v125", "vcc", "scc", "memory"
+#define VX_LOOP_VARIANT(F, C, U, L)                                                                                                                        \
+    if constexpr (FOREIGN == F && COUNT == C && UNITS == U && (LEVELS == 16) == L)                                                                          \
+        asm volatile(VX_LOOP_ASM(VX_LOOP_PICK_##F(VX_LEAF_EXITS_CSVO, VX_LEAF_EXITS_ESVO), VX_LOOP_PICK_##F(VX_TAKE_ENTRY_CSVO, VX_LOOP_PICK_##U(VX_TAKE_ENTRY_ESVO_UNITS, VX_TAKE_ENTRY_ESVO_BYTES)),          \
+                                 VX_LOOP_PICK_##C(VX_COUNT_TRIP, ""), VX_LOOP_PICK_##U(VX_LOAD_ENTRY_UNITS, VX_LOAD_ENTRY_BYTES),                          \
+                                 VX_LOOP_PICK_##L(VX_STACK_WRITE_16, VX_STACK_WRITE_13), VX_LOOP_PICK_##L(VX_STACK_READ_16, VX_STACK_READ_13)) VX_LOOP_OPERANDS)
+#define VX_LOOP_PICK_true(a, b) a
+#define VX_LOOP_PICK_false(a, b) b
+    VX_LOOP_VARIANT(false, false, false, false); VX_LOOP_VARIANT(false, false, false, true); VX_LOOP_VARIANT(false, false, true, false); VX_LOOP_VARIANT(false, false, true, true);
+    VX_LOOP_VARIANT(false, true, false, false);  VX_LOOP_VARIANT(false, true, false, true);  VX_LOOP_VARIANT(false, true, true, false);  VX_LOOP_VARIANT(false, true, true, true);
+    VX_LOOP_VARIANT(true, false, false, false);  VX_LOOP_VARIANT(true, false, false, true);  VX_LOOP_VARIANT(true, false, true, false);  VX_LOOP_VARIANT(true, false, true, true);
+    VX_LOOP_VARIANT(true, true, false, false);   VX_LOOP_VARIANT(true, true, false, true);   VX_LOOP_VARIANT(true, true, true, false);   VX_LOOP_VARIANT(true, true, true, true);
+#undef VX_LOOP_VARIANT
+#undef VX_LOOP_PICK_true
+#undef VX_LOOP_PICK_false
 #undef VX_LOOP_OPERANDS
     trips += n_trips;
     tr.px = __uint_as_float(px); tr.py = __uint_as_float(py); tr.pz = __uint_as_float(pz);
