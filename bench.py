@@ -45,9 +45,9 @@ def algorithmic_bytes(fmt, c):
 
 def measured_traffic(fmt):
     """HBM-side bytes per launch of the render kernel on this workload: a STORED artifact -- the committed rocprofv3 --pmc passes
-    of this same command (profiles/profile.sh -> profiles/round2/traffic.json, which names the commit it was measured at); PMC
+    of this same command (profiles/round3/profile_r3.sh -> profiles/round3/traffic.json, which names the commit it was measured at); PMC
     counters cannot be read from inside this run. Returns (bytes, source) or (None, None)."""
-    for rnd in ("round2", "round1"):
+    for rnd in ("round3", "round2", "round1"):
         try:
             t = json.loads((ROOT / "profiles" / rnd / "traffic.json").read_text())
             return t[fmt]["bytes_per_launch"], f"profiles/{rnd}/traffic.json" + (f" @ {t['commit']}" if "commit" in t else "")
@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--gather-timeout", type=float, default=30.0, help="sharded: seconds the first exchange may take before it is declared hung")
     ap.add_argument("--simulate-gather-failure", action="store_true", help="testing: make the library's exchange fail, to exercise the fall-back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sd500", action="store_true", help="skip the second line (the same frame with the game's shadow_distance = 500): profiler runs, whose per-kernel averages it would dilute")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (tile lists, RCCL gather, assembly) even with one rank; needs a torch.distributed.run launch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock target for the cpu_baseline sample (all host cores)")
@@ -412,7 +413,7 @@ def main():
     # The game's own shadow cut-off (500 blocks, src/gamelogic/world.rs:105-108; SURVEY.md 8d asks for both): the same frame with
     # shadow_distance = 500 -- from this altitude few or no hits are that near, so it is close to a primary-rays-only frame. One GPU only.
     sd500 = None
-    if not sharded:
+    if not sharded and not args.no_sd500:
         u500 = scenes.bench_camera(args.depth, st["h_max"], W, H, shadow_distance=500.0, render_shadows=True)
         rays500 = svo.render_counters(u500, W, H, 0, 1)["rays"]
         for _ in range(args.warmup):

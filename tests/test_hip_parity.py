@@ -615,6 +615,38 @@ def heightfield_svo(hip, fmt, depth=8):
 
 
 @pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("size", [(640, 360), (1000, 562)])
+def test_cost_ordered_queue_hands_out_every_subtile(hip, fmt, size):
+    """One frame at a time on the context's own stream the library hands a view's sub-tiles out most expensive first, through the table
+    order_kernel makes from the frame before last (a stable counting sort, 16 classes). Every frame is rendered into a buffer that was
+    ZEROED first: a sub-tile the table lost or listed twice would leave (or fight over) pixels, and every frame must be the first."""
+    import torch
+    from voxel_rs_amd import scenes
+
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(9, threads=4)
+    svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(scenes.synthetic_materials())
+    svo.set_textures(scenes.synthetic_textures(), 6)
+    svo.update_full(world)
+    svo.set_frames_in_flight(1)
+    w, h = size
+    u = scenes.bench_camera(9, st["h_max"], w, h, shadow_distance=3.0e38)
+    img = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    frames = []
+    for _ in range(7):
+        img.zero_()
+        torch.cuda.synchronize()
+        svo.render_device(u, w, h, img.data_ptr())
+        svo.sync()
+        frames.append(img.cpu().numpy().copy())
+    assert np.isfinite(frames[0]).all() and (frames[0][..., 3] == 1.0).all()  # every pixel written (alpha 1: sky or a lit hit)
+    for f in frames[1:]:
+        assert f.tobytes() == frames[0].tobytes()
+    svo.close()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
 def test_rgba8_target_is_as_image_of_the_float_frame(hip, fmt):
     import torch
     from voxel_rs_amd import scenes

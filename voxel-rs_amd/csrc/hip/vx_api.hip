@@ -970,49 +970,78 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneArgs sa, TraceArgs a, vx
 
 // Sorts a frame's sub-tiles for the next frame's queue (PersistentArgs::order): sixteen classes by the iteration count of the sub-tile's
 // longest ray (class = min(15, iterations / 16); entries without this frame's tag are class 0), the highest class first, screen
-// order within a class (a stable counting sort: the rays of neighbouring sub-tiles walk the same nodes). Four waves, each with a
-// contiguous quarter of the sub-tiles, 64 at a time: a lane's place inside its class is a ballot and a popcount. Small on purpose --
-// it runs behind a frame whose successor on the other streams fills the device: four wave slots are free long before a whole CU is.
+// order within a class (a stable counting sort: the rays of neighbouring sub-tiles walk the same nodes). ONE workgroup of 1024 threads:
+// thread t owns the contiguous run of sub-tiles [t * per, (t + 1) * per); (1) it counts its run's members of each class, (2) the
+// counts are scanned class by class across the threads -- a wave-level scan by lane shuffles, the sixteen waves' totals through LDS --
+// which gives every (class, thread) its first place in the table, (3) it walks its run again and puts every sub-tile in its place.
+// 32 K sub-tiles (1080p) are 32 per thread: a few microseconds (round 2's version -- four waves, a ballot per class and block of 64 --
+// took 180; it runs behind a frame on a stream of its own, but on the compute units the next frame wants).
 constexpr uint32_t kCostClasses = 16, kCostStep = 16;  // classes of the order table: iterations / kCostStep, capped
-__global__ __launch_bounds__(256) void order_kernel(const uint32_t* __restrict__ cost, uint32_t tag, uint32_t n, uint32_t* __restrict__ order) {
-    __shared__ uint32_t totals[4][kCostClasses];  // [wave][slot], slot 0 = the most expensive class
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t blocks = (n + 63u) / 64u, per = (blocks + 3u) / 4u;
-    const uint32_t first = wave * per < blocks ? wave * per : blocks, last = first + per < blocks ? first + per : blocks;
+constexpr uint32_t kOrderThreads = 1024;
+__global__ __launch_bounds__(kOrderThreads) void order_kernel(const uint32_t* __restrict__ cost, uint32_t tag, uint32_t n, uint32_t* __restrict__ order) {
+    __shared__ uint32_t wave_totals[kCostClasses][kOrderThreads / 64];  // [slot][wave], slot 0 = the most expensive class
+    __shared__ uint32_t slot_base[kCostClasses];
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
+    const uint32_t per = (n + kOrderThreads - 1u) / kOrderThreads;
+    const uint32_t first = t * per < n ? t * per : n, last = first + per < n ? first + per : n;
     auto slot_of = [&](uint32_t i) -> uint32_t {
-        if (i >= n) return kCostClasses;  // (beyond the end: no class)
         const uint32_t c = cost[i];
         const uint32_t cls = (c >> 12) == tag ? ((c & 0xfffu) / kCostStep < kCostClasses - 1u ? (c & 0xfffu) / kCostStep : kCostClasses - 1u) : 0u;
         return kCostClasses - 1u - cls;
     };
-    uint32_t mine[kCostClasses] = {};  // wave-uniform
-    for (uint32_t b = first; b < last; ++b) {
-        const uint32_t slot = slot_of(b * 64u + lane);
-#pragma unroll
-        for (uint32_t k = 0; k < kCostClasses; ++k) mine[k] += uint32_t(__popcll(__ballot(slot == k)));
-    }
-    if (lane == 0)
-        for (uint32_t k = 0; k < kCostClasses; ++k) totals[wave][k] = mine[k];
-    __syncthreads();
-    // where this wave's members of each class go: behind every more expensive class, and behind the same class of the waves before
-    uint32_t at[kCostClasses];
-    uint32_t run = 0;
-    for (uint32_t k = 0; k < kCostClasses; ++k) {
-        for (uint32_t w = 0; w < 4; ++w) {
-            if (w == wave) at[k] = run;
-            run += totals[w][k];
-        }
-    }
-    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64u - lane));
-    for (uint32_t b = first; b < last; ++b) {
-        const uint32_t i = b * 64u + lane;
+    // (1) this thread's members of each class: sixteen 16-bit counters in eight words (a run is shorter than 65536)
+    uint32_t packed[kCostClasses / 2] = {};
+#pragma unroll 8  // (eight loads in flight: a run is read by one thread, one dependent round trip per element otherwise)
+    for (uint32_t i = first; i < last; ++i) {
         const uint32_t slot = slot_of(i);
 #pragma unroll
-        for (uint32_t k = 0; k < kCostClasses; ++k) {
-            const unsigned long long m = __ballot(slot == k);
-            if (slot == k) order[at[k] + uint32_t(__popcll(m & below))] = i;
-            at[k] += uint32_t(__popcll(m));
+        for (uint32_t w = 0; w < kCostClasses / 2; ++w) packed[w] += (slot >> 1) == w ? (1u << ((slot & 1u) * 16u)) : 0u;
+    }
+    // (2) for every class: where this thread's members start = (members of more expensive classes) + (this class's members of the threads before)
+    uint32_t mine[kCostClasses], before[kCostClasses];
+#pragma unroll
+    for (uint32_t k = 0; k < kCostClasses; ++k) {
+        mine[k] = (packed[k >> 1] >> ((k & 1u) * 16u)) & 0xffffu;
+        uint32_t inc = mine[k];  // inclusive scan over the wave's lanes
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            inc += lane >= d ? up : 0u;
         }
+        before[k] = inc - mine[k];
+        if (lane == 63) wave_totals[k][wave] = inc;
+    }
+    __syncthreads();
+    if (t < kCostClasses) {  // thread k: class k's total; then the classes' bases by a scan over sixteen values (one wave)
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < kOrderThreads / 64; ++w) total += wave_totals[t][w];
+        uint32_t inc = total;
+#pragma unroll
+        for (uint32_t d = 1; d < kCostClasses; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            inc += t >= d ? up : 0u;
+        }
+        slot_base[t] = inc - total;
+    }
+    __syncthreads();
+    uint32_t at[kCostClasses];
+#pragma unroll
+    for (uint32_t k = 0; k < kCostClasses; ++k) {
+        uint32_t waves_before = 0;
+        for (uint32_t w = 0; w < wave; ++w) waves_before += wave_totals[k][w];
+        at[k] = slot_base[k] + waves_before + before[k];
+    }
+    // (3) every sub-tile of the run into its place
+#pragma unroll 8
+    for (uint32_t i = first; i < last; ++i) {
+        const uint32_t slot = slot_of(i);
+        uint32_t place = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kCostClasses; ++k) {
+            place = slot == k ? at[k] : place;
+            at[k] += slot == k ? 1u : 0u;
+        }
+        order[place] = i;
     }
 }
 
@@ -1581,7 +1610,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         const uint32_t g = hs->frames % 3;
         if (ctx->hot_sort) {
             HIP_TRY(hipStreamWaitEvent(ctx->order_stream, slot >= 0 ? ctx->frame_done[slot] : ctx->render_done, 0));
-            hipLaunchKernelGGL(order_kernel, dim3(1), dim3(256), 0, ctx->order_stream, hs->cost[g], hs->tag, order_subtiles, hs->order[g]);
+            hipLaunchKernelGGL(order_kernel, dim3(1), dim3(kOrderThreads), 0, ctx->order_stream, hs->cost[g], hs->tag, order_subtiles, hs->order[g]);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(hs->order_done[g], ctx->order_stream));
         }
