@@ -56,6 +56,25 @@ def measured_traffic(fmt):
     return None, None
 
 
+def issue_model(fmt):
+    """What bounds the kernel in practice: instruction issue. STORED artifacts: the render kernel's instruction counts per launch from the
+    committed --pmc passes (traffic.json: SQ_INSTS_VALU / SALU / VMEM_RD / LDS / SMEM) and the measured cost of an instruction with four
+    waves on a SIMD (issue_model.json: profiles/tools/valu_issue.hip). Returns a dict or None."""
+    try:
+        t = json.loads((ROOT / "profiles" / "round3" / "traffic.json").read_text())
+        m = json.loads((ROOT / "profiles" / "round3" / "issue_model.json").read_text())
+        r = t[fmt]
+        insts = sum(float(r.get(k) or 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
+        clock = float(m["clock_mhz"][fmt])
+        bound_ms = insts * float(m["simd_cycles_per_instruction"]) / float(m["simds"]) / (clock * 1e3)
+        return {"bound": "instruction issue (every SIMD issuing its waves' instructions back to back)", "instructions_per_launch": int(insts),
+                "valu_per_launch": int(r["SQ_INSTS_VALU"]), "salu_per_launch": int(r["SQ_INSTS_SALU"]), "valu_lane_utilisation": r.get("valu_lane_utilisation"),
+                "simd_cycles_per_instruction": m["simd_cycles_per_instruction"], "simds": m["simds"], "clock_mhz_in_kernel": clock,
+                "issue_bound_ms": round(bound_ms, 4), "source": f"profiles/round3/traffic.json @ {t.get('commit', '?')}, profiles/round3/issue_model.json"}
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def image_model_bytes(c):
     """What the kernel that is TIMED fetches by the same accounting: it walks the traversal image, whichever format the world is
     in -- one 8-byte entry per PUSH, a 4-byte value + the 32-byte material row + texel(s) per leaf test, nothing per iteration --
@@ -484,6 +503,13 @@ def main():
                 "timed_region_mode": f"{FRAMES} frames in flight (ms_per_step); kernel_span_ms_in_flight is a launch's own event span there",
                 # what the device sustains over the median timed block: bytes x frames / elapsed
                 "sustained_GBps": round(my_bytes * args.steps / max(elapsed, 1e-9) / 1e9, 3)}
+    # The HBM byte model is what the contract asks for, but this kernel's working set is cache resident and it is bound by instruction
+    # issue: the second, practical bound, with the fraction of it the kernel reaches one frame at a time and in the timed mode.
+    issue = issue_model(args.format) if (W, H, args.depth, world_size) == (1920, 1080, 12, 1) else None
+    if issue:
+        issue["frac_of_bound_one_frame_at_a_time"] = round(issue["issue_bound_ms"] / kernel_exclusive_ms, 4) if kernel_exclusive_ms > 0 else None
+        issue["frac_of_bound_timed_mode"] = round(issue["issue_bound_ms"] / (elapsed / args.steps * 1e3), 4)
+        roofline["issue"] = issue
 
     cpu = None
     if not args.no_cpu_baseline and world_size == 1:  # rank 0 at N = 1 only: a baseline of the workload, not of the scaling run

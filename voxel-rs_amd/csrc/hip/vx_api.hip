@@ -1205,9 +1205,14 @@ struct vx_context {
     bool image_enabled = true;  // VX_TRAVERSAL_IMAGE=0: traverse the world's own bytes
     bool image_ok = false;
     int kernel_version = 2;               // 2 = persistent wavefront kernel, 1 = one thread per pixel (kept for A/B runs)
-    // (service_min: 32 until round 3; with the hand-scheduled loop a trip costs a third less and fewer, fuller service phases win:
-    // profiles/round3/pass_d/sweep_csvo.txt)
-    uint32_t refill_min = 4, service_min = 56, foreign_min = 32;
+    // service_min = 64: a wave's lanes move in LOCKSTEP -- a sub-tile's 64 primary rays are traversed until the last of them has ended, then
+    // served together (hits shaded, misses painted), then the shadow rays, then the pixels lit and stored and the next sub-tile taken. Until
+    // round 3 it was 32 (lanes served when half the wave waited). With the hand-scheduled loop a trip costs a third less, and what a wave
+    // pays for is its service phases: 23 per frame at 32, 14 at 56, 12 at 64 -- and at 64 only every batch of rays is ONE sub-tile's (at 63
+    // a straggler carried into the next round shifts every later batch across two sub-tiles: 8 rounds for 7 sub-tiles): 9.2 -> 10.9 Grays/s
+    // from 63 to 64 (profiles/round3/pass_m, pass_o). Lanes whose rays end early idle until the slowest ray of the batch has ended (the rays
+    // of 8 x 8 neighbouring pixels are of similar length: 41 % of the loop's lane slots are used, against 62 % at 56 -- in fewer instructions).
+    uint32_t refill_min = 4, service_min = 64, foreign_min = 32;
     // Block ids 0..63 all of whose textures are opaque throughout (RenderParams::opaque_*): from host copies of what vx_set_materials and
     // vx_set_textures were given. opaque_layer[l] = every texel of layer l, on every mip level, has alpha > 0.
     std::vector<vx_material> host_materials;
