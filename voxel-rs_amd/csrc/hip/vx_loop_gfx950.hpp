@@ -61,7 +61,32 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 #define VX_STACK_WRITE_16 "v_lshl_add_u32 %[t1], %[sc], 7, %[lds16]\n ds_write2st64_b32 %[t0], %[ptr], %[tmax] offset1:16\n ds_write_b16_d16_hi %[t1], %[node]\n"
 #define VX_STACK_READ_13 "ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:3328\n ds_read_b32 %[node], %[oct] offset:6656\n"
 #define VX_STACK_READ_16 "v_lshl_add_u32 %[m], %[sc], 7, %[lds16]\n ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:4096\n ds_read_u16_d16_hi %[node], %[m]\n"
-#define VX_LOOP_ASM(LEAF_EXITS, TAKE_MASKS, COUNT, LOAD_ENTRY, STACK_WRITE, STACK_READ)                                                                                 \
+// who still traverses, and whether the wave goes on
+#define VX_LOOP_CONTROL(COUNT)                                                                                                     \
+        "s_mov_b64 exec, %[s_trav]\n"                                                                                              \
+        COUNT                                                                                                                      \
+        "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
+        "s_bcnt1_i32_b64 %[s_n], vcc\n"                                                                                            \
+        "s_cmp_gt_u32 %[s_n], %[keep]\n"                                                                                           \
+        "s_cbranch_scc1 1b\n"
+// POP (the execution mask = the lanes whose ADVANCE left the parent; %[t0] = the bits in which their corner changed)
+#define VX_TRIP_POP(STACK_READ)                                                                                                    \
+        "v_ffbh_u32_e32 %[t1], %[t0]\n"                                                                                            \
+        "v_sub_u32_e32 %[sc], 31, %[t1]\n"                       /* the highest differing bit */                                   \
+        "v_lshl_add_u32 %[oct], %[sc], 8, %[lds]\n"                                                                                \
+        STACK_READ                                                                                                                 \
+        "v_lshlrev_b32_e64 %[t1], %[sc], -1\n"                                                                                     \
+        "v_and_b32_e32 %[px], %[t1], %[px]\n"                                                                                      \
+        "v_and_b32_e32 %[py], %[t1], %[py]\n"                                                                                      \
+        "v_and_b32_e32 %[pz], %[t1], %[pz]\n"                                                                                      \
+        "v_mov_b32_e32 %[h], 0\n"                                                                                                  \
+        "v_cmpx_lt_u32_e32 vcc, 22, %[sc]\n"                     /* out of the octree */                                           \
+        "v_add_u32_e32 %[iter], 0xc0000000, %[iter]\n"           /* parked | kTravFinished << 28 */
+// The rays of a sub-tile's 64 pixels walk the upper levels of the tree together: in most trips every traversing lane PUSHes, or every
+// one ADVANCEs. The trip therefore has three tails behind its common part (the child, the entry request, the plane distances, the leaf
+// exits, the PUSH mask): the merged one (both kinds of lane), and the two it degenerates to when the mask is all or none -- 31 and 22
+// instructions shorter, the ADVANCE-only one without the wait for the entry it requested for nothing.
+#define VX_LOOP_ASM(LEAF_EXITS, TAKE_MASKS, COUNT, LOAD_ENTRY, STACK_WRITE, STACK_READ)                                            \
         "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
         "s_cmp_eq_u64 vcc, 0\n"                                                                                                    \
         "s_cbranch_scc1 9f\n"                                                                                                      \
@@ -94,6 +119,11 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_cmp_gt_i32_e32 vcc, 0, %[m]\n"                                                                                          \
         "v_cndmask_b32_e32 %[tq], %[inf], %[tmin], vcc\n"        /* t_min, or +inf where there is no child */                      \
         "v_cmp_le_f32_e64 %[s_push], %[tq], %[tvm]\n"            /* PUSH: a child, and t_min <= min(t_max, tc_max) */              \
+        "s_cmp_eq_u64 %[s_push], 0\n"                                                                                              \
+        "s_cbranch_scc1 4f\n"                                    /* nobody: the ADVANCE-only tail */                               \
+        "s_cmp_eq_u64 %[s_push], exec\n"                                                                                           \
+        "s_cbranch_scc1 5f\n"                                    /* everybody: the PUSH-only tail */                               \
+        /* ======== both kinds of lane ======== */                                                                                 \
         "v_cndmask_b32_e64 %[hm], 0, %[hf], %[s_push]\n"         /* half a cell | 0 */                                             \
         "v_cndmask_b32_e64 %[ot], -%[sx], 0, %[s_push]\n"        /* 0 | minus a cell */                                            \
         "v_cndmask_b32_e64 %[tmin], %[tcm], %[tmin], %[s_push]\n" /* ADVANCE: t_min = tc_max */                                    \
@@ -125,36 +155,72 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_mov_b32_e32 %[pz], %[nz]\n"                                                                                             \
         "v_lshlrev_b32_e64 %[t1], %[sc], 2\n"                                                                                      \
         "v_cmp_ge_u32_e32 vcc, %[t0], %[t1]\n"                                                                                     \
-        /* ---- POP ---- */                                                                                                        \
         "s_and_saveexec_b64 %[s_save], vcc\n"                                                                                      \
         "s_cbranch_execz 2f\n"                                                                                                     \
-        "v_ffbh_u32_e32 %[t1], %[t0]\n"                                                                                            \
-        "v_sub_u32_e32 %[sc], 31, %[t1]\n"                       /* the highest differing bit */                                   \
-        "v_lshl_add_u32 %[oct], %[sc], 8, %[lds]\n"                                                                                \
-        STACK_READ                                                                                                                 \
-        "v_lshlrev_b32_e64 %[t1], %[sc], -1\n"                                                                                     \
-        "v_and_b32_e32 %[px], %[t1], %[px]\n"                                                                                      \
-        "v_and_b32_e32 %[py], %[t1], %[py]\n"                                                                                      \
-        "v_and_b32_e32 %[pz], %[t1], %[pz]\n"                                                                                      \
-        "v_mov_b32_e32 %[h], 0\n"                                                                                                  \
-        "v_cmpx_lt_u32_e32 vcc, 22, %[sc]\n"                     /* out of the octree */                                           \
-        "v_add_u32_e32 %[iter], 0xc0000000, %[iter]\n"           /* parked | kTravFinished << 28 */                                \
+        VX_TRIP_POP(STACK_READ)                                                                                                    \
         "2:\n"                                                                                                                     \
-        /* ---- PUSH: the child becomes the node ---- */                                                                           \
+        /* PUSH: the child becomes the node */                                                                                     \
         "s_and_b64 exec, %[s_save], %[s_push]\n"                                                                                   \
         "v_add_u32_e32 %[sc], -1, %[sc]\n"                                                                                         \
         "v_mov_b32_e32 %[h], %[tcm]\n"                                                                                             \
         "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
         TAKE_MASKS                                                                                                                 \
-        /* ---- who still traverses ---- */                                                                                        \
-        "s_mov_b64 exec, %[s_trav]\n"                                                                                              \
-        COUNT                                                                                                                      \
         "s_waitcnt lgkmcnt(0)\n"                                                                                                   \
-        "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
-        "s_bcnt1_i32_b64 %[s_n], vcc\n"                                                                                            \
-        "s_cmp_gt_u32 %[s_n], %[keep]\n"                                                                                           \
-        "s_cbranch_scc1 1b\n"                                                                                                      \
+        VX_LOOP_CONTROL(COUNT)                                                                                                     \
+        "s_branch 9f\n"                                                                                                            \
+        /* ======== every lane ADVANCEs ======== */                                                                                \
+        "4:\n"                                                                                                                     \
+        "v_mov_b32_e32 %[tmin], %[tcm]\n"                                                                                          \
+        "v_cmp_ge_f32_e32 vcc, %[tcm], %[crx]\n"                                                                                   \
+        "v_cndmask_b32_e32 %[t1], 0, %[sx], vcc\n"                                                                                 \
+        "v_sub_f32_e32 %[nx], %[px], %[t1]\n"                                                                                      \
+        "v_cmp_ge_f32_e32 vcc, %[tcm], %[cry]\n"                                                                                   \
+        "v_cndmask_b32_e32 %[t1], 0, %[sx], vcc\n"                                                                                 \
+        "v_sub_f32_e32 %[ny], %[py], %[t1]\n"                                                                                      \
+        "v_cmp_ge_f32_e32 vcc, %[tcm], %[crz]\n"                                                                                   \
+        "v_cndmask_b32_e32 %[t1], 0, %[sx], vcc\n"                                                                                 \
+        "v_sub_f32_e32 %[nz], %[pz], %[t1]\n"                                                                                      \
+        "v_xor_b32_e32 %[t0], %[px], %[nx]\n"                                                                                      \
+        "v_bitop3_b32 %[t0], %[t0], %[py], %[ny] bitop3:0xf6\n"                                                                    \
+        "v_bitop3_b32 %[t0], %[t0], %[pz], %[nz] bitop3:0xf6\n"                                                                    \
+        "v_mov_b32_e32 %[px], %[nx]\n"                                                                                             \
+        "v_mov_b32_e32 %[py], %[ny]\n"                                                                                             \
+        "v_mov_b32_e32 %[pz], %[nz]\n"                                                                                             \
+        "v_lshlrev_b32_e64 %[t1], %[sc], 2\n"                                                                                      \
+        "v_cmp_ge_u32_e32 vcc, %[t0], %[t1]\n"                                                                                     \
+        "s_and_saveexec_b64 %[s_save], vcc\n"                                                                                      \
+        "s_cbranch_execz 6f\n"                                                                                                     \
+        VX_TRIP_POP(STACK_READ)                                                                                                    \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                                   \
+        "6:\n"                                                                                                                     \
+        VX_LOOP_CONTROL(COUNT)                                                                                                     \
+        "s_branch 9f\n"                                                                                                            \
+        /* ======== every lane PUSHes ======== */                                                                                  \
+        "5:\n"                                                                                                                     \
+        "v_fmac_f32_e32 %[crx], %[hf], %[tcx]\n"                 /* the centre planes' distances */                                \
+        "v_fmac_f32_e32 %[cry], %[hf], %[tcy]\n"                                                                                   \
+        "v_fmac_f32_e32 %[crz], %[hf], %[tcz]\n"                                                                                   \
+        "v_lshl_add_u32 %[t0], %[sc], 8, %[lds]\n"                                                                                 \
+        "s_mov_b64 %[s_save], exec\n"                                                                                              \
+        "v_cmpx_lt_f32_e32 vcc, %[tcm], %[h]\n"                                                                                    \
+        STACK_WRITE                                                                                                                \
+        "s_mov_b64 exec, %[s_save]\n"                                                                                              \
+        "v_cmp_lt_f32_e32 vcc, %[tmin], %[crx]\n"                                                                                  \
+        "v_cndmask_b32_e32 %[t1], 0, %[hf], vcc\n"                                                                                 \
+        "v_add_f32_e32 %[px], %[px], %[t1]\n"                                                                                      \
+        "v_cmp_lt_f32_e32 vcc, %[tmin], %[cry]\n"                                                                                  \
+        "v_cndmask_b32_e32 %[t1], 0, %[hf], vcc\n"                                                                                 \
+        "v_add_f32_e32 %[py], %[py], %[t1]\n"                                                                                      \
+        "v_cmp_lt_f32_e32 vcc, %[tmin], %[crz]\n"                                                                                  \
+        "v_cndmask_b32_e32 %[t1], 0, %[hf], vcc\n"                                                                                 \
+        "v_add_f32_e32 %[pz], %[pz], %[t1]\n"                                                                                      \
+        "v_add_u32_e32 %[sc], -1, %[sc]\n"                                                                                         \
+        "v_mov_b32_e32 %[h], %[tcm]\n"                                                                                             \
+        "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
+        "s_waitcnt vmcnt(0)\n"                                                                                                     \
+        TAKE_MASKS                                                                                                                 \
+        VX_LOOP_CONTROL(COUNT)                                                                                                     \
         "9:\n"                                                                                                                     \
         "s_mov_b64 exec, %[entry_exec]\n"
 
