@@ -349,8 +349,12 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 const uint32_t lds_slot0 = lds_base + fast_st.slot0;
                 // the 16-bit third plane: 2 * kPlane + (slot >> 1), the slot's offset being even and, for the resident scales, not negative
                 const uint32_t lds_aux0 = lds_base + 2u * FastStack::kPlane + uint32_t(int32_t(fast_st.slot0) >> 1);
-                if (a.timeline) traverse_loop_gfx950<SVO, FOREIGN != 0, true, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, loop_trips);
-                else traverse_loop_gfx950<SVO, FOREIGN != 0, false, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, loop_trips);
+                // (FOREIGN = VX_SVO_CSVO: the loop also ends when foreign_min lanes wait for their walk into a voxel; the build that lists such rays
+                // instead never waits for anything)
+                const uint32_t f_waiting = FOREIGN == VX_SVO_CSVO ? uint32_t(__popcll(__ballot(state == kForeign))) : 0u;
+                const uint32_t f_min = FOREIGN == VX_SVO_CSVO ? a.foreign_min : 0xffffffffu;
+                if (a.timeline) traverse_loop_gfx950<SVO, FOREIGN != 0, true, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips);
+                else traverse_loop_gfx950<SVO, FOREIGN != 0, false, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips);
                 // a lane the loop parked says why in bits 28..30 of its iteration count
                 const uint32_t why = (tr.iter >> 28) & 7u;
                 if (why) {
@@ -1212,7 +1216,9 @@ struct vx_context {
     // a straggler carried into the next round shifts every later batch across two sub-tiles: 8 rounds for 7 sub-tiles): 9.2 -> 10.9 Grays/s
     // from 63 to 64 (profiles/round3/pass_m, pass_o). Lanes whose rays end early idle until the slowest ray of the batch has ended (the rays
     // of 8 x 8 neighbouring pixels are of similar length: 41 % of the loop's lane slots are used, against 62 % at 56 -- in fewer instructions).
-    uint32_t refill_min = 4, service_min = 64, foreign_min = 32;
+    // (foreign_min -- deep CSVO worlds: how many lanes must wait for their walk into a voxel before a wave leaves the loop for it: 32 in
+    // round 2; what a frame pays for is the number of such phases, profiles/round3/pass_s/foreign_min.txt)
+    uint32_t refill_min = 4, service_min = 64, foreign_min = 48;
     // Block ids 0..63 all of whose textures are opaque throughout (RenderParams::opaque_*): from host copies of what vx_set_materials and
     // vx_set_textures were given. opaque_layer[l] = every texel of layer l, on every mip level, has alpha > 0.
     std::vector<vx_material> host_materials;

@@ -41,7 +41,14 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
     "v_add_u32_e32 %[iter], 0xdfffffff, %[iter]\n"               /* parked | kTravForeign << 28, and the iteration taken back */   \
     "v_cmpx_lt_f32_e32 vcc, 0, %[tmin]\n"                                                                                          \
     "v_add_u32_e32 %[iter], 0xc0000001, %[iter]\n"               /* t_min > 0 after all: parked | kTravAtLeaf << 28, the iteration counted (sum: + 0xa0000000) */ \
+    "s_andn2_b64 vcc, %[s_save], exec\n"                         /* the lanes that are led into a voxel: how many wait for that walk now */ \
+    "s_bcnt1_i32_b64 %[s_n], vcc\n"                                                                                                \
+    "s_add_u32 %[waiting], %[waiting], %[s_n]\n"                                                                                   \
     "s_andn2_b64 exec, %[s_trav], %[s_save]\n"
+// ... and when enough of them wait, the wave leaves the loop for the service phase that walks them together (the others' rays pause
+// where they are): a shadow ray that starts inside its voxel gets there after `depth` trips, all such rays of a batch in the same trip --
+// waiting for the other rays to END first would run the batch's two halves one after the other
+#define VX_FOREIGN_EXIT "s_cmp_ge_u32 %[waiting], %[fmin]\n s_cbranch_scc1 9f\n"
 // (an ESVO world's voxel is walked as an empty node whatever its place in the octant holds: vx_device.hpp, step_image)
 // (... and in the wide layout, where `ptr` is dereferenced unchecked, the image's first octant for its pointer)
 #define VX_TAKE_ENTRY_ESVO_BYTES "v_mov_b32_e32 %[ptr], v124\n v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[node], 0, v125, vcc\n"
@@ -64,7 +71,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 // who still traverses, and whether the wave goes on
 #define VX_LOOP_CONTROL(COUNT)                                                                                                     \
         "s_mov_b64 exec, %[s_trav]\n"                                                                                              \
-        COUNT                                                                                                                      \
+        COUNT    /* (also carries the FOREIGN builds' second exit) */                                                              \
         "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
         "s_bcnt1_i32_b64 %[s_n], vcc\n"                                                                                            \
         "s_cmp_gt_u32 %[s_n], %[keep]\n"                                                                                           \
@@ -233,7 +240,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 // passed a translucent voxel -- are rare and take the compiler's loop); kInsideVoxel is not maintained (nothing in a render reads it).
 template <int SVO, bool FOREIGN, bool COUNT, int LEVELS>
 __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image, const uint8_t* image_base, uint32_t lds_slot0, uint32_t lds_aux0, uint32_t keep_going,
-                                                     uint32_t& trips) {
+                                                     uint32_t foreign_waiting, uint32_t foreign_min, uint32_t& trips) {
     static_assert(SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE, "cursors on a traversal image");
     static_assert(LEVELS == 13 || LEVELS == 16, "stack layouts: Stack<64, true, true, 13> and Stack<64, true, true, 16, true>");
     constexpr bool UNITS = SVO == VX_SVO_IMAGE_WIDE;
@@ -248,20 +255,23 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
     // (wave-uniform by construction; the compiler is told so)
     keep_going = uint32_t(__builtin_amdgcn_readfirstlane(int(keep_going)));
     uint32_t n_trips = 0;
+    // FOREIGN: lanes that wait for their walk into a voxel (at entry: those of earlier rounds), and how many of them make the wave leave the loop
+    uint32_t waiting = uint32_t(__builtin_amdgcn_readfirstlane(int(foreign_waiting)));
+    foreign_min = uint32_t(__builtin_amdgcn_readfirstlane(int(foreign_min)));
 #define VX_LOOP_OPERANDS                                                                                                                                   \
         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tmin] "+v"(tr.t_min), [tmax] "+v"(tr.t_max), [h] "+v"(tr.h), [sc] "+v"(scale), [ptr] "+v"(tr.ptr),  \
-          [node] "+v"(tr.node), [iter] "+v"(tr.iter), [trips] "+s"(n_trips), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [oct] "=&v"(oct), [m] "=&v"(m), \
+          [node] "+v"(tr.node), [iter] "+v"(tr.iter), [trips] "+s"(n_trips), [waiting] "+s"(waiting), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [oct] "=&v"(oct), [m] "=&v"(m), \
           [nx] "=&v"(nx), [ny] "=&v"(ny), [nz] "=&v"(nz), [crx] "=&v"(crx), [cry] "=&v"(cry), [crz] "=&v"(crz), [tcm] "=&v"(tcm), [tvm] "=&v"(tvm),         \
           [tq] "=&v"(tq), [hf] "=&v"(hf), [hm] "=&v"(hm), [ot] "=&v"(ot), [sx] "=&v"(sx), [s_trav] "=&s"(s_trav), [s_push] "=&s"(s_push),                  \
           [s_save] "=&s"(s_save), [s_n] "=&s"(s_n)                                                                                                         \
         : [tcx] "v"(tr.tcx), [tcy] "v"(tr.tcy), [tcz] "v"(tr.tcz), [tbx] "v"(tr.tbx), [tby] "v"(tr.tby), [tbz] "v"(tr.tbz), [om] "v"(uint32_t(tr.octant_mask)), \
           [lds] "v"(lds_slot0), [lds16] "v"(lds_aux0), [inf] "v"(0x7f800000u), [rsrc] "s"(image), [base] "s"(image_base), [keep] "s"(keep_going), [k_cell] "s"(k_cell),           \
-          [k_half] "s"(k_half), [entry_exec] "s"(entry_exec)                                                                                               \
+          [k_half] "s"(k_half), [entry_exec] "s"(entry_exec), [fmin] "s"(foreign_min)                                                                                               \
         : "v122", "v123", "v124", "v125", "vcc", "scc", "memory"
 #define VX_LOOP_VARIANT(F, C, U, L)                                                                                                                        \
     if constexpr (FOREIGN == F && COUNT == C && UNITS == U && (LEVELS == 16) == L)                                                                          \
         asm volatile(VX_LOOP_ASM(VX_LOOP_PICK_##F(VX_LEAF_EXITS_CSVO, VX_LEAF_EXITS_ESVO), VX_LOOP_PICK_##F(VX_TAKE_ENTRY_CSVO, VX_LOOP_PICK_##U(VX_TAKE_ENTRY_ESVO_UNITS, VX_TAKE_ENTRY_ESVO_BYTES)),          \
-                                 VX_LOOP_PICK_##C(VX_COUNT_TRIP, ""), VX_LOOP_PICK_##U(VX_LOAD_ENTRY_UNITS, VX_LOAD_ENTRY_BYTES),                          \
+                                 VX_LOOP_PICK_##C(VX_COUNT_TRIP, "") VX_LOOP_PICK_##F(VX_FOREIGN_EXIT, ""), VX_LOOP_PICK_##U(VX_LOAD_ENTRY_UNITS, VX_LOAD_ENTRY_BYTES),                          \
                                  VX_LOOP_PICK_##L(VX_STACK_WRITE_16, VX_STACK_WRITE_13), VX_LOOP_PICK_##L(VX_STACK_READ_16, VX_STACK_READ_13)) VX_LOOP_OPERANDS)
 #define VX_LOOP_PICK_true(a, b) a
 #define VX_LOOP_PICK_false(a, b) b
