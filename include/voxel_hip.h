@@ -40,6 +40,17 @@ typedef enum vx_memory { VX_MEM_HOST = 0, VX_MEM_DEVICE = 1 } vx_memory;
  * to [0,1], round to the nearest of 255 steps, NaN -> 0 -- flipped vertically, so a whole image has its TOP row first. A quarter
  * of the bytes for a presenting embedder's read-back and for the multi-GPU gather. */
 typedef enum vx_format { VX_FORMAT_RGBA32F = 0, VX_FORMAT_RGBA8 = 1 } vx_format;
+/* What "identical to the reference" means for a pixel. Everything a ray's PATH depends on -- every traversal float (t, position, uv,
+ * the per-iteration t_min), hit identity, flags, step counts, and the shadow ray's origin and with it the normal-mapped normal -- is
+ * bit for bit the reference's arithmetic (fp32, no contraction, explicit fma where the shader says so, IEEE division and square root).
+ * The COLOUR of a pixel agrees with the CPU restatement of the shaders to 5e-6 absolute, for four stated reasons, all colour-only:
+ *   - pow() of the specular term is exp2(y * log2(x)) on the hardware's 1-ulp v_exp_f32 / v_log_f32 (GLSL's own definition) instead of a
+ *     correctly rounded powf: within 1.2e-7 absolute on its domain;
+ *   - acos() of the sky gradient is a degree-7 polynomial (Abramowitz & Stegun 4.4.46): 4.3e-7 rad;
+ *   - acos' argument is clamped to [-1, 1] (world.glsl:98 does not; the reference's expected image shows no undefined horizon pixels).
+ *     The restatement clamps too, so only the comparison with the reference's own PNG (tests/test_render_png.py, 1e-3) can see this one;
+ *   - the four texels of a bilinear tap are blended in byte units and the common 1/255 applied once (< 4e-7; > 0 in exactly the same
+ *     cases, so the alpha test that decides a hit is unaffected). */
 
 typedef struct vx_context vx_context; /* replaces `struct Svo` (svo.rs:56-73): owns every device object */
 
