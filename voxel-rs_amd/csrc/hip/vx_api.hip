@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         const unsigned long long c_loop = a.timeline ? __builtin_amdgcn_s_memtime() : 0ull;
         // The hand-scheduled loop (vx_loop_gfx950.hpp) for cursors on a byte-offset image that the resident stack levels cover. It does not
         // clear kHasAdjacentLeaf: a wave with a traversing ray that has just passed a translucent voxel takes the compiler's loop this time.
-        constexpr bool kAsmLoop = VX_ASM_LOOP != 0 && IMAGE && SHALLOW && (LV == kLdsLevels || LV == 16) && !HOT && !STATS;
+        constexpr bool kAsmLoop = VX_ASM_LOOP != 0 && IMAGE && SHALLOW && (LV == kLdsLevels || LV == 16 || LV == 12) && !HOT && !STATS;
         bool by_hand = false;
         if constexpr (kAsmLoop) {
             by_hand = __ballot((tr.flags & Trav<SVO>::kHasAdjacentLeaf) != 0 && tr.iter < uint32_t(kMaxSteps)) == 0;

@@ -51,23 +51,26 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 #define VX_FOREIGN_EXIT "s_cmp_ge_u32 %[waiting], %[fmin]\n s_cbranch_scc1 9f\n"
 // (an ESVO world's voxel is walked as an empty node whatever its place in the octant holds: vx_device.hpp, step_image)
 // (... and in the wide layout, where `ptr` is dereferenced unchecked, the image's first octant for its pointer)
-#define VX_TAKE_ENTRY_ESVO_BYTES "v_mov_b32_e32 %[ptr], v124\n v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[node], 0, v125, vcc\n"
-#define VX_TAKE_ENTRY_ESVO_UNITS "v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[ptr], 0, v124, vcc\n v_cndmask_b32_e32 %[node], 0, v125, vcc\n"
-#define VX_TAKE_ENTRY_CSVO "v_mov_b32_e32 %[ptr], v124\n v_mov_b32_e32 %[node], v125\n"
+#define VX_TAKE_ENTRY_ESVO_BYTES "v_mov_b32_e32 %[ptr], v" VX_E0 "\n v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[node], 0, v" VX_E1 ", vcc\n"
+#define VX_TAKE_ENTRY_ESVO_UNITS "v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[ptr], 0, v" VX_E0 ", vcc\n v_cndmask_b32_e32 %[node], 0, v" VX_E1 ", vcc\n"
+#define VX_TAKE_ENTRY_CSVO "v_mov_b32_e32 %[ptr], v" VX_E0 "\n v_mov_b32_e32 %[node], v" VX_E1 "\n"
 #define VX_COUNT_TRIP "s_add_u32 %[trips], %[trips], 1\n"
 // the entry of child `oct` of the octant at `ptr`: a byte offset through a raw buffer resource (out of range reads 0: any `ptr` is
 // harmless) | (images beyond 4 GiB, which no buffer resource reaches -- a structured one wraps at 4 GiB too, measured) an octant index in
 // 32-byte units: entry 4 * ptr + oct (the image is smaller than 32 GiB) behind a 64-bit base, so `ptr` has to stay a valid octant
-#define VX_LOAD_ENTRY_BYTES "v_lshl_add_u32 %[t1], %[oct], 3, %[ptr]\n buffer_load_dwordx2 v[124:125], %[t1], %[rsrc], 0 offen\n"
+#define VX_LOAD_ENTRY_BYTES "v_lshl_add_u32 %[t1], %[oct], 3, %[ptr]\n buffer_load_dwordx2 v[" VX_E0 ":" VX_E1 "], %[t1], %[rsrc], 0 offen\n"
 #define VX_LOAD_ENTRY_UNITS                                                                                                        \
-    "v_lshl_add_u32 v122, %[ptr], 2, %[oct]\n v_mov_b32_e32 v123, 0\n v_lshl_add_u64 v[122:123], v[122:123], 3, %[base]\n"         \
-    "global_load_dwordx2 v[124:125], v[122:123], off\n"
+    "v_lshl_add_u32 v" VX_A0 ", %[ptr], 2, %[oct]\n v_mov_b32_e32 v" VX_A1 ", 0\n v_lshl_add_u64 v[" VX_A0 ":" VX_A1 "], v[" VX_A0 ":" VX_A1 "], 3, %[base]\n"         \
+    "global_load_dwordx2 v[" VX_E0 ":" VX_E1 "], v[" VX_A0 ":" VX_A1 "], off\n"
 // the stack: 13 levels of three words (planes 13 x 256 bytes apart) | 16 levels with a 16-bit third plane (the masks' upper half: all a
 // cursor on an image needs), planes 16 x 256 bytes apart, the third at half the slot's offset behind them
 #define VX_STACK_WRITE_13 "ds_write2st64_b32 %[t0], %[ptr], %[tmax] offset1:13\n ds_write_b32 %[t0], %[node] offset:6656\n"
 #define VX_STACK_WRITE_16 "v_lshl_add_u32 %[t1], %[sc], 7, %[lds16]\n ds_write2st64_b32 %[t0], %[ptr], %[tmax] offset1:16\n ds_write_b16_d16_hi %[t1], %[node]\n"
 #define VX_STACK_READ_13 "ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:3328\n ds_read_b32 %[node], %[oct] offset:6656\n"
 #define VX_STACK_READ_16 "v_lshl_add_u32 %[m], %[sc], 7, %[lds16]\n ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:4096\n ds_read_u16_d16_hi %[node], %[m]\n"
+// ... | 12 levels with the 16-bit third plane (7.5 KB a wave: five waves per SIMD), planes 12 x 256 bytes apart
+#define VX_STACK_WRITE_12 "v_lshl_add_u32 %[t1], %[sc], 7, %[lds16]\n ds_write2st64_b32 %[t0], %[ptr], %[tmax] offset1:12\n ds_write_b16_d16_hi %[t1], %[node]\n"
+#define VX_STACK_READ_12 "v_lshl_add_u32 %[m], %[sc], 7, %[lds16]\n ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:3072\n ds_read_u16_d16_hi %[node], %[m]\n"
 // who still traverses, and whether the wave goes on
 #define VX_LOOP_CONTROL(COUNT)                                                                                                     \
         "s_mov_b64 exec, %[s_trav]\n"                                                                                              \
@@ -242,7 +245,7 @@ template <int SVO, bool FOREIGN, bool COUNT, int LEVELS>
 __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image, const uint8_t* image_base, uint32_t lds_slot0, uint32_t lds_aux0, uint32_t keep_going,
                                                      uint32_t foreign_waiting, uint32_t foreign_min, uint32_t& trips) {
     static_assert(SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE, "cursors on a traversal image");
-    static_assert(LEVELS == 13 || LEVELS == 16, "stack layouts: Stack<64, true, true, 13> and Stack<64, true, true, 16, true>");
+    static_assert(LEVELS == 12 || LEVELS == 13 || LEVELS == 16, "stack layouts: Stack<64, true, true, 13>, Stack<64, true, true, 16, true>, Stack<64, true, true, 12, true>");
     constexpr bool UNITS = SVO == VX_SVO_IMAGE_WIDE;
     uint32_t t0, t1, t2, oct, m, nx, ny, nz;
     float crx, cry, crz, tcm, tvm, tq, hf, hm, ot, sx;
@@ -267,18 +270,40 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
         : [tcx] "v"(tr.tcx), [tcy] "v"(tr.tcy), [tcz] "v"(tr.tcz), [tbx] "v"(tr.tbx), [tby] "v"(tr.tby), [tbz] "v"(tr.tbz), [om] "v"(uint32_t(tr.octant_mask)), \
           [lds] "v"(lds_slot0), [lds16] "v"(lds_aux0), [inf] "v"(0x7f800000u), [rsrc] "s"(image), [base] "s"(image_base), [keep] "s"(keep_going), [k_cell] "s"(k_cell),           \
           [k_half] "s"(k_half), [entry_exec] "s"(entry_exec), [fmin] "s"(foreign_min)                                                                                               \
-        : "v122", "v123", "v124", "v125", "vcc", "scc", "memory"
+        : "v" VX_A0, "v" VX_A1, "v" VX_E0, "v" VX_E1, "vcc", "scc", "memory"
 #define VX_LOOP_VARIANT(F, C, U, L)                                                                                                                        \
-    if constexpr (FOREIGN == F && COUNT == C && UNITS == U && (LEVELS == 16) == L)                                                                          \
+    if constexpr (FOREIGN == F && COUNT == C && UNITS == U && LEVELS == L)                                                                                  \
         asm volatile(VX_LOOP_ASM(VX_LOOP_PICK_##F(VX_LEAF_EXITS_CSVO, VX_LEAF_EXITS_ESVO), VX_LOOP_PICK_##F(VX_TAKE_ENTRY_CSVO, VX_LOOP_PICK_##U(VX_TAKE_ENTRY_ESVO_UNITS, VX_TAKE_ENTRY_ESVO_BYTES)),          \
                                  VX_LOOP_PICK_##C(VX_COUNT_TRIP, "") VX_LOOP_PICK_##F(VX_FOREIGN_EXIT, ""), VX_LOOP_PICK_##U(VX_LOAD_ENTRY_UNITS, VX_LOAD_ENTRY_BYTES),                          \
-                                 VX_LOOP_PICK_##L(VX_STACK_WRITE_16, VX_STACK_WRITE_13), VX_LOOP_PICK_##L(VX_STACK_READ_16, VX_STACK_READ_13)) VX_LOOP_OPERANDS)
+                                 VX_STACK_WRITE_##L, VX_STACK_READ_##L) VX_LOOP_OPERANDS)
 #define VX_LOOP_PICK_true(a, b) a
 #define VX_LOOP_PICK_false(a, b) b
-    VX_LOOP_VARIANT(false, false, false, false); VX_LOOP_VARIANT(false, false, false, true); VX_LOOP_VARIANT(false, false, true, false); VX_LOOP_VARIANT(false, false, true, true);
-    VX_LOOP_VARIANT(false, true, false, false);  VX_LOOP_VARIANT(false, true, false, true);  VX_LOOP_VARIANT(false, true, true, false);  VX_LOOP_VARIANT(false, true, true, true);
-    VX_LOOP_VARIANT(true, false, false, false);  VX_LOOP_VARIANT(true, false, false, true);  VX_LOOP_VARIANT(true, false, true, false);  VX_LOOP_VARIANT(true, false, true, true);
-    VX_LOOP_VARIANT(true, true, false, false);   VX_LOOP_VARIANT(true, true, false, true);   VX_LOOP_VARIANT(true, true, true, false);   VX_LOOP_VARIANT(true, true, true, true);
+    // (two pairs of fixed registers -- the entry a trip requests, the 64-bit address of it in the wide layout: an asm operand cannot name the
+    // halves of a pair -- at the top of the build's register budget: 128 at four waves per SIMD, 96 at five)
+#define VX_E0 "124"
+#define VX_E1 "125"
+#define VX_A0 "122"
+#define VX_A1 "123"
+    VX_LOOP_VARIANT(false, false, false, 13); VX_LOOP_VARIANT(false, false, false, 16); VX_LOOP_VARIANT(false, false, true, 13); VX_LOOP_VARIANT(false, false, true, 16);
+    VX_LOOP_VARIANT(false, true, false, 13); VX_LOOP_VARIANT(false, true, false, 16); VX_LOOP_VARIANT(false, true, true, 13); VX_LOOP_VARIANT(false, true, true, 16);
+    VX_LOOP_VARIANT(true, false, false, 13); VX_LOOP_VARIANT(true, false, false, 16); VX_LOOP_VARIANT(true, false, true, 13); VX_LOOP_VARIANT(true, false, true, 16);
+    VX_LOOP_VARIANT(true, true, false, 13); VX_LOOP_VARIANT(true, true, false, 16); VX_LOOP_VARIANT(true, true, true, 13); VX_LOOP_VARIANT(true, true, true, 16);
+#undef VX_E0
+#undef VX_E1
+#undef VX_A0
+#undef VX_A1
+#define VX_E0 "94"
+#define VX_E1 "95"
+#define VX_A0 "92"
+#define VX_A1 "93"
+    VX_LOOP_VARIANT(false, false, false, 12); VX_LOOP_VARIANT(false, false, true, 12);
+    VX_LOOP_VARIANT(false, true, false, 12); VX_LOOP_VARIANT(false, true, true, 12);
+    VX_LOOP_VARIANT(true, false, false, 12); VX_LOOP_VARIANT(true, false, true, 12);
+    VX_LOOP_VARIANT(true, true, false, 12); VX_LOOP_VARIANT(true, true, true, 12);
+#undef VX_E0
+#undef VX_E1
+#undef VX_A0
+#undef VX_A1
 #undef VX_LOOP_VARIANT
 #undef VX_LOOP_PICK_true
 #undef VX_LOOP_PICK_false
