@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
 // shows that `service_min` lanes are waiting (or nobody is left traversing); idle lanes are re-filled with new pixels
 // when `refill_min` of them are free. The common descend/advance/pop step therefore runs with most lanes active
 // instead of the ~30 % the one-thread-per-pixel kernel reached (profiles/round1/v1_*).
-enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4, kDeep = 5, kForeign = 6 };
+enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4, kDeep = 5, kForeign = 6, kHeld = 7 };
 static_assert(int(kTrav) == int(vxd::kTravContinue) && int(kLeaf) == int(vxd::kTravAtLeaf) && int(kMissed) == int(vxd::kTravFinished) &&
                   int(kDeep) == int(vxd::kTravDeep) && int(kForeign) == int(vxd::kTravForeign),
               "a TravStatus is stored as the lane's state");
@@ -138,6 +138,11 @@ struct PersistentArgs {
     uint32_t* next_counter;   // the set to clear
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
+    // Deep CSVO worlds: a shadow ray whose walk inside its voxel ENDS there (a phantom leaf is hit, or the ray leaves the octree) is held -- its
+    // distance in a register, kHeld -- until the next service phase that runs no such walks, instead of being lit, stored and its lane given a
+    // new pixel in the middle of its batch: the lanes of a wave stay in lockstep (one sub-tile, one kind of ray per round), and the phase
+    // that walks does nothing else.
+    uint32_t hold_resolved;
     uint32_t foreign_min;     // images of CSVO worlds: rays led into a voxel wait until this many of a wave's lanes are, and go together
     // Expensive sub-tiles first. A ray is a chain of dependent steps -- about 0.8 us per iteration on a busy device -- so a frame cannot
     // end before its longest rays do (up to ~300 iterations against a mean of ~30): handed out in screen order they start in mid-frame
@@ -281,6 +286,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     uint32_t out_index = 0;
     float primary_rd[3] = {0, 0, 0};  // kept while a primary ray is in flight: the sky needs it if the ray misses (world.glsl:135-138)
     float keep_color[4] = {0, 0, 0, 0}, keep_ds = 0.0f;
+    float held_t = -1.0f;  // FOREIGN = VX_SVO_CSVO: the distance of a shadow ray that ended inside its voxel (kHeld)
     vx_hit rec;            // HITS only
     uint32_t steps = 0;    // HITS only
     Counters ctr = {};
@@ -446,12 +452,14 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // The walk runs with only these lanes active, so they go together: a lane waits (parked, at no cost to the loop) until
         // foreign_min lanes of the wave are there, or until no lane is left that could traverse meanwhile.
         VX_PART_BEGIN(5);
+        bool walk_phase = false;  // (wave-uniform) this phase walks rays into their voxels
         if (FOREIGN == VX_SVO_CSVO) {
             const unsigned long long fm = __ballot(state == kForeign);
             // (unlikely: tells the register allocator that what the walk needs may be spilled around it, not across the phase)
             if (__builtin_expect(fm && (uint32_t(__popcll(fm)) >= a.foreign_min || __ballot(state == kTrav || state == kLeaf || state == kDone || state == kMissed || state == kDeep) == 0), 0)) {
                 uint32_t on_bytes = 0;
                 bool given_up = false;
+                walk_phase = a.hold_resolved != 0;
                 if (state == kForeign) {
                     tr.iter &= ~kParked;
                     const uint32_t before = tr.iter;
@@ -466,6 +474,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep)
                                                : (s == kTravAtLeaf ? kDone : (s == kTravFinished ? kMissed : kIdle));
                     if (state != kTrav) tr.iter |= kParked;
+                    if (walk_phase && shadow_ray && (state == kDone || state == kMissed)) {
+                        held_t = state == kDone ? res.t : -1.0f;
+                        state = kHeld;
+                    }
                 }
                 const unsigned long long gm = __ballot(given_up);
                 if (gm) {
@@ -494,6 +506,11 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             }
         }
 
+        if (FOREIGN == VX_SVO_CSVO && !walk_phase && state == kHeld) {  // a held shadow ray: all that is ever looked at is its distance
+            result_miss(res, false);
+            res.t = held_t;
+            state = kDone;
+        }
         VX_PART_END(5);
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
         VX_PART_BEGIN(1);
@@ -738,7 +755,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // ---- refill idle lanes from the sub-tile queue ----
         VX_PART_BEGIN(3);
         unsigned long long idle_mask = __ballot(state == kIdle);
-        if (!queue_empty && idle_mask && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
+        if (!queue_empty && idle_mask && !walk_phase && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
             if (STATS) ++refills;
             for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
                 if (cursor >= 64) {
@@ -1234,8 +1251,9 @@ struct vx_context {
     // from 63 to 64 (profiles/round3/pass_m, pass_o). Lanes whose rays end early idle until the slowest ray of the batch has ended (the rays
     // of 8 x 8 neighbouring pixels are of similar length: 41 % of the loop's lane slots are used, against 62 % at 56 -- in fewer instructions).
     // (foreign_min -- deep CSVO worlds: how many lanes must wait for their walk into a voxel before a wave leaves the loop for it: 32 in
-    // round 2; what a frame pays for is the number of such phases, profiles/round3/pass_s/foreign_min.txt)
-    uint32_t refill_min = 4, service_min = 64, foreign_min = 48;
+    // round 2; what a frame pays for is the number of such phases, profiles/round3/pass_s/foreign_min.txt, pass_y with held rays)
+    uint32_t refill_min = 4, service_min = 64, foreign_min = 40;
+    uint32_t hold_resolved = 1;  // VX_HOLD_RESOLVED (PersistentArgs::hold_resolved)
     // Block ids 0..63 all of whose textures are opaque throughout (RenderParams::opaque_*): from host copies of what vx_set_materials and
     // vx_set_textures were given. opaque_layer[l] = every texel of layer l, on every mip level, has alpha > 0.
     std::vector<vx_material> host_materials;
@@ -1503,6 +1521,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.refill_min = ctx->refill_min;
         a.service_min = ctx->service_min;
         a.foreign_min = ctx->foreign_min;
+        a.hold_resolved = ctx->hold_resolved;
         a.excursions = ctx->d_excursions;
         a.timeline = ctx->d_timeline;
         a.timeline_part = ctx->timeline_part;
@@ -1893,6 +1912,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_COMM_HEADROOM")) c->comm_headroom = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
+        if (const char* e = std::getenv("VX_HOLD_RESOLVED")) c->hold_resolved = std::atoi(e) != 0 ? 1u : 0u;
         if (const char* e = std::getenv("VX_FOREIGN_MIN")) c->foreign_min = uint32_t(std::max(1, std::min(64, std::atoi(e))));
         if (c->refill_min < 1) c->refill_min = 1;
         if (c->refill_min > 64) c->refill_min = 64;
