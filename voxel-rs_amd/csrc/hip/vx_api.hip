@@ -307,24 +307,34 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     // Wave w starts on sub-tile w without asking (a launch never has more waves than sub-tiles): 4096 waves do not open the frame by
     // queueing at one counter. The counter hands out the sub-tiles from gridDim.x on.
     uint32_t my_queue = blockIdx.x & (kQueues - 1u);  // wave-uniform: the dispenser this wave draws from
-    auto draw_ticket = [&]() -> uint32_t {
-        // the n-th ticket of dispenser c is sub-tile (first_c + n) * 8 + c, first_c = how many of the waves' own first sub-tiles are c's
-        uint32_t t = 0;
-        if (lane == 0) t = (((gridDim.x + kQueues - 1u - my_queue) >> 3) + atomicAdd(a.work_counter + my_queue * kQueueStride, 1u)) * kQueues + my_queue;
-        return t;
+    // A ticket is DRAWN (the atomic issued, its raw count -- lane 0's -- left in a vector register) and, later, SETTLED (the count waited for and
+    // made the sub-tile's number). Nothing between the two may touch the raw value: round 2's draw did the arithmetic at once, so the wave
+    // waited out the atomic's round trip (2-3 us) in every refill -- "ahead" in name only (the refill was 24 of the 70 us a wave spends in its
+    // service phases, profiles/round3/pass_p). (A wave's memory operations complete in order as far as its wait counter goes: the first wait
+    // for ANY later load waits for the atomic too. Drawn where it is, that is after the ray generation and set-up of a whole sub-tile.)
+    auto draw_raw = [&]() -> uint32_t {
+        uint32_t raw = 0;
+        if (lane == 0) raw = atomicAdd(a.work_counter + my_queue * kQueueStride, 1u);
+        return raw;
     };
+    // the n-th ticket of dispenser c is sub-tile (first_c + n) * 8 + c, first_c = how many of the waves' own first sub-tiles are c's
+    auto ticket_of = [&](uint32_t raw, uint32_t queue) -> uint32_t {
+        return (((gridDim.x + kQueues - 1u - queue) >> 3) + uint32_t(__builtin_amdgcn_readfirstlane(raw))) * kQueues + queue;
+    };
+    uint32_t ticket_raw = 0, ticket_queue = my_queue;  // the ticket drawn ahead: its raw count and the dispenser it came from
+    bool ticket_ahead = true, ticket_first = true;   // wave-uniform; the wave's first ticket is its own number: nothing was drawn
     // the ticket as the wave's value; a dispenser that has run dry sends the wave on to the next one (the frame's last stretch only)
-    auto settle_ticket = [&](uint32_t t) -> uint32_t {
-        t = __builtin_amdgcn_readfirstlane(t);
+    auto settle_ticket = [&]() -> uint32_t {
+        uint32_t t = ticket_ahead ? (ticket_first ? blockIdx.x : ticket_of(ticket_raw, ticket_queue)) : ticket_of(draw_raw(), my_queue);
+        ticket_ahead = false;
+        ticket_first = false;
         for (uint32_t tried = 1; t >= a.total_subtiles && tried < kQueues; ++tried) {
             my_queue = (my_queue + 1u) & (kQueues - 1u);
-            t = __builtin_amdgcn_readfirstlane(draw_ticket());
+            t = ticket_of(draw_raw(), my_queue);
         }
         return t;
     };
     if (blockIdx.x == 0 && lane < kQueues) a.next_counter[lane * kQueueStride] = 0u;
-    uint32_t ticket = blockIdx.x;                    // drawn ahead, not looked at yet
-    bool ticket_ahead = true;                        // wave-uniform
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
     // BATCH, wave-uniform: the wave's two rings
     uint4* const ring_r = BATCH ? reinterpret_cast<uint4*>(a.batch + size_t(blockIdx.x) * kWaveBatchBytes) : nullptr;
@@ -632,8 +642,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             const uint32_t n_idle = uint32_t(__popcll(idle_mask));
             if (idle_mask && (n_idle >= a.refill_min || idle_mask == ~0ull || queue_empty)) {
                 while (r_count < n_idle && !queue_empty) {
-                    const uint32_t t = settle_ticket(ticket_ahead ? ticket : draw_ticket());
-                    ticket_ahead = false;
+                    const uint32_t t = settle_ticket();
                     if (t >= a.total_subtiles) {
                         queue_empty = true;
                         if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
@@ -761,8 +770,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 if (cursor >= 64) {
                     // the ticket drawn ahead, if there is one (its round trip -- an atomic is carried out at the memory side -- ran under the
                     // traversal since)
-                    const uint32_t t = settle_ticket(ticket_ahead ? ticket : draw_ticket());
-                    ticket_ahead = false;
+                    const uint32_t t = settle_ticket();
                     if (t >= a.total_subtiles) {
                         queue_empty = true;
                         if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
@@ -772,9 +780,11 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     if (sub >= a.total_subtiles) sub = t;  // (never: a table of another view is not used)
                     cursor = 0;
                     ++taken;
-                    // one ahead -- but not in the frame's last stretch, where a sub-tile reserved by a busy wave is one an idle wave cannot take
+                    // one ahead (its round trip runs under the ray generation and set-up that follow, and the loop's first trip) -- but not in
+                    // the frame's last stretch, where a sub-tile reserved by a busy wave is one an idle wave cannot take
                     if (a.ticket_ahead && t + ((a.ticket_ahead - 1u) * gridDim.x >> 2) < a.total_subtiles) {
-                        ticket = draw_ticket();
+                        ticket_raw = draw_raw();
+                        ticket_queue = my_queue;
                         ticket_ahead = true;
                     }
                 }
