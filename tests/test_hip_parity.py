@@ -576,9 +576,13 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
         svo.set_textures(tex, 6)
         svo.update_full(world)  # a fresh buffer each time: the world's dirty ranges were consumed by the first update
         img, hits = svo.render(u, w, h, want_hits=True)
-        for _ in range(4):  # (from the third frame of a view on, the queue hands the sub-tiles out by last frame's cost)
+        for frame in range(4):  # (from the third frame of a view on, the queue hands the sub-tiles out by last frame's cost)
             img2, _ = svo.render(u, w, h)
-            assert img2.tobytes() == img.tobytes()
+            if img2.tobytes() != img.tobytes():
+                bad = np.argwhere((img2.view(np.uint32) != img.view(np.uint32)).any(axis=2))
+                y, x = bad[0]
+                raise AssertionError(f"{env}: image-only frame {frame} differs from the frame with hit records in {len(bad)} pixels, first (x={x}, y={y}): "
+                                     f"{img2[y, x]} against {img[y, x]}; {bad[:8].tolist()}")
         # (the occupancy counters describe how a kernel scheduled its lanes, not what the rays did)
         counters = {k: v for k, v in svo.render_counters(u, w, h).items() if k not in OCCUPANCY_COUNTERS}
         results.append((img, hits.tobytes(), counters))

@@ -31,6 +31,10 @@
 #ifndef VX_ASM_LOOP
 #define VX_ASM_LOOP 1
 #endif
+// the same for the 12-level stack of the five-waves build (VX_FIVE_WAVES=1, an experiment)
+#ifndef VX_ASM_LOOP_12
+#define VX_ASM_LOOP_12 1
+#endif
 
 using namespace vxd;
 
@@ -221,6 +225,34 @@ __device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderP
     atomicMax(&a.cost_cur[subtile_of(p, out_index)], (a.cur_tag << 12) | (iterations < 4095u ? iterations : 4095u));
 }
 
+// The same for a whole wave (every lane of the wave calls it; `done` = this lane's ray has just ended). With the lanes in lockstep the rays
+// that end in a service phase are one sub-tile's: their maximum is found in registers (four DPP steps inside a row of 16 lanes, the four
+// rows' results through scalar registers) and ONE lane notes it -- an atomic is carried out at the memory side of the L2s, 32 bytes of HBM
+// write traffic each, and a wave's next wait for memory waits for it too: 375 K of them a C3 frame, 12 MB. Lanes of several sub-tiles (any
+// other service_min): a note per lane, as before.
+__device__ __forceinline__ void note_cost_wave(const PersistentArgs& a, const RenderParams& p, bool done, uint32_t out_index, uint32_t iterations) {
+    if (!a.cost_cur) return;
+    const bool noting = done && iterations >= kCostFloor;
+    const unsigned long long m = __ballot(noting);
+    if (m == 0ull) return;
+    const uint32_t st = subtile_of(p, out_index);
+    const uint32_t st0 = uint32_t(__builtin_amdgcn_readlane(int(st), int(__builtin_ctzll(m))));
+    uint32_t v = noting ? (iterations < 4095u ? iterations : 4095u) : 0u;
+    if (__ballot(noting && st != st0) == 0ull) {
+        uint32_t o;
+        o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xF, 0xF, false)); v = v > o ? v : o;   // quad_perm [1,0,3,2]
+        o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x4E, 0xF, 0xF, false)); v = v > o ? v : o;   // quad_perm [2,3,0,1]
+        o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x141, 0xF, 0xF, false)); v = v > o ? v : o;  // row_half_mirror
+        o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x140, 0xF, 0xF, false)); v = v > o ? v : o;  // row_mirror
+        const uint32_t r0 = uint32_t(__builtin_amdgcn_readlane(int(v), 0)), r1 = uint32_t(__builtin_amdgcn_readlane(int(v), 16));
+        const uint32_t r2 = uint32_t(__builtin_amdgcn_readlane(int(v), 32)), r3 = uint32_t(__builtin_amdgcn_readlane(int(v), 48));
+        const uint32_t r01 = r0 > r1 ? r0 : r1, r23 = r2 > r3 ? r2 : r3, top = r01 > r23 ? r01 : r23;
+        if (threadIdx.x == 0) atomicMax(&a.cost_cur[st0], (a.cur_tag << 12) | top);
+    } else if (noting) {
+        atomicMax(&a.cost_cur[st], (a.cur_tag << 12) | v);
+    }
+}
+
 // BATCH kernels: a record is four 16-byte words; per wave 256 ray records and 128 result records
 constexpr uint32_t kRayRing = 256, kHitRing = 128;
 constexpr size_t kWaveBatchBytes = size_t(kRayRing + kHitRing) * 64;
@@ -352,7 +384,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         const unsigned long long c_loop = a.timeline ? __builtin_amdgcn_s_memtime() : 0ull;
         // The hand-scheduled loop (vx_loop_gfx950.hpp) for cursors on a byte-offset image that the resident stack levels cover. It does not
         // clear kHasAdjacentLeaf: a wave with a traversing ray that has just passed a translucent voxel takes the compiler's loop this time.
-        constexpr bool kAsmLoop = VX_ASM_LOOP != 0 && IMAGE && SHALLOW && (LV == kLdsLevels || LV == 16 || LV == 12) && !HOT && !STATS;
+        constexpr bool kAsmLoop = VX_ASM_LOOP != 0 && IMAGE && SHALLOW && (LV == kLdsLevels || LV == 16 || (LV == 12 && VX_ASM_LOOP_12 != 0)) && !HOT && !STATS;
         bool by_hand = false;
         if constexpr (kAsmLoop) {
             by_hand = __ballot((tr.flags & Trav<SVO>::kHasAdjacentLeaf) != 0 && tr.iter < uint32_t(kMaxSteps)) == 0;
@@ -473,9 +505,11 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                 if (state == kForeign) {
                     tr.iter &= ~kParked;
                     const uint32_t before = tr.iter;
-                    // (as a real call -- a register allocation of its own for the walk, the cursor handed over through scratch -- the walk takes 198
-                    // VGPRs and the kernel's occupancy with it: clang accepts a register bound only on kernels. Inlined, it costs the kernel's
-                    // service phases some forty spilled registers: profiles/round3/README.md)
+                    // (As a real call -- a register allocation of its own for the walk, the cursor and the result handed over through scratch: shared by
+                    // the kernels it takes 198 VGPRs and the kernel's occupancy with it; one copy per kernel build keeps the kernel's bound, and
+                    // the frame is a quarter slower -- 4K depth 13 2.58 -> 3.22 ms, what is saved and restored around the call is more than what
+                    // the service phases spill: profiles/round3/pass_ab. At three waves per SIMD (168 registers, 2 spilled) a service phase is a
+                    // third shorter and the frame 4-7 % longer for the waves that are missing: VX_DEEP_WAVES=3, pass_aa.)
                     const DevScene sc_bytes = make_scene(sa);
                     const TravStatus s = enter_voxel_on_bytes<SVO, FullStack, false, false>(sc, sc_bytes, tr, st, true, res);
                     on_bytes = tr.iter - before;
@@ -709,10 +743,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
         // ---- finished rays ----
         VX_PART_BEGIN(2);
+        note_cost_wave(a, p, state == kDone, out_index, tr.iter & ~kParked);
         if (state == kDone) {
             float color[4];
             bool write = true;
-            note_cost(a, p, out_index, tr.iter & ~kParked);
             if (!shadow_ray) {
                 PrimaryOutcome o;
                 shade_primary<kOpaqueFastPath>(sc, p, res, o, color_pending);
@@ -1246,6 +1280,7 @@ struct vx_context {
     bool batch_service = false;   // VX_BATCH=1 (experiment): image-only renders by the build that shades, lights and generates rays 64 records at a time
     uint8_t* d_batch[kFrameStreams + 1] = {};  // [slot + 1]: the waves' record rings of a BATCH kernel (PersistentArgs::batch)
     size_t batch_waves[kFrameStreams + 1] = {};
+    int deep_waves = 4;           // VX_DEEP_WAVES=3 (experiment, 4-7 % slower): the kernel with the excursion code (CSVO worlds of 13 and 14 levels) at three waves per SIMD, 168 VGPRs
     bool five_waves = false;      // VX_FIVE_WAVES=1 (experiment, 3 % slower): images of up to 12 levels on a 12-level stack with a 16-bit third plane, five waves per SIMD
     bool deep_stack = true;       // VX_DEEP_STACK=0: images of 14 to 16 levels on the 13-level stack with the hand-over (A/B)
     bool no_excursion = false;    // VX_NO_EXCURSION=1 (MEASUREMENT ONLY, wrong pixels): a CSVO world's image walked by the kernel without the excursion code
@@ -1450,6 +1485,10 @@ const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, 
     if constexpr (!HITS && !STATS) {
         // image-only renders of a CSVO world: rays that start inside a voxel are listed and run on the world's bytes afterwards (kForeignRerun)
         if (rerun && shallow && levels == kLdsLevels) return wide ? VX_K(VX_SVO_IMAGE_WIDE, false, false, 4, kForeignRerun, true) : VX_K(VX_SVO_IMAGE, false, false, 4, kForeignRerun, true);
+    }
+    if constexpr (!HITS && !STATS) {
+        if (ctx->deep_waves == 3 && !batch && shallow && levels == kLdsLevels)
+            return wide ? VX_K(VX_SVO_IMAGE_WIDE, false, false, 3, VX_SVO_CSVO, true) : VX_K(VX_SVO_IMAGE, false, false, 3, VX_SVO_CSVO, true);
     }
     return wide ? VX_IMG(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO) : VX_IMG(VX_SVO_IMAGE, VX_SVO_CSVO);
 #undef VX_IMG
@@ -1899,6 +1938,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FIVE_WAVES")) c->five_waves = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_DEEP_WAVES")) c->deep_waves = std::atoi(e) == 3 ? 3 : 4;
         if (const char* e = std::getenv("VX_BATCH")) c->batch_service = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FOREIGN_RERUN")) c->foreign_rerun = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VX_HOT_LEVELS")) c->hot_levels = std::atoi(e) != 0;

@@ -232,6 +232,9 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         TAKE_MASKS                                                                                                                 \
         VX_LOOP_CONTROL(COUNT)                                                                                                     \
         "9:\n"                                                                                                                     \
+        /* (the ADVANCE-only tail leaves its entry request in flight: it must have landed before the compiler's code reuses the pair -- */ \
+        /* at five waves per SIMD, where every register is in use, it did not always: one pixel in a few frames differed) */          \
+        "s_waitcnt vmcnt(0)\n"                                                                                                     \
         "s_mov_b64 exec, %[entry_exec]\n"
 
 // FOREIGN: the image of a CSVO world -- a ray about to be led into a voxel leaves the loop (kTravForeign, its iteration not counted);
