@@ -156,6 +156,7 @@ struct PersistentArgs {
     // stream draws its tickets through that table: `order` (null: screen order). Order only: no pixel's value depends on it.
     const uint32_t* order;          // [total_subtiles] sub-tile ids, or null
     uint32_t* cost_cur;             // [total_subtiles] tag << 12 | iterations of the sub-tile's longest ray this frame; null = do not note
+    uint32_t cost_floor;            // a wave notes its sub-tile's longest ray from this many iterations on (note_cost_wave)
     uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
     uint32_t ticket_ahead;          // 0 = no; 1 + g = waves draw their next sub-tile's ticket when they start on one (its round trip runs under the traversal),
                                     // except for the frame's last g quarter-grids of tickets
@@ -232,7 +233,7 @@ __device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderP
 // other service_min): a note per lane, as before.
 __device__ __forceinline__ void note_cost_wave(const PersistentArgs& a, const RenderParams& p, bool done, uint32_t out_index, uint32_t iterations) {
     if (!a.cost_cur) return;
-    const bool noting = done && iterations >= kCostFloor;
+    const bool noting = done && iterations >= a.cost_floor;
     const unsigned long long m = __ballot(noting);
     if (m == 0ull) return;
     const uint32_t st = subtile_of(p, out_index);
@@ -248,7 +249,7 @@ __device__ __forceinline__ void note_cost_wave(const PersistentArgs& a, const Re
         const uint32_t r2 = uint32_t(__builtin_amdgcn_readlane(int(v), 32)), r3 = uint32_t(__builtin_amdgcn_readlane(int(v), 48));
         const uint32_t r01 = r0 > r1 ? r0 : r1, r23 = r2 > r3 ? r2 : r3, top = r01 > r23 ? r01 : r23;
         if (threadIdx.x == 0) atomicMax(&a.cost_cur[st0], (a.cur_tag << 12) | top);
-    } else if (noting) {
+    } else if (noting && iterations >= kCostFloor) {
         atomicMax(&a.cost_cur[st], (a.cur_tag << 12) | v);
     }
 }
@@ -509,7 +510,9 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     // the kernels it takes 198 VGPRs and the kernel's occupancy with it; one copy per kernel build keeps the kernel's bound, and
                     // the frame is a quarter slower -- 4K depth 13 2.58 -> 3.22 ms, what is saved and restored around the call is more than what
                     // the service phases spill: profiles/round3/pass_ab. At three waves per SIMD (168 registers, 2 spilled) a service phase is a
-                    // third shorter and the frame 4-7 % longer for the waves that are missing: VX_DEEP_WAVES=3, pass_aa.)
+                    // third shorter -- three quarters of that because each of three waves gets a third of the SIMD's issue slots instead of a quarter --
+                    // and the frame 4-7 % longer for the waves that are missing: VX_DEEP_WAVES=3, pass_aa. What a lane carries through the walk put away
+                    // by hand around it -- ten values, 58 -> 38 spilled registers -- changes nothing: pass_ad. The spills are not what the walk costs.)
                     const DevScene sc_bytes = make_scene(sa);
                     const TravStatus s = enter_voxel_on_bytes<SVO, FullStack, false, false>(sc, sc_bytes, tr, st, true, res);
                     on_bytes = tr.iter - before;
@@ -1043,7 +1046,7 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneArgs sa, TraceArgs a, vx
 // took 180; it runs behind a frame on a stream of its own, but on the compute units the next frame wants).
 constexpr uint32_t kCostClasses = 16, kCostStep = 16;  // classes of the order table: iterations / kCostStep, capped
 constexpr uint32_t kOrderThreads = 1024;
-__global__ __launch_bounds__(kOrderThreads) void order_kernel(const uint32_t* __restrict__ cost, uint32_t tag, uint32_t n, uint32_t* __restrict__ order) {
+__global__ __launch_bounds__(kOrderThreads) void order_kernel(const uint32_t* __restrict__ cost, uint32_t tag, uint32_t n, uint32_t* __restrict__ order, uint32_t step) {
     __shared__ uint32_t wave_totals[kCostClasses][kOrderThreads / 64];  // [slot][wave], slot 0 = the most expensive class
     __shared__ uint32_t slot_base[kCostClasses];
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(kOrderThreads) void order_kernel(const uint32_t* __
     const uint32_t first = t * per < n ? t * per : n, last = first + per < n ? first + per : n;
     auto slot_of = [&](uint32_t i) -> uint32_t {
         const uint32_t c = cost[i];
-        const uint32_t cls = (c >> 12) == tag ? ((c & 0xfffu) / kCostStep < kCostClasses - 1u ? (c & 0xfffu) / kCostStep : kCostClasses - 1u) : 0u;
+        const uint32_t cls = (c >> 12) == tag ? ((c & 0xfffu) / step < kCostClasses - 1u ? (c & 0xfffu) / step : kCostClasses - 1u) : 0u;
         return kCostClasses - 1u - cls;
     };
     // (1) this thread's members of each class: sixteen 16-bit counters in eight words (a run is shorter than 65536)
@@ -1280,6 +1283,7 @@ struct vx_context {
     bool batch_service = false;   // VX_BATCH=1 (experiment): image-only renders by the build that shades, lights and generates rays 64 records at a time
     uint8_t* d_batch[kFrameStreams + 1] = {};  // [slot + 1]: the waves' record rings of a BATCH kernel (PersistentArgs::batch)
     size_t batch_waves[kFrameStreams + 1] = {};
+    uint32_t cost_floor = 64, cost_step = kCostStep;  // VX_COST_FLOOR, VX_COST_STEP: the order table's classes (note_cost_wave, order_kernel)
     int deep_waves = 4;           // VX_DEEP_WAVES=3 (experiment, 4-7 % slower): the kernel with the excursion code (CSVO worlds of 13 and 14 levels) at three waves per SIMD, 168 VGPRs
     bool five_waves = false;      // VX_FIVE_WAVES=1 (experiment, 3 % slower): images of up to 12 levels on a 12-level stack with a 16-bit third plane, five waves per SIMD
     bool deep_stack = true;       // VX_DEEP_STACK=0: images of 14 to 16 levels on the 13-level stack with the hand-over (A/B)
@@ -1577,6 +1581,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.ticket_ahead = ctx->ticket_ahead != 0 ? 1u + ctx->ahead_guard : 0u;
         a.order = nullptr;
         a.cost_cur = nullptr;
+        a.cost_floor = ctx->cost_floor;
         a.cur_tag = 0xfffffu;
         vx_context::HotState* hs = nullptr;
         // One frame at a time only (the context's own stream): with several frames in flight the next frame's waves fill the tail anyway,
@@ -1706,7 +1711,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         const uint32_t g = hs->frames % 3;
         if (ctx->hot_sort) {
             HIP_TRY(hipStreamWaitEvent(ctx->order_stream, slot >= 0 ? ctx->frame_done[slot] : ctx->render_done, 0));
-            hipLaunchKernelGGL(order_kernel, dim3(1), dim3(kOrderThreads), 0, ctx->order_stream, hs->cost[g], hs->tag, order_subtiles, hs->order[g]);
+            hipLaunchKernelGGL(order_kernel, dim3(1), dim3(kOrderThreads), 0, ctx->order_stream, hs->cost[g], hs->tag, order_subtiles, hs->order[g], ctx->cost_step);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(hs->order_done[g], ctx->order_stream));
         }
@@ -1938,6 +1943,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FIVE_WAVES")) c->five_waves = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_COST_FLOOR")) c->cost_floor = uint32_t(std::atoi(e));
+        if (const char* e = std::getenv("VX_COST_STEP")) c->cost_step = std::atoi(e) > 0 ? uint32_t(std::atoi(e)) : kCostStep;
         if (const char* e = std::getenv("VX_DEEP_WAVES")) c->deep_waves = std::atoi(e) == 3 ? 3 : 4;
         if (const char* e = std::getenv("VX_BATCH")) c->batch_service = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FOREIGN_RERUN")) c->foreign_rerun = std::atoi(e) != 0 ? 1 : 0;
