@@ -218,6 +218,31 @@ def test_heightfield_frame(hip, fmt, depth, size):
         assert gc["pixels"] == w * h
 
 
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("tex_size,levels", [(48, 5), (40, 4), (24, 4)])
+def test_textures_whose_height_is_not_a_power_of_two(hip, fmt, tex_size, levels):
+    """WRAP_T is REPEAT (texture_array.rs never sets it): for heights that are not powers of two the sampler's wrap is a modulo, not a mask
+    (TexLevel::repeat_t) -- frames, hit records and fetch counters against the oracle, with texture minification in play (lod > 0 from 15 blocks on)."""
+    from voxel_rs_amd import scenes
+
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(8, threads=4)
+    tex, mats = scenes.synthetic_textures(size=tex_size), scenes.synthetic_materials()
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, levels)
+    svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(mats)
+    svo.set_textures(tex, levels)
+    svo.update(world)
+    w, h = 224, 128
+    u = scenes.bench_camera(8, st["h_max"], w, h, shadow_distance=500.0, render_shadows=True)
+    img, hits = svo.render(u, w, h, want_hits=True)
+    cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
+    compare_frames(img, hits, cimg, chits)
+    assert (hits["lod"] > 0).mean() > 0.2  # (minified samples: both mip levels' wraps are exercised)
+    img2, _ = svo.render(u, w, h, want_hits=False)
+    assert img2.tobytes() == img.tobytes()
+
+
 @pytest.mark.parametrize("base,depth", [((200, 3, 201), 13), ((400, 3, 401), 14), ((800, 3, 801), 15)])
 @pytest.mark.parametrize("fmt", FMTS)
 def test_rays_from_inside_voxels_in_a_deep_world(hip, fmt, base, depth, monkeypatch):

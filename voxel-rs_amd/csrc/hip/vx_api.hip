@@ -293,7 +293,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     static_assert(FOREIGN != kForeignRerun || (!HITS && !STATS), "rays for the world's bytes are listed by image-only renders");
     static_assert(!SHALLOW || IMAGE, "only a traversal image bounds how deep a ray can get");
     static_assert(!BATCH || (!HITS && !STATS), "batched service phases: image-only renders");
-    const DevScene sc = IMAGE ? make_image_scene(sa) : make_scene(sa);
+    // (the image kernels are only launched for textures whose height is a power of two -- launch_render -- and say so to the sampler, a literal the
+    // compiler folds: REPEAT is a mask, nothing of the general wrap is in these kernels' code -- 1-3 % of a frame, profiles/round3/pass_af)
+    auto vouched = [](DevScene s) { s.tex.pow2_height = IMAGE; return s; };
+    const DevScene sc = vouched(IMAGE ? make_image_scene(sa) : make_scene(sa));
     const uint32_t lane = threadIdx.x;
     static_assert(LV == kLdsLevels || IMAGE, "only an image cursor's third stack word fits 16 bits");
     StackSpill spill;
@@ -495,6 +498,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // The walk runs with only these lanes active, so they go together: a lane waits (parked, at no cost to the loop) until
         // foreign_min lanes of the wave are there, or until no lane is left that could traverse meanwhile.
         VX_PART_BEGIN(5);
+        constexpr bool kOpaqueFastPath = !STATS && !BATCH;
+        bool color_pending = false;  // this lane's hit is of an opaque block and was found without its sample: its colour is still to be sampled
         bool walk_phase = false;  // (wave-uniform) this phase walks rays into their voxels
         if (FOREIGN == VX_SVO_CSVO) {
             const unsigned long long fm = __ballot(state == kForeign);
@@ -513,8 +518,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     // third shorter -- three quarters of that because each of three waves gets a third of the SIMD's issue slots instead of a quarter --
                     // and the frame 4-7 % longer for the waves that are missing: VX_DEEP_WAVES=3, pass_aa. What a lane carries through the walk put away
                     // by hand around it -- ten values, 58 -> 38 spilled registers -- changes nothing: pass_ad. The spills are not what the walk costs.)
-                    const DevScene sc_bytes = make_scene(sa);
-                    const TravStatus s = enter_voxel_on_bytes<SVO, FullStack, false, false>(sc, sc_bytes, tr, st, true, res);
+                    const DevScene sc_bytes = vouched(make_scene(sa));
+                    const TravStatus s = enter_voxel_on_bytes<SVO, FullStack, false, false, kOpaqueFastPath>(sc, sc_bytes, tr, st, true, res, p.opaque_lo, p.opaque_hi, &color_pending);
                     on_bytes = tr.iter - before;
                     // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there / given up (the pixel's turn comes later)
                     given_up = s == kTravForeign;
@@ -563,8 +568,6 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         VX_PART_BEGIN(1);
         // A voxel of a block whose textures are opaque throughout is a hit whatever the sample says (RenderParams::opaque_*): its leaf test
         // is the value and arithmetic. The hit's colour is sampled when the hit is shaded (a shadow ray's never is).
-        constexpr bool kOpaqueFastPath = !STATS && !BATCH;
-        bool color_pending = false;
         if (state == kLeaf) {
             tr.iter &= ~kParked;
             tr.sync_idx();
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     }
     // ---- second phase (FOREIGN = kForeignRerun): the rays this wave listed, on the world's own bytes ----
     if (FOREIGN == kForeignRerun) {
-        const DevScene sc_bytes = make_scene(sa);
+        const DevScene sc_bytes = vouched(make_scene(sa));
         Stack<64, false, false, int(FullStack::kStackBytes / (64u * 12u))> st2;  // (three full words per slot, over the same LDS: the first phase is over)
         st2.init(lane, &spill);
         const float to_light[3] = {-p.u.light_dir[0], -p.u.light_dir[1], -p.u.light_dir[2]};
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     }
     // ---- second phase (FOREIGN = VX_SVO_CSVO): the pixels this wave gave up on the image, whole, on the world's own bytes ----
     if (FOREIGN == VX_SVO_CSVO) {
-        const DevScene sc_bytes = make_scene(sa);
+        const DevScene sc_bytes = vouched(make_scene(sa));
         // (the byte cursor's stack entries are three full words: the plain layout, as many levels as fit the same LDS -- the first phase is over)
         Stack<64, false, false, int(FullStack::kStackBytes / (64u * 12u))> st2;
         st2.init(lane, &spill);
@@ -1531,7 +1534,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // persistent waves: as many 64-thread workgroups as the device keeps resident, fed from the sub-tile queue
         // Worlds are rendered from their traversal image; the instrumented variant stays on the world's own bytes so that its
         // counters are the reference's own fetches
-        const bool imaged = !STATS && ctx->image_ok;
+        // (... and only for textures whose height is a power of two: the image kernels' sampler wraps with a mask. Any other height renders
+        // on the world's own bytes, whose kernels carry the general wrap.)
+        const bool imaged = !STATS && ctx->image_ok && (ctx->tex.height & (ctx->tex.height - 1u)) == 0u;
         // The image holds at most `depth` levels (traversal_image.hpp). The deepest PUSH of a ray on the image of an ESVO world is
         // into a voxel (a ray that started inside it walks it as an empty node), out of a node at scale 23 - depth; on the image of a
         // CSVO world such a ray leaves for its excursion instead, and the deepest PUSH is one level higher. Where that is an LDS

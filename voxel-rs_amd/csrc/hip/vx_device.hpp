@@ -34,6 +34,9 @@ struct DevTextures {
     buf_t buf;                // mip chain, level l at level_offset[l], layout [layer][y][x][4]
     uint32_t width, height, layers, levels;
     const uint32_t* level_offset;  // [16], stays in the kernel-argument segment (no private copy: it is indexed per lane)
+    // The kernel vouches that `height` is a power of two (a literal `true` in kernels that are only launched for such textures: the sampler's
+    // REPEAT is then a mask and nothing of the general wrap is compiled in); false: the sampler looks at `height`.
+    bool pow2_height;
 };
 
 struct DevScene {
@@ -75,6 +78,7 @@ __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
     sc.tex.buf = make_buf(a.tex, a.tex_bytes);
     sc.tex.width = a.width; sc.tex.height = a.height; sc.tex.layers = a.layers; sc.tex.levels = a.levels;
     sc.tex.level_offset = a.level_offset;
+    sc.tex.pow2_height = false;
     sc.octree_scale = __uint_as_float(buf_u32(sc.world, 0));
     sc.root_ptr = buf_u32(sc.world, 4);
     sc.wide = a.world;
@@ -91,6 +95,7 @@ __device__ __forceinline__ DevScene make_image_scene(const SceneArgs& a) {
     sc.tex.buf = make_buf(a.tex, a.tex_bytes);
     sc.tex.width = a.width; sc.tex.height = a.height; sc.tex.layers = a.layers; sc.tex.levels = a.levels;
     sc.tex.level_offset = a.level_offset;
+    sc.tex.pow2_height = false;
     sc.octree_scale = __uint_as_float(buf_u32(sc.world, 0));
     sc.root_ptr = 0;
     sc.wide = a.image;
@@ -330,13 +335,22 @@ struct TexLevel {
         w = int(ww ? ww : 1);
         h = int(hh ? hh : 1);
         base = t.level_offset[level] + layer * uint32_t(h) * uint32_t(w) * 4u;
-        pow2_h = (t.height & (t.height - 1)) == 0;
+        pow2_h = t.pow2_height || (t.height & (t.height - 1)) == 0;
     }
     __device__ __forceinline__ int clamp_s(int x) const { x = x < 0 ? 0 : x; return x > w - 1 ? w - 1 : x; }
     __device__ __forceinline__ int repeat_t(int y) const {
         if (pow2_h) return y & (h - 1);
-        y %= h;
-        return y < 0 ? y + h : y;
+        // Any other height: |y| mod h by binary long division from |y|'s highest bit down -- a loop of five instructions, not `%` (the
+        // compiler's 32-bit modulo is ~35 instructions, inlined at every tap of every sample). Coordinates are within a row or two of
+        // the texture, so the loop makes about as many trips as h has bits.
+        const uint32_t uh = uint32_t(h), a = y < 0 ? 0u - uint32_t(y) : uint32_t(y);
+        uint32_t r = 0;
+#pragma unroll 1
+        for (int i = 31 - __builtin_clz(a | 1u); i >= 0; --i) {
+            r = (r << 1) | ((a >> i) & 1u);
+            r = r >= uh ? r - uh : r;
+        }
+        return int((y < 0 && r != 0u) ? uh - r : r);
     }
     __device__ __forceinline__ uint32_t offset(int x, int y) const { return base + (uint32_t(y) * uint32_t(w) + uint32_t(x)) * 4u; }
 };
@@ -351,7 +365,7 @@ __device__ __forceinline__ void sample_linear_bytes(const DevTextures& t, uint32
     const float fx = floorf(x), fy = floorf(y);
     const float ax = x - fx, ay = y - fy;
     const int i0 = int(fx), j0 = int(fy);
-    const int x0 = L.clamp_s(i0), x1 = L.clamp_s(i0 + 1), y0 = L.repeat_t(j0), y1 = L.repeat_t(j0 + 1);
+    const int x0 = L.clamp_s(i0), x1 = L.clamp_s(i0 + 1), y0 = L.repeat_t(j0), y1 = y0 + 1 == L.h ? 0 : y0 + 1;  // (= repeat_t(j0 + 1))
     const uint32_t r00 = buf_u32(t.buf, L.offset(x0, y0)), r10 = buf_u32(t.buf, L.offset(x1, y0));
     const uint32_t r01 = buf_u32(t.buf, L.offset(x0, y1)), r11 = buf_u32(t.buf, L.offset(x1, y1));
 #pragma unroll
@@ -1064,9 +1078,13 @@ struct Trav {
 // that the rest of the ray depends on (below).
 // `st` is a full stack (the excursion can go below the LDS-resident levels). The iteration `tr` stopped in is repeated here, so
 // `tr.iter` must not count it (the caller took it back, as for kTravDeep); on return `tr.iter` counts everything that ran.
-template <int IMGSVO, class ST, bool LIMIT = false, bool RESTART = true>
+// OPAQUE (the render kernel's image-only builds): a phantom leaf whose value is in the host's set of blocks that are opaque throughout
+// (`opaque_lo/hi`, RenderParams) is a hit without its sample, as in the kernel's own leaf tests (Trav::leaf_hit_opaque); `*color_pending` then
+// says that the hit's colour is still to be sampled (by whoever shades it: a shadow ray's never is).
+template <int IMGSVO, class ST, bool LIMIT = false, bool RESTART = true, bool OPAQUE = false>
 __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, const DevScene& bytes, Trav<IMGSVO>& tr, const ST& st,
-                                                           bool cast_translucent, Result& res) {
+                                                           bool cast_translucent, Result& res, uint32_t opaque_lo = 0u, uint32_t opaque_hi = 0u,
+                                                           bool* color_pending = nullptr) {
     static_assert(!ST::kFast, "the excursion needs every stack level");
     typedef Trav<VX_SVO_CSVO> ByteTrav;
     const int parent_scale = tr.scale;
@@ -1111,6 +1129,16 @@ __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, 
         // first trip: the iteration the image cursor stopped in, again -- PUSH into the voxel, or ADVANCE if the voxel's span is empty
         TravStatus s = tb.template step<false, false, LIMIT, ST>(bytes, bst, nullptr, nullptr);
         if (s == kTravAtLeaf) {
+            if constexpr (OPAQUE) {
+                const uint32_t value = tb.leaf_value(bytes);
+                const uint32_t set = value < 32u ? opaque_lo : opaque_hi;
+                if (value < 64u && ((set >> (value & 31u)) & 1u) != 0u && !(tb.flags & ByteTrav::kHasAdjacentLeaf)) {
+                    tb.leaf_hit_opaque(bytes, value, res);
+                    *color_pending = true;
+                    outcome = kTravAtLeaf;
+                    break;
+                }
+            }
             const LeafOutcome o = tb.template leaf_test<false, false>(bytes, bst, cast_translucent, res, nullptr, nullptr);
             if (o == kLeafHit) {
                 outcome = kTravAtLeaf;
