@@ -277,7 +277,7 @@ __device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); 
 // map, light -> the pixel, or a shadow-ray record; misses: the sky; shadow results: the lit pixel); primary rays are generated for
 // a whole sub-tile at a time. Leaf tests (they continue the traversal) and ray set-up stay with the lane. Same arithmetic per
 // pixel, same pixels.
-template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false, int LV = kLdsLevels, bool HOT = false, bool BATCH = false>
+template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false, int LV = kLdsLevels, bool HOT = false, bool BATCH = false, bool TL = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
     constexpr bool IMAGE = SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE;
@@ -295,6 +295,10 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     static_assert(!BATCH || (!HITS && !STATS), "batched service phases: image-only renders");
     // (the image kernels are only launched for textures whose height is a power of two -- launch_render -- and say so to the sampler, a literal the
     // compiler folds: REPEAT is a mask, nothing of the general wrap is in these kernels' code -- 1-3 % of a frame, profiles/round3/pass_af)
+    // TL: the build that fills in the wave timeline (VX_TIMELINE=1; profiles/timeline.py). Everywhere else the instrumentation is compiled out, not
+    // switched off: its stamps and counters are wave-uniform state that lives through the whole kernel, and with them the ESVO image kernel
+    // spilled 123 scalar registers instead of 50 and was 13 % longer (C3 +2 % without: profiles/round3/pass_ag).
+    if constexpr (!TL) a.timeline = nullptr;
     auto vouched = [](DevScene s) { s.tex.pow2_height = IMAGE; return s; };
     const DevScene sc = vouched(IMAGE ? make_image_scene(sa) : make_scene(sa));
     const uint32_t lane = threadIdx.x;
@@ -1474,6 +1478,18 @@ template <bool HITS, bool STATS>
 const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, int levels, bool batch, bool rerun) {
     const bool esvo = ctx->svo_type == VX_SVO_ESVO;
 #define VX_K(...) reinterpret_cast<const void*>(&render_persistent<__VA_ARGS__>)
+    // VX_TIMELINE=1: the instrumented builds of the image-only kernels on 13- and 16-level stacks (what profiles/timeline.py renders with); any
+    // other kernel leaves the timeline's rows untouched
+    if constexpr (!HITS && !STATS) {
+        if (ctx->d_timeline && imaged && shallow && !batch && (levels == kLdsLevels || levels == 16) && !ctx->hot_levels && ctx->deep_waves != 3) {
+            const bool wide = ctx->pub.layout == vximg::kOct64Wide;
+#define VX_TLK(IMAGE, FOREIGN) (levels == 16 ? VX_K(IMAGE, false, false, 4, FOREIGN, true, 16, false, false, true) : VX_K(IMAGE, false, false, 4, FOREIGN, true, kLdsLevels, false, false, true))
+            if (esvo || ctx->no_excursion) return wide ? VX_TLK(VX_SVO_IMAGE_WIDE, 0) : VX_TLK(VX_SVO_IMAGE, 0);
+            if (rerun && levels == kLdsLevels) return wide ? VX_K(VX_SVO_IMAGE_WIDE, false, false, 4, kForeignRerun, true, kLdsLevels, false, false, true) : VX_K(VX_SVO_IMAGE, false, false, 4, kForeignRerun, true, kLdsLevels, false, false, true);
+            return wide ? VX_TLK(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO) : VX_TLK(VX_SVO_IMAGE, VX_SVO_CSVO);
+#undef VX_TLK
+        }
+    }
     if (!imaged) {
         constexpr int W = (!HITS && !STATS) ? 4 : 1;
         if (!HITS && !STATS && ctx->min_waves != 4)
