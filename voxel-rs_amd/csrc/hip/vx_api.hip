@@ -1319,6 +1319,10 @@ struct vx_context {
     int waves_per_cu_cap = 0;             // experiment: fewer persistent waves than the occupancy limit
     int comm_headroom = 4;                // VX_COMM_HEADROOM: wave slots per CU a context with a communicator of more than one rank leaves free (LDS for RCCL's kernels)
     int cu_count = 256;
+    // VX_COMM_RESERVE_CUS=n (read at vx_create; bench.py sets it for ranks that exchange tiles): the streams renders run on are created with a CU
+    // mask that leaves n compute units out -- whole CUs for the exchange's and the assembly's workgroups instead of `comm_headroom` wave slots on
+    // every CU -- and a launch has (cu_count - n) x 16 persistent waves
+    int reserve_cus = 0;
     std::unordered_map<const void*, int> persistent_blocks;  // kernel -> resident 64-thread workgroups per CU, queried once
 
     // screen sharding: the Morton order of an image's tiles and its inverse, on the device, per image size seen
@@ -1658,8 +1662,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // of a rank's render rate; the gather itself could not be measured here -- one GPU per box).
         int per_cu_used = per_cu;
         if (ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu) per_cu_used = ctx->waves_per_cu_cap;
-        else if (ctx->comm_ranks > 1 && ctx->comm_headroom > 0 && per_cu > ctx->comm_headroom + 4) per_cu_used = per_cu - ctx->comm_headroom;
-        uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(per_cu_used);
+        else if (ctx->reserve_cus == 0 && ctx->comm_ranks > 1 && ctx->comm_headroom > 0 && per_cu > ctx->comm_headroom + 4) per_cu_used = per_cu - ctx->comm_headroom;
+        // (whole CUs reserved instead -- VX_COMM_RESERVE_CUS: the render streams' CU mask leaves them out -- : every other CU is filled)
+        uint32_t waves = uint32_t(ctx->cu_count - ctx->reserve_cus) * uint32_t(per_cu_used);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
         if (waves > 8192) a.timeline = nullptr;
         ctx->timeline_waves = a.timeline ? waves : 0;
@@ -1929,7 +1934,20 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     // the end then returns the real bytes plus zeros (what the word-wise reference reads), not an all-zero dword
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_world), c->capacity + kWorldPad));
     CREATE_TRY(hipMemset(c->d_world, 0, c->capacity + kWorldPad));
-    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    std::vector<uint32_t> cu_mask;  // (empty: no reservation)
+    {
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, device));
+        c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (const char* e = std::getenv("VX_COMM_RESERVE_CUS")) c->reserve_cus = std::max(0, std::min(std::atoi(e), c->cu_count / 2));
+        if (c->reserve_cus > 0) {
+            // the mask's LAST n bits stay clear (which CUs those are is the driver's numbering: a handful of whole CUs is all that matters)
+            cu_mask.assign(size_t(c->cu_count + 31) / 32, 0u);
+            for (int b = 0; b < c->cu_count - c->reserve_cus; ++b) cu_mask[size_t(b) >> 5] |= 1u << (b & 31);
+        }
+    }
+    if (!cu_mask.empty()) CREATE_TRY(hipExtStreamCreateWithCUMask(&c->stream, uint32_t(cu_mask.size()), cu_mask.data()));
+    else CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&c->render_done, hipEventDisableTiming));
@@ -1941,7 +1959,9 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
         const int prio = (i & 1) ? prio_greatest : prio_least;
-        CREATE_TRY(hipStreamCreateWithPriority(&c->frame_stream[i], hipStreamNonBlocking, prio));
+        // (a stream with a CU mask has a hardware queue of its own)
+        if (!cu_mask.empty()) CREATE_TRY(hipExtStreamCreateWithCUMask(&c->frame_stream[i], uint32_t(cu_mask.size()), cu_mask.data()));
+        else CREATE_TRY(hipStreamCreateWithPriority(&c->frame_stream[i], hipStreamNonBlocking, prio));
         CREATE_TRY(hipEventCreateWithFlags(&c->frame_done[i], hipEventDisableTiming));
         CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_frame_counter[i]), 2 * kQueues * kQueueStride * sizeof(uint32_t)));
         CREATE_TRY(hipMemset(c->d_frame_counter[i], 0, 2 * kQueues * kQueueStride * sizeof(uint32_t)));
@@ -1952,9 +1972,6 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_excursions), 8 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(c->d_excursions, 0, 8 * sizeof(unsigned long long)));
     {
-        hipDeviceProp_t prop;
-        CREATE_TRY(hipGetDeviceProperties(&prop, device));
-        c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("VX_MIN_WAVES")) c->min_waves = std::atoi(e);
         if (const char* e = std::getenv("VX_FRAMES_IN_FLIGHT")) c->frames_in_flight = std::atoi(e);
