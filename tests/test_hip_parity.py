@@ -578,7 +578,8 @@ OCCUPANCY_COUNTERS = ("wave_steps", "services", "refills", "tail_wave_steps", "t
 def test_kernel_versions_agree(hip, fmt, monkeypatch):
     """The persistent wavefront kernel (default) and the one-thread-per-pixel kernel write identical images and hit
     records, for several refill/service thresholds (they only reorder work between lanes), from the traversal image (default),
-    from the world's own bytes, and from the image layout for more than 4 GiB (octant indices behind a 64-bit pointer)."""
+    from the world's own bytes, from the image layout for more than 4 GiB (octant indices behind a 64-bit pointer), from the instrumented
+    (timeline) builds, on streams with a CU mask, with other classes of the order table."""
     from voxel_rs_amd import scenes
 
     world = vra.World(SVO_TYPES[fmt])
@@ -590,9 +591,11 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     for env in ({"VX_RENDER_KERNEL": "1"}, {"VX_RENDER_KERNEL": "2"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"},
                 {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "64", "VX_SERVICE_MIN": "64"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"},
                 {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_WIDE_IMAGE": "1", "VX_MIN_WAVES": "1"},
-                {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_MIN": "1"}, {"VX_FIVE_WAVES": "1"}, {"VX_BATCH": "1"}, {"VX_TICKET_AHEAD": "1"}, {"VX_TICKET_AHEAD": "0", "VX_FRAMES_IN_FLIGHT": "3"}, {"VX_FOREIGN_RERUN": "0"}):
+                {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_MIN": "1"}, {"VX_FIVE_WAVES": "1"}, {"VX_BATCH": "1"}, {"VX_TICKET_AHEAD": "1"}, {"VX_TICKET_AHEAD": "0", "VX_FRAMES_IN_FLIGHT": "3"}, {"VX_FOREIGN_RERUN": "0"},
+                {"VX_TIMELINE": "1"}, {"VX_TIMELINE": "1", "VX_FOREIGN_RERUN": "0"}, {"VX_COMM_RESERVE_CUS": "8"}, {"VX_COST_FLOOR": "0", "VX_COST_STEP": "4"}):
         for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_MIN_WAVES", "VX_HOT_LEVELS", "VX_HOT_FIRST",
-                  "VX_FOREIGN_MIN", "VX_FIVE_WAVES", "VX_BATCH", "VX_TICKET_AHEAD", "VX_FRAMES_IN_FLIGHT", "VX_FOREIGN_RERUN"):
+                  "VX_FOREIGN_MIN", "VX_FIVE_WAVES", "VX_BATCH", "VX_TICKET_AHEAD", "VX_FRAMES_IN_FLIGHT", "VX_FOREIGN_RERUN", "VX_TIMELINE", "VX_COMM_RESERVE_CUS",
+                  "VX_COST_FLOOR", "VX_COST_STEP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
