@@ -579,7 +579,7 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     """The persistent wavefront kernel (default) and the one-thread-per-pixel kernel write identical images and hit
     records, for several refill/service thresholds (they only reorder work between lanes), from the traversal image (default),
     from the world's own bytes, from the image layout for more than 4 GiB (octant indices behind a 64-bit pointer), from the instrumented
-    (timeline) builds, on streams with a CU mask, with other classes of the order table."""
+    (timeline) builds, on streams with a CU mask, with other classes of the order table, with and without sorted passes."""
     from voxel_rs_amd import scenes
 
     world = vra.World(SVO_TYPES[fmt])
@@ -592,10 +592,11 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
                 {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "64", "VX_SERVICE_MIN": "64"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"},
                 {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_WIDE_IMAGE": "1", "VX_MIN_WAVES": "1"},
                 {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_MIN": "1"}, {"VX_FIVE_WAVES": "1"}, {"VX_BATCH": "1"}, {"VX_TICKET_AHEAD": "1"}, {"VX_TICKET_AHEAD": "0", "VX_FRAMES_IN_FLIGHT": "3"}, {"VX_FOREIGN_RERUN": "0"},
-                {"VX_TIMELINE": "1"}, {"VX_TIMELINE": "1", "VX_FOREIGN_RERUN": "0"}, {"VX_COMM_RESERVE_CUS": "8"}, {"VX_COST_FLOOR": "0", "VX_COST_STEP": "4"}):
+                {"VX_TIMELINE": "1"}, {"VX_TIMELINE": "1", "VX_FOREIGN_RERUN": "0"}, {"VX_COMM_RESERVE_CUS": "8"}, {"VX_COST_FLOOR": "0", "VX_COST_STEP": "4"},
+                {"VX_SORTED": "0"}, {"VX_SORT_EVERY_FRAME": "1"}, {"VX_SORT_EVERY_FRAME": "1", "VX_HOT_FIRST": "0"}, {"VX_SORTED": "0", "VX_TIMELINE": "1"}):
         for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_MIN_WAVES", "VX_HOT_LEVELS", "VX_HOT_FIRST",
                   "VX_FOREIGN_MIN", "VX_FIVE_WAVES", "VX_BATCH", "VX_TICKET_AHEAD", "VX_FRAMES_IN_FLIGHT", "VX_FOREIGN_RERUN", "VX_TIMELINE", "VX_COMM_RESERVE_CUS",
-                  "VX_COST_FLOOR", "VX_COST_STEP"):
+                  "VX_COST_FLOOR", "VX_COST_STEP", "VX_SORTED", "VX_SORT_EVERY_FRAME"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -604,7 +605,7 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
         svo.set_textures(tex, 6)
         svo.update_full(world)  # a fresh buffer each time: the world's dirty ranges were consumed by the first update
         img, hits = svo.render(u, w, h, want_hits=True)
-        for frame in range(4):  # (from the third frame of a view on, the queue hands the sub-tiles out by last frame's cost)
+        for frame in range(7):  # (from the third frame of a view on, the queue hands the sub-tiles out by last frame's cost, and the passes are last frames' sorted ones)
             img2, _ = svo.render(u, w, h)
             if img2.tobytes() != img.tobytes():
                 bad = np.argwhere((img2.view(np.uint32) != img.view(np.uint32)).any(axis=2))

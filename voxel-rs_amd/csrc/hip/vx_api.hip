@@ -157,6 +157,18 @@ struct PersistentArgs {
     const uint32_t* order;          // [total_subtiles] sub-tile ids, or null
     uint32_t* cost_cur;             // [total_subtiles] tag << 12 | iterations of the sub-tile's longest ray this frame; null = do not note
     uint32_t cost_floor;            // a wave notes its sub-tile's longest ray from this many iterations on (note_cost_wave)
+    // SORTED builds (render_persistent): the unit of the queue is a PASS -- 64 pixels of a block of four sub-tiles (16x16 pixels), put together by
+    // what the block's pixels cost two frames ago in this view on this stream (unit = 4 x block + pass). `perm_in` [unit][lane] = the pixel a
+    // lane takes (a byte: sub-tile of the block << 6 | place in the sub-tile's Morton order). A wave that has rendered a pass leaves its pixels
+    // and their costs in `pass_out` [unit][lane] (cost << 8 | pixel); the wave that takes a block's pass 0 also reads the block's four records
+    // of the LAST frame (`pass_in`) and makes the NEXT frame's passes of the block (partition_block -> `perm_out`). Between writer and reader
+    // of every table lies a kernel boundary: no wave ever waits for another, nothing is fenced. Any permutation is a correct frame; a view's
+    // first frames read tables that say "sub-tile by sub-tile".
+    const uint32_t* pass_in;
+    uint32_t* pass_out;
+    const uint8_t* perm_in;
+    uint8_t* perm_out;
+    uint32_t sort_turn;  // a block is re-sorted when (block + sort_turn) % 4 == 0 -- every fourth frame of its stream --, its passes kept otherwise (~0: always)
     uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
     uint32_t ticket_ahead;          // 0 = no; 1 + g = waves draw their next sub-tile's ticket when they start on one (its round trip runs under the traversal),
                                     // except for the frame's last g quarter-grids of tickets
@@ -220,6 +232,23 @@ __device__ __forceinline__ uint32_t subtile_of(const RenderParams& p, uint32_t o
     return local_tile * 16u + ((sx & 1u) | ((sy & 1u) << 1) | ((sx & 2u) << 1) | ((sy & 2u) << 2));
 }
 
+// the maximum of a value over the wave's 64 lanes (every lane active), as a wave-uniform value: four DPP steps inside a row of 16 lanes, the four
+// rows' results through scalar registers
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    uint32_t o;
+    o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xF, 0xF, false)); v = v > o ? v : o;   // quad_perm [1,0,3,2]
+    o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x4E, 0xF, 0xF, false)); v = v > o ? v : o;   // quad_perm [2,3,0,1]
+    o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x141, 0xF, 0xF, false)); v = v > o ? v : o;  // row_half_mirror
+    o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x140, 0xF, 0xF, false)); v = v > o ? v : o;  // row_mirror
+    const uint32_t r0 = uint32_t(__builtin_amdgcn_readlane(int(v), 0)), r1 = uint32_t(__builtin_amdgcn_readlane(int(v), 16));
+    const uint32_t r2 = uint32_t(__builtin_amdgcn_readlane(int(v), 32)), r3 = uint32_t(__builtin_amdgcn_readlane(int(v), 48));
+    const uint32_t r01 = r0 > r1 ? r0 : r1, r23 = r2 > r3 ? r2 : r3;
+    return r01 > r23 ? r01 : r23;
+}
+
+// this lane's rank among the set lanes of a wave mask
+__device__ __forceinline__ uint32_t rank_in_mask(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)); }
+
 // a ray of this pixel has just ended after `iterations` loop iterations: the sub-tile's entry keeps the maximum
 __device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderParams& p, uint32_t out_index, uint32_t iterations) {
     if (iterations < kCostFloor || !a.cost_cur) return;
@@ -231,26 +260,80 @@ __device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderP
 // rows' results through scalar registers) and ONE lane notes it -- an atomic is carried out at the memory side of the L2s, 32 bytes of HBM
 // write traffic each, and a wave's next wait for memory waits for it too: 375 K of them a C3 frame, 12 MB. Lanes of several sub-tiles (any
 // other service_min): a note per lane, as before.
-__device__ __forceinline__ void note_cost_wave(const PersistentArgs& a, const RenderParams& p, bool done, uint32_t out_index, uint32_t iterations) {
+// (UNIT: the wave's lanes are all of one unit of the queue, `unit` -- a SORTED build's block)
+template <bool UNIT = false>
+__device__ __forceinline__ void note_cost_wave(const PersistentArgs& a, const RenderParams& p, bool done, uint32_t out_index, uint32_t iterations, uint32_t unit = 0u) {
     if (!a.cost_cur) return;
     const bool noting = done && iterations >= a.cost_floor;
     const unsigned long long m = __ballot(noting);
     if (m == 0ull) return;
-    const uint32_t st = subtile_of(p, out_index);
-    const uint32_t st0 = uint32_t(__builtin_amdgcn_readlane(int(st), int(__builtin_ctzll(m))));
+    const uint32_t st = UNIT ? unit : subtile_of(p, out_index);
+    const uint32_t st0 = UNIT ? unit : uint32_t(__builtin_amdgcn_readlane(int(st), int(__builtin_ctzll(m))));
     uint32_t v = noting ? (iterations < 4095u ? iterations : 4095u) : 0u;
-    if (__ballot(noting && st != st0) == 0ull) {
-        uint32_t o;
-        o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xF, 0xF, false)); v = v > o ? v : o;   // quad_perm [1,0,3,2]
-        o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x4E, 0xF, 0xF, false)); v = v > o ? v : o;   // quad_perm [2,3,0,1]
-        o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x141, 0xF, 0xF, false)); v = v > o ? v : o;  // row_half_mirror
-        o = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x140, 0xF, 0xF, false)); v = v > o ? v : o;  // row_mirror
-        const uint32_t r0 = uint32_t(__builtin_amdgcn_readlane(int(v), 0)), r1 = uint32_t(__builtin_amdgcn_readlane(int(v), 16));
-        const uint32_t r2 = uint32_t(__builtin_amdgcn_readlane(int(v), 32)), r3 = uint32_t(__builtin_amdgcn_readlane(int(v), 48));
-        const uint32_t r01 = r0 > r1 ? r0 : r1, r23 = r2 > r3 ? r2 : r3, top = r01 > r23 ? r01 : r23;
+    if (UNIT || __ballot(noting && st != st0) == 0ull) {
+        const uint32_t top = wave_max_u32(v);
         if (threadIdx.x == 0) atomicMax(&a.cost_cur[st0], (a.cur_tag << 12) | top);
     } else if (noting && iterations >= kCostFloor) {
         atomicMax(&a.cost_cur[st], (a.cur_tag << 12) | v);
+    }
+}
+
+// SORTED builds: a block's 256 pixels into four passes of 64 by what their rays cost. v[r] = the record of the pixel lane `lane` of pass r rendered
+// (cost << 8 | pixel); out = the block's four passes in the next frame's table, 64 bytes each: the cheapest 64 pixels are pass 0 ... the most
+// expensive pass 3 -- with the lanes in lockstep a pass costs what its longest ray costs, so rays of a kind go together (the C3 frame: a
+// quarter fewer trips of the traversal loop than sub-tile by sub-tile, profiles/round3/pass_al). Three boundaries by bisection on the cost
+// (wave-wide counts are ballots), ties split by (r, lane) so that every pass gets exactly 64 pixels; a pixel's place in its pass = its rank
+// there. ~700 instructions a block, once a block and frame.
+__device__ __forceinline__ void partition_block(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint8_t* out) {
+    const uint32_t v[4] = {v0, v1, v2, v3};
+    uint32_t c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = (v[r] >> 8) < 1023u ? (v[r] >> 8) : 1023u;
+    auto count_le = [&](uint32_t t) -> uint32_t {
+        uint32_t n = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) n += uint32_t(__popcll(__ballot(c[r] <= t)));
+        return n;
+    };
+    // the smallest T in [lo, hi] with count_le(T) >= target (count_le(hi) >= target holds)
+    auto boundary = [&](uint32_t lo, uint32_t hi, uint32_t target) -> uint32_t {
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (count_le(mid) >= target) hi = mid;
+            else lo = mid + 1u;
+        }
+        return lo;
+    };
+    uint32_t T[3];
+    T[1] = boundary(0u, 1023u, 128u);
+    T[0] = boundary(0u, T[1], 64u);
+    T[2] = boundary(T[1], 1023u, 192u);
+    uint32_t g[4] = {0u, 0u, 0u, 0u};  // the pass each of this lane's four pixels goes to
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint32_t below = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) below += uint32_t(__popcll(__ballot(c[r] < T[k])));
+        const uint32_t need = 64u * uint32_t(k + 1) - below;  // of the pixels that cost exactly T[k], this many stay below the boundary
+        uint32_t seen = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool eq = c[r] == T[k];
+            const unsigned long long m = __ballot(eq);
+            g[r] += (c[r] > T[k] || (eq && seen + rank_in_mask(m) >= need)) ? 1u : 0u;
+            seen += uint32_t(__popcll(m));
+        }
+    }
+#pragma unroll
+    for (uint32_t pass = 0; pass < 4; ++pass) {
+        uint32_t seen = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool mine = g[r] == pass;
+            const unsigned long long m = __ballot(mine);
+            if (mine) out[pass * 64u + seen + rank_in_mask(m)] = uint8_t(v[r]);
+            seen += uint32_t(__popcll(m));
+        }
     }
 }
 
@@ -277,7 +360,7 @@ __device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); 
 // map, light -> the pixel, or a shadow-ray record; misses: the sky; shadow results: the lit pixel); primary rays are generated for
 // a whole sub-tile at a time. Leaf tests (they continue the traversal) and ray set-up stay with the lane. Same arithmetic per
 // pixel, same pixels.
-template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false, int LV = kLdsLevels, bool HOT = false, bool BATCH = false, bool TL = false>
+template <int SVO, bool HITS, bool STATS, int MINW = 1, int FOREIGN = 0, bool SHALLOW = false, int LV = kLdsLevels, bool HOT = false, bool BATCH = false, bool TL = false, bool SORTED = false>
 __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
     constexpr bool IMAGE = SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE;
@@ -293,6 +376,9 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     static_assert(FOREIGN != kForeignRerun || (!HITS && !STATS), "rays for the world's bytes are listed by image-only renders");
     static_assert(!SHALLOW || IMAGE, "only a traversal image bounds how deep a ray can get");
     static_assert(!BATCH || (!HITS && !STATS), "batched service phases: image-only renders");
+    // SORTED: the queue hands out passes -- 64 pixels of a block of four sub-tiles that last frame's costs put together (PersistentArgs::perm_in,
+    // partition_block) -- instead of sub-tiles; lanes are refilled only when all 64 are idle: a pass is a batch
+    static_assert(!SORTED || (IMAGE && !HITS && !STATS && !BATCH && !HOT && FOREIGN != VX_SVO_CSVO), "sorted passes: image-only renders without the excursion");
     // (the image kernels are only launched for textures whose height is a power of two -- launch_render -- and say so to the sampler, a literal the
     // compiler folds: REPEAT is a mask, nothing of the general wrap is in these kernels' code -- 1-3 % of a frame, profiles/round3/pass_af)
     // TL: the build that fills in the wave timeline (VX_TIMELINE=1; profiles/timeline.py). Everywhere else the instrumentation is compiled out, not
@@ -334,6 +420,13 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     uint32_t wave_steps = 0, services = 0, refills = 0, tail_wave_steps = 0, tail_iterations = 0;  // STATS only, wave-uniform
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
+    // SORTED: a pass is in flight (its unit: `sub`); this lane's pixel of it and what the pixel has cost so far
+    bool have_unit = false;
+    uint32_t pid = 0, cacc = 0;
+    // ... and the NEXT pass, looked up ahead (in a service phase in the middle of the pass in flight: the ticket drawn for it has long arrived,
+    // and the look-up's two dependent loads -- order table, pixel table -- run under the rest of the pass instead of in front of the next)
+    bool next_known = false;
+    uint32_t next_ticket = 0, next_sub = 0, next_pid = 0;
     bool queue_empty = false;
     const unsigned long long t_start = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long t_empty = 0ull;
@@ -373,6 +466,29 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             t = ticket_of(draw_raw(), my_queue);
         }
         return t;
+    };
+    // SORTED: the next pass -- its ticket settled, its unit and this lane's pixel of it looked up
+    auto look_ahead = [&]() {
+        const uint32_t t = settle_ticket();
+        next_ticket = t;
+        if (t < a.total_subtiles) {
+            // most expensive first, or screen order -- with a block's four passes on consecutive tickets of ONE dispenser (ticket t = 8 n + c is
+            // dispenser c's n-th): a dispenser serves the waves of one XCD, and a pass spans its whole block -- four L2s would each fetch the
+            // block's part of the world otherwise (cycles per trip of the loop 832 against 788, profiles/round3/pass_an)
+            const uint32_t in_turn = t < (a.total_subtiles & ~31u) ? (((t >> 5) * 8u + (t & 7u)) << 2) | ((t >> 3) & 3u) : t;
+            uint32_t u = a.order ? uint32_t(__builtin_amdgcn_readfirstlane(a.order[t])) : in_turn;
+            if (u >= a.total_subtiles) u = t;
+            next_sub = u;
+            next_pid = a.perm_in[size_t(u) * 64u + lane];
+            if ((u & 3u) == 0u) {  // a block's pass 0: the next frame's passes of the block
+                if (a.sort_turn == 0xffffffffu || (((u >> 2) + a.sort_turn) & 3u) == 0u) {  // ... from what the last frame's cost (its turn: 6 us of a wave's time, every fourth frame)
+                    const uint32_t* rec4 = a.pass_in + size_t(u) * 64u + lane;
+                    partition_block(rec4[0], rec4[64], rec4[128], rec4[192], a.perm_out + size_t(u) * 64u);
+                } else {  // ... as they are
+                    reinterpret_cast<uint32_t*>(a.perm_out + size_t(u) * 64u)[lane] = reinterpret_cast<const uint32_t*>(a.perm_in + size_t(u) * 64u)[lane];
+                }
+            }
+        }
     };
     if (blockIdx.x == 0 && lane < kQueues) a.next_counter[lane * kQueueStride] = 0u;
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
@@ -753,10 +869,15 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
         // ---- finished rays ----
         VX_PART_BEGIN(2);
-        note_cost_wave(a, p, state == kDone, out_index, tr.iter & ~kParked);
+        // (SORTED: the pixel looked up ahead is waited for HERE, where nothing is in flight in front of it -- a wave's wait counter is in order: behind
+        // this phase's pixel stores the same wait would be for them too, 2.5 us a pass)
+        if constexpr (SORTED) asm volatile("" : "+v"(next_pid));
+        if constexpr (SORTED) note_cost_wave<true>(a, p, state == kDone, out_index, tr.iter & ~kParked, sub);
+        else note_cost_wave(a, p, state == kDone, out_index, tr.iter & ~kParked);
         if (state == kDone) {
             float color[4];
             bool write = true;
+            if constexpr (SORTED) cacc += tr.iter & ~kParked;
             if (!shadow_ray) {
                 PrimaryOutcome o;
                 shade_primary<kOpaqueFastPath>(sc, p, res, o, color_pending);
@@ -807,7 +928,55 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         VX_PART_END(2);
         // ---- refill idle lanes from the sub-tile queue ----
         VX_PART_BEGIN(3);
-        unsigned long long idle_mask = __ballot(state == kIdle);
+        if constexpr (SORTED) {
+            const bool pass_over = !queue_empty && __ballot(state != kIdle || new_ray) == 0ull;  // every pixel of the pass is stored
+            // the next pass is looked up in the middle of this one, when its ticket has been drawn -- or now, if that has not happened (ONE copy of
+            // the look-up and of the partition it can contain in the kernel's code)
+            if (!queue_empty && !next_known && (pass_over || (have_unit && ticket_ahead))) {
+                look_ahead();
+                next_known = true;
+            }
+            if (pass_over) {
+                // the pass that has ended: its pixels and what they cost, for the next frame of this view on this stream
+                if (have_unit) a.pass_out[size_t(sub) * 64u + lane] = (cacc << 8) | pid;
+                next_known = false;
+                const uint32_t t = next_ticket;
+                if (t >= a.total_subtiles) {
+                    queue_empty = true;
+                    if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
+                } else {
+                    sub = next_sub;
+                    pid = next_pid;
+                    ++taken;
+                    if (a.ticket_ahead && t + ((a.ticket_ahead - 1u) * gridDim.x >> 2) < a.total_subtiles) {
+                        ticket_raw = draw_raw();
+                        ticket_queue = my_queue;
+                        ticket_ahead = true;
+                    }
+                    const uint32_t local_tile = sub >> 4, s = (sub & 12u) | (pid >> 6);
+                    const uint32_t tile = p.tile_count > 1 ? p.tile_order[local_tile * p.tile_count + p.tile_rank] : local_tile;
+                    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+                    const uint32_t sx = (s & 1u) | ((s >> 1) & 2u), sy = ((s >> 1) & 1u) | ((s >> 2) & 2u);
+                    uint32_t lx, ly;
+                    lane_to_xy(pid & 63u, lx, ly);
+                    const uint32_t in_x = sx * 8 + lx, in_y = sy * 8 + ly;
+                    const uint32_t px_x = tx * kTile + in_x, px_y = ty * kTile + in_y;
+                    out_index = p.tile_count > 1 ? local_tile * (kTile * kTile) + in_y * kTile + in_x : image_index(p, px_x, px_y);
+                    cacc = 0;
+                    if (px_x < p.width && px_y < p.height) {
+                        primary_ray(p, px_x, px_y, new_ro, new_rd);
+                        primary_rd[0] = new_rd[0]; primary_rd[1] = new_rd[1]; primary_rd[2] = new_rd[2];
+                        new_ray = true;
+                        shadow_ray = false;
+                    } else if (p.tile_count > 1) {
+                        const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // padding pixel of an edge tile: keep the compact tile list fully defined
+                        if (out) store_pixel(p, out, out_index, zero);
+                    }
+                }
+                have_unit = !queue_empty;
+            }
+        }
+        unsigned long long idle_mask = SORTED ? 0ull : __ballot(state == kIdle);
         if (!queue_empty && idle_mask && !walk_phase && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
             if (STATS) ++refills;
             for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
@@ -1043,6 +1212,18 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneArgs sa, TraceArgs a, vx
     *n_frames = tk.n_frames;
 }
 
+// SORTED builds' tables before a view's first frame: every pass = a sub-tile of its block in Morton order (what an unsorted build renders), nothing
+// has cost anything
+__global__ __launch_bounds__(256) void pass_identity_kernel(uint32_t* __restrict__ rec, uint8_t* __restrict__ perm0, uint8_t* __restrict__ perm1, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // [unit][lane]
+    if (i < n) {
+        const uint32_t pixel = (((i >> 6) & 3u) << 6) | (i & 63u);
+        rec[i] = pixel;
+        perm0[i] = uint8_t(pixel);
+        perm1[i] = uint8_t(pixel);
+    }
+}
+
 // Sorts a frame's sub-tiles for the next frame's queue (PersistentArgs::order): sixteen classes by the iteration count of the sub-tile's
 // longest ray (class = min(15, iterations / 16); entries without this frame's tag are class 0), the highest class first, screen
 // order within a class (a stable counting sort: the rays of neighbouring sub-tiles walk the same nodes). ONE workgroup of 1024 threads:
@@ -1243,6 +1424,17 @@ struct vx_context {
     };
     hipStream_t order_stream = nullptr;
     HotState hot[kFrameStreams + 1];  // [slot + 1]
+    // SORTED builds: per stream, the pass tables (PersistentArgs::perm_in / perm_out) of the view rendered there; they take turns
+    struct SortState {
+        uint32_t* rec[2] = {nullptr, nullptr};  // [unit][lane]: cost << 8 | pixel
+        uint8_t* perm[2] = {nullptr, nullptr};  // [unit][lane]: pixel
+        size_t units = 0;   // capacity
+        int cur = 0;        // the tables the next frame reads
+        uint32_t frames = 0;  // frames of the view issued on this stream
+        uint32_t width = 0, height = 0, tile_rank = 0, tile_count = 0;  // the view (0 = none)
+    };
+    SortState sorted_state[kFrameStreams + 1];  // [slot + 1]
+    bool sorted_passes = true;                  // VX_SORTED=0: the unsorted builds everywhere (A/B)
     bool hot_first = true;            // VX_HOT_FIRST=0: sub-tiles in plain order (A/B)
     bool hot_use = true, hot_note = true, hot_sort = true;  // VX_HOT_FIRST bits (measurement): 1 use the table, 2 note costs, 4 run the order kernel
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
@@ -1479,9 +1671,24 @@ int check_ready(vx_context* ctx) {
 // where the image's depth rules deep pushes out). The image-only build of the hot variants is held to 128 VGPRs (4 waves per SIMD).
 // levels: the LDS-resident stack levels of an image kernel -- kLdsLevels, or 16 (16-bit third plane) for images of 14 to 16 levels
 template <bool HITS, bool STATS>
-const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, int levels, bool batch, bool rerun) {
+const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, int levels, bool batch, bool rerun, bool* sorted) {
     const bool esvo = ctx->svo_type == VX_SVO_ESVO;
+    *sorted = false;
 #define VX_K(...) reinterpret_cast<const void*>(&render_persistent<__VA_ARGS__>)
+    // The SORTED builds (blocks of four sub-tiles in four passes chosen by last frame's costs): image-only renders with the lanes in lockstep,
+    // on 13- and 16-level stacks, of worlds whose image needs no excursion (ESVO; CSVO of at most 12 levels, which list such rays)
+    if constexpr (!HITS && !STATS) {
+        if (ctx->sorted_passes && ctx->service_min >= 64 && imaged && shallow && !batch && (levels == kLdsLevels || levels == 16) && !ctx->hot_levels &&
+            (esvo || ctx->no_excursion || (rerun && levels == kLdsLevels))) {
+            const bool wide = ctx->pub.layout == vximg::kOct64Wide;
+            const bool tl = ctx->d_timeline != nullptr;
+            *sorted = true;
+#define VX_SK(IMAGE, FOREIGN, LV) (tl ? VX_K(IMAGE, false, false, 4, FOREIGN, true, LV, false, false, true, true) : VX_K(IMAGE, false, false, 4, FOREIGN, true, LV, false, false, false, true))
+            if (esvo || ctx->no_excursion) return levels == 16 ? (wide ? VX_SK(VX_SVO_IMAGE_WIDE, 0, 16) : VX_SK(VX_SVO_IMAGE, 0, 16)) : (wide ? VX_SK(VX_SVO_IMAGE_WIDE, 0, kLdsLevels) : VX_SK(VX_SVO_IMAGE, 0, kLdsLevels));
+            return wide ? VX_SK(VX_SVO_IMAGE_WIDE, kForeignRerun, kLdsLevels) : VX_SK(VX_SVO_IMAGE, kForeignRerun, kLdsLevels);
+#undef VX_SK
+        }
+    }
     // VX_TIMELINE=1: the instrumented builds of the image-only kernels on 13- and 16-level stacks (what profiles/timeline.py renders with); any
     // other kernel leaves the timeline's rows untouched
     if constexpr (!HITS && !STATS) {
@@ -1581,7 +1788,8 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // the bytes (profiles/round2/foreign_rerun/).
         const bool rerun = imaged && ctx->svo_type == VX_SVO_CSVO && !HITS && !STATS && !batch && shallow && levels == kLdsLevels && !ctx->no_excursion &&
                            (ctx->foreign_rerun == 1 || (ctx->foreign_rerun < 0 && depth <= 12u));
-        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels, batch, rerun);
+        bool sorted = false;
+        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels, batch, rerun, &sorted);
         size_t wave_lds = levels == 16 ? Stack<64, false, false, 16, true>::kBytes : (levels == 12 ? Stack<64, false, false, 12, true>::kBytes : Stack<64>::kBytes);
         if (fn == reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true>))
             wave_lds = Stack<64, false, false, kLdsLevels, true, true>::kBytes;
@@ -1595,7 +1803,46 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // (`tickets` counts this stream's launches: its sets of dispensers take turns)
         a.work_counter = work_counter + size_t(tickets & 1u) * (kQueues * kQueueStride);
         a.next_counter = work_counter + size_t((tickets & 1u) ^ 1u) * (kQueues * kQueueStride);
-        a.total_subtiles = p.n_local_tiles * 16;
+        a.total_subtiles = p.n_local_tiles * 16;  // (the queue's units: sub-tiles, or a SORTED build's passes)
+        a.pass_in = nullptr;
+        a.pass_out = nullptr;
+        a.perm_in = nullptr;
+        a.perm_out = nullptr;
+        a.sort_turn = 0;
+        if (sorted) {
+            vx_context::SortState& ss = ctx->sorted_state[slot + 1];
+            const size_t units = a.total_subtiles;
+            const bool same = ss.width == p.width && ss.height == p.height && ss.tile_rank == p.tile_rank && ss.tile_count == p.tile_count && ss.units >= units;
+            if (ss.units < units) {  // (grow: earlier frames of this stream use the old tables)
+                HIP_TRY(hipStreamSynchronize(stream));
+                void* old_tables[] = {ss.rec[0], ss.rec[1], ss.perm[0], ss.perm[1]};
+                for (void* q : old_tables)
+                    if (q) (void)hipFree(q);
+                ss.rec[0] = ss.rec[1] = nullptr;
+                ss.perm[0] = ss.perm[1] = nullptr;
+                ss.units = 0;
+                const size_t cap = units + units / 4 + 64;
+                for (int g = 0; g < 2; ++g) {
+                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ss.rec[g]), cap * 64 * sizeof(uint32_t)));
+                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ss.perm[g]), cap * 64));
+                }
+                ss.units = cap;
+            }
+            if (!same) {  // a view's first frame on this stream: sub-tile by sub-tile
+                const uint32_t n = uint32_t(units * 64);
+                hipLaunchKernelGGL(pass_identity_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, ss.rec[ss.cur], ss.perm[0], ss.perm[1], n);
+                HIP_TRY(hipGetLastError());
+                ss.width = p.width; ss.height = p.height; ss.tile_rank = p.tile_rank; ss.tile_count = p.tile_count;
+            }
+            a.pass_in = ss.rec[ss.cur];
+            a.pass_out = ss.rec[ss.cur ^ 1];
+            a.perm_in = ss.perm[ss.cur];
+            a.perm_out = ss.perm[ss.cur ^ 1];
+            if (!same) ss.frames = 0;
+            a.sort_turn = std::getenv("VX_SORT_EVERY_FRAME") ? 0xffffffffu : (ss.frames & 0xffffu);  // (the variable: every block every frame, a measurement)
+            ss.frames += 1;
+            ss.cur ^= 1;
+        }
         a.refill_min = ctx->refill_min;
         a.service_min = ctx->service_min;
         a.foreign_min = ctx->foreign_min;
@@ -1981,6 +2228,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FIVE_WAVES")) c->five_waves = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_SORTED")) c->sorted_passes = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_COST_FLOOR")) c->cost_floor = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_COST_STEP")) c->cost_step = std::atoi(e) > 0 ? uint32_t(std::atoi(e)) : kCostStep;
         if (const char* e = std::getenv("VX_DEEP_WAVES")) c->deep_waves = std::atoi(e) == 3 ? 3 : 4;
@@ -2051,6 +2299,11 @@ void vx_destroy(vx_context* c) {
             if (hs.order[g]) (void)hipFree(hs.order[g]);
             if (hs.order_done[g]) (void)hipEventDestroy(hs.order_done[g]);
         }
+    }
+    for (auto& ss : c->sorted_state) {
+        void* tables[] = {ss.rec[0], ss.rec[1], ss.perm[0], ss.perm[1]};
+        for (void* q : tables)
+            if (q) (void)hipFree(q);
     }
     for (auto& e : c->gather_done)
         if (e) (void)hipEventDestroy(e);
