@@ -1431,10 +1431,18 @@ struct vx_context {
         size_t units = 0;   // capacity
         int cur = 0;        // the tables the next frame reads
         uint32_t frames = 0;  // frames of the view issued on this stream
+        // The uniforms of the last image-only frame on this stream: passes are sorted by what pixels cost in EARLIER frames, which says something
+        // about this frame only if the view has not moved -- under a camera that turns by a tenth of a degree a frame the stale passes are 8 %
+        // slower than plain sub-tiles (a random 64 of a block's 256 pixels hold one of its long rays almost surely; 8 x 8 neighbours often do
+        // not: profiles/round3/pass_aq). So a frame is rendered by a SORTED build only if its uniforms are the last frame's, bit for bit.
+        vx_uniforms last_u = {};
+        bool last_u_valid = false;
+        bool live = false;    // the last frame here was a SORTED build's: its records and passes are there
         uint32_t width = 0, height = 0, tile_rank = 0, tile_count = 0;  // the view (0 = none)
     };
     SortState sorted_state[kFrameStreams + 1];  // [slot + 1]
     bool sorted_passes = true;                  // VX_SORTED=0: the unsorted builds everywhere (A/B)
+    bool sorted_always = false;                 // VX_SORTED=2: sorted passes also for views that move (measurement)
     bool hot_first = true;            // VX_HOT_FIRST=0: sub-tiles in plain order (A/B)
     bool hot_use = true, hot_note = true, hot_sort = true;  // VX_HOT_FIRST bits (measurement): 1 use the table, 2 note costs, 4 run the order kernel
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
@@ -1671,14 +1679,14 @@ int check_ready(vx_context* ctx) {
 // where the image's depth rules deep pushes out). The image-only build of the hot variants is held to 128 VGPRs (4 waves per SIMD).
 // levels: the LDS-resident stack levels of an image kernel -- kLdsLevels, or 16 (16-bit third plane) for images of 14 to 16 levels
 template <bool HITS, bool STATS>
-const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, int levels, bool batch, bool rerun, bool* sorted) {
+const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, int levels, bool batch, bool rerun, bool still, bool* sorted) {
     const bool esvo = ctx->svo_type == VX_SVO_ESVO;
     *sorted = false;
 #define VX_K(...) reinterpret_cast<const void*>(&render_persistent<__VA_ARGS__>)
     // The SORTED builds (blocks of four sub-tiles in four passes chosen by last frame's costs): image-only renders with the lanes in lockstep,
     // on 13- and 16-level stacks, of worlds whose image needs no excursion (ESVO; CSVO of at most 12 levels, which list such rays)
     if constexpr (!HITS && !STATS) {
-        if (ctx->sorted_passes && ctx->service_min >= 64 && imaged && shallow && !batch && (levels == kLdsLevels || levels == 16) && !ctx->hot_levels &&
+        if (ctx->sorted_passes && still && ctx->service_min >= 64 && imaged && shallow && !batch && (levels == kLdsLevels || levels == 16) && !ctx->hot_levels &&
             (esvo || ctx->no_excursion || (rerun && levels == kLdsLevels))) {
             const bool wide = ctx->pub.layout == vximg::kOct64Wide;
             const bool tl = ctx->d_timeline != nullptr;
@@ -1788,8 +1796,16 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // the bytes (profiles/round2/foreign_rerun/).
         const bool rerun = imaged && ctx->svo_type == VX_SVO_CSVO && !HITS && !STATS && !batch && shallow && levels == kLdsLevels && !ctx->no_excursion &&
                            (ctx->foreign_rerun == 1 || (ctx->foreign_rerun < 0 && depth <= 12u));
+        // (a view that has not moved since the last image-only frame on this stream -- or VX_SORTED=2: always -- may be rendered in sorted passes)
+        vx_context::SortState& ss_view = ctx->sorted_state[slot + 1];
+        const bool still = !HITS && !STATS && (ctx->sorted_always || (ss_view.last_u_valid && std::memcmp(&ss_view.last_u, &p.u, sizeof(vx_uniforms)) == 0));
+        if (!HITS && !STATS) {
+            ss_view.last_u = p.u;
+            ss_view.last_u_valid = true;
+        }
         bool sorted = false;
-        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels, batch, rerun, &sorted);
+        const void* fn = persistent_kernel<HITS, STATS>(ctx, imaged, shallow, levels, batch, rerun, still, &sorted);
+        if (!sorted && !HITS && !STATS) ss_view.live = false;
         size_t wave_lds = levels == 16 ? Stack<64, false, false, 16, true>::kBytes : (levels == 12 ? Stack<64, false, false, 12, true>::kBytes : Stack<64>::kBytes);
         if (fn == reinterpret_cast<const void*>(&render_persistent<VX_SVO_IMAGE, false, false, 4, 0, true, kLdsLevels, true>))
             wave_lds = Stack<64, false, false, kLdsLevels, true, true>::kBytes;
@@ -1812,7 +1828,8 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         if (sorted) {
             vx_context::SortState& ss = ctx->sorted_state[slot + 1];
             const size_t units = a.total_subtiles;
-            const bool same = ss.width == p.width && ss.height == p.height && ss.tile_rank == p.tile_rank && ss.tile_count == p.tile_count && ss.units >= units;
+            const bool same = ss.live && ss.width == p.width && ss.height == p.height && ss.tile_rank == p.tile_rank && ss.tile_count == p.tile_count && ss.units >= units;
+            ss.live = true;
             if (ss.units < units) {  // (grow: earlier frames of this stream use the old tables)
                 HIP_TRY(hipStreamSynchronize(stream));
                 void* old_tables[] = {ss.rec[0], ss.rec[1], ss.perm[0], ss.perm[1]};
@@ -2228,7 +2245,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FIVE_WAVES")) c->five_waves = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VX_SORTED")) c->sorted_passes = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_SORTED")) { c->sorted_passes = std::atoi(e) != 0; c->sorted_always = std::atoi(e) == 2; }
         if (const char* e = std::getenv("VX_COST_FLOOR")) c->cost_floor = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_COST_STEP")) c->cost_step = std::atoi(e) > 0 ? uint32_t(std::atoi(e)) : kCostStep;
         if (const char* e = std::getenv("VX_DEEP_WAVES")) c->deep_waves = std::atoi(e) == 3 ? 3 : 4;
