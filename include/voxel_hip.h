@@ -231,7 +231,10 @@ int vx_get_stats(const vx_context* ctx, vx_stats* out);
 
 /* Svo::render (svo.rs:196-229) = world.glsl main for every pixel: primary ray, shading, <=1 shadow ray, sky.
  * Device targets are written asynchronously on the context's stream (vx_sync = the render fence); host
- * targets return when the image is in place. */
+ * targets return when the image is in place.
+ * Scheduling only, never a pixel's value: image-only renders use what earlier frames of the same view on the same stream cost -- the
+ * order in which work is handed out, and (a view whose uniforms are bit for bit the last frame's) which pixels a wave's lanes take
+ * together -- so a view that stands still renders faster from its third frame on; a moving view is not affected. */
 int vx_render(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, const vx_target* target);
 /* Svo::raycast (svo.rs:233-255) = picker.glsl over `count` tasks (no 100-task cap); synchronous like the
  * reference's fence wait (:248-249). Host pointers. */
