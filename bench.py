@@ -501,6 +501,10 @@ def main():
                 # the same with the timed region's own launch policy (frame streams, screen order), every frame waited for
                 "kernel_exclusive_ms_timed_policy": round(kernel_exclusive_frame_stream_ms, 4),
                 "timed_region_mode": f"{FRAMES} frames in flight (ms_per_step); kernel_span_ms_in_flight is a launch's own event span there",
+                # the timed frames are one view, rendered again and again: what the library keeps between frames of such a view
+                "temporal_reuse": ("scheduling only, identical pixels: a still view's frames are rendered in sorted passes (64 pixels of a 16x16 block put "
+                                   "together by what they cost in earlier frames; VX_SORTED=0: 8 % slower), the one-frame-at-a-time pass also hands work "
+                                   "out most expensive first; under a moving camera neither applies: profiles/round3/pass_aq"),
                 # what the device sustains over the median timed block: bytes x frames / elapsed
                 "sustained_GBps": round(my_bytes * args.steps / max(elapsed, 1e-9) / 1e9, 3)}
     # The HBM byte model is what the contract asks for, but this kernel's working set is cache resident and it is bound by instruction
