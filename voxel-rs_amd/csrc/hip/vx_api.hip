@@ -1798,7 +1798,10 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
                            (ctx->foreign_rerun == 1 || (ctx->foreign_rerun < 0 && depth <= 12u));
         // (a view that has not moved since the last image-only frame on this stream -- or VX_SORTED=2: always -- may be rendered in sorted passes)
         vx_context::SortState& ss_view = ctx->sorted_state[slot + 1];
-        const bool still = !HITS && !STATS && (ctx->sorted_always || (ss_view.last_u_valid && std::memcmp(&ss_view.last_u, &p.u, sizeof(vx_uniforms)) == 0));
+        // (... and only if it casts shadow rays: primary rays alone are too much of a length for sorting to pay -- 7 % fewer trips against 18 %,
+        // less than the tables cost: C2 0.178 against 0.172 ms)
+        const bool still = !HITS && !STATS && p.u.render_shadows != 0 &&
+                           (ctx->sorted_always || (ss_view.last_u_valid && std::memcmp(&ss_view.last_u, &p.u, sizeof(vx_uniforms)) == 0));
         if (!HITS && !STATS) {
             ss_view.last_u = p.u;
             ss_view.last_u_valid = true;
