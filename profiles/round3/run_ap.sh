@@ -8,4 +8,4 @@ run() { VX_TIMELINE=1 VX_TIMELINE_PART=$2 timeout 200 python3 profiles/timeline.
 run "sorted, every 4th" 3 | tee $O/sorted4.txt
 run "sorted, every 4th" 0 | tee -a $O/sorted4.txt
 VX_SORT_EVERY_FRAME=1 run "sorted, every frame" 3 | tee -a $O/sorted4.txt
-for fif in 2 4; do for so in 1 0; do for f in csvo esvo; do VX_SORTED=$so timeout 300 python3 bench.py --format $f --no-cpu-baseline --no-sd500 --repeats 9 --frames-in-flight $fif 2>/dev/null | tail -n 1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('fif $fif sorted $so $f', d['value'], d['ms_per_step'], d['roofline']['kernel_exclusive_ms'], d['roofline']['kernel_exclusive_ms_timed_policy'])"; done; done; done | tee -a $O/sorted4.txt
+for fif in 2; do for so in 1 0; do for f in csvo esvo; do VX_SORTED=$so timeout 300 python3 bench.py --format $f --no-cpu-baseline --no-sd500 --repeats 9 --frames-in-flight $fif 2>/dev/null | tail -n 1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('fif $fif sorted $so $f', d['value'], d['ms_per_step'], d['roofline']['kernel_exclusive_ms'], d['roofline']['kernel_exclusive_ms_timed_policy'])"; done; done; done | tee -a $O/sorted4.txt

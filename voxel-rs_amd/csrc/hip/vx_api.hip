@@ -423,10 +423,6 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     // SORTED: a pass is in flight (its unit: `sub`); this lane's pixel of it and what the pixel has cost so far
     bool have_unit = false;
     uint32_t pid = 0, cacc = 0;
-    // ... and the NEXT pass, looked up ahead (in a service phase in the middle of the pass in flight: the ticket drawn for it has long arrived,
-    // and the look-up's two dependent loads -- order table, pixel table -- run under the rest of the pass instead of in front of the next)
-    bool next_known = false;
-    uint32_t next_ticket = 0, next_sub = 0, next_pid = 0;
     bool queue_empty = false;
     const unsigned long long t_start = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long t_empty = 0ull;
@@ -467,28 +463,13 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         }
         return t;
     };
-    // SORTED: the next pass -- its ticket settled, its unit and this lane's pixel of it looked up
-    auto look_ahead = [&]() {
-        const uint32_t t = settle_ticket();
-        next_ticket = t;
-        if (t < a.total_subtiles) {
-            // most expensive first, or screen order -- with a block's four passes on consecutive tickets of ONE dispenser (ticket t = 8 n + c is
-            // dispenser c's n-th): a dispenser serves the waves of one XCD, and a pass spans its whole block -- four L2s would each fetch the
-            // block's part of the world otherwise (cycles per trip of the loop 832 against 788, profiles/round3/pass_an)
-            const uint32_t in_turn = t < (a.total_subtiles & ~31u) ? (((t >> 5) * 8u + (t & 7u)) << 2) | ((t >> 3) & 3u) : t;
-            uint32_t u = a.order ? uint32_t(__builtin_amdgcn_readfirstlane(a.order[t])) : in_turn;
-            if (u >= a.total_subtiles) u = t;
-            next_sub = u;
-            next_pid = a.perm_in[size_t(u) * 64u + lane];
-            if ((u & 3u) == 0u) {  // a block's pass 0: the next frame's passes of the block
-                if (a.sort_turn == 0xffffffffu || (((u >> 2) + a.sort_turn) & 3u) == 0u) {  // ... from what the last frame's cost (its turn: 6 us of a wave's time, every fourth frame)
-                    const uint32_t* rec4 = a.pass_in + size_t(u) * 64u + lane;
-                    partition_block(rec4[0], rec4[64], rec4[128], rec4[192], a.perm_out + size_t(u) * 64u);
-                } else {  // ... as they are
-                    reinterpret_cast<uint32_t*>(a.perm_out + size_t(u) * 64u)[lane] = reinterpret_cast<const uint32_t*>(a.perm_in + size_t(u) * 64u)[lane];
-                }
-            }
-        }
+    // SORTED: the unit of a ticket -- most expensive first, or screen order with a block's four passes on consecutive tickets of ONE dispenser
+    // (ticket t = 8 n + c is dispenser c's n-th): a dispenser serves the waves of one XCD, and a pass spans its whole block -- four L2s would
+    // each fetch the block's part of the world otherwise (cycles per trip of the loop 832 against 788, profiles/round3/pass_an)
+    auto unit_of = [&](uint32_t t) -> uint32_t {
+        const uint32_t in_turn = t < (a.total_subtiles & ~31u) ? (((t >> 5) * 8u + (t & 7u)) << 2) | ((t >> 3) & 3u) : t;
+        const uint32_t u = a.order ? uint32_t(__builtin_amdgcn_readfirstlane(a.order[t])) : in_turn;
+        return u < a.total_subtiles ? u : t;
     };
     if (blockIdx.x == 0 && lane < kQueues) a.next_counter[lane * kQueueStride] = 0u;
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
@@ -869,9 +850,6 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
         // ---- finished rays ----
         VX_PART_BEGIN(2);
-        // (SORTED: the pixel looked up ahead is waited for HERE, where nothing is in flight in front of it -- a wave's wait counter is in order: behind
-        // this phase's pixel stores the same wait would be for them too, 2.5 us a pass)
-        if constexpr (SORTED) asm volatile("" : "+v"(next_pid));
         if constexpr (SORTED) note_cost_wave<true>(a, p, state == kDone, out_index, tr.iter & ~kParked, sub);
         else note_cost_wave(a, p, state == kDone, out_index, tr.iter & ~kParked);
         if (state == kDone) {
@@ -929,29 +907,29 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         // ---- refill idle lanes from the sub-tile queue ----
         VX_PART_BEGIN(3);
         if constexpr (SORTED) {
-            const bool pass_over = !queue_empty && __ballot(state != kIdle || new_ray) == 0ull;  // every pixel of the pass is stored
-            // the next pass is looked up in the middle of this one, when its ticket has been drawn -- or now, if that has not happened (ONE copy of
-            // the look-up and of the partition it can contain in the kernel's code)
-            if (!queue_empty && !next_known && (pass_over || (have_unit && ticket_ahead))) {
-                look_ahead();
-                next_known = true;
-            }
-            if (pass_over) {
+            if (!queue_empty && __ballot(state != kIdle || new_ray) == 0ull) {  // every pixel of the pass is stored
                 // the pass that has ended: its pixels and what they cost, for the next frame of this view on this stream
                 if (have_unit) a.pass_out[size_t(sub) * 64u + lane] = (cacc << 8) | pid;
-                next_known = false;
-                const uint32_t t = next_ticket;
+                const uint32_t t = settle_ticket();
                 if (t >= a.total_subtiles) {
                     queue_empty = true;
                     if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
                 } else {
-                    sub = next_sub;
-                    pid = next_pid;
+                    sub = unit_of(t);
+                    pid = a.perm_in[size_t(sub) * 64u + lane];
                     ++taken;
                     if (a.ticket_ahead && t + ((a.ticket_ahead - 1u) * gridDim.x >> 2) < a.total_subtiles) {
                         ticket_raw = draw_raw();
                         ticket_queue = my_queue;
                         ticket_ahead = true;
+                    }
+                    if ((sub & 3u) == 0u) {  // a block's pass 0: the next frame's passes of the block
+                        if (a.sort_turn == 0xffffffffu || (((sub >> 2) + a.sort_turn) & 3u) == 0u) {  // ... from what the last frame's cost (its turn: 6 us of a wave's time, every fourth frame)
+                            const uint32_t* rec4 = a.pass_in + size_t(sub) * 64u + lane;
+                            partition_block(rec4[0], rec4[64], rec4[128], rec4[192], a.perm_out + size_t(sub) * 64u);
+                        } else {  // ... as they are
+                            reinterpret_cast<uint32_t*>(a.perm_out + size_t(sub) * 64u)[lane] = reinterpret_cast<const uint32_t*>(a.perm_in + size_t(sub) * 64u)[lane];
+                        }
                     }
                     const uint32_t local_tile = sub >> 4, s = (sub & 12u) | (pid >> 6);
                     const uint32_t tile = p.tile_count > 1 ? p.tile_order[local_tile * p.tile_count + p.tile_rank] : local_tile;
