@@ -420,9 +420,9 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
     uint32_t wave_steps = 0, services = 0, refills = 0, tail_wave_steps = 0, tail_iterations = 0;  // STATS only, wave-uniform
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
-    // SORTED: a pass is in flight (its unit: `sub`); this lane's pixel of it and what the pixel has cost so far
+    // SORTED: a pass is in flight (its unit: `sub`); this lane's record of it: what its pixel has cost so far << 8 | the pixel
     bool have_unit = false;
-    uint32_t pid = 0, cacc = 0;
+    uint32_t rec_now = 0;
     bool queue_empty = false;
     const unsigned long long t_start = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long t_empty = 0ull;
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if (state == kDone) {
             float color[4];
             bool write = true;
-            if constexpr (SORTED) cacc += tr.iter & ~kParked;
+            if constexpr (SORTED) rec_now += (tr.iter & ~kParked) << 8;
             if (!shadow_ray) {
                 PrimaryOutcome o;
                 shade_primary<kOpaqueFastPath>(sc, p, res, o, color_pending);
@@ -909,14 +909,15 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if constexpr (SORTED) {
             if (!queue_empty && __ballot(state != kIdle || new_ray) == 0ull) {  // every pixel of the pass is stored
                 // the pass that has ended: its pixels and what they cost, for the next frame of this view on this stream
-                if (have_unit) a.pass_out[size_t(sub) * 64u + lane] = (cacc << 8) | pid;
+                if (have_unit) a.pass_out[size_t(sub) * 64u + lane] = rec_now;
                 const uint32_t t = settle_ticket();
                 if (t >= a.total_subtiles) {
                     queue_empty = true;
                     if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
                 } else {
                     sub = unit_of(t);
-                    pid = a.perm_in[size_t(sub) * 64u + lane];
+                    const uint32_t pid = a.perm_in[size_t(sub) * 64u + lane];
+                    rec_now = pid;
                     ++taken;
                     if (a.ticket_ahead && t + ((a.ticket_ahead - 1u) * gridDim.x >> 2) < a.total_subtiles) {
                         ticket_raw = draw_raw();
@@ -940,7 +941,6 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     const uint32_t in_x = sx * 8 + lx, in_y = sy * 8 + ly;
                     const uint32_t px_x = tx * kTile + in_x, px_y = ty * kTile + in_y;
                     out_index = p.tile_count > 1 ? local_tile * (kTile * kTile) + in_y * kTile + in_x : image_index(p, px_x, px_y);
-                    cacc = 0;
                     if (px_x < p.width && px_y < p.height) {
                         primary_ray(p, px_x, px_y, new_ro, new_rd);
                         primary_rd[0] = new_rd[0]; primary_rd[1] = new_rd[1]; primary_rd[2] = new_rd[2];
