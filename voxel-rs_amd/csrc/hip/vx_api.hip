@@ -260,7 +260,7 @@ __device__ __forceinline__ void note_cost(const PersistentArgs& a, const RenderP
 // rows' results through scalar registers) and ONE lane notes it -- an atomic is carried out at the memory side of the L2s, 32 bytes of HBM
 // write traffic each, and a wave's next wait for memory waits for it too: 375 K of them a C3 frame, 12 MB. Lanes of several sub-tiles (any
 // other service_min): a note per lane, as before.
-// (UNIT: the wave's lanes are all of one unit of the queue, `unit` -- a SORTED build's block)
+// (UNIT: the wave's lanes are all of one unit of the queue, `unit` -- a SORTED build's pass)
 template <bool UNIT = false>
 __device__ __forceinline__ void note_cost_wave(const PersistentArgs& a, const RenderParams& p, bool done, uint32_t out_index, uint32_t iterations, uint32_t unit = 0u) {
     if (!a.cost_cur) return;
@@ -1402,7 +1402,8 @@ struct vx_context {
     };
     hipStream_t order_stream = nullptr;
     HotState hot[kFrameStreams + 1];  // [slot + 1]
-    // SORTED builds: per stream, the pass tables (PersistentArgs::perm_in / perm_out) of the view rendered there; they take turns
+    // SORTED builds: per stream, the records and pass tables (PersistentArgs::pass_in / pass_out, perm_in / perm_out) of the view rendered there; each
+    // pair takes turns
     struct SortState {
         uint32_t* rec[2] = {nullptr, nullptr};  // [unit][lane]: cost << 8 | pixel
         uint8_t* perm[2] = {nullptr, nullptr};  // [unit][lane]: pixel
@@ -1661,7 +1662,8 @@ const void* persistent_kernel(const vx_context* ctx, bool imaged, bool shallow, 
     const bool esvo = ctx->svo_type == VX_SVO_ESVO;
     *sorted = false;
 #define VX_K(...) reinterpret_cast<const void*>(&render_persistent<__VA_ARGS__>)
-    // The SORTED builds (blocks of four sub-tiles in four passes chosen by last frame's costs): image-only renders with the lanes in lockstep,
+    // The SORTED builds (the queue's units are passes: 64 pixels of a block of four sub-tiles, chosen by earlier frames' costs): image-only renders of a
+    // view that stands still (`still`), with the lanes in lockstep,
     // on 13- and 16-level stacks, of worlds whose image needs no excursion (ESVO; CSVO of at most 12 levels, which list such rays)
     if constexpr (!HITS && !STATS) {
         if (ctx->sorted_passes && still && ctx->service_min >= 64 && imaged && shallow && !batch && (levels == kLdsLevels || levels == 16) && !ctx->hot_levels &&
