@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--format", default="esvo")
     ap.add_argument("--degrees", type=float, default=0.25)
     ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--start", type=float, default=0.0, help="the view's yaw at frame 0, degrees")
+    ap.add_argument("--pitch", type=float, default=-0.35, help="the view direction's y component")
     args = ap.parse_args()
     import torch
 
@@ -36,8 +38,8 @@ def main():
     images = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
 
     def uniforms(i):
-        a = math.radians(args.degrees * i)
-        fwd = (0.6 * math.cos(a) - 0.7 * math.sin(a), -0.35, 0.6 * math.sin(a) + 0.7 * math.cos(a))
+        a = math.radians(args.start + args.degrees * i)
+        fwd = (0.6 * math.cos(a) - 0.7 * math.sin(a), args.pitch, 0.6 * math.sin(a) + 0.7 * math.cos(a))
         eye = (0.5 * n + 0.02 * i * (args.degrees != 0), st["h_max"] + 0.05 * n, 0.5 * n)
         return scenes.render_params_to_uniforms(eye, fwd, (0.0, 1.0, 0.0), math.radians(72.0), W / H, 0.3, (-1.0, -1.0, -1.0), True, 3.0e38)
 
@@ -50,7 +52,7 @@ def main():
         svo.render_device(us[i], W, H, images[i % 2].data_ptr())
     svo.sync()
     ms = (time.perf_counter() - t0) * 1e3 / args.frames
-    print(json.dumps({"format": args.format, "degrees_per_frame": args.degrees, "frames": args.frames, "ms_per_frame": round(ms, 4)}))
+    print(json.dumps({"format": args.format, "degrees_per_frame": args.degrees, "start": args.start, "pitch": args.pitch, "frames": args.frames, "ms_per_frame": round(ms, 4)}))
 
 
 if __name__ == "__main__":

@@ -850,8 +850,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
         // ---- finished rays ----
         VX_PART_BEGIN(2);
-        if constexpr (SORTED) note_cost_wave<true>(a, p, state == kDone, out_index, tr.iter & ~kParked, sub);
-        else note_cost_wave(a, p, state == kDone, out_index, tr.iter & ~kParked);
+        if constexpr (!SORTED) note_cost_wave(a, p, state == kDone, out_index, tr.iter & ~kParked);  // (a SORTED build notes a pass when it has ended)
         if (state == kDone) {
             float color[4];
             bool write = true;
@@ -909,7 +908,15 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         if constexpr (SORTED) {
             if (!queue_empty && __ballot(state != kIdle || new_ray) == 0ull) {  // every pixel of the pass is stored
                 // the pass that has ended: its pixels and what they cost, for the next frame of this view on this stream
-                if (have_unit) a.pass_out[size_t(sub) * 64u + lane] = rec_now;
+                if (have_unit) {
+                    a.pass_out[size_t(sub) * 64u + lane] = rec_now;
+                    // ... and what the pass cost -- its dearest pixel, primary and shadow ray together: half of it is what the order table's
+                    // classes are of -- for "expensive passes first" (this wave is the pass's only writer: a plain store)
+                    if (a.cost_cur) {
+                        const uint32_t top = wave_max_u32(rec_now >> 8) >> 1;
+                        if (lane == 0) a.cost_cur[sub] = (a.cur_tag << 12) | (top < 4095u ? top : 4095u);
+                    }
+                }
                 const uint32_t t = settle_ticket();
                 if (t >= a.total_subtiles) {
                     queue_empty = true;
