@@ -624,6 +624,44 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
         assert np.nanmax(np.abs(r[0] - results[0][0])) <= COLOR_TOL
 
 
+@pytest.mark.parametrize("fmt", FMTS)
+def test_sorted_passes_across_view_changes(hip, fmt):
+    """A still view is rendered in sorted passes (64 pixels of a 16x16 block put together by earlier frames' costs), a view that has just changed is
+    not, and a view that comes back starts over: whatever the tables hold, every frame is the frame -- device-resident targets on the frame
+    streams (two in flight) and host targets on the context's own stream, two views and two sizes in turn."""
+    import torch
+    from voxel_rs_amd import scenes
+
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(8, threads=4)
+    svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(scenes.synthetic_materials())
+    svo.set_textures(scenes.synthetic_textures(), 6)
+    svo.update(world)
+    sizes = ((250, 130), (192, 160))
+    views = {}
+    for w, h in sizes:
+        ua = scenes.bench_camera(8, st["h_max"], w, h)
+        ub = scenes.render_params_to_uniforms((100.0, st["h_max"] + 20.0, 90.0), (-0.5, -0.4, 0.6), (0.0, 1.0, 0.0), 1.2, w / h, 0.3, (-1.0, -1.0, -1.0), True, 500.0)
+        for name, u in (("a", ua), ("b", ub)):
+            views[(name, w, h)] = (u, svo.render(u, w, h, want_hits=True)[0])
+    svo.set_frames_in_flight(2)
+    targets = {(w, h): [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)] for w, h in sizes}
+    sequence = [("a", 0)] * 7 + [("b", 0)] * 2 + [("a", 0)] * 6 + [("a", 1)] * 5 + [("b", 1)] * 6 + [("a", 0)] * 5
+    for i, (name, size) in enumerate(sequence):
+        w, h = sizes[size]
+        u, ref = views[(name, w, h)]
+        t = targets[(w, h)][i % 2]
+        svo.render_device(u, w, h, t.data_ptr())
+        if i % 3 == 2 or i == len(sequence) - 1:  # (frames stay in flight most of the time)
+            svo.sync()
+            assert t.cpu().numpy().tobytes() == ref.tobytes(), (i, name, size)
+        img, _ = svo.render(u, w, h)  # the context's own stream has tables of its own
+        assert img.tobytes() == ref.tobytes(), (i, name, size, "host target")
+    svo.sync()
+    svo.close()
+
+
 # ---- output formats, presentation ring, lifetime, fall-back, the library's own gather ---------------------------------------------
 
 
