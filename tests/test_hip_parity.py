@@ -593,10 +593,10 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
                 {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_WIDE_IMAGE": "1", "VX_MIN_WAVES": "1"},
                 {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_MIN": "1"}, {"VX_FIVE_WAVES": "1"}, {"VX_BATCH": "1"}, {"VX_TICKET_AHEAD": "1"}, {"VX_TICKET_AHEAD": "0", "VX_FRAMES_IN_FLIGHT": "3"}, {"VX_FOREIGN_RERUN": "0"},
                 {"VX_TIMELINE": "1"}, {"VX_TIMELINE": "1", "VX_FOREIGN_RERUN": "0"}, {"VX_COMM_RESERVE_CUS": "8"}, {"VX_COST_FLOOR": "0", "VX_COST_STEP": "4"},
-                {"VX_SORTED": "0"}, {"VX_SORT_EVERY_FRAME": "1"}, {"VX_SORT_EVERY_FRAME": "1", "VX_HOT_FIRST": "0"}, {"VX_SORTED": "0", "VX_TIMELINE": "1"}):
+                {"VX_SORTED": "0"}, {"VX_SORT_PERIOD": "1"}, {"VX_SORT_PERIOD": "2", "VX_HOT_FIRST": "0"}, {"VX_SORTED": "0", "VX_TIMELINE": "1"}):
         for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_MIN_WAVES", "VX_HOT_LEVELS", "VX_HOT_FIRST",
                   "VX_FOREIGN_MIN", "VX_FIVE_WAVES", "VX_BATCH", "VX_TICKET_AHEAD", "VX_FRAMES_IN_FLIGHT", "VX_FOREIGN_RERUN", "VX_TIMELINE", "VX_COMM_RESERVE_CUS",
-                  "VX_COST_FLOOR", "VX_COST_STEP", "VX_SORTED", "VX_SORT_EVERY_FRAME"):
+                  "VX_COST_FLOOR", "VX_COST_STEP", "VX_SORTED", "VX_SORT_PERIOD"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -168,7 +168,7 @@ struct PersistentArgs {
     uint32_t* pass_out;
     const uint8_t* perm_in;
     uint8_t* perm_out;
-    uint32_t sort_turn;  // a block is re-sorted when (block + sort_turn) % 4 == 0 -- every fourth frame of its stream --, its passes kept otherwise (~0: always)
+    uint32_t sort_turn, sort_mask;  // a block is re-sorted when ((block + sort_turn) & sort_mask) == 0 -- every fourth frame of its stream: mask 3 --, its passes kept otherwise
     uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
     uint32_t ticket_ahead;          // 0 = no; 1 + g = waves draw their next sub-tile's ticket when they start on one (its round trip runs under the traversal),
                                     // except for the frame's last g quarter-grids of tickets
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                         ticket_ahead = true;
                     }
                     if ((sub & 3u) == 0u) {  // a block's pass 0: the next frame's passes of the block
-                        if (a.sort_turn == 0xffffffffu || (((sub >> 2) + a.sort_turn) & 3u) == 0u) {  // ... from what the last frame's cost (its turn: 6 us of a wave's time, every fourth frame)
+                        if ((((sub >> 2) + a.sort_turn) & a.sort_mask) == 0u) {  // ... from what the last frame's cost (its turn: 6 us of a wave's time, every fourth frame)
                             const uint32_t* rec4 = a.pass_in + size_t(sub) * 64u + lane;
                             partition_block(rec4[0], rec4[64], rec4[128], rec4[192], a.perm_out + size_t(sub) * 64u);
                         } else {  // ... as they are
@@ -1429,6 +1429,7 @@ struct vx_context {
     SortState sorted_state[kFrameStreams + 1];  // [slot + 1]
     bool sorted_passes = true;                  // VX_SORTED=0: the unsorted builds everywhere (A/B)
     bool sorted_always = false;                 // VX_SORTED=2: sorted passes also for views that move (measurement)
+    uint32_t sort_mask = 3;                     // VX_SORT_PERIOD (a power of two, default 4; VX_SORT_EVERY_FRAME=1 = 1): a block is re-sorted every so many frames of its stream
     bool hot_first = true;            // VX_HOT_FIRST=0: sub-tiles in plain order (A/B)
     bool hot_use = true, hot_note = true, hot_sort = true;  // VX_HOT_FIRST bits (measurement): 1 use the table, 2 note costs, 4 run the order kernel
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
@@ -1815,6 +1816,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.perm_in = nullptr;
         a.perm_out = nullptr;
         a.sort_turn = 0;
+        a.sort_mask = 3;
         if (sorted) {
             vx_context::SortState& ss = ctx->sorted_state[slot + 1];
             const size_t units = a.total_subtiles;
@@ -1846,7 +1848,8 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             a.perm_in = ss.perm[ss.cur];
             a.perm_out = ss.perm[ss.cur ^ 1];
             if (!same) ss.frames = 0;
-            a.sort_turn = std::getenv("VX_SORT_EVERY_FRAME") ? 0xffffffffu : (ss.frames & 0xffffu);  // (the variable: every block every frame, a measurement)
+            a.sort_turn = ss.frames & 0xffffu;
+            a.sort_mask = ctx->sort_mask;
             ss.frames += 1;
             ss.cur ^= 1;
         }
@@ -2235,6 +2238,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_NO_EXCURSION")) c->no_excursion = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_DEEP_STACK")) c->deep_stack = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FIVE_WAVES")) c->five_waves = std::atoi(e) != 0;
+        if (const char* e = std::getenv("VX_SORT_PERIOD")) { uint32_t n = uint32_t(std::max(1, std::atoi(e))), m = 1; while (m * 2 <= n && m < 1024) m *= 2; c->sort_mask = m - 1; }
+        if (std::getenv("VX_SORT_EVERY_FRAME")) c->sort_mask = 0;
         if (const char* e = std::getenv("VX_SORTED")) { c->sorted_passes = std::atoi(e) != 0; c->sorted_always = std::atoi(e) == 2; }
         if (const char* e = std::getenv("VX_COST_FLOOR")) c->cost_floor = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_COST_STEP")) c->cost_step = std::atoi(e) > 0 ? uint32_t(std::atoi(e)) : kCostStep;
