@@ -361,7 +361,9 @@ int vx_image_info(const vx_context* ctx, uint64_t out[4]);
 /* CSVO worlds rendered from their traversal image: since creation (or the last reset), [0] rays that were led into the voxel they
  * started in and made that walk on the world's own bytes, [1] those of them whose pixel was rendered again on the bytes (the walk
  * overwrote cursor state the rest of the ray depends on), [2] service phases of the render kernel that ran such walks (the rays of a
- * wave go together), [3] loop iterations made on the world's own bytes. Waits for every frame in flight. */
+ * wave go together), [3] loop iterations made on the world's own bytes. Waits for every frame in flight. Counting costs frame time (atomics
+ * on one line from every wave) and is OFF until asked for: reset = 1 zeroes the counters and counts from now on, 2 zeroes them and stops
+ * counting, 0 only reads. */
 int vx_excursion_counters(vx_context* ctx, uint64_t out[4], int reset);
 /* hipStream_t the context launches on (as void*), for callers that order their own work after it. */
 void* vx_stream(vx_context* ctx);

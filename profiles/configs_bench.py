@@ -76,14 +76,19 @@ def main():
             frame(i)
         svo.sync()
         torch.cuda.synchronize()
+        # the walks inside voxels, counted over frames of their own: the counting costs frame time (vx_excursion_counters)
         svo.excursion_counters(reset=True)
+        for i in range(args.steps):
+            frame(i)
+        svo.sync()
+        torch.cuda.synchronize()
+        exc = svo.excursion_counters(stop=True)
         t0 = time.perf_counter()
         for i in range(args.steps):
             frame(i)
         svo.sync()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / args.steps
-        exc = svo.excursion_counters()
         print(json.dumps({"config": name, "format": args.format, "depth": depth, "width": w, "height": h, "supersample": ss, "shadows": shadows,
                           "world_MB": round(world.size_in_bytes / 1e6, 1), "rays_per_frame": int(rays), "ms_per_frame": round(ms, 4),
                           "Mrays_per_s": round(rays / ms / 1e3, 1),

@@ -26,6 +26,13 @@ extern unsigned char* vx_smem;
 #define VX_NOINLINE
 
 inline uint32_t bit_at(uint32_t v, int pos) { return (v >> pos) & 1u; }
+inline uint32_t rev_bits32(uint32_t v) {
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+    v = ((v >> 8) & 0x00ff00ffu) | ((v & 0x00ff00ffu) << 8);
+    return (v >> 16) | (v << 16);
+}
 inline void sched_fence() {}
 inline float sky_acos(float x) { return acosf(x); }
 inline float gmin3(float x, float y, float z) { float m = y < x ? y : x; return z < m ? z : m; }

@@ -108,7 +108,7 @@ RESULT_DTYPE = np.dtype([("t", "<f4"), ("value", "<u4"), ("face_id", "<i4"), ("p
                          ("inside_voxel", "<i4")])
 
 
-def image_cast(lib, fmt, world, mats, tex, mips, tasks, cast_translucent, layout, shallow, restart_in_place=False):
+def image_cast(lib, fmt, world, mats, tex, mips, tasks, cast_translucent, layout, shallow, walk_mode=2):
     from voxel_rs_amd import hip
 
     frame = world.frame(pad_words=0)
@@ -121,7 +121,7 @@ def image_cast(lib, fmt, world, mats, tex, mips, tasks, cast_translucent, layout
     level_offset = (C.c_uint32 * 16)(*[int(o) for o in offsets])
     out = np.zeros(len(tasks), dtype=RESULT_DTYPE)
     steps = np.zeros(len(tasks), dtype=np.uint32)
-    lib.devhost_image_cast(1 if fmt == "esvo" else 2, layout, int(shallow), int(restart_in_place), frame.ctypes.data_as(C.c_void_p), C.c_uint64(frame.size * 4),
+    lib.devhost_image_cast(1 if fmt == "esvo" else 2, layout, int(shallow), int(walk_mode), frame.ctypes.data_as(C.c_void_p), C.c_uint64(frame.size * 4),
                            image.ctypes.data_as(C.c_void_p), C.c_uint64(image.size * 4), origin.ctypes.data_as(C.c_void_p),
                            mats.ctypes.data_as(C.c_void_p), mats.size, chain.ctypes.data_as(C.c_void_p), tex.shape[2], tex.shape[1], tex.shape[0],
                            len(levels), level_offset, tasks.ctypes.data_as(C.c_void_p), len(tasks), int(cast_translucent),
@@ -170,9 +170,14 @@ def test_image_traversal_with_rays_from_inside_voxels(devhost, golden, fmt, layo
     exp, esteps = oracle_cast(scene, tasks, cast_translucent)
     assert (exp["inside_voxel"] != 0).sum() > 100 and (exp["t"] > 0).sum() > 300
     for shallow in (True, False):
-        for restart_in_place in (False, True):  # the two ways a walk that overwrote the byte cursor's leaf pointers is dealt with
-            got, gsteps = image_cast(devhost, fmt, world, mats, tex, mips, tasks, cast_translucent, layout, shallow, restart_in_place)
+        # 2 = the lean walk the render kernel makes (walk_voxel_on_bytes); 0 / 1 = the general byte cursor (enter_voxel_on_bytes), a walk that
+        # overwrote the cursor's leaf pointers given up / started over in place
+        for walk_mode in (2, 0, 1):
+            got, gsteps = image_cast(devhost, fmt, world, mats, tex, mips, tasks, cast_translucent, layout, shallow, walk_mode)
             assert_same_casts(got, gsteps, exp, esteps)
+            if fmt == "csvo" and walk_mode == 2:
+                devhost.devhost_given_up.restype = C.c_uint32
+                assert devhost.devhost_given_up() < 0.2 * (exp["inside_voxel"] != 0).sum()  # (the lean walk serves most of them itself)
 
 
 @pytest.mark.parametrize("fmt", ["esvo", "csvo"])

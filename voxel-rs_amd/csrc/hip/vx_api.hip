@@ -591,7 +591,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     w[2] = make_uint4(fbits(keep_ds), 0u, 0u, 0u);
                     state = kIdle;
                 }
-                if (lane == 0) atomicAdd(&a.excursions[0], (unsigned long long)k);
+                if (a.excursions && lane == 0) atomicAdd(&a.excursions[0], (unsigned long long)k);
             }
         }
 
@@ -619,8 +619,9 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     // third shorter -- three quarters of that because each of three waves gets a third of the SIMD's issue slots instead of a quarter --
                     // and the frame 4-7 % longer for the waves that are missing: VX_DEEP_WAVES=3, pass_aa. What a lane carries through the walk put away
                     // by hand around it -- ten values, 58 -> 38 spilled registers -- changes nothing: pass_ad. The spills are not what the walk costs.)
-                    const DevScene sc_bytes = vouched(make_scene(sa));
-                    const TravStatus s = enter_voxel_on_bytes<SVO, FullStack, false, false, kOpaqueFastPath>(sc, sc_bytes, tr, st, true, res, p.opaque_lo, p.opaque_hi, &color_pending);
+                    // (round 4: the walk as its own lean state machine on the image cursor's own registers and LDS slots, vx_device.hpp)
+                    const TravStatus s = walk_voxel_on_bytes<SVO, FullStack, false, kOpaqueFastPath, !kOpaqueFastPath>(sc, make_buf(sa.world, clamp_u32(sa.world_bytes)), tr, st, true, res,
+                                                                                                                        p.opaque_lo, p.opaque_hi, &color_pending);
                     on_bytes = tr.iter - before;
                     // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there / given up (the pixel's turn comes later)
                     given_up = s == kTravForeign;
@@ -648,13 +649,18 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     my_fill += k;
                     if (lane == 0) chunk[1] = my_fill;
                 }
-                unsigned long long sum = on_bytes;
-                for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
-                if (lane == 0) {  // (a few atomics per service phase that has such rays: measurement for free)
-                    atomicAdd(&a.excursions[0], (unsigned long long)__popcll(fm));
-                    if (gm) atomicAdd(&a.excursions[1], (unsigned long long)__popcll(gm));
-                    atomicAdd(&a.excursions[2], 1ull);
-                    atomicAdd(&a.excursions[3], sum);
+                // Counted only on request (vx_excursion_counters): four atomics on ONE line from every walk phase of every wave -- 65 M a second in a
+                // depth-14 frame -- are more than the memory side carries out there, and the wave's next wait for memory waits for them (as for the
+                // sub-tile queue's single counter in round 2)
+                if (a.excursions) {
+                    unsigned long long sum = on_bytes;
+                    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+                    if (lane == 0) {
+                        atomicAdd(&a.excursions[0], (unsigned long long)__popcll(fm));
+                        if (gm) atomicAdd(&a.excursions[1], (unsigned long long)__popcll(gm));
+                        atomicAdd(&a.excursions[2], 1ull);
+                        atomicAdd(&a.excursions[3], sum);
+                    }
                 }
             }
         }
@@ -1453,7 +1459,8 @@ struct vx_context {
     unsigned long long* d_counters = nullptr;
 
     uint32_t* d_work_counter = nullptr;
-    unsigned long long* d_excursions = nullptr;  // [3], see PersistentArgs
+    unsigned long long* d_excursions = nullptr;  // [4], see PersistentArgs
+    bool count_excursions = false;               // vx_excursion_counters(.., 1) switches the counting on (it costs: see render_persistent)
     unsigned long long* d_timeline = nullptr;    // VX_TIMELINE=1: [8192][8], the last launch's waves (PersistentArgs::timeline)
     uint32_t timeline_waves = 0;
     uint32_t timeline_part = 0;   // VX_TIMELINE_PART
@@ -1773,6 +1780,13 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             levels = 16;
             shallow = true;
         }
+        // Deep CSVO worlds (13 levels and more: half of the shadow rays or all of them start inside their voxel and walk it on the world's bytes,
+        // walk_voxel_on_bytes): the 16-level stack as well -- what the walk pushes inside a voxel then lands in LDS slots (three levels below
+        // the voxel's parent at depth 13, two at 14: 96 % / 82 % of the walks go no deeper) instead of the scratch-backed spill array
+        if (imaged && ctx->svo_type == VX_SVO_CSVO && depth >= 13u && depth <= 16u + slack && ctx->deep_stack) {
+            levels = 16;
+            shallow = true;
+        }
         // shallower images, up to 12 levels, image-only renders: 12 resident levels in 7.5 KB, five waves per SIMD
         if (!HITS && shallow && levels == kLdsLevels && depth <= 12u + slack && ctx->five_waves && !ctx->hot_levels) levels = 12;
         // image-only renders: the build with batched service phases (render_persistent, BATCH)
@@ -1857,7 +1871,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.service_min = ctx->service_min;
         a.foreign_min = ctx->foreign_min;
         a.hold_resolved = ctx->hold_resolved;
-        a.excursions = ctx->d_excursions;
+        a.excursions = ctx->count_excursions ? ctx->d_excursions : nullptr;
         a.timeline = ctx->d_timeline;
         a.timeline_part = ctx->timeline_part;
         a.ticket_ahead = ctx->ticket_ahead != 0 ? 1u + ctx->ahead_guard : 0u;
@@ -3246,6 +3260,8 @@ int vx_excursion_counters(vx_context* ctx, uint64_t out[4], int reset) {
     HIP_TRY(hipMemcpy(h, ctx->d_excursions, sizeof h, hipMemcpyDeviceToHost));
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
     if (reset) HIP_TRY(hipMemset(ctx->d_excursions, 0, sizeof h));
+    if (reset == 1) ctx->count_excursions = true;
+    if (reset == 2) ctx->count_excursions = false;
     return VX_OK;
 }
 

@@ -296,6 +296,18 @@ __device__ __forceinline__ uint32_t csvo_read_leaf(const DevScene& sc, uint32_t 
     return csvo_u32(sc, material_section_ptr + material_section_offset * 4 + preceding * 4);
 }
 
+// the same on a bare buffer resource over the world's bytes (walk_voxel_on_bytes)
+__device__ __forceinline__ uint32_t csvo_read_leaf_at(buf_t world, uint32_t material_section_ptr, uint32_t pre_leaf_ptr, uint32_t ptr, uint32_t idx) {
+    auto u32_at = [&](uint32_t p) -> uint32_t { return buf_u32(world, 8u + csvo_clamp(p)); };
+    const uint32_t material_section_offset = u32_at(pre_leaf_ptr + 1) & 0xffffu;
+    const int leaf_index = int(ptr - (pre_leaf_ptr + 3));
+    const int bit_mark = leaf_index * 8 + int(idx);
+    const uint32_t v0 = u32_at(pre_leaf_ptr + 3) & low_bits(bit_mark < 32 ? bit_mark : 32);
+    const uint32_t v1 = u32_at(pre_leaf_ptr + 7) & low_bits(bit_mark - 32 > 0 ? bit_mark - 32 : 0);
+    const uint32_t preceding = __popc(v0) + __popc(v1);
+    return u32_at(material_section_ptr + material_section_offset * 4 + preceding * 4);
+}
+
 __device__ __forceinline__ vx_material material_at(const DevScene& sc, uint32_t value) {
     // 32-byte rows: two 16-byte loads; block ids beyond the table read as an all-zero row (range-checked by the V#)
     const uint32_t off = value < 0x07ffffffu ? value * 32u : 0xffffffe0u;
@@ -1026,15 +1038,12 @@ struct Trav {
         leaf_record(sc, f, value, dst, leaf_lod(dst), res);
     }
 
-    // HIT phase (svo.esvo.glsl:185-265) for a ray whose step() returned kTravAtLeaf. kLeafHit: the leaf is the result
-    // (res filled in). Otherwise the translucent leaf is recorded and the ADVANCE half of the iteration is run.
-    template <bool TRACE, bool STATS, class ST>
-    __device__ __forceinline__ LeafOutcome leaf_test(const DevScene& sc, const ST& st, bool cast_translucent, Result& res, TracePtr tk,
-                                                     Counters* ctr) {
-        if (STATS) ctr->leaf_tests++;
+    // The HIT phase proper (svo.esvo.glsl:185-265) for a voxel of block `value`: true = the leaf is the result (res filled in); false = a
+    // translucent leaf that is not, recorded as the last one passed -- the caller runs the ADVANCE half of the iteration.
+    template <bool STATS = false>
+    __device__ __forceinline__ bool leaf_test_value(const DevScene& sc, uint32_t value, bool cast_translucent, Result& res, Counters* ctr = nullptr) {
         const float octree_scale = sc.octree_scale;
         const float inv_scale = __uint_as_float(0x7f000000u - __float_as_uint(octree_scale));  // 2^depth, exact
-        const uint32_t value = leaf_value(sc);
         const LeafSurface f = leaf_surface();
 
         const vx_material mat = material_at(sc, value);
@@ -1053,11 +1062,20 @@ struct Trav {
         if ((tex_color[3] > 0.0f || !cast_translucent) && first_of_kind) {
             leaf_record(sc, f, value, dst, tex_lod, res);
             res.color[0] = tex_color[0]; res.color[1] = tex_color[1]; res.color[2] = tex_color[2]; res.color[3] = tex_color[3];
-            return kLeafHit;
+            return true;
         }
         flags |= kHasAdjacentLeaf;
         last_leaf_value = value;
-        // the rest of this iteration: ADVANCE (svo.esvo.glsl:324 onwards)
+        return false;
+    }
+
+    // HIT phase for a ray whose step() returned kTravAtLeaf. kLeafHit: the leaf is the result (res filled in). Otherwise the translucent
+    // leaf is recorded and the ADVANCE half of the iteration is run (svo.esvo.glsl:324 onwards).
+    template <bool TRACE, bool STATS, class ST>
+    __device__ __forceinline__ LeafOutcome leaf_test(const DevScene& sc, const ST& st, bool cast_translucent, Result& res, TracePtr tk,
+                                                     Counters* ctr) {
+        if (STATS) ctr->leaf_tests++;
+        if (leaf_test_value<STATS>(sc, leaf_value(sc), cast_translucent, res, ctr)) return kLeafHit;
         const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
         return advance<TRACE>(sc, st, tcrx, tcry, tcrz, gmin3(tcrx, tcry, tcrz), tk) ? kLeafPassed : kLeafPassedAndFinished;
     }
@@ -1185,6 +1203,145 @@ __device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, 
     tr.ptr = tb.ptr; tr.node = tb.node;
     tr.last_leaf_value = tb.last_leaf_value; tr.flags = tb.flags; tr.iter = tb.iter;
     return outcome;
+}
+
+// ---- the same walk as its own lean state machine (round 4) -----------------------------------------------------------
+//
+// enter_voxel_on_bytes runs the reference's whole byte cursor -- every node kind, chunk boundaries, a cursor of thirty fields copied in
+// and out, pushes into a scratch-backed stack -- for a walk that is 3.2 iterations long on average (profiles/round4/tools/excursion_stats.py:
+// 58 % of the walks are PUSH + one ADVANCE that pops out again, 69 % never leave the voxel's own node, 97 % never cross a phantom chunk
+// boundary). What a walk inside a voxel can meet is much less than what the byte cursor can decode:
+//   * the voxel's parent is a leaf-mask byte L (depth 1), the voxel's "node" N0 the byte at L + 3 + popcount(L's mask below the voxel)
+//     (read_next_ptr's leaf-node case, svo.csvo.glsl:114-115) read as a child mask whose children are all leaves (depth 0 < 2);
+//   * below N0 the depth counter has wrapped (0 - 1 = 0xffffffff, svo.csvo.glsl:399): every node down there is an internal node --
+//     u16 header, 1/2/4-byte offset table (svo.csvo.glsl:56-97) -- and none of its children is a leaf;
+//   * depth never comes back to 2 or 3 in there, so `pre_leaf_pointer` is never touched; `material_section_ptr` only by a phantom chunk
+//     boundary (a 4-byte table entry with bit 31 set) -- and a walk that crosses one is GIVEN UP (kTravForeign: the caller renders the
+//     pixel whole on the world's own bytes, with the reference's own cursor). So is a walk that would push below scale 0 (the child
+//     index is read off the position's mantissa bits here) and, unless FULL_LEAF, one that meets a phantom leaf whose block is not in
+//     the opaque set. Giving up is always correct; it only costs time.
+// Without boundaries a node's depth is a function of its scale (N0: depth 0 at the parent's scale - 1, one less per level), so a stack
+// entry inside the voxel is {byte pointer, t_max, 16-bit header}: it fits the image cursor's own LDS slots below the voxel's parent --
+// which this ray's image cursor never uses -- 16-bit third plane included. The cursor's floats live in the image cursor `tr`
+// throughout (nothing is copied), the voxel's parent takes part as a byte node whose header is the image node's child mask (no load),
+// and the origin table gives L and what read_leaf needs. One loop, whose iterations are the reference's iterations (`tr.iter` counts
+// them; the iteration `tr` stopped in is the first one here: the caller took it back).
+// Returns kTravContinue (back on the image: `tr` is the cursor to go on with), kTravAtLeaf (`res` is the hit; OPAQUE: `*color_pending`),
+// kTravFinished (a miss) or kTravForeign (given up).
+template <int IMGSVO, class ST, bool LIMIT = false, bool OPAQUE = false, bool FULL_LEAF = true>
+__device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, buf_t world, Trav<IMGSVO>& tr, const ST& st, bool cast_translucent,
+                                                          Result& res, uint32_t opaque_lo = 0u, uint32_t opaque_hi = 0u, bool* color_pending = nullptr) {
+    static_assert(!ST::kFast, "the walk needs the levels below the voxel");
+    typedef Trav<IMGSVO> T;
+    auto u32_at = [&](uint32_t p) -> uint32_t { return buf_u32(world, 8u + csvo_clamp(p)); };
+    const int parent_scale = tr.scale;
+    const uint32_t img_ptr = tr.ptr, img_node = tr.node;
+    // origin table: [0] = byte pointer of L, [1] = k << 29 | (L - material section), k = L's place among its depth-2 parent's leaf-mask bytes
+    const uint64_t unit = T::WIDE ? uint64_t(tr.ptr) : uint64_t(tr.ptr >> 5);
+    const uint32_t o0 = mem_u32(img.origin + unit * 8u), o1 = mem_u32(img.origin + unit * 8u + 4u);
+    uint32_t bp = o0;  // the byte node the cursor examines: L first
+    // its header in the 2-bits-per-child form (tag 01 per present child of a 1-bit level, csvo_header()): L's is the image node's child mask
+    // (child c at bit 31 - c there)
+    uint32_t hd = rev_bits32(img_node) & 0xffu;
+    hd = (hd | (hd << 4)) & 0x0f0fu;
+    hd = (hd | (hd << 2)) & 0x3333u;
+    hd = (hd | (hd << 1)) & 0x5555u;
+    for (;;) {
+        if (tr.iter >= uint32_t(kMaxSteps)) return kTravFinished;
+        if (LIMIT && tr.max_dst >= 0.0f && tr.t_min > tr.max_dst) return kTravFinished;
+        ++tr.iter;
+        const int dp = tr.scale - parent_scale + 1;  // the node's depth (svo.csvo.glsl:254): 1 = L, 0 = N0, below: wrapped
+        const uint32_t oct = uint32_t(tr.idx_from_position() ^ tr.octant_mask);
+        const float tcrx = __builtin_fmaf(tr.px, tr.tcx, -tr.tbx), tcry = __builtin_fmaf(tr.py, tr.tcy, -tr.tby), tcrz = __builtin_fmaf(tr.pz, tr.tcz, -tr.tbz);
+        const float tc_max = gmin3(tcrx, tcry, tcrz);
+        const uint32_t tag = (hd >> (oct * 2u)) & 3u;
+        const bool is_child = tag != 0u, is_leaf = is_child && dp >= 0;
+        const bool descend = is_child && tr.t_min <= tr.t_max;
+        if (!descend) tr.flags &= ~T::kHasAdjacentLeaf;
+        bool advance = true;
+        if (descend && is_leaf && tr.t_min > 0.0f) {
+            // a phantom leaf (a child of N0: the voxel's parent is left for the image as soon as the cursor is back at it), svo.csvo.glsl:296-372
+            const uint32_t value = csvo_read_leaf_at(world, o0 - (o1 & 0x1fffffffu), o0 - 3u - (o1 >> 29), bp, oct);
+            bool decided = false;
+            if constexpr (OPAQUE) {
+                const uint32_t set = value < 32u ? opaque_lo : opaque_hi;
+                if (value < 64u && ((set >> (value & 31u)) & 1u) != 0u && !(tr.flags & T::kHasAdjacentLeaf)) {
+                    tr.leaf_hit_opaque(img, value, res);
+                    *color_pending = true;
+                    return kTravAtLeaf;
+                }
+            }
+            if constexpr (FULL_LEAF) {
+                if (tr.leaf_test_value(img, value, cast_translucent, res)) return kTravAtLeaf;
+                decided = true;  // passed: a translucent leaf, recorded; the rest of the iteration is the ADVANCE
+            }
+            if (!decided) return kTravForeign;
+        } else if (descend) {
+            if (is_leaf && tr.t_min == 0.0f) tr.flags |= T::kInsideVoxel;
+            const float tv_max = gmin(tr.t_max, tc_max);
+            if (tr.t_min <= tv_max) {
+                // ---- PUSH (svo.csvo.glsl:387-426) ----
+                if (tr.scale == 0) return kTravForeign;  // (below scale 0 the child index is no longer a mantissa bit)
+                const uint32_t offset = csvo_tag_bytes(hd & ((1u << (oct * 2u)) - 1u));
+                uint32_t next = bp + 3u + offset;  // out of L or N0 (read_next_ptr's leaf-node case)
+                if (dp < 0) {
+                    const uint32_t table = bp + 2u;
+                    const uint32_t e = u32_at(table + offset) & (0xffffffffu >> ((0x001018u >> ((tag - 1u) * 8u)) & 0xffu));
+                    if (e & 0x80000000u) return kTravForeign;  // a phantom chunk boundary
+                    next = table + csvo_tag_bytes(hd) + e;
+                }
+                if (tr.scale == parent_scale) st.push(tr.scale, img_ptr, tr.t_max, img_node);  // (the way back needs the image's entry; written whether or not tc_max < h: see enter_voxel_on_bytes)
+                else if (tc_max < tr.h) st.push(tr.scale, bp, tr.t_max, hd << 16);
+                const float half = tr.scale_exp2 * 0.5f;
+                const float tcenx = __builtin_fmaf(half, tr.tcx, tcrx), tceny = __builtin_fmaf(half, tr.tcy, tcry), tcenz = __builtin_fmaf(half, tr.tcz, tcrz);
+                tr.h = tc_max;
+                --tr.scale;
+                tr.scale_exp2 = half;
+                if (tr.t_min < tcenx) tr.px += half;
+                if (tr.t_min < tceny) tr.py += half;
+                if (tr.t_min < tcenz) tr.pz += half;
+                tr.t_max = tv_max;
+                bp = next;
+                // the child's header: N0's one byte spread to tags, a u16 below it
+                const uint32_t raw = u32_at(bp);
+                uint32_t x = raw & 0xffu;
+                x = (x | (x << 4)) & 0x0f0fu;
+                x = (x | (x << 2)) & 0x3333u;
+                x = (x | (x << 1)) & 0x5555u;
+                hd = dp == 1 ? x : (raw & 0xffffu);
+                advance = false;
+            }
+        }
+        if (advance) {
+            // ---- ADVANCE, POP (svo.csvo.glsl:432-506; the child index is the position's bit at `scale`: see Trav::advance) ----
+            const float ax = tc_max >= tcrx ? tr.scale_exp2 : 0.0f, ay = tc_max >= tcry ? tr.scale_exp2 : 0.0f, az = tc_max >= tcrz ? tr.scale_exp2 : 0.0f;
+            tr.t_min = tc_max;
+            tr.px -= ax; tr.py -= ay; tr.pz -= az;
+            const uint32_t differing_bits = (__float_as_uint(tr.px + ax) ^ __float_as_uint(tr.px)) | (__float_as_uint(tr.py + ay) ^ __float_as_uint(tr.py)) |
+                                            (__float_as_uint(tr.pz + az) ^ __float_as_uint(tr.pz));
+            if (differing_bits >= (2u << tr.scale)) {
+                tr.scale = 31 - __builtin_clz(differing_bits);
+                if (uint32_t(tr.scale) >= uint32_t(kMaxScale)) return kTravFinished;
+                tr.scale_exp2 = pow2i(tr.scale - kMaxScale);
+                uint32_t p, a;
+                st.pop(tr.scale, p, tr.t_max, a);
+                const uint32_t keep = 0xffffffffu << tr.scale;
+                tr.px = __uint_as_float(__float_as_uint(tr.px) & keep);
+                tr.py = __uint_as_float(__float_as_uint(tr.py) & keep);
+                tr.pz = __uint_as_float(__float_as_uint(tr.pz) & keep);
+                tr.h = 0.0f;
+                if (tr.scale >= parent_scale) {  // back among real nodes: the slot holds an image entry
+                    tr.ptr = p;
+                    tr.node = a;
+                    return kTravContinue;
+                }
+                bp = p;
+                hd = a >> 16;
+            } else if (tr.scale == parent_scale) {
+                return kTravContinue;  // (the voxel's span was empty: a step to a sibling voxel, still at the voxel's parent -- ptr and node untouched)
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ void result_miss(Result& res, bool inside_voxel) {

@@ -45,6 +45,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char vx_smem[];
 // bit `pos` of `v` (one v_bfe_u32)
 __device__ __forceinline__ uint32_t bit_at(uint32_t v, int pos) { return __builtin_amdgcn_ubfe(v, uint32_t(pos), 1u); }
 
+// the 32 bits of `v` in reverse order (one v_bfrev_b32)
+__device__ __forceinline__ uint32_t rev_bits32(uint32_t v) { return __builtin_bitreverse32(v); }
+
 // instruction-scheduling fence: nothing is moved across it (orders memory requests against the arithmetic that hides them)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

@@ -376,9 +376,11 @@ class Svo:
         _check(lib().vx_image_info(self._h, C.byref(out)))
         return {"layout": int(out[0]), "image_bytes": int(out[1]), "origin_bytes": int(out[2]), "chunks": int(out[3])}
 
-    def excursion_counters(self, reset=True):
+    def excursion_counters(self, reset=True, stop=False):
+        """Reads the counters of the walks inside voxels. reset=True zeroes them and (re)starts the counting -- it is off until first asked for, it
+        costs frame time --; stop=True zeroes them and switches it off again."""
         out = (_u64 * 4)()
-        _check(lib().vx_excursion_counters(self._h, C.byref(out), int(reset)))
+        _check(lib().vx_excursion_counters(self._h, C.byref(out), 2 if stop else int(reset)))
         return {"rays": int(out[0]), "started_over": int(out[1]), "service_phases": int(out[2]), "iterations_on_bytes": int(out[3])}
 
     def profile_enable(self, on=True):
