@@ -75,7 +75,6 @@ extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t worl
 template <int IMG, int FOREIGN, bool SHALLOW, int LV = kLdsLevels>
 static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float pos[3], const float dir[3], float max_dst, bool cast_translucent,
                        int walk_mode, vx_result* out, uint32_t* steps, uint32_t* given_up = nullptr) {
-    const bool restart_in_place = walk_mode == 1;
     StackSpill spill;
     typedef Stack<1, false, false, LV, (LV > kLdsLevels)> FullStack;  // (16 levels: the 16-bit third plane, like the kernel's)
     typedef Stack<1, true, SHALLOW, LV, (LV > kLdsLevels)> FastStack;
@@ -108,7 +107,7 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
             continue;
         }
         if (s == kTravForeign) {
-            if (walk_mode >= 2) {
+            {
                 // the lean walk (walk_voxel_on_bytes): what it gives up on is run whole on the world's own bytes, like the render kernel does
                 // (3: the image-only render kernels' build -- phantom leaves of opaque blocks are hits without their sample, whose colour
                 // is sampled when the hit is shaded; any other phantom leaf is given up)
@@ -129,23 +128,6 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
                 if (s == kTravForeign) {
                     uint32_t n = 0;
                     Stack<1, false> st2;
-                    st2.init(0, &spill);
-                    intersect<VX_SVO_CSVO, false, false, true>(sc_bytes, pos, dir, max_dst, cast_translucent, st2, res, n, nullptr, nullptr);
-                    out->t = res.t; out->value = res.value; out->face_id = res.face_id;
-                    std::memcpy(out->pos, res.pos, 12); std::memcpy(out->uv, res.uv, 8); std::memcpy(out->color, res.color, 16);
-                    out->lod = res.lod; out->inside_voxel = res.inside_voxel ? 1 : 0;
-                    *steps = n;
-                    return;
-                }
-            } else if (restart_in_place && LV == kLdsLevels) {
-                s = enter_voxel_on_bytes<IMG, FullStack, true, (LV == kLdsLevels)>(sc, sc_bytes, tr, st, cast_translucent, res);
-            } else {
-                // what the render kernel does: a ray whose walk inside the voxel overwrote the byte cursor's leaf pointers is given up
-                // here and run whole on the world's own bytes later (its pixel goes on the wave's list)
-                s = enter_voxel_on_bytes<IMG, FullStack, true, false>(sc, sc_bytes, tr, st, cast_translucent, res);
-                if (s == kTravForeign) {
-                    uint32_t n = 0;
-                    Stack<1, false> st2;  // (the byte cursor's entries are three full words: the plain layout over the same memory)
                     st2.init(0, &spill);
                     intersect<VX_SVO_CSVO, false, false, true>(sc_bytes, pos, dir, max_dst, cast_translucent, st2, res, n, nullptr, nullptr);
                     out->t = res.t; out->value = res.value; out->face_id = res.face_id;
@@ -177,8 +159,8 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
 static uint32_t g_given_up = 0;
 extern "C" uint32_t devhost_given_up(void) { const uint32_t n = g_given_up; g_given_up = 0; return n; }
 
-// walk_mode (images of CSVO worlds, a ray led into a voxel): 0 = enter_voxel_on_bytes, rays it gives up on run whole on the bytes; 1 = the same,
-// started over in place; 2 = the lean walk (walk_voxel_on_bytes)
+// walk_mode (images of CSVO worlds, a ray led into a voxel: walk_voxel_on_bytes; what it gives up on is run whole on the world's bytes):
+// 2 = with the full leaf test inside the voxel, 3 = the image-only render kernels' build
 extern "C" void devhost_image_cast(int svo_type, int layout, int shallow, int walk_mode, const uint8_t* world, uint64_t world_bytes, const uint8_t* image, uint64_t image_bytes,
                                    const uint8_t* origin, const vx_material* mats, uint32_t n_mats, const uint8_t* tex, uint32_t tw, uint32_t th,
                                    uint32_t layers, uint32_t levels, const uint32_t* level_offset, const vx_picker_task* tasks, uint32_t n,
@@ -199,7 +181,7 @@ extern "C" void devhost_image_cast(int svo_type, int layout, int shallow, int wa
     for (uint32_t i = 0; i < n; ++i) {
         const bool ct = cast_translucent != 0;
 #define CAST(IMG, FOREIGN, SHALLOW) image_cast<IMG, FOREIGN, SHALLOW>(sc, sc_bytes, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, ct, walk_mode, &results[i], &steps[i], &g_given_up)
-#define CAST16(IMG, FOREIGN) image_cast<IMG, FOREIGN, true, 16>(sc, sc_bytes, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, ct, walk_mode >= 2 ? walk_mode : 0, &results[i], &steps[i], &g_given_up)
+#define CAST16(IMG, FOREIGN) image_cast<IMG, FOREIGN, true, 16>(sc, sc_bytes, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, ct, walk_mode, &results[i], &steps[i], &g_given_up)
         if (shallow == 2) {  // the kernel build with 16 resident stack levels
             if (svo_type == 1) { if (layout == 1) CAST16(VX_SVO_IMAGE, 0); else CAST16(VX_SVO_IMAGE_WIDE, 0); }
             else { if (layout == 1) CAST16(VX_SVO_IMAGE, VX_SVO_CSVO); else CAST16(VX_SVO_IMAGE_WIDE, VX_SVO_CSVO); }

@@ -12,11 +12,15 @@ namespace vxd {
 
 struct buf_t { const uint8_t* p; uint32_t bytes; };
 inline buf_t make_buf(const void* p, uint32_t bytes) { return buf_t{static_cast<const uint8_t*>(p), bytes}; }
-// like the V#'s range check: a read that does not fit returns 0
-inline uint32_t buf_u32(buf_t b, uint32_t off) { uint32_t v = 0; if (uint64_t(off) + 4 <= b.bytes) std::memcpy(&v, b.p + off, 4); return v; }
+// like the V#'s range check with the zero padding the product keeps behind every buffer it reads unaligned: bytes beyond the end read as 0
+inline void buf_read(buf_t b, uint32_t off, void* out, uint32_t n) {
+    std::memset(out, 0, n);
+    if (off < b.bytes) std::memcpy(out, b.p + off, b.bytes - off < n ? b.bytes - off : n);
+}
+inline uint32_t buf_u32(buf_t b, uint32_t off) { uint32_t v; buf_read(b, off, &v, 4); return v; }
 inline uint32_t buf_u8(buf_t b, uint32_t off) { return off < b.bytes ? b.p[off] : 0u; }
-inline uint4 buf_u128(buf_t b, uint32_t off) { uint4 v = {0, 0, 0, 0}; if (uint64_t(off) + 16 <= b.bytes) std::memcpy(&v, b.p + off, 16); return v; }
-inline uint2 buf_u64(buf_t b, uint32_t off) { uint2 v = {0, 0}; if (uint64_t(off) + 8 <= b.bytes) std::memcpy(&v, b.p + off, 8); return v; }
+inline uint4 buf_u128(buf_t b, uint32_t off) { uint4 v; buf_read(b, off, &v, 16); return v; }
+inline uint2 buf_u64(buf_t b, uint32_t off) { uint2 v; buf_read(b, off, &v, 8); return v; }
 inline uint2 mem_u64(const uint8_t* p) { uint2 v; std::memcpy(&v, p, 8); return v; }
 inline uint32_t mem_u32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 

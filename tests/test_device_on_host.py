@@ -170,14 +170,45 @@ def test_image_traversal_with_rays_from_inside_voxels(devhost, golden, fmt, layo
     exp, esteps = oracle_cast(scene, tasks, cast_translucent)
     assert (exp["inside_voxel"] != 0).sum() > 100 and (exp["t"] > 0).sum() > 300
     for shallow in (True, False):
-        # 2 = the lean walk the render kernel makes (walk_voxel_on_bytes); 0 / 1 = the general byte cursor (enter_voxel_on_bytes), a walk that
-        # overwrote the cursor's leaf pointers given up / started over in place
-        for walk_mode in (2, 0, 1):
-            got, gsteps = image_cast(devhost, fmt, world, mats, tex, mips, tasks, cast_translucent, layout, shallow, walk_mode)
+        got, gsteps = image_cast(devhost, fmt, world, mats, tex, mips, tasks, cast_translucent, layout, shallow)
+        assert_same_casts(got, gsteps, exp, esteps)
+        if fmt == "csvo":
+            devhost.devhost_given_up.restype = C.c_uint32
+            assert devhost.devhost_given_up() < 0.2 * (exp["inside_voxel"] != 0).sum()  # (the walk serves most of them itself)
+
+
+def test_lean_walk_as_the_image_only_kernels_run_it(devhost, golden):
+    """The render kernel's build of the walk inside a voxel: phantom leaves of opaque blocks are hits without their sample (the colour is
+    sampled when the hit is shaded), any other phantom leaf is given up -- and what is given up is run whole on the world's own bytes:
+    the same results and iteration counts. The rays are what the shadow rays of a deep world are: from a primary hit's position, which
+    lies inside its voxel, towards the light."""
+    from voxel_rs_amd import scenes
+
+    world = vra.World(2)
+    st = world.build_heightfield(9, threads=4)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    scene = orc.OracleScene(2, world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    w, h = 96, 54
+    u = scenes.bench_camera(9, st["h_max"], w, h, shadow_distance=3.0e38)
+    _, hits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
+    sel = hits[(hits["flags"] & 2) != 0]
+    tasks = np.zeros(len(sel), dtype=orc.PICKER_TASK_DTYPE)
+    tasks["pos"] = sel["pos"]
+    tasks["dir"] = -np.asarray(u.light_dir[:], dtype=np.float32)
+    tasks["max_dst"] = -1
+    exp, esteps = oracle_cast(scene, tasks, 1)
+    assert (exp["inside_voxel"] != 0).sum() > 1000
+    opaque = 0
+    for b in range(len(mats)):
+        if all(tex[max(0, int(mats[b][k]))][:, :, 3].min() > 0 for k in ("tex_top", "tex_side", "tex_bottom")):
+            opaque |= 1 << b
+    devhost.devhost_set_opaque(opaque & 0xffffffff, opaque >> 32)
+    devhost.devhost_given_up.restype = C.c_uint32
+    for walk_mode in (2, 3):
+        for layout, shallow in ((1, True), (1, 2), (2, 2)):
+            got, gsteps = image_cast(devhost, "csvo", world, mats.view(orc.MATERIAL_DTYPE), tex, 6, tasks, 1, layout, shallow, walk_mode=walk_mode)
             assert_same_casts(got, gsteps, exp, esteps)
-            if fmt == "csvo" and walk_mode == 2:
-                devhost.devhost_given_up.restype = C.c_uint32
-                assert devhost.devhost_given_up() < 0.2 * (exp["inside_voxel"] != 0).sum()  # (the lean walk serves most of them itself)
+            assert devhost.devhost_given_up() < 0.1 * len(tasks)
 
 
 @pytest.mark.parametrize("fmt", ["esvo", "csvo"])

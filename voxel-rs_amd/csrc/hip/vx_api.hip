@@ -142,11 +142,6 @@ struct PersistentArgs {
     uint32_t* next_counter;   // the set to clear
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
-    // Deep CSVO worlds: a shadow ray whose walk inside its voxel ENDS there (a phantom leaf is hit, or the ray leaves the octree) is held -- its
-    // distance in a register, kHeld -- until the next service phase that runs no such walks, instead of being lit, stored and its lane given a
-    // new pixel in the middle of its batch: the lanes of a wave stay in lockstep (one sub-tile, one kind of ray per round), and the phase
-    // that walks does nothing else.
-    uint32_t hold_resolved;
     uint32_t foreign_min;     // images of CSVO worlds: rays led into a voxel wait until this many of a wave's lanes are, and go together
     // Expensive sub-tiles first. A ray is a chain of dependent steps -- about 0.8 us per iteration on a busy device -- so a frame cannot
     // end before its longest rays do (up to ~300 iterations against a mean of ~30): handed out in screen order they start in mid-frame
@@ -180,7 +175,7 @@ struct PersistentArgs {
 };
 
 // Images of CSVO worlds: pixels a wave gave up on the image (a ray's walk inside the voxel it started in overwrote what the rest of
-// the ray depends on, vx_device.hpp: enter_voxel_on_bytes) -- a few in a thousand. The wave renders them whole on the world's own
+// the ray depends on, vx_device.hpp: walk_voxel_on_bytes) -- a few in a hundred. The wave renders them whole on the world's own
 // bytes once the tile queue is empty and its rays are done (a second phase of the same kernel, not a second kernel: its registers
 // overlay the first phase's, and a frame stays one command).
 struct PixelList {
@@ -346,7 +341,7 @@ __device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); 
 
 // IMAGE = the rays walk the traversal image of the world (traversal_image.hpp) instead of its own bytes. FOREIGN (an image of a
 // CSVO world; = VX_SVO_CSVO): a ray that is about to be led into the voxel it started in makes that excursion on the world's own
-// bytes and comes back to the image (vx_device.hpp, enter_voxel_on_bytes) -- in the service phase, like every other rare and
+// bytes and comes back to the image (vx_device.hpp, walk_voxel_on_bytes) -- in the service phase, like every other rare and
 // expensive thing a ray can need. (The image of an ESVO world serves such rays itself.)
 // SHALLOW: no ray can push below the LDS-resident stack levels (the host knows the image's depth): no hand-over test in the loop.
 // LV: stack levels resident in LDS -- 13 (three u32 planes); 16 with a 16-bit third plane (image cursors: worlds of 14 to 16 levels
@@ -558,42 +553,43 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             if (state != kTrav) tr.iter |= kParked;
         }
 
-        // ---- rays that are led into a voxel (they started inside it), image of a CSVO world: listed for the world's own bytes ----
-        if (FOREIGN == kForeignRerun) {
-            const bool listed = state == kForeign;
+        // ---- rays for the world's own bytes: taken down in the wave's list (chunks of 64 records: pixel | shadow << 31, the origin in octree space,
+        // the colour to be lit, diffuse + specular), their lanes freed; the wave runs them when its queue is empty and its rays are done ----
+        auto list_rays = [&](bool listed) {
             const unsigned long long fm = __ballot(listed);
-            if (fm) {
-                const uint32_t k = uint32_t(__popcll(fm)), r = rank_in(fm);
-                const uint32_t room = my_chunk ? kRayChunkRecords - my_fill : 0u;
-                uint32_t* cur = todo.chunks + size_t(my_chunk ? my_chunk - 1 : 0u) * kRayChunkDwords;
-                uint32_t* dst = cur + kRayChunkHeader + (my_fill + r) * kRayRecordDwords;
-                if (k > room) {  // (the records beyond the chunk's 64 start the next one)
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(todo.next_chunk, 1u);
-                    c = __builtin_amdgcn_readfirstlane(c) & todo.mask;
-                    uint32_t* fresh = todo.chunks + size_t(c) * kRayChunkDwords;
-                    if (lane == 0) {
-                        fresh[0] = my_chunk;
-                        fresh[1] = k - room;
-                        if (my_chunk) cur[1] = kRayChunkRecords;
-                    }
-                    if (r >= room) dst = fresh + kRayChunkHeader + (r - room) * kRayRecordDwords;
-                    my_chunk = c + 1;
-                    my_fill = k - room;
-                } else {
-                    my_fill += k;
-                    if (lane == 0) cur[1] = my_fill;
+            if (!fm) return;
+            const uint32_t k = uint32_t(__popcll(fm)), r = rank_in(fm);
+            const uint32_t room = my_chunk ? kRayChunkRecords - my_fill : 0u;
+            uint32_t* cur = todo.chunks + size_t(my_chunk ? my_chunk - 1 : 0u) * kRayChunkDwords;
+            uint32_t* dst = cur + kRayChunkHeader + (my_fill + r) * kRayRecordDwords;
+            if (k > room) {  // (the records beyond the chunk's 64 start the next one)
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(todo.next_chunk, 1u);
+                c = __builtin_amdgcn_readfirstlane(c) & todo.mask;
+                uint32_t* fresh = todo.chunks + size_t(c) * kRayChunkDwords;
+                if (lane == 0) {
+                    fresh[0] = my_chunk;
+                    fresh[1] = k - room;
+                    if (my_chunk) cur[1] = kRayChunkRecords;
                 }
-                if (listed) {
-                    uint4* w = reinterpret_cast<uint4*>(dst);
-                    w[0] = make_uint4(out_index | (shadow_ray ? 0x80000000u : 0u), fbits(tr.rox), fbits(tr.roy), fbits(tr.roz));
-                    w[1] = make_uint4(fbits(keep_color[0]), fbits(keep_color[1]), fbits(keep_color[2]), fbits(keep_color[3]));
-                    w[2] = make_uint4(fbits(keep_ds), 0u, 0u, 0u);
-                    state = kIdle;
-                }
-                if (a.excursions && lane == 0) atomicAdd(&a.excursions[0], (unsigned long long)k);
+                if (r >= room) dst = fresh + kRayChunkHeader + (r - room) * kRayRecordDwords;
+                my_chunk = c + 1;
+                my_fill = k - room;
+            } else {
+                my_fill += k;
+                if (lane == 0) cur[1] = my_fill;
             }
-        }
+            if (listed) {
+                uint4* w = reinterpret_cast<uint4*>(dst);
+                w[0] = make_uint4(out_index | (shadow_ray ? 0x80000000u : 0u), fbits(tr.rox), fbits(tr.roy), fbits(tr.roz));
+                w[1] = make_uint4(fbits(keep_color[0]), fbits(keep_color[1]), fbits(keep_color[2]), fbits(keep_color[3]));
+                w[2] = make_uint4(fbits(keep_ds), 0u, 0u, 0u);
+                state = kIdle;
+            }
+            if (a.excursions && lane == 0) atomicAdd(&a.excursions[FOREIGN == kForeignRerun ? 0 : 1], (unsigned long long)k);
+        };
+        // (FOREIGN = kForeignRerun: every ray that is led into a voxel -- a few dozen a frame in worlds of at most 12 levels)
+        if (FOREIGN == kForeignRerun) list_rays(state == kForeign);
 
         // ---- ... or (FOREIGN = VX_SVO_CSVO) the excursion on the world's own bytes ----
         // The walk runs with only these lanes active, so they go together: a lane waits (parked, at no cost to the loop) until
@@ -601,15 +597,24 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         VX_PART_BEGIN(5);
         constexpr bool kOpaqueFastPath = !STATS && !BATCH;
         bool color_pending = false;  // this lane's hit is of an opaque block and was found without its sample: its colour is still to be sampled
-        bool walk_phase = false;  // (wave-uniform) this phase walks rays into their voxels
+        // (wave-uniform) This phase walks rays into their voxels -- and does nothing else: the shadow rays of a sub-tile reach their voxels in the same
+        // trip of the loop, the wave leaves the loop for their walk at once (foreign_min 1), and the lanes that are parked for another reason at that
+        // moment -- at a leaf, finished -- stay parked until the phase in which everybody is (round 3 served them here: a lane whose primary ray was
+        // shaded in a walk phase started its shadow ray in the middle of its sub-tile's batch, and the wave made 16 % more trips of the loop than for
+        // the ESVO world, profiles/round4/pass_e). A shadow ray whose walk ENDS in the voxel (a phantom leaf is hit, the ray leaves the octree) is held
+        // likewise -- its distance in a register, kHeld -- until then. (A primary ray that ends there -- an eye inside a voxel -- is served here: its
+        // result lives in this phase.)
+        bool walk_phase = false;
+        bool walked = false;  // this lane made a walk in this phase
         if (FOREIGN == VX_SVO_CSVO) {
             const unsigned long long fm = __ballot(state == kForeign);
             // (unlikely: tells the register allocator that what the walk needs may be spilled around it, not across the phase)
             if (__builtin_expect(fm && (uint32_t(__popcll(fm)) >= a.foreign_min || __ballot(state == kTrav || state == kLeaf || state == kDone || state == kMissed || state == kDeep) == 0), 0)) {
                 uint32_t on_bytes = 0;
                 bool given_up = false;
-                walk_phase = a.hold_resolved != 0;
+                walk_phase = true;
                 if (state == kForeign) {
+                    walked = true;
                     tr.iter &= ~kParked;
                     const uint32_t before = tr.iter;
                     // (As a real call -- a register allocation of its own for the walk, the cursor and the result handed over through scratch: shared by
@@ -628,13 +633,18 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep)
                                                : (s == kTravAtLeaf ? kDone : (s == kTravFinished ? kMissed : kIdle));
                     if (state != kTrav) tr.iter |= kParked;
-                    if (walk_phase && shadow_ray && (state == kDone || state == kMissed)) {
+                    if (shadow_ray && (state == kDone || state == kMissed)) {
                         held_t = state == kDone ? res.t : -1.0f;
                         state = kHeld;
                     }
                 }
+                // What the walk gave up on (a phantom chunk boundary, a phantom leaf of a block with holes, a straggler: walk_voxel_on_bytes) is run on the
+                // world's own bytes at the end of the wave's life: image-only renders list the RAY (a shadow ray: only the shadow ray); renders
+                // with hit records list the pixel, which is then rendered whole -- record and all.
                 const unsigned long long gm = __ballot(given_up);
-                if (gm) {
+                if constexpr (!HITS) {
+                    list_rays(given_up);
+                } else if (gm) {
                     const uint32_t k = uint32_t(__popcll(gm));
                     if (my_chunk == 0 || my_fill + k > kChunkEntries) {  // a fresh chunk always has room for a whole wave
                         uint32_t c = 0;
@@ -657,7 +667,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
                     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
                     if (lane == 0) {
                         atomicAdd(&a.excursions[0], (unsigned long long)__popcll(fm));
-                        if (gm) atomicAdd(&a.excursions[1], (unsigned long long)__popcll(gm));
+                        if (HITS && gm) atomicAdd(&a.excursions[1], (unsigned long long)__popcll(gm));  // (image-only renders: counted by list_rays)
                         atomicAdd(&a.excursions[2], 1ull);
                         atomicAdd(&a.excursions[3], sum);
                     }
@@ -671,11 +681,12 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             state = kDone;
         }
         VX_PART_END(5);
+        const bool serve = FOREIGN != VX_SVO_CSVO || !walk_phase || walked;  // (a walk phase serves nobody but its walkers)
         // ---- leaf tests (svo.esvo.glsl:185-265) for the parked lanes ----
         VX_PART_BEGIN(1);
         // A voxel of a block whose textures are opaque throughout is a hit whatever the sample says (RenderParams::opaque_*): its leaf test
         // is the value and arithmetic. The hit's colour is sampled when the hit is shaded (a shadow ray's never is).
-        if (state == kLeaf) {
+        if (state == kLeaf && serve) {
             tr.iter &= ~kParked;
             tr.sync_idx();
             bool tested = false;
@@ -695,7 +706,7 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             }
             if (state != kTrav) tr.iter |= kParked;
         }
-        if (state == kMissed) {
+        if (state == kMissed && serve) {
             result_miss(res, tr.inside_voxel());
             state = kDone;
         }
@@ -856,8 +867,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
 
         // ---- finished rays ----
         VX_PART_BEGIN(2);
-        if constexpr (!SORTED) note_cost_wave(a, p, state == kDone, out_index, tr.iter & ~kParked);  // (a SORTED build notes a pass when it has ended)
-        if (state == kDone) {
+        if constexpr (!SORTED) note_cost_wave(a, p, state == kDone && serve, out_index, tr.iter & ~kParked);  // (a SORTED build notes a pass when it has ended)
+        if (state == kDone && serve) {
             float color[4];
             bool write = true;
             if constexpr (SORTED) rec_now += (tr.iter & ~kParked) << 8;
@@ -1045,8 +1056,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
         row[3] = taken | ((unsigned long long)(service_phases & 0xfffu) << 20) | ((unsigned long long)in_service << 32);  // sub-tiles, service phases, ticks spent in them
         row[4] = __builtin_amdgcn_s_memtime() - c_start; row[5] = loop_cycles; row[6] = loop_trips; row[7] = 0;
     }
-    // ---- second phase (FOREIGN = kForeignRerun): the rays this wave listed, on the world's own bytes ----
-    if (FOREIGN == kForeignRerun) {
+    // ---- second phase (image-only renders of a CSVO world): the rays this wave listed, on the world's own bytes ----
+    if (FOREIGN == kForeignRerun || (FOREIGN == VX_SVO_CSVO && !HITS)) {
         const DevScene sc_bytes = vouched(make_scene(sa));
         Stack<64, false, false, int(FullStack::kStackBytes / (64u * 12u))> st2;  // (three full words per slot, over the same LDS: the first phase is over)
         st2.init(lane, &spill);
@@ -1090,8 +1101,8 @@ __global__ __launch_bounds__(64, MINW) void render_persistent(SceneArgs sa, Rend
             }
         }
     }
-    // ---- second phase (FOREIGN = VX_SVO_CSVO): the pixels this wave gave up on the image, whole, on the world's own bytes ----
-    if (FOREIGN == VX_SVO_CSVO) {
+    // ---- second phase (FOREIGN = VX_SVO_CSVO, renders with hit records): the pixels this wave gave up on the image, whole, on the world's own bytes ----
+    if (FOREIGN == VX_SVO_CSVO && HITS) {
         const DevScene sc_bytes = vouched(make_scene(sa));
         // (the byte cursor's stack entries are three full words: the plain layout, as many levels as fit the same LDS -- the first phase is over)
         Stack<64, false, false, int(FullStack::kStackBytes / (64u * 12u))> st2;
@@ -1503,7 +1514,6 @@ struct vx_context {
     // (foreign_min -- deep CSVO worlds: how many lanes must wait for their walk into a voxel before a wave leaves the loop for it: 32 in
     // round 2; what a frame pays for is the number of such phases, profiles/round3/pass_s/foreign_min.txt, pass_y with held rays)
     uint32_t refill_min = 4, service_min = 64, foreign_min = 40;
-    uint32_t hold_resolved = 1;  // VX_HOLD_RESOLVED (PersistentArgs::hold_resolved)
     // Block ids 0..63 all of whose textures are opaque throughout (RenderParams::opaque_*): from host copies of what vx_set_materials and
     // vx_set_textures were given. opaque_layer[l] = every texel of layer l, on every mip level, has alpha > 0.
     std::vector<vx_material> host_materials;
@@ -1870,7 +1880,6 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.refill_min = ctx->refill_min;
         a.service_min = ctx->service_min;
         a.foreign_min = ctx->foreign_min;
-        a.hold_resolved = ctx->hold_resolved;
         a.excursions = ctx->count_excursions ? ctx->d_excursions : nullptr;
         a.timeline = ctx->d_timeline;
         a.timeline_part = ctx->timeline_part;
@@ -1947,8 +1956,10 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             size_t& have = slot >= 0 ? ctx->frame_todo_chunks[slot] : ctx->main_todo_chunks;
             // (kForeignRerun: chunks of 64 rays, eight times the size: every pixel can list one ray; a chunk is full before the wave starts
             // the next)
-            const size_t need = rerun ? (size_t(p.n_local_tiles) * kTile * kTile / kRayChunkRecords + waves + 1) * (kRayChunkDwords / kChunkDwords)
-                                      : size_t(p.n_local_tiles) * kTile * kTile / 63 + waves + 1;
+            // (image-only renders list rays -- whichever build --, renders with hit records pixels)
+            const bool ray_list = !HITS;
+            const size_t need = ray_list ? (size_t(p.n_local_tiles) * kTile * kTile / kRayChunkRecords + waves + 1) * (kRayChunkDwords / kChunkDwords)
+                                         : size_t(p.n_local_tiles) * kTile * kTile / 63 + waves + 1;
             if (have < need) {
                 if (ring) {
                     HIP_TRY(hipStreamSynchronize(stream));
@@ -1964,7 +1975,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             }
             todo.next_chunk = ring;
             todo.chunks = ring + 32;
-            todo.mask = uint32_t((rerun ? have / (kRayChunkDwords / kChunkDwords) : have) - 1);
+            todo.mask = uint32_t((ray_list ? have / (kRayChunkDwords / kChunkDwords) : have) - 1);
         }
         a.batch = nullptr;
         if (batch) {
@@ -2281,7 +2292,6 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_COMM_HEADROOM")) c->comm_headroom = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
-        if (const char* e = std::getenv("VX_HOLD_RESOLVED")) c->hold_resolved = std::atoi(e) != 0 ? 1u : 0u;
         if (const char* e = std::getenv("VX_FOREIGN_MIN")) c->foreign_min = uint32_t(std::max(1, std::min(64, std::atoi(e))));
         if (c->refill_min < 1) c->refill_min = 1;
         if (c->refill_min > 64) c->refill_min = 64;

@@ -50,7 +50,7 @@ struct DevScene {
     const uint8_t* wide;
     uint64_t wide_bytes;
     // CSVO worlds only: where the image's voxel-parent octants come from in the world's own bytes (traversal_image.hpp, origin
-    // table), two dwords per 32-byte unit of the image -- read when a ray is led INTO a voxel (Trav::enter_voxel_on_bytes)
+    // table), two dwords per 32-byte unit of the image -- read when a ray is led INTO a voxel (walk_voxel_on_bytes)
     const uint8_t* origin;
 };
 
@@ -165,14 +165,10 @@ struct Stack {
     static constexpr uint32_t kHotBytes = HOT ? 9u * 64u : 0u;
     static constexpr uint32_t kBytes = kStackBytes + kHotBytes;  // dynamic LDS a block of THREADS threads needs
     uint32_t slot0;  // byte offset of this thread's slot for scale 0 of a (virtual) full-height plane; may be "negative"
-    // (non-FAST) scales below this one go to the spill array even if they are LDS resident: enter_voxel_on_bytes keeps what the byte
-    // cursor pushes inside a voxel -- 32-bit third words -- out of the image's slots
-    int lds_floor;
     VX_AS_PRIVATE StackSpill* spill;
 
     __device__ __forceinline__ void init(uint32_t tid, StackSpill* sp) {
         slot0 = tid * 4u - uint32_t(kBaseScale) * THREADS * 4u;
-        lds_floor = kBaseScale;
         spill = (VX_AS_PRIVATE StackSpill*)sp;
     }
     __device__ __forceinline__ VX_AS_LDS uint32_t* at(uint32_t byte) const { return (VX_AS_LDS uint32_t*)((VX_AS_LDS unsigned char*)vx_smem + byte); }
@@ -197,7 +193,7 @@ struct Stack {
         VX_AS_LDS uint32_t* d = at(kStackBytes + 64u + lane * 8u);
         d[0] = e.x; d[1] = e.y;
     }
-    __device__ __forceinline__ bool resident(int scale) const { return FAST || (scale >= lds_floor && scale < kMaxScale); }
+    __device__ __forceinline__ bool resident(int scale) const { return FAST || (scale >= kBaseScale && scale < kMaxScale); }
 
     __device__ __forceinline__ void push(int scale, uint32_t p, float t, uint32_t a) const {
         if (resident(scale)) {
@@ -439,7 +435,7 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
 // kTravForeign (FOREIGN steps only: the traversal image of a CSVO world): the ray is about to be led INTO a voxel (it started
 // inside it, svo.csvo.glsl:293-295). What the reference does in there depends on the bytes that follow the voxel's parent in the
 // world's own buffer (read_next_ptr, svo.csvo.glsl:107-115, applied below the leaves), so the caller lets the ray make that
-// excursion on the world's own bytes and bring it back to the image (enter_voxel_on_bytes). The iteration is repeated there: the
+// excursion on the world's own bytes and bring it back to the image (walk_voxel_on_bytes). The iteration is repeated there: the
 // caller takes `iter` back by one, as for kTravDeep. (An ESVO world's image needs none of this: see the PUSH in step_with.)
 // (the values are the render kernel's lane states -- kTrav, kLeaf, kMissed, kDeep, kForeign -- so that it can store a status as is)
 enum TravStatus : int { kTravContinue = 1, kTravAtLeaf = 2, kTravFinished = 4, kTravDeep = 5, kTravForeign = 6 };
@@ -548,7 +544,7 @@ struct Trav {
     }
 
     // The cursor at the root, for the ray whose constants (origin, direction, t_coef, t_bias, octant_mask, max_dst) are in place:
-    // the second half of the reference's set-up (svo.esvo.glsl:126-150). Also how a ray is started over (enter_voxel_on_bytes).
+    // the second half of the reference's set-up (svo.esvo.glsl:126-150).
     template <bool TRACE = false>
     __device__ __forceinline__ void start(const DevScene& sc, TracePtr tk = nullptr) {
         scale = kMaxScale - 1;
@@ -790,7 +786,7 @@ struct Trav {
                 // own masks are zero in everything the serializer writes (esvo.rs:465-485 never ORs a leaf's masks into its parent's
                 // header; the transcoder refuses worlds where that is not so), so the reference walks the voxel as an empty node: so
                 // do we, whatever the entry holds (an octant of voxels has values where others have entries). The pointer is never used.
-                // The image of a CSVO world never gets here (FOREIGN: Trav::enter_voxel_on_bytes).
+                // The image of a CSVO world never gets here (FOREIGN: walk_voxel_on_bytes).
                 if (!kAhead) w1 = (!FOREIGN && is_leaf) ? 0u : e.y;
             } else if (!CSVO) {
                 // the child's pointer word and the header word with its masks, both in the octant at `ptr`
@@ -1085,149 +1081,38 @@ struct Trav {
 //
 // The image cursor `tr` stopped with kTravForeign: child `idx` of the node it examines (a voxel's parent, i.e. the image of a
 // leaf-mask byte L of the world, svo.csvo.glsl:114-115) is a voxel the ray's origin lies in. The reference now PUSHes into the
-// voxel: it takes the byte at L + 3 + popcount(L's mask below idx) for the voxel's "node" and keeps going on whatever follows
-// (phantom leaves with materials looked up through read_leaf included) until the ray steps out of the voxel. That walk only
-// makes sense on the world's own bytes, so it is made there, with the reference's own cursor, from exactly the state the image
-// cursor is in -- the image's origin table (traversal_image.hpp) says where L, its depth-2 parent and the chunk's material
-// section are in the world. It ends when (a) a POP brings the ray back to the voxel's parent or above: from there on every
-// node is a real one again and the ray continues on the image (kTravContinue: `tr` is the cursor to go on with; the stack
-// slots at and above the parent's scale hold image entries, the excursion only ever writes below them); (b) a phantom leaf
-// is accepted (kTravAtLeaf: `res` is the hit); (c) the ray ends (kTravFinished: a miss); (d) the walk overwrote cursor state
-// that the rest of the ray depends on (below).
-// `st` is a full stack (the excursion can go below the LDS-resident levels). The iteration `tr` stopped in is repeated here, so
-// `tr.iter` must not count it (the caller took it back, as for kTravDeep); on return `tr.iter` counts everything that ran.
-// OPAQUE (the render kernel's image-only builds): a phantom leaf whose value is in the host's set of blocks that are opaque throughout
-// (`opaque_lo/hi`, RenderParams) is a hit without its sample, as in the kernel's own leaf tests (Trav::leaf_hit_opaque); `*color_pending` then
-// says that the hit's colour is still to be sampled (by whoever shades it: a shadow ray's never is).
-template <int IMGSVO, class ST, bool LIMIT = false, bool RESTART = true, bool OPAQUE = false>
-__device__ __forceinline__ TravStatus enter_voxel_on_bytes(const DevScene& img, const DevScene& bytes, Trav<IMGSVO>& tr, const ST& st,
-                                                           bool cast_translucent, Result& res, uint32_t opaque_lo = 0u, uint32_t opaque_hi = 0u,
-                                                           bool* color_pending = nullptr) {
-    static_assert(!ST::kFast, "the excursion needs every stack level");
-    typedef Trav<VX_SVO_CSVO> ByteTrav;
-    const int parent_scale = tr.scale;
-    const uint32_t img_ptr = tr.ptr, img_node = tr.node;
-    const float parent_t_max = tr.t_max;
-
-    static_assert(!(ST::kAux16 && RESTART), "a 16-bit third plane cannot hold the byte cursor's entries from the root down");
-    // what the byte cursor pushes inside the voxel stays out of the LDS slots (they are the image's; theirs may be 16-bit)
-    ST bst = st;
-    bst.lds_floor = parent_scale > ST::kBaseScale ? parent_scale : ST::kBaseScale;
-    // (every field of `tr` is written back from `tb` at the single exit below: nothing of `tr` is live while the byte cursor runs)
-    ByteTrav tb;
-    tb.rox = tr.rox; tb.roy = tr.roy; tb.roz = tr.roz; tb.rdx = tr.rdx; tb.rdy = tr.rdy; tb.rdz = tr.rdz;
-    tb.tcx = tr.tcx; tb.tcy = tr.tcy; tb.tcz = tr.tcz; tb.tbx = tr.tbx; tb.tby = tr.tby; tb.tbz = tr.tbz;
-    tb.px = tr.px; tb.py = tr.py; tb.pz = tr.pz;
-    tb.t_min = tr.t_min; tb.t_max = tr.t_max; tb.h = tr.h; tb.scale_exp2 = tr.scale_exp2; tb.max_dst = tr.max_dst;
-    tb.last_leaf_value = tr.last_leaf_value; tb.flags = tr.flags;
-    tb.scale = tr.scale; tb.octant_mask = tr.octant_mask; tb.iter = tr.iter;
-    tb.idx = tr.idx_from_position();  // (the image cursor reads the child index off the position)
-    // origin table: two dwords per 32-byte unit of the image, [0] = byte pointer of L, [1] = k << 29 | (L - material section),
-    // k = L's place among its depth-2 parent's leaf-mask bytes
-    const uint64_t unit = Trav<IMGSVO>::WIDE ? uint64_t(tr.ptr) : uint64_t(tr.ptr >> 5);
-    const uint32_t o0 = mem_u32(img.origin + unit * 8u), o1 = mem_u32(img.origin + unit * 8u + 4u);
-    tb.ptr = o0;
-    tb.depth = 1;
-    tb.material_section_ptr = o0 - (o1 & 0x1fffffffu);
-    tb.pre_leaf_pointer = o0 - 3u - (o1 >> 29);
-    tb.node = tb.csvo_header(bytes);
-    // The byte cursor carries two pieces of state besides its stack that the walk inside the voxel may overwrite (a phantom depth-2
-    // node, a phantom chunk boundary): `pre_leaf_pointer` and `material_section_ptr`, which say where read_leaf finds a voxel's
-    // material (svo.csvo.glsl:119-133). The reference goes on with whatever they hold when the ray is back among real nodes. If that
-    // is what they held before -- or, for pre_leaf_pointer, if the ray is back above the voxel's parent, where the next depth-2 node
-    // it enters sets it afresh (svo.csvo.glsl:283) -- the rest of the ray is what the image gives. If not, the voxels it hits from
-    // there on report materials read through the overwritten pointers: such a ray has to be run on the world's own bytes from the
-    // root, with the reference's cursor throughout. RESTART: that is done here and now (`for_good`); otherwise kTravForeign is
-    // returned and the caller sees to it (the render kernel, whose lanes walk in lockstep, puts the pixel on a list for later).
-    const uint32_t true_material_section = tb.material_section_ptr, true_pre_leaf = tb.pre_leaf_pointer;
-
-    TravStatus outcome;
-    bool first = true, for_good = false;
-    for (;;) {
-        // first trip: the iteration the image cursor stopped in, again -- PUSH into the voxel, or ADVANCE if the voxel's span is empty
-        TravStatus s = tb.template step<false, false, LIMIT, ST>(bytes, bst, nullptr, nullptr);
-        if (s == kTravAtLeaf) {
-            if constexpr (OPAQUE) {
-                const uint32_t value = tb.leaf_value(bytes);
-                const uint32_t set = value < 32u ? opaque_lo : opaque_hi;
-                if (value < 64u && ((set >> (value & 31u)) & 1u) != 0u && !(tb.flags & ByteTrav::kHasAdjacentLeaf)) {
-                    tb.leaf_hit_opaque(bytes, value, res);
-                    *color_pending = true;
-                    outcome = kTravAtLeaf;
-                    break;
-                }
-            }
-            const LeafOutcome o = tb.template leaf_test<false, false>(bytes, bst, cast_translucent, res, nullptr, nullptr);
-            if (o == kLeafHit) {
-                outcome = kTravAtLeaf;
-                break;
-            }
-            s = o == kLeafPassed ? kTravContinue : kTravFinished;
-        }
-        if (s == kTravFinished) {
-            outcome = kTravFinished;
-            break;
-        }
-        if (for_good) continue;
-        const bool was_first = first;
-        first = false;
-        if (tb.scale < parent_scale) {
-            // inside the voxel. The PUSH wrote the parent's entry as the byte cursor sees it (where the reference's `tc_max < h` let
-            // it): the way back needs the image's (writing it where the reference wrote nothing is harmless: such a slot is never popped)
-            if (was_first) bst.push(parent_scale, img_ptr, parent_t_max, img_node);
-            continue;
-        }
-        // back among real nodes
-        if (tb.material_section_ptr != true_material_section || (tb.scale == parent_scale && tb.pre_leaf_pointer != true_pre_leaf)) {
-            if (!RESTART) {
-                outcome = kTravForeign;
-                break;
-            }
-            tb.start(bytes);
-            for_good = true;
-            continue;
-        }
-        if (was_first && tb.scale == parent_scale) {  // advanced to a sibling voxel: still at the voxel's parent, whose image node is the same
-            tb.ptr = img_ptr;
-            tb.node = img_node;
-        } else {  // the slot the POP read holds an image entry (the byte cursor misread it): read it as one
-            uint32_t a;
-            bst.pop(tb.scale, tb.ptr, tb.t_max, a);
-            tb.node = a;
-        }
-        outcome = kTravContinue;
-        break;
-    }
-    tr.px = tb.px; tr.py = tb.py; tr.pz = tb.pz;
-    tr.t_min = tb.t_min; tr.t_max = tb.t_max; tr.h = tb.h; tr.scale = tb.scale; tr.scale_exp2 = tb.scale_exp2;
-    tr.ptr = tb.ptr; tr.node = tb.node;
-    tr.last_leaf_value = tb.last_leaf_value; tr.flags = tb.flags; tr.iter = tb.iter;
-    return outcome;
-}
-
-// ---- the same walk as its own lean state machine (round 4) -----------------------------------------------------------
-//
-// enter_voxel_on_bytes runs the reference's whole byte cursor -- every node kind, chunk boundaries, a cursor of thirty fields copied in
-// and out, pushes into a scratch-backed stack -- for a walk that is 3.2 iterations long on average (profiles/round4/tools/excursion_stats.py:
-// 58 % of the walks are PUSH + one ADVANCE that pops out again, 69 % never leave the voxel's own node, 97 % never cross a phantom chunk
-// boundary). What a walk inside a voxel can meet is much less than what the byte cursor can decode:
-//   * the voxel's parent is a leaf-mask byte L (depth 1), the voxel's "node" N0 the byte at L + 3 + popcount(L's mask below the voxel)
-//     (read_next_ptr's leaf-node case, svo.csvo.glsl:114-115) read as a child mask whose children are all leaves (depth 0 < 2);
+// voxel: it takes the byte at L + 3 + popcount(L's mask below idx) for the voxel's "node" N0 and keeps going on whatever follows
+// (phantom leaves with materials looked up through read_leaf included) until the ray steps out of the voxel. That walk only makes
+// sense on the world's own bytes, so it is made there -- as a lean state machine of its own (round 4; until then the reference's
+// whole byte cursor ran here, every node kind, a cursor of thirty fields copied in and out, a scratch-backed stack), for a walk
+// that is 3.2 iterations long on average (profiles/round4/tools/excursion_stats.py: 58 % of the walks are PUSH + one ADVANCE that
+// pops out again, 69 % never leave N0, 97 % never cross a phantom chunk boundary). What a walk inside a voxel can meet is much less
+// than what the byte cursor can decode:
+//   * N0 is read as a child mask whose children are all leaves (depth 0 < 2);
 //   * below N0 the depth counter has wrapped (0 - 1 = 0xffffffff, svo.csvo.glsl:399): every node down there is an internal node --
 //     u16 header, 1/2/4-byte offset table (svo.csvo.glsl:56-97) -- and none of its children is a leaf;
 //   * depth never comes back to 2 or 3 in there, so `pre_leaf_pointer` is never touched; `material_section_ptr` only by a phantom chunk
-//     boundary (a 4-byte table entry with bit 31 set) -- and a walk that crosses one is GIVEN UP (kTravForeign: the caller renders the
-//     pixel whole on the world's own bytes, with the reference's own cursor). So is a walk that would push below scale 0 (the child
+//     boundary (a 4-byte table entry with bit 31 set) -- and a walk that crosses one is GIVEN UP (kTravForeign: the caller runs the
+//     ray on the world's own bytes, with the reference's own cursor). So is a walk that would push below scale 0 (the child
 //     index is read off the position's mantissa bits here) and, unless FULL_LEAF, one that meets a phantom leaf whose block is not in
 //     the opaque set. Giving up is always correct; it only costs time.
 // Without boundaries a node's depth is a function of its scale (N0: depth 0 at the parent's scale - 1, one less per level), so a stack
 // entry inside the voxel is {byte pointer, t_max, 16-bit header}: it fits the image cursor's own LDS slots below the voxel's parent --
 // which this ray's image cursor never uses -- 16-bit third plane included. The cursor's floats live in the image cursor `tr`
-// throughout (nothing is copied), the voxel's parent takes part as a byte node whose header is the image node's child mask (no load),
-// and the origin table gives L and what read_leaf needs. One loop, whose iterations are the reference's iterations (`tr.iter` counts
-// them; the iteration `tr` stopped in is the first one here: the caller took it back).
-// Returns kTravContinue (back on the image: `tr` is the cursor to go on with), kTravAtLeaf (`res` is the hit; OPAQUE: `*color_pending`),
-// kTravFinished (a miss) or kTravForeign (given up).
+// throughout (nothing is copied), and the voxel's parent takes part as a byte node whose header is the image node's child mask.
+// What a walk phase costs is its slowest lane: the lanes of a wave walk together, a walk is 3 iterations long on average and 15 for the
+// slowest of a sub-tile's rays, and an iteration is ~150 instructions at a quarter of a SIMD's issue slots -- the loads matter less than that
+// (tried, profiles/round4/pass_i: the voxels' N0 bytes kept beside the origin entry so that two walks in three read nothing of the world --
+// no gain; nodes below N0 fetched as 16 bytes, a PUSH's table entry taken from them -- 3 % slower; a cap on the stragglers of a phase, the
+// capped rays run on the bytes -- the rerun costs what the cap saves, pass_d).
+// It ends when a POP brings the ray back to the voxel's parent or above: from there on every node is a real one again and the ray
+// continues on the image (the stack slots at and above the parent's scale hold image entries, the walk only ever writes below them).
+// One loop, whose iterations are the reference's iterations (`tr.iter` counts them; the iteration `tr` stopped in is the first one
+// here: the caller took it back). `st` is a full stack (the walk can go below the LDS-resident levels).
+// Returns kTravContinue (back on the image: `tr` is the cursor to go on with), kTravAtLeaf (`res` is the hit; OPAQUE: a phantom leaf
+// whose value is in the host's set of blocks that are opaque throughout -- `opaque_lo/hi`, RenderParams -- is a hit without its sample,
+// as in the kernel's own leaf tests, and `*color_pending` says that its colour is still to be sampled), kTravFinished (a miss) or
+// kTravForeign (given up).
 template <int IMGSVO, class ST, bool LIMIT = false, bool OPAQUE = false, bool FULL_LEAF = true>
 __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, buf_t world, Trav<IMGSVO>& tr, const ST& st, bool cast_translucent,
                                                           Result& res, uint32_t opaque_lo = 0u, uint32_t opaque_hi = 0u, bool* color_pending = nullptr) {
@@ -1286,11 +1171,12 @@ __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, b
                 uint32_t next = bp + 3u + offset;  // out of L or N0 (read_next_ptr's leaf-node case)
                 if (dp < 0) {
                     const uint32_t table = bp + 2u;
-                    const uint32_t e = u32_at(table + offset) & (0xffffffffu >> ((0x001018u >> ((tag - 1u) * 8u)) & 0xffu));
+                    const uint32_t word = u32_at(table + offset);
+                    const uint32_t e = word & (0xffffffffu >> ((0x001018u >> ((tag - 1u) * 8u)) & 0xffu));
                     if (e & 0x80000000u) return kTravForeign;  // a phantom chunk boundary
                     next = table + csvo_tag_bytes(hd) + e;
                 }
-                if (tr.scale == parent_scale) st.push(tr.scale, img_ptr, tr.t_max, img_node);  // (the way back needs the image's entry; written whether or not tc_max < h: see enter_voxel_on_bytes)
+                if (tr.scale == parent_scale) st.push(tr.scale, img_ptr, tr.t_max, img_node);  // (the way back needs the image's entry; written whether or not tc_max < h: harmless, the slot holds nothing else the ray could pop)
                 else if (tc_max < tr.h) st.push(tr.scale, bp, tr.t_max, hd << 16);
                 const float half = tr.scale_exp2 * 0.5f;
                 const float tcenx = __builtin_fmaf(half, tr.tcx, tcrx), tceny = __builtin_fmaf(half, tr.tcy, tcry), tcenz = __builtin_fmaf(half, tr.tcz, tcrz);
