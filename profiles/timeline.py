@@ -12,6 +12,7 @@ from pathlib import Path
 
 os.environ["VX_TIMELINE"] = "1"
 ROOT = Path(__file__).resolve().parent.parent
+os.environ.setdefault("VX_LIB_DIR", str(ROOT / "voxel-rs_amd" / "lib" / "lib_tl"))  # the library's timeline build (make tl)
 sys.path.insert(0, str(ROOT))
 from _pkg import load_package  # noqa: E402
 

@@ -4,10 +4,13 @@ Bar: hit identity, step counts and every traversal float (t, po
 BIT-EXACT against the oracle; shaded colour within COLOR_TOL (libm vs ocml in pow/acos). The reference's own golden
 vectors are replayed through the GPU with the tolerances the reference's tests state (1e-5).
 """
+import os
+from pathlib import Path
+
 import numpy as np
 import pytest
 
-from helpers import SVO_TYPES, build_world, golden_materials, golden_textures, oracle_scene, orc, vra
+from helpers import ROOT, SVO_TYPES, build_world, golden_materials, golden_textures, oracle_scene, orc, vra
 
 pytestmark = pytest.mark.gpu
 
@@ -578,8 +581,9 @@ OCCUPANCY_COUNTERS = ("wave_steps", "services", "refills", "tail_wave_steps", "t
 def test_kernel_versions_agree(hip, fmt, monkeypatch):
     """The persistent wavefront kernel (default) and the one-thread-per-pixel kernel write identical images and hit
     records, for several refill/service thresholds (they only reorder work between lanes), from the traversal image (default),
-    from the world's own bytes, from the image layout for more than 4 GiB (octant indices behind a 64-bit pointer), from the instrumented
-    (timeline) builds, on streams with a CU mask, with other classes of the order table, with and without sorted passes."""
+    from the world's own bytes, from the image layout for more than 4 GiB (octant indices behind a 64-bit pointer), with the LDS copy of
+    the top levels, with and without the order table and sorted passes, with the walk inside voxels in the render loop of a small world,
+    with three frames in flight. (The library's timeline build: test_timeline_build_renders_the_same_frames.)"""
     from voxel_rs_amd import scenes
 
     world = vra.World(SVO_TYPES[fmt])
@@ -588,15 +592,12 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     w, h = 250, 130
     u = scenes.bench_camera(8, st["h_max"], w, h)
     results = []
-    for env in ({"VX_RENDER_KERNEL": "1"}, {"VX_RENDER_KERNEL": "2"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"},
-                {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "64", "VX_SERVICE_MIN": "64"}, {"VX_RENDER_KERNEL": "2", "VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"},
-                {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_WIDE_IMAGE": "1", "VX_MIN_WAVES": "1"},
-                {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_MIN": "1"}, {"VX_FIVE_WAVES": "1"}, {"VX_BATCH": "1"}, {"VX_TICKET_AHEAD": "1"}, {"VX_TICKET_AHEAD": "0", "VX_FRAMES_IN_FLIGHT": "3"}, {"VX_FOREIGN_RERUN": "0"},
-                {"VX_TIMELINE": "1"}, {"VX_TIMELINE": "1", "VX_FOREIGN_RERUN": "0"}, {"VX_COMM_RESERVE_CUS": "8"}, {"VX_COST_FLOOR": "0", "VX_COST_STEP": "4"},
-                {"VX_SORTED": "0"}, {"VX_SORT_PERIOD": "1"}, {"VX_SORT_PERIOD": "2", "VX_HOT_FIRST": "0"}, {"VX_SORTED": "0", "VX_TIMELINE": "1"}):
-        for k in ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_MIN_WAVES", "VX_HOT_LEVELS", "VX_HOT_FIRST",
-                  "VX_FOREIGN_MIN", "VX_FIVE_WAVES", "VX_BATCH", "VX_TICKET_AHEAD", "VX_FRAMES_IN_FLIGHT", "VX_FOREIGN_RERUN", "VX_TIMELINE", "VX_COMM_RESERVE_CUS",
-                  "VX_COST_FLOOR", "VX_COST_STEP", "VX_SORTED", "VX_SORT_PERIOD"):
+    knobs = ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_HOT_LEVELS", "VX_HOT_FIRST", "VX_FRAMES_IN_FLIGHT",
+             "VX_FOREIGN_RERUN", "VX_SORTED", "VX_SORT_PERIOD")
+    for env in ({"VX_RENDER_KERNEL": "1"}, {}, {"VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"}, {"VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"},
+                {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_RERUN": "0"},
+                {"VX_SORTED": "0"}, {"VX_SORT_PERIOD": "1"}, {"VX_FRAMES_IN_FLIGHT": "3"}):
+        for k in knobs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -622,6 +623,53 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
         assert np.array_equal(np.isnan(r[0]), np.isnan(results[0][0]))
         print("max colour difference between kernel versions:", np.nanmax(np.abs(r[0] - results[0][0])))
         assert np.nanmax(np.abs(r[0] - results[0][0])) <= COLOR_TOL
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_timeline_build_renders_the_same_frames(hip, fmt):
+    """The library's timeline build (voxel-rs_amd/lib/lib_tl: the image-only kernels stamp every wave's life, profiles/timeline.py) renders
+    the frames of the plain library, byte for byte, and fills in its rows: run in a process of its own (a process loads one of the two)."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+
+    from voxel_rs_amd import scenes
+
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(8, threads=4)
+    svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(scenes.synthetic_materials())
+    svo.set_textures(scenes.synthetic_textures(), 6)
+    svo.update_full(world)
+    w, h = 250, 130
+    u = scenes.bench_camera(8, st["h_max"], w, h)
+    img, _ = svo.render(u, w, h)
+    svo.close()
+    code = f"""
+import hashlib, json, os, sys
+sys.path.insert(0, {str(ROOT)!r})
+from _pkg import load_package
+vra = load_package()
+from voxel_rs_amd import hip, scenes
+import torch
+world = vra.World({SVO_TYPES[fmt]}); st = world.build_heightfield(8, threads=4)
+svo = hip.Svo({SVO_TYPES[fmt]}, world.size_in_bytes + (1 << 20))
+svo.set_materials(scenes.synthetic_materials()); svo.set_textures(scenes.synthetic_textures(), 6); svo.update_full(world)
+svo.set_frames_in_flight(1)
+u = scenes.bench_camera(8, st["h_max"], {w}, {h})
+image = torch.zeros(({h}, {w}, 4), dtype=torch.float32, device="cuda")
+for _ in range(3): svo.render_device(u, {w}, {h}, image.data_ptr())
+svo.sync()
+t = svo.timeline()
+print(json.dumps(dict(sha=hashlib.sha256(image.cpu().numpy().tobytes()).hexdigest(), waves=int(len(t)), lived=int((t[:, 2] > t[:, 0]).sum()), trips=int(t[:, 6].sum()))))
+"""
+    env = dict(os.environ, VX_TIMELINE="1", VX_LIB_DIR=str(Path(ROOT) / "voxel-rs_amd" / "lib" / "lib_tl"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["sha"] == hashlib.sha256(img.tobytes()).hexdigest()
+    assert d["waves"] > 0 and d["lived"] == d["waves"] and d["trips"] > d["waves"]
 
 
 @pytest.mark.parametrize("fmt", FMTS)

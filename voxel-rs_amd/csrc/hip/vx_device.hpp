@@ -16,6 +16,7 @@
 #include <vx_platform.hpp>  // the gfx950 primitives this file is written in (buffer loads, LDS address spaces, v_min3 ...)
 
 #include "voxel_hip.h"
+#include "vx_args.hpp"
 
 // 1 = the render loop's step on a traversal image is Trav::step_image (PUSH and ADVANCE merged into one instruction stream); 0 = step_with's
 // own paths (the round-2 loop, kept for A/B builds)
@@ -25,8 +26,6 @@
 
 namespace vxd {
 
-constexpr int kMaxSteps = 1000;       // svo.esvo.glsl:18
-constexpr int kMaxScale = 23;         // svo.esvo.glsl:21
 constexpr float kEps = 1.1920929e-7f;  // exp2(-23), svo.esvo.glsl:24
 constexpr uint32_t kInvalidPtr = 0xffffffffu;
 
@@ -52,21 +51,6 @@ struct DevScene {
     // CSVO worlds only: where the image's voxel-parent octants come from in the world's own bytes (traversal_image.hpp, origin
     // table), two dwords per 32-byte unit of the image -- read when a ray is led INTO a voxel (walk_voxel_on_bytes)
     const uint8_t* origin;
-};
-
-// what the host passes to a kernel; expanded into a DevScene (descriptors in SGPRs) at kernel entry
-struct SceneArgs {
-    const uint8_t* world;
-    uint64_t world_bytes;
-    const vx_material* materials;
-    uint32_t n_materials;
-    const uint8_t* tex;
-    uint32_t tex_bytes;
-    uint32_t width, height, layers, levels;
-    uint32_t level_offset[16];
-    const uint8_t* image;   // the traversal image of the world (traversal_image.hpp), or null
-    uint64_t image_bytes;
-    const uint8_t* origin;  // its origin table (CSVO worlds), or null
 };
 
 __device__ __forceinline__ uint32_t clamp_u32(uint64_t v) { return v < 0xffffffffull ? uint32_t(v) : 0xffffffffu; }
@@ -130,7 +114,6 @@ struct Counters {  // per-thread, reduced by the instrumented kernel
 // interpreting leaf bytes as nodes (svo.esvo.glsl:183-185 / svo.csvo.glsl:293-295 only treat a leaf as a hit when t_min > 0);
 // its stack arrays hold MAX_SCALE + 1 entries (svo.esvo.glsl:28-30), so those pushes are kept too -- in a per-thread spill
 // array that ordinary rays never touch.
-constexpr int kLdsLevels = 13;                          // the default: three u32 planes, 9.75 KB per wave, 16 waves per CU
 constexpr int kLdsBaseScale = kMaxScale - kLdsLevels;   // scales [kLdsBaseScale, 22] are LDS resident
 
 // per-thread backing store for the levels below the LDS-resident ones (lives in scratch)
@@ -452,14 +435,6 @@ struct TraceSink {
 };
 
 typedef VX_AS_PRIVATE TraceSink* TracePtr;
-
-// third node format, internal to the library: the 64-byte-octant traversal image of a CSVO world (traversal_image.hpp, kOct64)
-#define VX_SVO_IMAGE 3
-// the same with octant INDICES for pointers and 64-bit addressing: images beyond 4 GiB (traversal_image.hpp, kOct64Wide)
-#define VX_SVO_IMAGE_WIDE 4
-// an ESVO world buffer of 4 GiB and more: the reference's format unchanged (descriptors[] indices are 32 bits, esvo.rs:74-101),
-// read through a 64-bit pointer with an explicit range check instead of the V#'s
-#define VX_SVO_ESVO_BIG 5
 
 template <int SVO>
 struct Trav {
@@ -1265,23 +1240,6 @@ __device__ __forceinline__ void intersect(const DevScene& sc, const float ro_in[
 
 // ---- world.glsl -----------------------------------------------------------------------------------------------
 
-struct RenderParams {
-    vx_uniforms u;
-    float tan_half_fovy;   // tanf(fovy * 0.5f), evaluated on the host (world.glsl:115)
-    float ray_origin[3];   // (view * vec4(0,0,0,1)).xyz / .w, the same for every pixel: evaluated on the host (world.glsl:118)
-    uint32_t affine_view;  // the view matrix's last row is (0,0,0,1): the per-pixel perspective divide is a division by exactly 1
-    uint32_t width, height;
-    uint32_t tiles_x, tiles_y;
-    uint32_t tile_rank, tile_count, n_local_tiles;
-    // screen sharding (tile_count > 1): the image's 32x32 tiles in Morton order of their (x, y) -- this context renders the tiles
-    // tile_order[k * tile_count + tile_rank], k = 0 .. n_local_tiles - 1 (device memory; null when the whole image is rendered)
-    const uint32_t* tile_order;
-    uint32_t rgba8;  // the target holds RGBA8 pixels (vx_target.format): 4 bytes each, and a whole image has its TOP row first
-    // block ids 0..63 whose textures -- all three faces, every texel of every mip level -- have alpha > 0: a voxel of such a block is a hit
-    // whatever the sample (Trav::leaf_hit_opaque). The host derives it from the material rows and the mip chain (vx_api.hip).
-    uint32_t opaque_lo, opaque_hi;
-};
-
 // A pixel's place in the target and its value there. RGBA32F: the image2D of world.glsl:10 (row 0 = bottom). RGBA8: what
 // Framebuffer::as_image makes of it (src/graphics/framebuffer.rs:97-111) -- glReadPixels(RGBA, UNSIGNED_BYTE), i.e. clamp to [0,1]
 // and round to the nearest of 255 steps (NaN -> 0), rows flipped so that the top row comes first; tile lists keep their tile-local
@@ -1306,12 +1264,6 @@ __device__ __forceinline__ float dot3(const float a[3], const float b[3]) { retu
 __device__ __forceinline__ void normalize3(const float v[3], float out[3]) {
     const float len = sqrtf(dot3(v, v));
     out[0] = v[0] / len; out[1] = v[1] / len; out[2] = v[2] / len;
-}
-
-// (view * vec4(0,0,0,1)).xyz / .w (world.glsl:118), in the operation order primary_ray uses for the look-at point
-__host__ __device__ inline void view_origin(const float* m, float ro[3]) {
-    const float ow = m[3] * 0.0f + m[7] * 0.0f + m[11] * 0.0f + m[15] * 1.0f;
-    for (int r = 0; r < 3; ++r) ro[r] = (m[r] * 0.0f + m[4 + r] * 0.0f + m[8 + r] * 0.0f + m[12 + r] * 1.0f) / ow;
 }
 
 // world.glsl:110-129

@@ -68,9 +68,6 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 #define VX_STACK_WRITE_16 "v_lshl_add_u32 %[t1], %[sc], 7, %[lds16]\n ds_write2st64_b32 %[t0], %[ptr], %[tmax] offset1:16\n ds_write_b16_d16_hi %[t1], %[node]\n"
 #define VX_STACK_READ_13 "ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:3328\n ds_read_b32 %[node], %[oct] offset:6656\n"
 #define VX_STACK_READ_16 "v_lshl_add_u32 %[m], %[sc], 7, %[lds16]\n ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:4096\n ds_read_u16_d16_hi %[node], %[m]\n"
-// ... | 12 levels with the 16-bit third plane (7.5 KB a wave: five waves per SIMD), planes 12 x 256 bytes apart
-#define VX_STACK_WRITE_12 "v_lshl_add_u32 %[t1], %[sc], 7, %[lds16]\n ds_write2st64_b32 %[t0], %[ptr], %[tmax] offset1:12\n ds_write_b16_d16_hi %[t1], %[node]\n"
-#define VX_STACK_READ_12 "v_lshl_add_u32 %[m], %[sc], 7, %[lds16]\n ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:3072\n ds_read_u16_d16_hi %[node], %[m]\n"
 // who still traverses, and whether the wave goes on
 #define VX_LOOP_CONTROL(COUNT)                                                                                                     \
         "s_mov_b64 exec, %[s_trav]\n"                                                                                              \
@@ -233,7 +230,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         VX_LOOP_CONTROL(COUNT)                                                                                                     \
         "9:\n"                                                                                                                     \
         /* (the ADVANCE-only tail leaves its entry request in flight: it must have landed before the compiler's code reuses the pair -- */ \
-        /* at five waves per SIMD, where every register is in use, it did not always: one pixel in a few frames differed) */          \
+        /* where every register is in use it did not always: one pixel in a few frames differed) */                                    \
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
         "s_mov_b64 exec, %[entry_exec]\n"
 
@@ -248,7 +245,7 @@ template <int SVO, bool FOREIGN, bool COUNT, int LEVELS>
 __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image, const uint8_t* image_base, uint32_t lds_slot0, uint32_t lds_aux0, uint32_t keep_going,
                                                      uint32_t foreign_waiting, uint32_t foreign_min, uint32_t& trips) {
     static_assert(SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE, "cursors on a traversal image");
-    static_assert(LEVELS == 12 || LEVELS == 13 || LEVELS == 16, "stack layouts: Stack<64, true, true, 13>, Stack<64, true, true, 16, true>, Stack<64, true, true, 12, true>");
+    static_assert(LEVELS == 13 || LEVELS == 16, "stack layouts: Stack<64, true, true, 13>, Stack<64, true, true, 16, true>");
     constexpr bool UNITS = SVO == VX_SVO_IMAGE_WIDE;
     uint32_t t0, t1, t2, oct, m, nx, ny, nz;
     float crx, cry, crz, tcm, tvm, tq, hf, hm, ot, sx;
@@ -282,7 +279,7 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
 #define VX_LOOP_PICK_true(a, b) a
 #define VX_LOOP_PICK_false(a, b) b
     // (two pairs of fixed registers -- the entry a trip requests, the 64-bit address of it in the wide layout: an asm operand cannot name the
-    // halves of a pair -- at the top of the build's register budget: 128 at four waves per SIMD, 96 at five)
+    // halves of a pair -- at the top of the build's register budget: 128 at four waves per SIMD)
 #define VX_E0 "124"
 #define VX_E1 "125"
 #define VX_A0 "122"
@@ -291,18 +288,6 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
     VX_LOOP_VARIANT(false, true, false, 13); VX_LOOP_VARIANT(false, true, false, 16); VX_LOOP_VARIANT(false, true, true, 13); VX_LOOP_VARIANT(false, true, true, 16);
     VX_LOOP_VARIANT(true, false, false, 13); VX_LOOP_VARIANT(true, false, false, 16); VX_LOOP_VARIANT(true, false, true, 13); VX_LOOP_VARIANT(true, false, true, 16);
     VX_LOOP_VARIANT(true, true, false, 13); VX_LOOP_VARIANT(true, true, false, 16); VX_LOOP_VARIANT(true, true, true, 13); VX_LOOP_VARIANT(true, true, true, 16);
-#undef VX_E0
-#undef VX_E1
-#undef VX_A0
-#undef VX_A1
-#define VX_E0 "94"
-#define VX_E1 "95"
-#define VX_A0 "92"
-#define VX_A1 "93"
-    VX_LOOP_VARIANT(false, false, false, 12); VX_LOOP_VARIANT(false, false, true, 12);
-    VX_LOOP_VARIANT(false, true, false, 12); VX_LOOP_VARIANT(false, true, true, 12);
-    VX_LOOP_VARIANT(true, false, false, 12); VX_LOOP_VARIANT(true, false, true, 12);
-    VX_LOOP_VARIANT(true, true, false, 12); VX_LOOP_VARIANT(true, true, true, 12);
 #undef VX_E0
 #undef VX_E1
 #undef VX_A0
