@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s (primary + shadow) at 1920x1080 on a synthetic depth-12 SVO (BASELINE.json).
 
-One "step" = one frame: vx_render of this rank's screen tiles (primary ray, shading, one shadow ray per lit pixel,
-sky) plus, for N > 1, the RCCL gather of the finished tiles to rank 0 and their assembly into the image.
+One "step" = one frame of a camera that MOVES EVERY FRAME, as the reference's frame loop moves it (src/gamelogic/game.rs:111-148): the
+view turns by a quarter of a degree and walks a twelfth of a block per frame. A frame = vx_render of this rank's screen tiles (primary
+ray, shading, one shadow ray per lit pixel, sky) plus, for N > 1, the RCCL gather of the finished tiles to rank 0 and their assembly.
 
     python bench.py                      # 1 GPU, C3 workload (configs[2] of BASELINE.json)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line. `roofline.achieved` = algorithmic bytes per launch (step counters of the instrumented
-kernel variant x the byte model of DESIGN.md) / the render kernel's average duration, measured with HIP events on the
-stream it is launched on. `cpu_baseline` = the C oracle (restatement of the reference's GLSL; the reference has no CPU
-raycast) timed on this box's host cores over a bounded sample of the same frame.
+Rank 0 prints ONE JSON line. `value` = the rays of the K timed frames / their time. `roofline.achieved` = algorithmic bytes per launch
+(step counters of the instrumented kernel variant x the byte model of DESIGN.md, averaged over the K views) / the render kernel's
+average duration, measured with HIP events on the stream it is launched on. `still_view` = the same with a camera that stands still
+(round 3's headline). `cpu_baseline` = the C oracle (restatement of the reference's GLSL; the reference has no CPU raycast) timed on
+this box's host cores over a bounded sample of the first view's frame.
 """
 import argparse
 import json
@@ -25,6 +27,10 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s achievable)
+PROFILE_ROUNDS = ("round4", "round3", "round2", "round1")
+
+
+# ---- byte models ---------------------------------------------------------------------------------------------------
 
 
 def algorithmic_bytes(fmt, c):
@@ -43,11 +49,19 @@ def algorithmic_bytes(fmt, c):
     return trav + shade
 
 
+def image_model_bytes(c):
+    """What the kernel that is TIMED fetches by the same accounting: it walks the traversal image, whichever format the world is
+    in -- one 8-byte entry per PUSH, a 4-byte value + the 32-byte material row + texel(s) per leaf test, nothing per iteration --
+    plus the same per-pixel terms."""
+    nearest = c["leaf_tests"] - c["leaf_tests_trilinear"]
+    return 8 * c["pushes"] + c["leaf_tests"] * (4 + 32) + nearest * 4 + c["leaf_tests_trilinear"] * 32 + 16 * c["pixels"] + c["lit_pixels"] * (32 + 4)
+
+
 def measured_traffic(fmt):
     """HBM-side bytes per launch of the render kernel on this workload: a STORED artifact -- the committed rocprofv3 --pmc passes
-    of this same command (profiles/round3/profile_r3.sh -> profiles/round3/traffic.json, which names the commit it was measured at); PMC
+    of this same command (profiles/roundN/profile.sh -> profiles/roundN/traffic.json, which names the commit it was measured at); PMC
     counters cannot be read from inside this run. Returns (bytes, source) or (None, None)."""
-    for rnd in ("round3", "round2", "round1"):
+    for rnd in PROFILE_ROUNDS:
         try:
             t = json.loads((ROOT / "profiles" / rnd / "traffic.json").read_text())
             return t[fmt]["bytes_per_launch"], f"profiles/{rnd}/traffic.json" + (f" @ {t['commit']}" if "commit" in t else "")
@@ -60,30 +74,369 @@ def issue_model(fmt):
     """What bounds the kernel in practice: instruction issue. STORED artifacts: the render kernel's instruction counts per launch from the
     committed --pmc passes (traffic.json: SQ_INSTS_VALU / SALU / VMEM_RD / LDS / SMEM) and the measured cost of an instruction with four
     waves on a SIMD (issue_model.json: profiles/tools/valu_issue.hip). Returns a dict or None."""
-    try:
-        t = json.loads((ROOT / "profiles" / "round3" / "traffic.json").read_text())
-        m = json.loads((ROOT / "profiles" / "round3" / "issue_model.json").read_text())
-        r = t[fmt]
-        insts = sum(float(r.get(k) or 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
-        clock = float(m["clock_mhz"][fmt])
-        bound_ms = insts * float(m["simd_cycles_per_instruction"]) / float(m["simds"]) / (clock * 1e3)
-        return {"bound": "instruction issue (every SIMD issuing its waves' instructions back to back)", "instructions_per_launch": int(insts),
-                "valu_per_launch": int(r["SQ_INSTS_VALU"]), "salu_per_launch": int(r["SQ_INSTS_SALU"]), "valu_lane_utilisation": r.get("valu_lane_utilisation"),
-                "simd_cycles_per_instruction": m["simd_cycles_per_instruction"], "simds": m["simds"], "clock_mhz_in_kernel": clock,
-                "issue_bound_ms": round(bound_ms, 4), "source": f"profiles/round3/traffic.json @ {t.get('commit', '?')}, profiles/round3/issue_model.json"}
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+    for rnd in PROFILE_ROUNDS:
+        try:
+            t = json.loads((ROOT / "profiles" / rnd / "traffic.json").read_text())
+            m = json.loads((ROOT / "profiles" / "round3" / "issue_model.json").read_text())
+            r = t[fmt]
+            insts = sum(float(r.get(k) or 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
+            clock = float(m["clock_mhz"][fmt])
+            bound_ms = insts * float(m["simd_cycles_per_instruction"]) / float(m["simds"]) / (clock * 1e3)
+            return {"bound": "instruction issue (every SIMD issuing its waves' instructions back to back)", "instructions_per_launch": int(insts),
+                    "valu_per_launch": int(r["SQ_INSTS_VALU"]), "salu_per_launch": int(r["SQ_INSTS_SALU"]), "valu_lane_utilisation": r.get("valu_lane_utilisation"),
+                    "wait_share_of_wave_cycles": (round(r["SQ_WAIT_ANY"] / r["SQ_WAVE_CYCLES"], 3) if r.get("SQ_WAIT_ANY") and r.get("SQ_WAVE_CYCLES") else None),
+                    "simd_cycles_per_instruction": m["simd_cycles_per_instruction"], "simds": m["simds"], "clock_mhz_in_kernel": clock,
+                    "issue_bound_ms": round(bound_ms, 4), "source": f"profiles/{rnd}/traffic.json @ {t.get('commit', '?')}, profiles/round3/issue_model.json"}
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
 
 
-def image_model_bytes(c):
-    """What the kernel that is TIMED fetches by the same accounting: it walks the traversal image, whichever format the world is
-    in -- one 8-byte entry per PUSH, a 4-byte value + the 32-byte material row + texel(s) per leaf test, nothing per iteration --
-    plus the same per-pixel terms."""
-    nearest = c["leaf_tests"] - c["leaf_tests_trilinear"]
-    return 8 * c["pushes"] + c["leaf_tests"] * (4 + 32) + nearest * 4 + c["leaf_tests_trilinear"] * 32 + 16 * c["pixels"] + c["lit_pixels"] * (32 + 4)
+# ---- the workload -----------------------------------------------------------------------------------------------------------------
 
 
-def main():
+def moving_uniforms(scenes, depth, h_max, W, H, i):
+    """Frame i of the camera's path: the §8d view, turned by a quarter of a degree a frame about the vertical and walked forward at 5
+    blocks a second (at 60 frames a second). Every primary hit casts its shadow ray ("primary + 1 shadow ray" of configs[2]): the game's
+    default cut-off of 500 blocks would cast almost none from this altitude (the `shadow_distance_500` object)."""
+    n = float(1 << depth)
+    a = math.radians(0.25 * i)
+    fwd = (0.6 * math.cos(a) - 0.7 * math.sin(a), -0.35, 0.6 * math.sin(a) + 0.7 * math.cos(a))
+    eye = (0.5 * n + 0.05 * i, h_max + 0.05 * n, 0.5 * n + 0.066 * i)
+    return scenes.render_params_to_uniforms(eye, fwd, (0.0, 1.0, 0.0), math.radians(72.0), W / H, 0.3, (-1.0, -1.0, -1.0), True, 3.0e38)
+
+
+class Workload:
+    """The scene (replicated per GPU: every rank builds and uploads the same serialized SVO), the camera's path and the work per frame of this rank."""
+
+    def __init__(self, args, vra, hip, scenes, rank, world_size, local_rank):
+        self.args, self.rank, self.world_size = args, rank, world_size
+        self.fmt = vra.SVO_ESVO if args.format == "esvo" else vra.SVO_CSVO
+        W, H = args.width, args.height
+        t0 = time.time()
+        self.world = vra.World(self.fmt)
+        self.st = self.world.build_heightfield(args.depth)
+        self.build_s = time.time() - t0
+        self.tex = scenes.asset_textures(ROOT / "tests" / "golden" / "textures") if args.textures == "assets" else scenes.synthetic_textures()
+        self.mats = scenes.synthetic_materials()
+        self.svo = hip.Svo(self.fmt, self.world.size_in_bytes + (16 << 20), device=local_rank)
+        self.svo.set_materials(self.mats)
+        self.svo.set_textures(self.tex, 6)
+        t0 = time.time()
+        self.svo.update(self.world)
+        self.upload_s = time.time() - t0
+        # the K views of a timed block (every block walks the same path: its first view follows its last one, a cut)
+        self.path = [moving_uniforms(scenes, args.depth, self.st["h_max"], W, H, i) for i in range(args.steps)]
+        self.still = scenes.bench_camera(args.depth, self.st["h_max"], W, H, shadow_distance=3.0e38, render_shadows=True)
+        # work per frame: deterministic for a fixed scene / camera, counted by the instrumented kernel for this rank's tiles
+        self.counters = [self.svo.render_counters(u, W, H, rank, world_size) for u in self.path]
+        self.rays_per_block = sum(c["rays"] for c in self.counters)
+        self.bytes_per_frame = sum(algorithmic_bytes(args.format, c) for c in self.counters) / len(self.counters)
+        self.image_bytes_per_frame = sum(image_model_bytes(c) for c in self.counters) / len(self.counters)
+
+
+class SingleGpu:
+    """Frames into device memory, FRAMES in flight (the library rotates over that many streams; its default is 2): one image per frame in flight."""
+
+    sharded = False
+
+    def __init__(self, args, wl, torch):
+        self.wl, self.svo, self.W, self.H = wl, wl.svo, args.width, args.height
+        self.frames = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else 2
+        self.svo.set_frames_in_flight(self.frames)
+        self.images = [torch.zeros((self.H, self.W, 4), dtype=torch.float32, device="cuda") for _ in range(self.frames)]
+        torch.cuda.synchronize()  # zero fills run on torch's stream, the renderer on its own
+        self.i = 0
+        self.view = None  # None: the path; else one view again and again
+        self.profile_on = False
+
+    def step(self):
+        u = self.view if self.view is not None else self.wl.path[self.i % len(self.wl.path)]
+        self.svo.render_device(u, self.W, self.H, self.images[self.i % self.frames].data_ptr())
+        self.i += 1
+
+    def flush(self):
+        pass
+
+
+class Sharded:
+    """The N > 1 path: every rank renders its tiles of the frame into a compact list, the lists are gathered to rank 0 and assembled.
+    What travels: the tiles as RGBA8 (Framebuffer::as_image's bytes) by default -- the exchange is bound by the links into rank 0, (N - 1) / N of
+    every frame, one xGMI link per peer: a 1080p RGBA32F frame is 33 MB, i.e. 16.6 / 8.3 / 4.2 MB per link at N = 2 / 4 / 8, which at ~77 GB/s a
+    direction is 1.3 x the time the ranks take to RENDER their shares; RGBA8 is a quarter of that, and of rank 0's assembly pass.
+    The exchange: the library's own (vx_gather_tiles: grouped ncclSend / ncclRecv on the render context's communicator and stream), checked on
+    its first frames -- a watchdog on vx_gather_query (a collective a peer never joins must not hang the run) and rank 0's assembled frame
+    against the whole frame rendered on its own GPU --, or torch.distributed.gather (nccl backend = RCCL as well) if that fails, in the
+    same process (never re-exec a process that has touched the GPU)."""
+
+    sharded = True
+
+    def __init__(self, args, wl, torch, dist, hip, rank, world_size):
+        from voxel_rs_amd.sharding import FrameSharder
+
+        self.args, self.wl, self.svo, self.torch, self.dist, self.hip = args, wl, wl.svo, torch, dist, hip
+        self.rank, self.world_size, self.W, self.H = rank, world_size, args.width, args.height
+        self.FrameSharder = FrameSharder
+        self.vx_fmt = hip.VX_FORMAT_RGBA8 if args.gather_format == "rgba8" else hip.VX_FORMAT_RGBA32F
+        # frames in flight: the smaller a rank's share of the frame, the longer its tail relative to its body (a frame cannot
+        # finish before its longest ray) and the more frames it takes to keep the device full
+        frames = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else min(8, max(3, world_size))
+        # frames per collective (1: every frame is gathered as soon as it is rendered; more: fewer, larger messages)
+        self.group = max(1, min(args.gather_group if args.gather_group else 1, frames))
+        self.frames = frames - frames % self.group
+        self.svo.set_frames_in_flight(self.frames)
+        self.i = 0
+        self.view = None
+        self.last_view = None
+        self.profile_on = False
+        self.gather_events = []  # torch path: (start, stop) event pairs around the collective, on torch's stream
+        self.gather_used, self.gather_note, self.comm_hung = None, None, False
+        self.sharder = None
+        self._choose_exchange()
+
+    # -- one frame
+    def _render_tiles(self, tiles):
+        u = self.view if self.view is not None else self.wl.path[self.i % len(self.wl.path)]
+        self.last_view = u
+        self.svo.render_device(u, self.W, self.H, tiles.data_ptr(), tile_rank=self.rank, tile_count=self.world_size, fmt=self.vx_fmt)
+        self.i += 1
+
+    def step(self):
+        self.sharder.step()
+
+    def flush(self):
+        self.sharder.flush()
+
+    # -- the two exchanges
+    def _build(self, library_gather):
+        torch, svo, dist, rank, world_size, args = self.torch, self.svo, self.dist, self.rank, self.world_size, self.args
+        FRAMES, GROUP, W, H, vx_fmt = self.frames, self.group, self.W, self.H, self.vx_fmt
+        exchange_stream = svo.comm_stream if library_gather else torch.cuda.current_stream().cuda_stream
+        exchange_done = [torch.cuda.Event() for _ in range(FRAMES // GROUP)]
+        recorded = [False] * (FRAMES // GROUP)
+        tickets = {}
+        state = {"last_ticket": None}
+
+        def assemble(gathered, image):
+            # on the exchange's stream: ordered after the gather by construction, and the render streams stay free for the
+            # next frame's tiles. `gathered` is [rank][tile]... with the ranks a whole group of frames apart.
+            svo.assemble_tiles_format(gathered.data_ptr(), gathered.stride(0) // 4, world_size, W, H, image.data_ptr(), vx_fmt, exchange_stream)
+
+        def before_render(g):
+            # a render into a tile list waits for whatever still reads it: the gather AND rank 0's assembly (the ticket covers both)
+            if library_gather:
+                if g in tickets:
+                    svo.wait_gather(tickets[g])
+            elif recorded[g]:
+                svo.wait_event(exchange_done[g].cuda_event)
+
+        def after_render():
+            if not library_gather:
+                svo.stream_wait_render(torch.cuda.current_stream().cuda_stream)
+
+        def after_exchange(g):
+            if library_gather:
+                if rank == 0:
+                    tickets[g] = state["last_ticket"]  # (re-recorded behind the assembly by vx_assemble_tiles_format)
+            else:
+                exchange_done[g].record(torch.cuda.current_stream())
+                recorded[g] = True
+
+        def gather(tiles, gathered):
+            g = sh._g  # (the group being exchanged)
+            if library_gather:
+                if args.simulate_gather_failure:
+                    raise RuntimeError("simulated failure of the library's gather (--simulate-gather-failure)")
+                state["last_ticket"] = tickets[g] = svo.gather_tiles(tiles.data_ptr(), tiles.numel() * tiles.element_size(),
+                                                                    gathered.data_ptr() if rank == 0 else None, root=0)
+            else:
+                if self.profile_on:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                dist.gather(tiles, [gathered[r] for r in range(world_size)] if rank == 0 else None, dst=0)
+                if self.profile_on:
+                    ev[1].record()
+                    self.gather_events.append(ev)
+
+        sh = self.FrameSharder(W, H, rank, world_size, dist, "cuda", self._render_tiles, assemble, before_render=before_render, after_render=after_render,
+                               after_exchange=after_exchange, buffers=FRAMES, group=GROUP, gather=gather, pixel_format=args.gather_format)
+        if not library_gather:
+            # (torch's gather wants its own send buffer: the root's list is not rendered in place)
+            sh.tiles = [torch.zeros((GROUP, sh.n_max, 32, 32, 4), dtype=sh.dtype, device="cuda") for _ in range(FRAMES // GROUP)]
+            torch.cuda.synchronize()
+        sh.query = (lambda: svo.gather_query(state["last_ticket"]) if state["last_ticket"] is not None else 1) if library_gather else None
+        return sh
+
+    def whole_frame(self, u):
+        torch = self.torch
+        img = torch.zeros((self.H, self.W, 4), dtype=torch.uint8 if self.vx_fmt == self.hip.VX_FORMAT_RGBA8 else torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        self.svo.render_device(u, self.W, self.H, img.data_ptr(), fmt=self.vx_fmt)
+        self.svo.sync()
+        return img
+
+    def frame_is_whole(self):
+        """rank 0: what the path delivered last, against the same frame rendered whole on this GPU"""
+        sh = self.sharder
+        whole = self.whole_frame(self.last_view)
+        if self.world_size > 1:
+            got = sh.image
+        else:
+            # one rank (--force-sharded): tile_count 1 means "the whole frame, row-major" to vx_render, so this rank's "tile list" is the
+            # frame itself and the assembly kernel (which runs for its cost) scatters something that is no tile list -- the check is
+            # on what the gather delivered. (An RGBA8 frame is stored top row first, a tile list bottom row first: same here, the
+            # "list" IS the frame.)
+            got = sh.last_gathered[0].reshape(-1)[:self.H * self.W * 4].view(self.H, self.W, 4)
+        a, b = whole.contiguous().view(self.torch.uint8), got.contiguous().view(self.torch.uint8)
+        return bool(self.torch.equal(a, b))
+
+    def _first_frames_ok(self, seconds):
+        """GROUP frames through the whole path, watched: the exchange must come back within `seconds` on every rank and rank 0's assembled frame must
+        be the whole render's."""
+        sh, torch = self.sharder, self.torch
+        ok = 1
+        try:
+            for _ in range(self.group):
+                sh.step()
+            sh.flush()
+            if sh.query is not None:
+                deadline = time.time() + seconds
+                while True:
+                    q = sh.query()
+                    if q != 0:
+                        ok = 1 if q == 1 else 0
+                        break
+                    if time.time() > deadline:
+                        ok = 0
+                        break
+                    time.sleep(0.002)
+            if ok:
+                self.svo.sync()
+                torch.cuda.synchronize()
+                if self.rank == 0:
+                    ok = 1 if self.frame_is_whole() else 0
+        except Exception as e:  # an error code from the library (VX_ERR_HIP with RCCL's message), or the simulated one
+            print(f"[bench rank {self.rank}] exchange failed: {e}", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    def _choose_exchange(self):
+        args, torch, dist = self.args, self.torch, self.dist
+        if args.gather in ("auto", "library"):
+            try:
+                # the render context owns the RCCL communicator the tiles travel over (vx_comm_init); torch.distributed only carries the
+                # id to the ranks and the barriers / statistics of this script
+                uid = [self.hip.comm_unique_id() if self.rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                self.svo.comm_init(self.world_size, self.rank, uid[0])
+                self.sharder = self._build(True)
+                init_ok = 1
+            except Exception as e:
+                print(f"[bench rank {self.rank}] vx_comm_init failed: {e}", file=sys.stderr)
+                init_ok = 0
+            flag = torch.tensor([init_ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) and self._first_frames_ok(args.gather_timeout):
+                self.gather_used = "library"
+                return
+            if args.gather == "library":
+                raise SystemExit("--gather library: the library's exchange failed its first frames (see stderr); --gather auto falls back to torch.distributed")
+            # the other exchange, in this process. The library's communicator is left alone (destroying one with a collective in flight can block).
+            self.gather_note = "the library's vx_gather_tiles failed its first frames on this node; fell back in-process"
+            self.comm_hung = True
+        self.sharder = self._build(False)
+        self.gather_used = "torch"
+        if not self._first_frames_ok(args.gather_timeout):
+            self.gather_note = (self.gather_note + "; " if self.gather_note else "") + "torch.distributed.gather's first frames did not reproduce the whole render"
+
+    def exchange_profile(self):
+        """(ms summed, exchanges) of the timed region: time on the exchange's stream from the first send / receive to the last"""
+        if self.gather_used == "library":
+            return self.svo.comm_profile_read()
+        self.torch.cuda.synchronize()
+        out = sum(a.elapsed_time(b) for a, b in self.gather_events), len(self.gather_events)
+        self.gather_events.clear()
+        return out
+
+
+# ---- measurements -----------------------------------------------------------------------------------------------------------------
+
+
+def cpu_baseline(args, wl, orc):
+    """The C oracle on this box's host cores over a bounded sample of the path's first view: all cores (about --cpu-seconds) and one thread (about 4 s)."""
+    W, H = args.width, args.height
+    scene = orc.OracleScene(wl.fmt, wl.world.frame(), wl.mats.view(orc.MATERIAL_DTYPE), wl.tex, 6)
+    ou = orc.Uniforms.from_buffer_copy(bytes(wl.path[0]))
+    cores = orc.lib().or_max_threads()
+    # warm up the thread pool and the page cache on a thin band, then time one band of a tenth of the frame to decide
+    # between whole frames and bands (a frame this size takes well under a second on a server CPU)
+    scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 8), want_hits=False, counters=orc.Counters(), threads=cores)
+    t0 = time.perf_counter()
+    scene.render(ou, W, H, rect=(0, H // 2 - H // 20, W, H // 2 + H // 20), want_hits=False, counters=orc.Counters(), threads=cores)
+    frame_estimate_s = 10.0 * (time.perf_counter() - t0)
+    cc = orc.Counters()
+    if frame_estimate_s <= args.cpu_seconds:
+        reps = 0
+        t0 = time.perf_counter()
+        while reps < 400 and (reps == 0 or time.perf_counter() - t0 < args.cpu_seconds):
+            scene.render(ou, W, H, want_hits=False, counters=cc, threads=cores)
+            reps += 1
+        cpu_s = time.perf_counter() - t0
+        sample = f"{reps} x the whole {W}x{H} frame"
+    else:
+        bands = 8
+        band_h = max(int(H * args.cpu_seconds / frame_estimate_s) // bands, 1)
+        t0 = time.perf_counter()
+        for b in range(bands):
+            y0 = int((b + 0.5) * H / bands) - band_h // 2
+            scene.render(ou, W, H, rect=(0, max(y0, 0), W, min(y0 + band_h, H)), want_hits=False, counters=cc, threads=cores)
+        cpu_s = time.perf_counter() - t0
+        sample = f"{bands} bands x {band_h} rows of the {W}x{H} frame"
+    # and on ONE thread (BASELINE.md §2: "1 thread, and all host cores"): bands of rows spread over the frame, about 4 s of work
+    c1 = orc.Counters()
+    scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 2), want_hits=False, counters=c1, threads=1)  # (warm)
+    t0 = time.perf_counter()
+    scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 16), want_hits=False, counters=c1, threads=1)
+    per_row_s = (time.perf_counter() - t0) / 16
+    rows = max(2, min(H // 8, int(4.0 / max(per_row_s, 1e-6)) // 8))
+    c1 = orc.Counters()
+    t0 = time.perf_counter()
+    for b in range(8):
+        y0 = int((b + 0.5) * H / 8) - rows // 2
+        scene.render(ou, W, H, rect=(0, max(y0, 0), W, min(y0 + rows, H)), want_hits=False, counters=c1, threads=1)
+    one_s = time.perf_counter() - t0
+    return {"value": round(cc.rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{sample} (the path's first view): {cc.rays} rays in {cpu_s:.2f} s (C restatement of the GLSL path, OpenMP; the reference has no CPU raycast)",
+            "single_thread": {"value": round(c1.rays / one_s / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                              "sample": f"8 bands x {rows} rows of the {W}x{H} frame: {c1.rays} rays in {one_s:.2f} s"}}
+
+
+def picker_latency(wl, hip, np):
+    """vx_raycast is synchronous per call, like the reference's fence wait (svo.rs:248-249), and the game's physics calls it at 250 Hz
+    (src/gamelogic/game.rs:90,130-134): a batch of 80 tasks (the reference's own: one entity's AABB fan, svo_picker.rs:311-536) and C1's 65,536."""
+    out = {}
+    n = float(1 << wl.args.depth)
+    rng = np.random.default_rng(1)
+    for name, count in (("reference_batch_80", 80), ("c1_65536", 65536)):
+        tasks = np.zeros(count, dtype=hip.PICKER_TASK_DTYPE)
+        tasks["pos"] = (np.float32([0.5 * n, wl.st["h_max"] + 4.0, 0.5 * n]) + rng.uniform(-8, 8, size=(count, 3))).astype(np.float32)
+        d = rng.normal(size=(count, 3))
+        tasks["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        tasks["max_dst"] = 32.0
+        for _ in range(5):
+            wl.svo.raycast(tasks)
+        reps = 200 if count < 1000 else 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            wl.svo.raycast(tasks)
+        us = (time.perf_counter() - t0) / reps * 1e6
+        out[name] = {"rays": count, "us_per_call": round(us, 2), "Mrays_s": round(count / us, 3)}
+    return out
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -105,14 +458,17 @@ def main():
     ap.add_argument("--gather-timeout", type=float, default=30.0, help="sharded: seconds the first exchange may take before it is declared hung")
     ap.add_argument("--simulate-gather-failure", action="store_true", help="testing: make the library's exchange fail, to exercise the fall-back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sd500", action="store_true", help="skip the second line (the same frame with the game's shadow_distance = 500): profiler runs, whose per-kernel averages it would dilute")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary blocks (still view, shadow_distance 500, picker): profiler runs, whose per-kernel averages they would dilute")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (tile lists, RCCL gather, assembly) even with one rank; needs a torch.distributed.run launch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock target for the cpu_baseline sample (all host cores)")
     ap.add_argument("--textures", choices=["assets", "procedural"], default="assets",
                     help="assets: the reference's own 64x64 textures (tests/golden/textures) for the blocks the terrain uses")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
     import numpy as np
     import torch
 
@@ -145,426 +501,167 @@ def main():
             os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
-    fmt = vra.SVO_ESVO if args.format == "esvo" else vra.SVO_CSVO
     W, H = args.width, args.height
-
-    # ---- scene: replicated per GPU (every rank builds and uploads the same serialized SVO) ------------------------------
-    t0 = time.time()
-    world = vra.World(fmt)
-    st = world.build_heightfield(args.depth)
-    build_s = time.time() - t0
-    tex = scenes.asset_textures(ROOT / "tests" / "golden" / "textures") if args.textures == "assets" else scenes.synthetic_textures()
-    mats = scenes.synthetic_materials()
-    svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20), device=local_rank)
-    svo.set_materials(mats)
-    svo.set_textures(tex, 6)
-    t0 = time.time()
-    svo.update(world)
-    upload_s = time.time() - t0
-    # every primary hit casts its shadow ray ("primary + 1 shadow ray" of configs[2]); the game's default cut-off of
-    # 500 blocks would cast almost none from this altitude
-    uniforms = scenes.bench_camera(args.depth, st["h_max"], W, H, shadow_distance=3.0e38, render_shadows=True)
-
-    # ---- work per frame: deterministic for a fixed scene/camera -----------------------------------------------------------
-    counters = svo.render_counters(uniforms, W, H, rank, world_size)
-    my_rays = counters["rays"]
-    my_bytes = algorithmic_bytes(args.format, counters)
-
-    gather_used, gather_note, comm_hung = None, None, False
-    if sharded:
-        from voxel_rs_amd.sharding import FrameSharder
-
-        # What travels: the tiles as RGBA8 (Framebuffer::as_image's bytes, vx_format) by default. The exchange is bound by the links
-        # into rank 0 -- (N - 1) / N of every frame, one xGMI link per peer: a 1080p RGBA32F frame is 33 MB, i.e. 16.6 / 8.3 / 4.2 MB
-        # per link at N = 2 / 4 / 8, which at ~77 GB/s a direction is 1.3 x the time the ranks take to RENDER their shares; RGBA8 is
-        # a quarter of that, and a quarter of rank 0's assembly pass.
-        vx_fmt = hip.VX_FORMAT_RGBA8 if args.gather_format == "rgba8" else hip.VX_FORMAT_RGBA32F
-        # frames in flight: the smaller a rank's share of the frame, the longer its tail relative to its body (a frame cannot
-        # finish before its longest ray) and the more frames it takes to keep the device full
-        FRAMES = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else min(8, max(3, world_size))
-        # frames per collective (1: every frame is gathered as soon as it is rendered; more: fewer, larger messages)
-        GROUP = args.gather_group if args.gather_group else 1
-        GROUP = max(1, min(GROUP, FRAMES))
-        FRAMES -= FRAMES % GROUP
-        svo.set_frames_in_flight(FRAMES)
-        gather_events = []  # torch path: (start, stop) event pairs around the collective, on torch's stream
-
-        def render_tiles(tiles):
-            svo.render_device(uniforms, W, H, tiles.data_ptr(), tile_rank=rank, tile_count=world_size, fmt=vx_fmt)
-
-        def build_sharder(library_gather):
-            """The whole N > 1 path with one of the two exchanges: the library's own (vx_gather_tiles: grouped ncclSend / ncclRecv on the
-            render context's communicator and stream) or torch.distributed.gather (nccl backend = RCCL as well)."""
-            exchange_stream = svo.comm_stream if library_gather else torch.cuda.current_stream().cuda_stream
-            exchange_done = [torch.cuda.Event() for _ in range(FRAMES // GROUP)]
-            recorded = [False] * (FRAMES // GROUP)
-            tickets = {}
-
-            def assemble(gathered, image):
-                # on the exchange's stream: ordered after the gather by construction, and the render streams stay free for the
-                # next frame's tiles. `gathered` is [rank][tile]... with the ranks a whole group of frames apart.
-                svo.assemble_tiles_format(gathered.data_ptr(), gathered.stride(0) // 4, world_size, W, H, image.data_ptr(), vx_fmt, exchange_stream)
-
-            def before_render(g):
-                # a render into a tile list waits for whatever still reads it: the gather AND rank 0's assembly (the ticket covers both)
-                if library_gather:
-                    if g in tickets:
-                        svo.wait_gather(tickets[g])
-                elif recorded[g]:
-                    svo.wait_event(exchange_done[g].cuda_event)
-
-            def after_render():
-                if not library_gather:
-                    svo.stream_wait_render(torch.cuda.current_stream().cuda_stream)
-
-            def after_exchange(g):
-                if library_gather:
-                    if rank == 0:
-                        tickets[g] = state["last_ticket"]  # (re-recorded behind the assembly by vx_assemble_tiles_format)
-                else:
-                    exchange_done[g].record(torch.cuda.current_stream())
-                    recorded[g] = True
-
-            state = {"last_ticket": None}
-
-            def gather(tiles, gathered):
-                g = sh._g  # (the group being exchanged)
-                if library_gather:
-                    if args.simulate_gather_failure:
-                        raise RuntimeError("simulated failure of the library's gather (--simulate-gather-failure)")
-                    state["last_ticket"] = tickets[g] = svo.gather_tiles(tiles.data_ptr(), tiles.numel() * tiles.element_size(),
-                                                                        gathered.data_ptr() if rank == 0 else None, root=0)
-                else:
-                    timed = svo_profile["on"]
-                    if timed:
-                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                        ev[0].record()
-                    dist.gather(tiles, [gathered[r] for r in range(world_size)] if rank == 0 else None, dst=0)
-                    if timed:
-                        ev[1].record()
-                        gather_events.append(ev)
-
-            sh = FrameSharder(W, H, rank, world_size, dist, "cuda", render_tiles, assemble, before_render=before_render, after_render=after_render,
-                              after_exchange=after_exchange, buffers=FRAMES, group=GROUP, gather=gather, pixel_format=args.gather_format)
-            if not library_gather:
-                # (torch's gather wants its own send buffer: the root's list is not rendered in place)
-                sh.tiles = [torch.zeros((GROUP, sh.n_max, 32, 32, 4), dtype=sh.dtype, device="cuda") for _ in range(FRAMES // GROUP)]
-                torch.cuda.synchronize()
-            sh.query = (lambda: svo.gather_query(state["last_ticket"]) if state["last_ticket"] is not None else 1) if library_gather else None
-            return sh
-
-        svo_profile = {"on": False}
-
-        def whole_frame():
-            img = torch.zeros((H, W, 4), dtype=torch.uint8 if vx_fmt == hip.VX_FORMAT_RGBA8 else torch.float32, device="cuda")
-            torch.cuda.synchronize()
-            svo.render_device(uniforms, W, H, img.data_ptr(), fmt=vx_fmt)
-            svo.sync()
-            return img
-
-        def frame_is_whole(sh):
-            """rank 0: what the path delivered, against the same frame rendered whole on this GPU"""
-            whole = whole_frame()
-            if world_size > 1:
-                got = sh.image
-            else:
-                # one rank (--force-sharded): tile_count 1 means "the whole frame, row-major" to vx_render, so this rank's "tile list" is the
-                # frame itself and the assembly kernel (which runs for its cost) scatters something that is no tile list -- the check is
-                # on what the gather delivered. (An RGBA8 frame is stored top row first, a tile list bottom row first: same here, the
-                # "list" IS the frame.)
-                got = sh.last_gathered[0].reshape(-1)[:H * W * 4].view(H, W, 4)
-            a, b = whole.contiguous().view(torch.uint8), got.contiguous().view(torch.uint8)
-            return bool(torch.equal(a, b))
-
-        def first_frames_ok(sh, seconds):
-            """GROUP frames through the whole path, watched: the exchange must come back within `seconds` on every rank (a collective a
-            peer never joins would otherwise hang the benchmark) and rank 0's assembled frame must be the whole render's."""
-            ok = 1
-            try:
-                for _ in range(GROUP):
-                    sh.step()
-                sh.flush()
-                if sh.query is not None:
-                    deadline = time.time() + seconds
-                    while True:
-                        q = sh.query()
-                        if q != 0:
-                            ok = 1 if q == 1 else 0
-                            break
-                        if time.time() > deadline:
-                            ok = 0
-                            break
-                        time.sleep(0.002)
-                if ok:
-                    svo.sync()
-                    torch.cuda.synchronize()
-                    if rank == 0:
-                        ok = 1 if frame_is_whole(sh) else 0
-            except Exception as e:  # an error code from the library (VX_ERR_HIP with RCCL's message), or the simulated one
-                print(f"[bench rank {rank}] exchange failed: {e}", file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            return bool(int(flag.item()))
-
-        want_library = args.gather in ("auto", "library")
-        sharder = None
-        if want_library:
-            try:
-                # the render context owns the RCCL communicator the tiles travel over (vx_comm_init); torch.distributed only carries the
-                # id to the ranks and the barriers / statistics of this script
-                uid = [hip.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                svo.comm_init(world_size, rank, uid[0])
-                sharder = build_sharder(True)
-                init_ok = 1
-            except Exception as e:
-                print(f"[bench rank {rank}] vx_comm_init failed: {e}", file=sys.stderr)
-                init_ok = 0
-            flag = torch.tensor([init_ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) and first_frames_ok(sharder, args.gather_timeout):
-                gather_used = "library"
-            elif args.gather == "library":
-                raise SystemExit("--gather library: the library's exchange failed its first frames (see stderr); --gather auto falls back to torch.distributed")
-            else:
-                # never re-exec a process that has touched the GPU: the other exchange, in this process. The library's communicator is left
-                # alone (destroying one with a collective in flight can block).
-                gather_note = "the library's vx_gather_tiles failed its first frames on this node; fell back in-process"
-                comm_hung = True
-                sharder = None
-        if sharder is None:
-            sharder = build_sharder(False)
-            gather_used = "torch"
-            if not first_frames_ok(sharder, args.gather_timeout):
-                gather_note = (gather_note + "; " if gather_note else "") + "torch.distributed.gather's first frames did not reproduce the whole render"
-        step = sharder.step
-        flush = sharder.flush
-    else:
-        # frames in flight (the library rotates over that many streams; its default is 2): one image per frame in flight
-        FRAMES = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else 2
-        svo.set_frames_in_flight(FRAMES)
-        images = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(FRAMES)]
-        torch.cuda.synchronize()  # zero fills run on torch's stream, the renderer on its own
-        state = {"i": 0}
-
-        def step():
-            svo.render_device(uniforms, W, H, images[state["i"] % FRAMES].data_ptr())
-            state["i"] += 1
-
-        def flush():
-            pass
+    wl = Workload(args, vra, hip, scenes, rank, world_size, local_rank)
+    svo = wl.svo
+    run = Sharded(args, wl, torch, dist, hip, rank, world_size) if sharded else SingleGpu(args, wl, torch)
 
     def barrier():
-        flush()  # (sharded: a group of frames that has not been exchanged yet)
+        run.flush()  # (sharded: a group of frames that has not been exchanged yet)
         svo.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_blocks(repeats):
+        """--steps frames between two barriers, `repeats` times back to back: block times and host issue times"""
+        blocks, enqueue = [], []
+        for _ in range(max(repeats, 1)):
+            barrier()
+            run.i = 0  # every block walks the path from its first view
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run.step()
+            enqueue.append(time.perf_counter() - t0)  # host time to issue the steps (the loop is asynchronous)
+            barrier()
+            blocks.append(time.perf_counter() - t0)
+        return blocks, enqueue
+
     for _ in range(args.warmup):
-        step()
+        run.step()
     barrier()
     # The timed block -- exactly --steps frames between two barriers -- is run --repeats times back to back and the MEDIAN block is
     # what is reported: 50 frames are 25 ms of GPU time, too little for one sample to stand on.
     svo.profile_enable(True)
-    if sharded:
-        svo_profile["on"] = True
-    blocks, enqueue = [], []
-    for _ in range(max(args.repeats, 1)):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        enqueue.append(time.perf_counter() - t0)  # host time to issue the steps (the loop is asynchronous)
-        barrier()
-        blocks.append(time.perf_counter() - t0)
+    run.profile_on = True
+    blocks, enqueue = timed_blocks(args.repeats)
     kernel_ms, launches = svo.profile_read()
-    # the exchanges of the timed region: time on the exchange's stream from the first send / receive to the last (the wait for the
-    # slowest peer included)
-    gather_ms, gathers = 0.0, 0
-    if sharded:
-        svo_profile["on"] = False
-        if gather_used == "library":
-            gather_ms, gathers = svo.comm_profile_read()
-        else:
-            torch.cuda.synchronize()
-            gather_ms, gathers = sum(a.elapsed_time(b) for a, b in gather_events), len(gather_events)
-            gather_events.clear()
+    gather_ms, gathers = run.exchange_profile() if sharded else (0.0, 0)
+    run.profile_on = False
     svo.profile_enable(False)
     enqueue_s = sorted(enqueue)[len(enqueue) // 2]
 
     # One frame at a time (outside the timed region): with several frames in flight a kernel's HIP-event span includes the time it
     # shares the device with its neighbours, so the kernel's OWN duration -- what the roofline fraction is defined on -- is measured
-    # with the device to itself, twice:
+    # with the device to itself, over the path's views, twice:
     #  (a) the timed region's own launch policy: the frame streams, every frame waited for before the next is issued;
-    #  (b) the library's one-frame-at-a-time mode (set_frames_in_flight(1): the context's own stream, where it hands out a view's
-    #      sub-tiles most expensive first -- the table is made from the frame before last -- so that the longest rays start early):
-    #      what a consumer that presents every frame runs, and the same command rocprofv3 is run on for profiles/ (VX_FRAMES_IN_FLIGHT=1).
-    barrier()
-    svo.profile_enable(True)
-    for _ in range(20):
-        step()
-        flush()
-        svo.sync()
-    barrier()
-    exclusive_ms, exclusive_launches = svo.profile_read()
-    if sharded and gather_used == "library":
-        svo.comm_profile_read()
-    svo.profile_enable(False)
-    kernel_exclusive_frame_stream_ms = exclusive_ms / max(exclusive_launches, 1)
+    #  (b) the library's one-frame-at-a-time mode (set_frames_in_flight(1): the context's own stream): what a consumer that presents
+    #      every frame runs, and the same command rocprofv3 is run on for profiles/ (--frames-in-flight 1).
+    def exclusive(n):
+        barrier()
+        run.i = 0
+        svo.profile_enable(True)
+        for _ in range(n):
+            run.step()
+            run.flush()
+            svo.sync()
+        barrier()
+        ms, k = svo.profile_read()
+        if sharded and run.gather_used == "library":
+            svo.comm_profile_read()
+        svo.profile_enable(False)
+        return ms / max(k, 1)
+
+    kernel_exclusive_frame_stream_ms = exclusive(min(args.steps, 25))
     kernel_exclusive_ms = kernel_exclusive_frame_stream_ms
     if not sharded:
         svo.set_frames_in_flight(1)
         for _ in range(4):
-            step()
-        barrier()
-        svo.profile_enable(True)
-        for _ in range(20):
-            step()
-        barrier()
-        exclusive_ms, exclusive_launches = svo.profile_read()
-        svo.profile_enable(False)
-        svo.set_frames_in_flight(FRAMES)
-        kernel_exclusive_ms = exclusive_ms / max(exclusive_launches, 1)
+            run.step()
+        kernel_exclusive_ms = exclusive(min(args.steps, 25))
+        svo.set_frames_in_flight(run.frames)
 
-    # The game's own shadow cut-off (500 blocks, src/gamelogic/world.rs:105-108; SURVEY.md 8d asks for both): the same frame with
-    # shadow_distance = 500 -- from this altitude few or no hits are that near, so it is close to a primary-rays-only frame. One GPU only.
-    sd500 = None
-    if not sharded and not args.no_sd500:
-        u500 = scenes.bench_camera(args.depth, st["h_max"], W, H, shadow_distance=500.0, render_shadows=True)
-        rays500 = svo.render_counters(u500, W, H, 0, 1)["rays"]
-        for _ in range(args.warmup):
-            svo.render_device(u500, W, H, images[0].data_ptr())
-        svo.sync()
-        t500 = []
-        for _ in range(5):
-            svo.sync()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                svo.render_device(u500, W, H, images[i % FRAMES].data_ptr())
-            svo.sync()
-            t500.append(time.perf_counter() - t0)
-        ms500 = sorted(t500)[2] / args.steps * 1e3
-        sd500 = {"shadow_distance": 500.0, "rays_per_frame": int(rays500), "ms_per_step": round(ms500, 4), "value": round(rays500 / (ms500 * 1e-3) / 1e6, 3),
-                 "unit": "Mrays/s", "note": "the timed frame casts a shadow ray from every primary hit (shadow_distance = inf); this is the game's default cut-off"}
+    # Secondary blocks (one GPU): the camera standing still (round 3's headline: the same view again and again), the game's own shadow
+    # cut-off (500 blocks, src/gamelogic/world.rs:105-108: from this altitude few or no hits are that near, so it is close to a
+    # primary-rays-only frame; SURVEY.md 8d asks for both), the picker's latency.
+    still, sd500, picker = None, None, None
+    if not sharded and not args.no_extras:
+        def view_block(u, repeats=9):
+            rays = svo.render_counters(u, W, H, 0, 1)["rays"]
+            run.view = u
+            for _ in range(args.warmup):
+                run.step()
+            b, _ = timed_blocks(repeats)
+            run.view = None
+            ms = sorted(b)[len(b) // 2] / args.steps * 1e3
+            return {"rays_per_frame": int(rays), "ms_per_step": round(ms, 4), "value": round(rays / (ms * 1e-3) / 1e6, 3), "unit": "Mrays/s"}
+
+        still = view_block(wl.still)
+        still["note"] = "the §8d view, again and again (round 3's headline; its sorted passes -- a still-view-only gain -- are gone: profiles/round4/pass_k)"
+        sd500 = view_block(scenes.bench_camera(args.depth, wl.st["h_max"], W, H, shadow_distance=500.0, render_shadows=True), 5)
+        sd500.update({"shadow_distance": 500.0, "note": "the timed frames cast a shadow ray from every primary hit (shadow_distance = inf); this is the game's default cut-off, a still view"})
+        picker = picker_latency(wl, hip, np)
 
     times = torch.tensor(blocks, dtype=torch.float64, device="cuda")
-    stats = torch.tensor([float(my_rays), float(my_bytes), kernel_ms / max(launches, 1), kernel_exclusive_ms, gather_ms / max(gathers, 1)],
+    stats = torch.tensor([float(wl.rays_per_block), float(wl.bytes_per_frame), kernel_ms / max(launches, 1), kernel_exclusive_ms, gather_ms / max(gathers, 1)],
                          dtype=torch.float64, device="cuda")
     per_rank = None
     if dist is not None:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)  # per block: the slowest rank
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        total_rays = float(sm[0])
+        total_rays_per_block = float(sm[0])
         every = [torch.zeros_like(stats) for _ in range(world_size)]
         dist.all_gather(every, stats)
-        per_rank = [{"rank": r, "rays": int(e[0]), "kernel_span_ms_in_flight": round(float(e[2]), 4), "kernel_exclusive_ms": round(float(e[3]), 4),
+        per_rank = [{"rank": r, "rays_per_block": int(e[0]), "kernel_span_ms_in_flight": round(float(e[2]), 4), "kernel_exclusive_ms": round(float(e[3]), 4),
                      "exchange_ms": round(float(e[4]), 4)} for r, e in enumerate(every)]
     else:
-        total_rays = float(my_rays)
+        total_rays_per_block = float(wl.rays_per_block)
     block_s = sorted(float(t) for t in times)
     elapsed = block_s[len(block_s) // 2]
     # sharded: the frame rank 0 assembled last against the same frame rendered whole on this GPU (outside the timed region)
-    sharded_frame_identical = None
-    if sharded and rank == 0:
-        sharded_frame_identical = frame_is_whole(sharder)
+    sharded_frame_identical = run.frame_is_whole() if sharded and rank == 0 else None
     if rank != 0:
-        if sharded and gather_used == "library":
+        if sharded and run.gather_used == "library":
             svo.comm_destroy()
         if dist is not None:
             dist.destroy_process_group()
-        if comm_hung:
+        if sharded and run.comm_hung:
             os._exit(0)  # (a communicator with a collective that never completed: its teardown can block)
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = total_rays / (ms_per_step * 1e-3) / 1e6  # Mrays/s, whole job
+    value = total_rays_per_block / elapsed / 1e6  # Mrays/s, whole job
     kernel_avg_ms = kernel_ms / max(launches, 1)
+    my_bytes = wl.bytes_per_frame
     achieved = my_bytes / (kernel_exclusive_ms * 1e-3) / 1e9 if kernel_exclusive_ms > 0 else 0.0
-    traffic, traffic_source = measured_traffic(args.format) if (W, H, args.depth, world_size) == (1920, 1080, 12, 1) else (None, None)
+    reference_shape = (W, H, args.depth, world_size) == (1920, 1080, 12, 1)
+    traffic, traffic_source = measured_traffic(args.format) if reference_shape else (None, None)
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "traffic_source": traffic_source, "kernel": "render_persistent",
-                # achieved = algorithmic bytes per launch / the kernel's own duration: one frame at a time on one stream, HIP events around
-                # each launch (20 launches after the timed region); the same figure as rocprofv3's average with VX_FRAMES_IN_FLIGHT=1
-                "kernel_exclusive_ms": round(kernel_exclusive_ms, 4),
+                # achieved = algorithmic bytes per launch / the kernel's own duration: one frame at a time on one stream, HIP events bracketing
+                # each launch (what rocprofv3's kernel duration is 6-8 % below: the bracket includes the launch's own start and end)
+                "kernel_exclusive_ms": round(kernel_exclusive_ms, 4), "kernel_exclusive_ms_is": "HIP-event bracket around each launch",
                 # per-launch event span inside the timed region: with frames in flight the spans overlap (span x launches > elapsed)
                 "kernel_span_ms_in_flight": round(kernel_avg_ms, 4), "launches": launches,
-                "algorithmic_bytes_per_launch": int(my_bytes), "bytes_per_ray": round(my_bytes / max(my_rays, 1), 2),
-                "byte_model": "the reference's own fetches (SURVEY.md 8d), counted by the instrumented kernel on the world's own bytes",
-                "image_model_bytes_per_launch": int(image_model_bytes(counters)),
-                "frames_in_flight": FRAMES, **({"frames_per_gather": GROUP} if sharded else {}),
-                "kernel_exclusive_mode": ("one frame at a time on the context's own stream (set_frames_in_flight(1)): sub-tiles handed out most expensive first"
+                "algorithmic_bytes_per_launch": int(my_bytes), "bytes_per_ray": round(my_bytes * args.steps / max(wl.rays_per_block, 1), 2),
+                "byte_model": "the reference's own fetches (SURVEY.md 8d), counted by the instrumented kernel on the world's own bytes, mean of the path's views",
+                "image_model_bytes_per_launch": int(wl.image_bytes_per_frame),
+                "frames_in_flight": run.frames, **({"frames_per_gather": run.group} if sharded else {}),
+                "kernel_exclusive_mode": ("one frame at a time on the context's own stream (set_frames_in_flight(1))"
                                           if not sharded else "every frame waited for before the next is issued; the timed region's streams and launch policy"),
-                # the same with the timed region's own launch policy (frame streams, screen order), every frame waited for
+                # the same with the timed region's own launch policy (frame streams), every frame waited for
                 "kernel_exclusive_ms_timed_policy": round(kernel_exclusive_frame_stream_ms, 4),
-                "timed_region_mode": f"{FRAMES} frames in flight (ms_per_step); kernel_span_ms_in_flight is a launch's own event span there",
-                # the timed frames are one view, rendered again and again: what the library keeps between frames of such a view
-                "temporal_reuse": ("scheduling only, identical pixels: a still view's frames are rendered in sorted passes (64 pixels of a 16x16 block put "
-                                   "together by what they cost in earlier frames; VX_SORTED=0: 8 % slower), the one-frame-at-a-time pass also hands work "
-                                   "out most expensive first; under a moving camera neither applies: profiles/round3/pass_aq"),
+                "timed_region_mode": f"{run.frames} frames in flight (ms_per_step); kernel_span_ms_in_flight is a launch's own event span there",
+                "temporal_reuse": "none: every frame is a new view, and nothing a frame leaves behind is used by the next",
                 # what the device sustains over the median timed block: bytes x frames / elapsed
                 "sustained_GBps": round(my_bytes * args.steps / max(elapsed, 1e-9) / 1e9, 3)}
     # The HBM byte model is what the contract asks for, but this kernel's working set is cache resident and it is bound by instruction
     # issue: the second, practical bound, with the fraction of it the kernel reaches one frame at a time and in the timed mode.
-    issue = issue_model(args.format) if (W, H, args.depth, world_size) == (1920, 1080, 12, 1) else None
+    issue = issue_model(args.format) if reference_shape else None
     if issue:
         issue["frac_of_bound_one_frame_at_a_time"] = round(issue["issue_bound_ms"] / kernel_exclusive_ms, 4) if kernel_exclusive_ms > 0 else None
-        issue["frac_of_bound_timed_mode"] = round(issue["issue_bound_ms"] / (elapsed / args.steps * 1e3), 4)
+        issue["frac_of_bound_timed_mode"] = round(issue["issue_bound_ms"] / ms_per_step, 4)
         roofline["issue"] = issue
 
     cpu = None
     if not args.no_cpu_baseline and world_size == 1:  # rank 0 at N = 1 only: a baseline of the workload, not of the scaling run
         from oracle import oracle as orc  # the checker, timed here as the CPU baseline ("port": the reference has no CPU raycast)
 
-        scene = orc.OracleScene(fmt, world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
-        ou = orc.Uniforms.from_buffer_copy(bytes(uniforms))
-        cores = orc.lib().or_max_threads()
-        # warm up the thread pool and the page cache on a thin band, then time one band of a tenth of the frame to decide
-        # between whole frames and bands (a frame this size takes well under a second on a server CPU)
-        scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 8), want_hits=False, counters=orc.Counters(), threads=cores)
-        t0 = time.perf_counter()
-        scene.render(ou, W, H, rect=(0, H // 2 - H // 20, W, H // 2 + H // 20), want_hits=False, counters=orc.Counters(), threads=cores)
-        frame_estimate_s = 10.0 * (time.perf_counter() - t0)
-        cc = orc.Counters()
-        if frame_estimate_s <= args.cpu_seconds:
-            # repeat the whole frame until about cpu_seconds of wall time on all host cores have been timed
-            reps = 0
-            t0 = time.perf_counter()
-            while reps < 400 and (reps == 0 or time.perf_counter() - t0 < args.cpu_seconds):
-                scene.render(ou, W, H, want_hits=False, counters=cc, threads=cores)
-                reps += 1
-            cpu_s = time.perf_counter() - t0
-            sample = f"{reps} x the whole {W}x{H} frame"
-        else:
-            bands = 8
-            band_h = max(int(H * args.cpu_seconds / frame_estimate_s) // bands, 1)
-            t0 = time.perf_counter()
-            for b in range(bands):
-                y0 = int((b + 0.5) * H / bands) - band_h // 2
-                scene.render(ou, W, H, rect=(0, max(y0, 0), W, min(y0 + band_h, H)), want_hits=False, counters=cc, threads=cores)
-            cpu_s = time.perf_counter() - t0
-            sample = f"{bands} bands x {band_h} rows of the {W}x{H} frame"
-        # and on ONE thread (BASELINE.md §2: "1 thread, and all host cores"): bands of rows spread over the frame, about 4 s of work
-        c1 = orc.Counters()
-        scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 2), want_hits=False, counters=c1, threads=1)  # (warm)
-        t0 = time.perf_counter()
-        scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 16), want_hits=False, counters=c1, threads=1)
-        per_row_s = (time.perf_counter() - t0) / 16
-        rows = max(2, min(H // 8, int(4.0 / max(per_row_s, 1e-6)) // 8))
-        c1 = orc.Counters()
-        t0 = time.perf_counter()
-        for b in range(8):
-            y0 = int((b + 0.5) * H / 8) - rows // 2
-            scene.render(ou, W, H, rect=(0, max(y0, 0), W, min(y0 + rows, H)), want_hits=False, counters=c1, threads=1)
-        one_s = time.perf_counter() - t0
-        cpu = {"value": round(cc.rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-               "sample": f"{sample}: {cc.rays} rays in {cpu_s:.2f} s (C restatement of the GLSL path, OpenMP; the reference has no CPU raycast)",
-               "single_thread": {"value": round(c1.rays / one_s / 1e6, 4), "unit": "Mrays/s", "cores": 1,
-                                 "sample": f"8 bands x {rows} rows of the {W}x{H} frame: {c1.rays} rays in {one_s:.2f} s"}}
+        cpu = cpu_baseline(args, wl, orc)
 
+    rays_per_frame = total_rays_per_block / args.steps
     out = {
         "metric": "Mrays/sec (primary+shadow) at 1920x1080, depth-12 SVO; achieved HBM GB/s",
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -572,21 +669,24 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"C3: {W}x{H} primary + 1 shadow ray per lit pixel, textured + normal-mapped shading, depth-{args.depth} SVO "
-                               f"({args.format.upper()} nodes), 1 frame per step", "svo_format": args.format, "svo_bytes": world.size_in_bytes,
-                   "leaves": st["leaves"], "chunks": st["chunks"], "textures": args.textures, "rays_per_frame": int(total_rays), "primary_rays": W * H,
+                               f"({args.format.upper()} nodes), 1 frame per step, the camera moves every frame (0.25 degrees, 0.083 blocks)",
+                   "svo_format": args.format, "svo_bytes": wl.world.size_in_bytes,
+                   "leaves": wl.st["leaves"], "chunks": wl.st["chunks"], "textures": args.textures, "rays_per_frame": int(rays_per_frame), "primary_rays": W * H,
+                   "camera": "a new view every frame: the §8d view turned by 0.25 degrees per frame about the vertical and walked 0.083 blocks per frame (5 blocks a second at 60 Hz)",
                    "parallelism": f"screen tiles (32x32, Morton order, round-robin) over {world_size} GPU(s), SVO replicated, RCCL gather to rank 0",
-                   **({"rccl_ranks": world_size, "gather": "vx_gather_tiles (grouped ncclSend/ncclRecv on the render context's own communicator)" if gather_used == "library"
-                       else "torch.distributed.gather (nccl backend)", "gather_requested": args.gather, **({"gather_note": gather_note} if gather_note else {}),
-                       "gather_format": args.gather_format, "bytes_gathered_per_frame": int((world_size - 1) * sharder.n_max * 1024 * (4 if args.gather_format == "rgba8" else 16)),
-                       "exchange_ms_per_gather_rank0": round(gather_ms / max(gathers, 1), 4), "per_rank": per_rank} if sharded else {}),
-                   **({"sharded_frame_identical_to_whole_render": sharded_frame_identical} if sharded else {}),
-                   "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 3),
+                   **({"rccl_ranks": world_size, "gather": "vx_gather_tiles (grouped ncclSend/ncclRecv on the render context's own communicator)" if run.gather_used == "library"
+                       else "torch.distributed.gather (nccl backend)", "gather_requested": args.gather, **({"gather_note": run.gather_note} if run.gather_note else {}),
+                       "gather_format": args.gather_format, "bytes_gathered_per_frame": int((world_size - 1) * run.sharder.n_max * 1024 * (4 if args.gather_format == "rgba8" else 16)),
+                       "exchange_ms_per_gather_rank0": round(gather_ms / max(gathers, 1), 4), "per_rank": per_rank,
+                       "sharded_frame_identical_to_whole_render": sharded_frame_identical} if sharded else {}),
+                   "scene_build_s": round(wl.build_s, 2), "upload_s": round(wl.upload_s, 3),
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4)},
-        "roofline": roofline, "cpu_baseline": cpu, **({"shadow_distance_500": sd500} if sd500 else {}),
+        "roofline": roofline, "cpu_baseline": cpu, **({"still_view": still} if still else {}), **({"shadow_distance_500": sd500} if sd500 else {}),
+        **({"picker": picker} if picker else {}),
     }
     # the JSON line is the LAST thing on stdout: tear the communicators down first (RCCL prints a banner through C stdio, which
     # is flushed at exit otherwise) and flush C's buffers before Python's
-    if sharded and gather_used == "library":
+    if sharded and run.gather_used == "library":
         svo.comm_destroy()
     if dist is not None:
         dist.destroy_process_group()
@@ -595,7 +695,7 @@ def main():
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
     print(json.dumps(out), flush=True)
-    if comm_hung:
+    if sharded and run.comm_hung:
         os._exit(0)
 
 

@@ -582,7 +582,7 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     """The persistent wavefront kernel (default) and the one-thread-per-pixel kernel write identical images and hit
     records, for several refill/service thresholds (they only reorder work between lanes), from the traversal image (default),
     from the world's own bytes, from the image layout for more than 4 GiB (octant indices behind a 64-bit pointer), with the LDS copy of
-    the top levels, with and without the order table and sorted passes, with the walk inside voxels in the render loop of a small world,
+    the top levels, with and without the order table, with the walk inside voxels in the render loop of a small world,
     with three frames in flight. (The library's timeline build: test_timeline_build_renders_the_same_frames.)"""
     from voxel_rs_amd import scenes
 
@@ -593,10 +593,10 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     u = scenes.bench_camera(8, st["h_max"], w, h)
     results = []
     knobs = ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_HOT_LEVELS", "VX_HOT_FIRST", "VX_FRAMES_IN_FLIGHT",
-             "VX_FOREIGN_RERUN", "VX_SORTED", "VX_SORT_PERIOD")
+             "VX_FOREIGN_RERUN")
     for env in ({"VX_RENDER_KERNEL": "1"}, {}, {"VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"}, {"VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"},
                 {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_RERUN": "0"},
-                {"VX_SORTED": "0"}, {"VX_SORT_PERIOD": "1"}, {"VX_FRAMES_IN_FLIGHT": "3"}):
+                {"VX_FRAMES_IN_FLIGHT": "3"}):
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -673,10 +673,57 @@ print(json.dumps(dict(sha=hashlib.sha256(image.cpu().numpy().tobytes()).hexdiges
 
 
 @pytest.mark.parametrize("fmt", FMTS)
-def test_sorted_passes_across_view_changes(hip, fmt):
-    """A still view is rendered in sorted passes (64 pixels of a 16x16 block put together by earlier frames' costs), a view that has just changed is
-    not, and a view that comes back starts over: whatever the tables hold, every frame is the frame -- device-resident targets on the frame
-    streams (two in flight) and host targets on the context's own stream, two views and two sizes in turn."""
+def test_frames_of_a_moving_camera(hip, fmt):
+    """The reference's frame loop moves the camera every frame (src/gamelogic/game.rs:111-148): thirty frames of a view that turns by a quarter of
+    a degree a frame and walks, rendered as the benchmark renders them -- image-only, device resident, two frames in flight -- are, every one,
+    byte for byte the frame of the render with hit records (another build of the kernel, one frame at a time), and three of them within the
+    colour tolerance of the oracle's with its hit records exactly."""
+    import math
+
+    import torch
+    from voxel_rs_amd import scenes
+
+    depth, w, h = 9, 480, 270
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(depth, threads=4)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update_full(world)
+    scene = orc.OracleScene(SVO_TYPES[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    n = float(1 << depth)
+
+    def uniforms(i):
+        a = math.radians(0.25 * i)
+        fwd = (0.6 * math.cos(a) - 0.7 * math.sin(a), -0.35, 0.6 * math.sin(a) + 0.7 * math.cos(a))
+        eye = (0.5 * n + 0.08 * i, st["h_max"] + 0.05 * n, 0.5 * n - 0.03 * i)
+        return scenes.render_params_to_uniforms(eye, fwd, (0.0, 1.0, 0.0), math.radians(72.0), w / h, 0.3, (-1.0, -1.0, -1.0), True, 3.0e38)
+
+    frames = 30
+    us = [uniforms(i) for i in range(frames)]
+    images = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(frames)]
+    torch.cuda.synchronize()
+    svo.set_frames_in_flight(2)
+    for i in range(frames):
+        svo.render_device(us[i], w, h, images[i].data_ptr())
+    svo.sync()
+    for i in range(frames):
+        img, hits = svo.render(us[i], w, h, want_hits=True)
+        got = images[i].cpu().numpy()
+        assert got.tobytes() == img.tobytes(), f"frame {i} of the moving view differs from the render with hit records"
+        if i in (0, 11, frames - 1):
+            cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(us[i])), w, h)
+            assert hits.tobytes() == chits.tobytes(), f"frame {i}: hit records differ from the oracle's"
+            assert np.nanmax(np.abs(got - cimg)) <= COLOR_TOL
+    svo.close()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_views_and_sizes_in_turn(hip, fmt):
+    """Views that stand still, change, come back, in two sizes: whatever a stream keeps between its frames (the order table of a view's
+    sub-tiles), every frame is the frame -- device-resident targets on the frame streams (two in flight) and host targets on the context's
+    own stream, two views and two sizes in turn."""
     import torch
     from voxel_rs_amd import scenes
 

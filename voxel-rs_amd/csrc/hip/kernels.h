@@ -12,15 +12,13 @@ namespace vxk {
 // world's own bytes: one build per format, it writes hit records and counters where the pointers it is given are not null) or VX_SVO_IMAGE /
 // VX_SVO_IMAGE_WIDE (the traversal image). For an image: hits = the build that also writes hit records (looser register bound); foreign =
 // 0 (the image of an ESVO world), VX_SVO_CSVO (rays led into a voxel walk it on the world's bytes) or kForeignRerun (they are listed and
-// run afterwards); levels = LDS-resident stack levels, 13 or 16; hot = the LDS copy of the top two levels; sorted = the queue's units are
-// sorted passes.
+// run afterwards); levels = LDS-resident stack levels, 13 or 16; hot = the LDS copy of the top two levels.
 struct RenderBuild {
     int svo;
     bool hits;
     int foreign;
     int levels;
     bool hot;
-    bool sorted;
 };
 const void* render_persistent_fn(const RenderBuild& b);  // null: there is no such build
 size_t render_persistent_lds(const RenderBuild& b);      // dynamic LDS of one wave
@@ -34,7 +32,6 @@ hipError_t launch_render_v1(int svo, uint32_t blocks, hipStream_t stream, const 
 hipError_t launch_resolve_2x2(hipStream_t stream, const void* src_rgba32f, uint32_t w, uint32_t h, void* dst_rgba32f);
 hipError_t launch_picker(int svo, hipStream_t stream, const vxd::SceneArgs& sc, const vx_picker_task* tasks, uint32_t n, vx_picker_result* results);
 hipError_t launch_trace(int svo, hipStream_t stream, const vxd::SceneArgs& sc, const TraceArgs& a, vx_result* result, vx_frame* frames, uint32_t max_frames, uint32_t* n_frames);
-hipError_t launch_pass_identity(hipStream_t stream, uint32_t* rec, uint8_t* perm0, uint8_t* perm1, uint32_t n);
 hipError_t launch_order(hipStream_t stream, const uint32_t* cost, uint32_t tag, uint32_t n, uint32_t* order);
 hipError_t launch_scatter(hipStream_t stream, uint32_t pieces, const uint64_t* table, const uint8_t* packed);
 hipError_t launch_assemble(hipStream_t stream, int format, const void* tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width, uint32_t height, uint32_t tiles_x,

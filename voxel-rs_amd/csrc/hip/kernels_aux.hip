@@ -73,18 +73,6 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneArgs sa, TraceArgs a, vx
     *n_frames = tk.n_frames;
 }
 
-// SORTED builds' tables before a view's first frame: every pass = a sub-tile of its block in Morton order (what an unsorted build renders), nothing
-// has cost anything
-__global__ __launch_bounds__(256) void pass_identity_kernel(uint32_t* __restrict__ rec, uint8_t* __restrict__ perm0, uint8_t* __restrict__ perm1, uint32_t n) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // [unit][lane]
-    if (i < n) {
-        const uint32_t pixel = (((i >> 6) & 3u) << 6) | (i & 63u);
-        rec[i] = pixel;
-        perm0[i] = uint8_t(pixel);
-        perm1[i] = uint8_t(pixel);
-    }
-}
-
 // Sorts a frame's sub-tiles for the next frame's queue (PersistentArgs::order): sixteen classes by the iteration count of the sub-tile's
 // longest ray (class = min(15, iterations / 16); entries without this frame's tag are class 0), the highest class first, screen
 // order within a class (a stable counting sort: the rays of neighbouring sub-tiles walk the same nodes). ONE workgroup of 1024 threads:
@@ -243,11 +231,6 @@ hipError_t launch_trace(int svo, hipStream_t stream, const SceneArgs& sc, const 
     else if (svo == VX_SVO_ESVO) hipLaunchKernelGGL((trace_kernel<VX_SVO_ESVO>), dim3(1), dim3(64), lds, stream, sc, a, result, frames, max_frames, n_frames);
     else if (svo == VX_SVO_CSVO) hipLaunchKernelGGL((trace_kernel<VX_SVO_CSVO>), dim3(1), dim3(64), lds, stream, sc, a, result, frames, max_frames, n_frames);
     else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
-hipError_t launch_pass_identity(hipStream_t stream, uint32_t* rec, uint8_t* perm0, uint8_t* perm1, uint32_t n) {
-    hipLaunchKernelGGL(pass_identity_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, rec, perm0, perm1, n);
     return hipGetLastError();
 }
 

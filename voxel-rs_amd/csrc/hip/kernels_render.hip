@@ -154,89 +154,25 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return r01 > r23 ? r01 : r23;
 }
 
-// this lane's rank among the set lanes of a wave mask
-__device__ __forceinline__ uint32_t rank_in_mask(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)); }
-
 // A ray of a pixel has just ended after `iterations` loop iterations: the sub-tile's entry keeps the maximum.
 // For a whole wave (every lane of the wave calls it; `done` = this lane's ray has just ended). With the lanes in lockstep the rays
 // that end in a service phase are one sub-tile's: their maximum is found in registers (four DPP steps inside a row of 16 lanes, the four
 // rows' results through scalar registers) and ONE lane notes it -- an atomic is carried out at the memory side of the L2s, 32 bytes of HBM
 // write traffic each, and a wave's next wait for memory waits for it too: 375 K of them a C3 frame, 12 MB. Lanes of several sub-tiles (any
 // other service_min): a note per lane, as before.
-// (UNIT: the wave's lanes are all of one unit of the queue, `unit` -- a SORTED build's pass)
-template <bool UNIT = false>
-__device__ __forceinline__ void note_cost_wave(const PersistentArgs& a, const RenderParams& p, bool done, uint32_t out_index, uint32_t iterations, uint32_t unit = 0u) {
+__device__ __forceinline__ void note_cost_wave(const PersistentArgs& a, const RenderParams& p, bool done, uint32_t out_index, uint32_t iterations) {
     if (!a.cost_cur) return;
     const bool noting = done && iterations >= kCostFloor;
     const unsigned long long m = __ballot(noting);
     if (m == 0ull) return;
-    const uint32_t st = UNIT ? unit : subtile_of(p, out_index);
-    const uint32_t st0 = UNIT ? unit : uint32_t(__builtin_amdgcn_readlane(int(st), int(__builtin_ctzll(m))));
+    const uint32_t st = subtile_of(p, out_index);
+    const uint32_t st0 = uint32_t(__builtin_amdgcn_readlane(int(st), int(__builtin_ctzll(m))));
     uint32_t v = noting ? (iterations < 4095u ? iterations : 4095u) : 0u;
-    if (UNIT || __ballot(noting && st != st0) == 0ull) {
+    if (__ballot(noting && st != st0) == 0ull) {
         const uint32_t top = wave_max_u32(v);
         if (threadIdx.x == 0) atomicMax(&a.cost_cur[st0], (a.cur_tag << 12) | top);
     } else if (noting && iterations >= kCostFloor) {
         atomicMax(&a.cost_cur[st], (a.cur_tag << 12) | v);
-    }
-}
-
-// SORTED builds: a block's 256 pixels into four passes of 64 by what their rays cost. v[r] = the record of the pixel lane `lane` of pass r rendered
-// (cost << 8 | pixel); out = the block's four passes in the next frame's table, 64 bytes each: the cheapest 64 pixels are pass 0 ... the most
-// expensive pass 3 -- with the lanes in lockstep a pass costs what its longest ray costs, so rays of a kind go together (the C3 frame: a
-// quarter fewer trips of the traversal loop than sub-tile by sub-tile, profiles/round3/pass_al). Three boundaries by bisection on the cost
-// (wave-wide counts are ballots), ties split by (r, lane) so that every pass gets exactly 64 pixels; a pixel's place in its pass = its rank
-// there. ~700 instructions a block, once a block and frame.
-__device__ __forceinline__ void partition_block(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint8_t* out) {
-    const uint32_t v[4] = {v0, v1, v2, v3};
-    uint32_t c[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c[r] = (v[r] >> 8) < 1023u ? (v[r] >> 8) : 1023u;
-    auto count_le = [&](uint32_t t) -> uint32_t {
-        uint32_t n = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) n += uint32_t(__popcll(__ballot(c[r] <= t)));
-        return n;
-    };
-    // the smallest T in [lo, hi] with count_le(T) >= target (count_le(hi) >= target holds)
-    auto boundary = [&](uint32_t lo, uint32_t hi, uint32_t target) -> uint32_t {
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (count_le(mid) >= target) hi = mid;
-            else lo = mid + 1u;
-        }
-        return lo;
-    };
-    uint32_t T[3];
-    T[1] = boundary(0u, 1023u, 128u);
-    T[0] = boundary(0u, T[1], 64u);
-    T[2] = boundary(T[1], 1023u, 192u);
-    uint32_t g[4] = {0u, 0u, 0u, 0u};  // the pass each of this lane's four pixels goes to
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        uint32_t below = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) below += uint32_t(__popcll(__ballot(c[r] < T[k])));
-        const uint32_t need = 64u * uint32_t(k + 1) - below;  // of the pixels that cost exactly T[k], this many stay below the boundary
-        uint32_t seen = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool eq = c[r] == T[k];
-            const unsigned long long m = __ballot(eq);
-            g[r] += (c[r] > T[k] || (eq && seen + rank_in_mask(m) >= need)) ? 1u : 0u;
-            seen += uint32_t(__popcll(m));
-        }
-    }
-#pragma unroll
-    for (uint32_t pass = 0; pass < 4; ++pass) {
-        uint32_t seen = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool mine = g[r] == pass;
-            const unsigned long long m = __ballot(mine);
-            if (mine) out[pass * 64u + seen + rank_in_mask(m)] = uint8_t(v[r]);
-            seen += uint32_t(__popcll(m));
-        }
     }
 }
 
@@ -252,10 +188,10 @@ __device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); 
 // voxel on the world's own bytes in a service phase and comes back to the image (vx_device.hpp, walk_voxel_on_bytes); kForeignRerun: it is
 // listed and run on the bytes afterwards. (The image of an ESVO world serves such rays itself.)
 // HOT (experiment X1): the image's root octant and its eight child octants copied into LDS, PUSHes out of them served from there.
-// SORTED: see PersistentArgs. HITS / STATS: hit records and the instrumented counters are written where the pointers are not null; the kernels
+// HITS / STATS: hit records and the instrumented counters are written where the pointers are not null; the kernels
 // on the world's own bytes are built once per format with both (they are the fall-back and the instrumented path, not the fast one).
 constexpr int min_waves_of(int svo, bool hits) { return ((svo == VX_SVO_IMAGE || svo == VX_SVO_IMAGE_WIDE) && !hits) ? 4 : 1; }
-template <int SVO, bool HITS, bool STATS, int FOREIGN = 0, int LV = kLdsLevels, bool HOT = false, bool SORTED = false>
+template <int SVO, bool HITS, bool STATS, int FOREIGN = 0, int LV = kLdsLevels, bool HOT = false>
 __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent(SceneArgs sa, RenderParams p, PersistentArgs a, float4* __restrict__ out,
                                                         vx_hit* __restrict__ hits, unsigned long long* __restrict__ counters, PixelList todo) {
     constexpr bool IMAGE = SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE;
@@ -270,9 +206,6 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
     static_assert(FOREIGN == 0 || (IMAGE && (FOREIGN == VX_SVO_CSVO || FOREIGN == kForeignRerun)), "FOREIGN: the image of a CSVO world");
     static_assert(FOREIGN != kForeignRerun || (!HITS && !STATS), "rays for the world's bytes are listed by image-only renders");
     constexpr bool SHALLOW = IMAGE;  // no ray can push below the LDS-resident stack levels (the host launches an image kernel only for worlds they cover)
-    // SORTED: the queue hands out passes -- 64 pixels of a block of four sub-tiles that last frame's costs put together (PersistentArgs::perm_in,
-    // partition_block) -- instead of sub-tiles; lanes are refilled only when all 64 are idle: a pass is a batch
-    static_assert(!SORTED || (IMAGE && !HITS && !STATS && !HOT && FOREIGN != VX_SVO_CSVO), "sorted passes: image-only renders without the walk");
     // (the image kernels are only launched for textures whose height is a power of two -- launch_render -- and say so to the sampler, a literal the
     // compiler folds: REPEAT is a mask, nothing of the general wrap is in these kernels' code -- 1-3 % of a frame, profiles/round3/pass_af)
     // TL: the library's timeline build (make tl: -DVX_TIMELINE_BUILD=1; profiles/timeline.py) fills in the wave timeline. Everywhere else the
@@ -315,9 +248,6 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
     uint32_t wave_steps = 0, services = 0, refills = 0, tail_wave_steps = 0, tail_iterations = 0;  // STATS only, wave-uniform
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
-    // SORTED: a pass is in flight (its unit: `sub`); this lane's record of it: what its pixel has cost so far << 8 | the pixel
-    bool have_unit = false;
-    uint32_t rec_now = 0;
     bool queue_empty = false;
     const unsigned long long t_start = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long t_empty = 0ull;
@@ -357,14 +287,6 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
             t = ticket_of(draw_raw(), my_queue);
         }
         return t;
-    };
-    // SORTED: the unit of a ticket -- most expensive first, or screen order with a block's four passes on consecutive tickets of ONE dispenser
-    // (ticket t = 8 n + c is dispenser c's n-th): a dispenser serves the waves of one XCD, and a pass spans its whole block -- four L2s would
-    // each fetch the block's part of the world otherwise (cycles per trip of the loop 832 against 788, profiles/round3/pass_an)
-    auto unit_of = [&](uint32_t t) -> uint32_t {
-        const uint32_t in_turn = t < (a.total_subtiles & ~31u) ? (((t >> 5) * 8u + (t & 7u)) << 2) | ((t >> 3) & 3u) : t;
-        const uint32_t u = a.order ? uint32_t(__builtin_amdgcn_readfirstlane(a.order[t])) : in_turn;
-        return u < a.total_subtiles ? u : t;
     };
     if (blockIdx.x == 0 && lane < kQueues) a.next_counter[lane * kQueueStride] = 0u;
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
@@ -605,11 +527,10 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
 
         // ---- finished rays ----
         VX_PART_BEGIN(2);
-        if constexpr (!SORTED) note_cost_wave(a, p, state == kDone && serve, out_index, tr.iter & ~kParked);  // (a SORTED build notes a pass when it has ended)
+        note_cost_wave(a, p, state == kDone && serve, out_index, tr.iter & ~kParked);
         if (state == kDone && serve) {
             float color[4];
             bool write = true;
-            if constexpr (SORTED) rec_now += (tr.iter & ~kParked) << 8;
             if (!shadow_ray) {
                 PrimaryOutcome o;
                 shade_primary<kOpaqueFastPath>(sc, p, res, o, color_pending);
@@ -660,63 +581,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
         VX_PART_END(2);
         // ---- refill idle lanes from the sub-tile queue ----
         VX_PART_BEGIN(3);
-        if constexpr (SORTED) {
-            if (!queue_empty && __ballot(state != kIdle || new_ray) == 0ull) {  // every pixel of the pass is stored
-                // the pass that has ended: its pixels and what they cost, for the next frame of this view on this stream
-                if (have_unit) {
-                    a.pass_out[size_t(sub) * 64u + lane] = rec_now;
-                    // ... and what the pass cost -- its dearest pixel, primary and shadow ray together: half of it is what the order table's
-                    // classes are of -- for "expensive passes first" (this wave is the pass's only writer: a plain store)
-                    if (a.cost_cur) {
-                        const uint32_t top = wave_max_u32(rec_now >> 8) >> 1;
-                        if (lane == 0) a.cost_cur[sub] = (a.cur_tag << 12) | (top < 4095u ? top : 4095u);
-                    }
-                }
-                const uint32_t t = settle_ticket();
-                if (t >= a.total_subtiles) {
-                    queue_empty = true;
-                    if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
-                } else {
-                    sub = unit_of(t);
-                    const uint32_t pid = a.perm_in[size_t(sub) * 64u + lane];
-                    rec_now = pid;
-                    ++taken;
-                    if (a.ticket_ahead && t + ((a.ticket_ahead - 1u) * gridDim.x >> 2) < a.total_subtiles) {
-                        ticket_raw = draw_raw();
-                        ticket_queue = my_queue;
-                        ticket_ahead = true;
-                    }
-                    if ((sub & 3u) == 0u) {  // a block's pass 0: the next frame's passes of the block
-                        if ((((sub >> 2) + a.sort_turn) & a.sort_mask) == 0u) {  // ... from what the last frame's cost (its turn: 6 us of a wave's time, every fourth frame)
-                            const uint32_t* rec4 = a.pass_in + size_t(sub) * 64u + lane;
-                            partition_block(rec4[0], rec4[64], rec4[128], rec4[192], a.perm_out + size_t(sub) * 64u);
-                        } else {  // ... as they are
-                            reinterpret_cast<uint32_t*>(a.perm_out + size_t(sub) * 64u)[lane] = reinterpret_cast<const uint32_t*>(a.perm_in + size_t(sub) * 64u)[lane];
-                        }
-                    }
-                    const uint32_t local_tile = sub >> 4, s = (sub & 12u) | (pid >> 6);
-                    const uint32_t tile = p.tile_count > 1 ? p.tile_order[local_tile * p.tile_count + p.tile_rank] : local_tile;
-                    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-                    const uint32_t sx = (s & 1u) | ((s >> 1) & 2u), sy = ((s >> 1) & 1u) | ((s >> 2) & 2u);
-                    uint32_t lx, ly;
-                    lane_to_xy(pid & 63u, lx, ly);
-                    const uint32_t in_x = sx * 8 + lx, in_y = sy * 8 + ly;
-                    const uint32_t px_x = tx * kTile + in_x, px_y = ty * kTile + in_y;
-                    out_index = p.tile_count > 1 ? local_tile * (kTile * kTile) + in_y * kTile + in_x : image_index(p, px_x, px_y);
-                    if (px_x < p.width && px_y < p.height) {
-                        primary_ray(p, px_x, px_y, new_ro, new_rd);
-                        primary_rd[0] = new_rd[0]; primary_rd[1] = new_rd[1]; primary_rd[2] = new_rd[2];
-                        new_ray = true;
-                        shadow_ray = false;
-                    } else if (p.tile_count > 1) {
-                        const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // padding pixel of an edge tile: keep the compact tile list fully defined
-                        if (out) store_pixel(p, out, out_index, zero);
-                    }
-                }
-                have_unit = !queue_empty;
-            }
-        }
-        unsigned long long idle_mask = SORTED ? 0ull : __ballot(state == kIdle);
+        unsigned long long idle_mask = __ballot(state == kIdle);
         if (!queue_empty && idle_mask && !walk_phase && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
             if (STATS) ++refills;
             for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
@@ -889,34 +754,29 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
 namespace vxk {
 
 #define VX_K(...) reinterpret_cast<const void*>(&render_persistent<__VA_ARGS__>)
-// The builds that exist (18): on the world's own bytes one per format, with hit records and counters; on a traversal image, image-only: worlds
-// without walks (ESVO) on 13 levels / 16 levels / 16 levels in the wide layout, each also in sorted passes; CSVO worlds whose inside-voxel rays
-// are listed (at most 12 levels: 13-level stack), also in sorted passes, or walk (16 levels, both layouts); with hit records: 16 levels, both
-// layouts, with and without the walk; the LDS copy of the top levels (experiment X1).
+// The builds that exist (14): on the world's own bytes one per format, with hit records and counters; on a traversal image, image-only: worlds
+// without walks (ESVO) on 13 levels / 16 levels / 16 levels in the wide layout; CSVO worlds whose inside-voxel rays are listed (at most 12
+// levels: 13-level stack) or walk (16 levels, both layouts); with hit records: 16 levels, both layouts, with and without the walk; the LDS
+// copy of the top levels (experiment X1).
 const void* render_persistent_fn(const RenderBuild& b) {
     const bool image = b.svo == VX_SVO_IMAGE || b.svo == VX_SVO_IMAGE_WIDE, wide = b.svo == VX_SVO_IMAGE_WIDE;
     if (!image) {
-        if (b.foreign != 0 || b.hot || b.sorted) return nullptr;
+        if (b.foreign != 0 || b.hot) return nullptr;
         return b.svo == VX_SVO_ESVO ? VX_K(VX_SVO_ESVO, true, true) : (b.svo == VX_SVO_ESVO_BIG ? VX_K(VX_SVO_ESVO_BIG, true, true) : (b.svo == VX_SVO_CSVO ? VX_K(VX_SVO_CSVO, true, true) : nullptr));
     }
-    if (b.hot) return (!wide && !b.hits && b.foreign == 0 && b.levels == kLdsLevels && !b.sorted) ? VX_K(VX_SVO_IMAGE, false, false, 0, kLdsLevels, true) : nullptr;
+    if (b.hot) return (!wide && !b.hits && b.foreign == 0 && b.levels == kLdsLevels) ? VX_K(VX_SVO_IMAGE, false, false, 0, kLdsLevels, true) : nullptr;
     if (b.hits) {
-        if (b.levels != 16 || b.sorted) return nullptr;
+        if (b.levels != 16) return nullptr;
         if (b.foreign == 0) return wide ? VX_K(VX_SVO_IMAGE_WIDE, true, false, 0, 16) : VX_K(VX_SVO_IMAGE, true, false, 0, 16);
         if (b.foreign == VX_SVO_CSVO) return wide ? VX_K(VX_SVO_IMAGE_WIDE, true, false, VX_SVO_CSVO, 16) : VX_K(VX_SVO_IMAGE, true, false, VX_SVO_CSVO, 16);
         return nullptr;
     }
     if (b.foreign == 0) {
-        if (b.levels == 16) {
-            if (wide) return b.sorted ? VX_K(VX_SVO_IMAGE_WIDE, false, false, 0, 16, false, true) : VX_K(VX_SVO_IMAGE_WIDE, false, false, 0, 16);
-            return b.sorted ? VX_K(VX_SVO_IMAGE, false, false, 0, 16, false, true) : VX_K(VX_SVO_IMAGE, false, false, 0, 16);
-        }
-        if (b.levels == kLdsLevels && !wide) return b.sorted ? VX_K(VX_SVO_IMAGE, false, false, 0, kLdsLevels, false, true) : VX_K(VX_SVO_IMAGE, false, false, 0, kLdsLevels);
-        return nullptr;
+        if (b.levels == 16) return wide ? VX_K(VX_SVO_IMAGE_WIDE, false, false, 0, 16) : VX_K(VX_SVO_IMAGE, false, false, 0, 16);
+        return (b.levels == kLdsLevels && !wide) ? VX_K(VX_SVO_IMAGE, false, false, 0, kLdsLevels) : nullptr;
     }
-    if (b.foreign == kForeignRerun)
-        return (!wide && b.levels == kLdsLevels) ? (b.sorted ? VX_K(VX_SVO_IMAGE, false, false, kForeignRerun, kLdsLevels, false, true) : VX_K(VX_SVO_IMAGE, false, false, kForeignRerun, kLdsLevels)) : nullptr;
-    if (b.foreign == VX_SVO_CSVO && b.levels == 16 && !b.sorted) return wide ? VX_K(VX_SVO_IMAGE_WIDE, false, false, VX_SVO_CSVO, 16) : VX_K(VX_SVO_IMAGE, false, false, VX_SVO_CSVO, 16);
+    if (b.foreign == kForeignRerun) return (!wide && b.levels == kLdsLevels) ? VX_K(VX_SVO_IMAGE, false, false, kForeignRerun, kLdsLevels) : nullptr;
+    if (b.foreign == VX_SVO_CSVO && b.levels == 16) return wide ? VX_K(VX_SVO_IMAGE_WIDE, false, false, VX_SVO_CSVO, 16) : VX_K(VX_SVO_IMAGE, false, false, VX_SVO_CSVO, 16);
     return nullptr;
 }
 #undef VX_K

@@ -183,27 +183,8 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // 13 three-word levels where they suffice and no walk wants the room below the leaves; 16 (16-bit third plane) else
         build.levels = !imaged ? kLdsLevels : ((HITS || wide || depth > uint32_t(kLdsLevels) || (csvo && !rerun)) ? 16 : kLdsLevels);
         build.hot = imaged && ctx->hot_levels && !HITS && !wide && !csvo && build.levels == kLdsLevels;
-        // (a view that has not moved since the last image-only frame on this stream -- or VX_SORTED=2: always -- may be rendered in sorted passes)
-        vx_context::SortState& ss_view = ctx->sorted_state[slot + 1];
-        // (... and only if it casts shadow rays: primary rays alone are too much of a length for sorting to pay -- 7 % fewer trips against 18 %,
-        // less than the tables cost: C2 0.178 against 0.172 ms)
-        const bool still = !HITS && !STATS && p.u.render_shadows != 0 &&
-                           (ctx->sorted_always || (ss_view.last_u_valid && std::memcmp(&ss_view.last_u, &p.u, sizeof(vx_uniforms)) == 0));
-        if (!HITS && !STATS) {
-            ss_view.last_u = p.u;
-            ss_view.last_u_valid = true;
-        }
-        // The SORTED builds (the queue's units are passes: 64 pixels of a block of four sub-tiles, chosen by earlier frames' costs): image-only renders
-        // of a view that stands still, with the lanes in lockstep, of worlds whose image needs no walk in the loop (ESVO; CSVO of at most 12 levels)
-        build.sorted = imaged && !HITS && ctx->sorted_passes && still && ctx->service_min >= 64 && !build.hot && build.foreign != VX_SVO_CSVO;
         const void* fn = vxk::render_persistent_fn(build);
-        if (!fn && build.sorted) {
-            build.sorted = false;
-            fn = vxk::render_persistent_fn(build);
-        }
         if (!fn) return fail(VX_ERR_STATE, "no render kernel for this world (library built without it)");
-        const bool sorted = build.sorted;
-        if (!sorted && !HITS && !STATS) ss_view.live = false;
         const size_t wave_lds = vxk::render_persistent_lds(build);
         int& per_cu = ctx->persistent_blocks[fn];
         if (per_cu == 0) {
@@ -215,48 +196,7 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // (`tickets` counts this stream's launches: its sets of dispensers take turns)
         a.work_counter = work_counter + size_t(tickets & 1u) * (kQueues * kQueueStride);
         a.next_counter = work_counter + size_t((tickets & 1u) ^ 1u) * (kQueues * kQueueStride);
-        a.total_subtiles = p.n_local_tiles * 16;  // (the queue's units: sub-tiles, or a SORTED build's passes)
-        a.pass_in = nullptr;
-        a.pass_out = nullptr;
-        a.perm_in = nullptr;
-        a.perm_out = nullptr;
-        a.sort_turn = 0;
-        a.sort_mask = 3;
-        if (sorted) {
-            vx_context::SortState& ss = ctx->sorted_state[slot + 1];
-            const size_t units = a.total_subtiles;
-            const bool same = ss.live && ss.width == p.width && ss.height == p.height && ss.tile_rank == p.tile_rank && ss.tile_count == p.tile_count && ss.units >= units;
-            ss.live = true;
-            if (ss.units < units) {  // (grow: earlier frames of this stream use the old tables)
-                HIP_TRY(hipStreamSynchronize(stream));
-                void* old_tables[] = {ss.rec[0], ss.rec[1], ss.perm[0], ss.perm[1]};
-                for (void* q : old_tables)
-                    if (q) (void)hipFree(q);
-                ss.rec[0] = ss.rec[1] = nullptr;
-                ss.perm[0] = ss.perm[1] = nullptr;
-                ss.units = 0;
-                const size_t cap = units + units / 4 + 64;
-                for (int g = 0; g < 2; ++g) {
-                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ss.rec[g]), cap * 64 * sizeof(uint32_t)));
-                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ss.perm[g]), cap * 64));
-                }
-                ss.units = cap;
-            }
-            if (!same) {  // a view's first frame on this stream: sub-tile by sub-tile
-                const uint32_t n = uint32_t(units * 64);
-                HIP_TRY(vxk::launch_pass_identity(stream, ss.rec[ss.cur], ss.perm[0], ss.perm[1], n));
-                ss.width = p.width; ss.height = p.height; ss.tile_rank = p.tile_rank; ss.tile_count = p.tile_count;
-            }
-            a.pass_in = ss.rec[ss.cur];
-            a.pass_out = ss.rec[ss.cur ^ 1];
-            a.perm_in = ss.perm[ss.cur];
-            a.perm_out = ss.perm[ss.cur ^ 1];
-            if (!same) ss.frames = 0;
-            a.sort_turn = ss.frames & 0xffffu;
-            a.sort_mask = ctx->sort_mask;
-            ss.frames += 1;
-            ss.cur ^= 1;
-        }
+        a.total_subtiles = p.n_local_tiles * 16;
         a.refill_min = ctx->refill_min;
         a.service_min = ctx->service_min;
         a.excursions = ctx->count_excursions ? ctx->d_excursions : nullptr;
@@ -567,14 +507,12 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     CREATE_TRY(hipMemset(c->d_excursions, 0, 8 * sizeof(unsigned long long)));
     {
         // The knobs that stay (tests and measurements; none of them changes a pixel): which kernel, how many frames in flight, the image
-        // on / off / wide / capped, sorted passes, the order table, the LDS copy of the top levels, the lockstep thresholds.
+        // on / off / wide / capped, the order table, the LDS copy of the top levels, the lockstep thresholds.
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("VX_FRAMES_IN_FLIGHT")) c->frames_in_flight = std::atoi(e);
         if (c->frames_in_flight < 1) c->frames_in_flight = 1;
         if (c->frames_in_flight > vx_context::kFrameStreams) c->frames_in_flight = vx_context::kFrameStreams;
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VX_SORT_PERIOD")) { uint32_t n = uint32_t(std::max(1, std::atoi(e))), m = 1; while (m * 2 <= n && m < 1024) m *= 2; c->sort_mask = m - 1; }
-        if (const char* e = std::getenv("VX_SORTED")) { c->sorted_passes = std::atoi(e) != 0; c->sorted_always = std::atoi(e) == 2; }
         if (const char* e = std::getenv("VX_FOREIGN_RERUN")) c->foreign_rerun = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VX_HOT_LEVELS")) c->hot_levels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_HOT_FIRST")) c->hot_first = std::atoi(e) != 0;
@@ -631,11 +569,6 @@ void vx_destroy(vx_context* c) {
             if (hs.order[g]) (void)hipFree(hs.order[g]);
             if (hs.order_done[g]) (void)hipEventDestroy(hs.order_done[g]);
         }
-    }
-    for (auto& ss : c->sorted_state) {
-        void* tables[] = {ss.rec[0], ss.rec[1], ss.perm[0], ss.perm[1]};
-        for (void* q : tables)
-            if (q) (void)hipFree(q);
     }
     for (auto& e : c->gather_done)
         if (e) (void)hipEventDestroy(e);

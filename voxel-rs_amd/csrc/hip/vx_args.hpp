@@ -94,18 +94,6 @@ struct PersistentArgs {
     // stream draws its tickets through that table: `order` (null: screen order). Order only: no pixel's value depends on it.
     const uint32_t* order;          // [total_subtiles] sub-tile ids, or null
     uint32_t* cost_cur;             // [total_subtiles] tag << 12 | iterations of the sub-tile's longest ray this frame; null = do not note
-    // SORTED builds (render_persistent): the unit of the queue is a PASS -- 64 pixels of a block of four sub-tiles (16x16 pixels), put together by
-    // what the block's pixels cost two frames ago in this view on this stream (unit = 4 x block + pass). `perm_in` [unit][lane] = the pixel a
-    // lane takes (a byte: sub-tile of the block << 6 | place in the sub-tile's Morton order). A wave that has rendered a pass leaves its pixels
-    // and their costs in `pass_out` [unit][lane] (cost << 8 | pixel); the wave that takes a block's pass 0 also reads the block's four records
-    // of the LAST frame (`pass_in`) and makes the NEXT frame's passes of the block (partition_block -> `perm_out`). Between writer and reader
-    // of every table lies a kernel boundary: no wave ever waits for another, nothing is fenced. Any permutation is a correct frame; a view's
-    // first frames read tables that say "sub-tile by sub-tile".
-    const uint32_t* pass_in;
-    uint32_t* pass_out;
-    const uint8_t* perm_in;
-    uint8_t* perm_out;
-    uint32_t sort_turn, sort_mask;  // a block is re-sorted when ((block + sort_turn) & sort_mask) == 0 -- every fourth frame of its stream: mask 3 --, its passes kept otherwise
     uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
     uint32_t ticket_ahead;          // 1 + g: waves draw their next sub-tile's ticket when they start on one (its round trip runs under the traversal),
                                     // except for the frame's last g quarter-grids of tickets

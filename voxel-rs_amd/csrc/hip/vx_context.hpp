@@ -79,27 +79,6 @@ struct vx_context {
     };
     hipStream_t order_stream = nullptr;
     HotState hot[kFrameStreams + 1];  // [slot + 1]
-    // SORTED builds: per stream, the records and pass tables (PersistentArgs::pass_in / pass_out, perm_in / perm_out) of the view rendered there; each
-    // pair takes turns
-    struct SortState {
-        uint32_t* rec[2] = {nullptr, nullptr};  // [unit][lane]: cost << 8 | pixel
-        uint8_t* perm[2] = {nullptr, nullptr};  // [unit][lane]: pixel
-        size_t units = 0;   // capacity
-        int cur = 0;        // the tables the next frame reads
-        uint32_t frames = 0;  // frames of the view issued on this stream
-        // The uniforms of the last image-only frame on this stream: passes are sorted by what pixels cost in EARLIER frames, which says something
-        // about this frame only if the view has not moved -- under a camera that turns by a tenth of a degree a frame the stale passes are 8 %
-        // slower than plain sub-tiles (a random 64 of a block's 256 pixels hold one of its long rays almost surely; 8 x 8 neighbours often do
-        // not: profiles/round3/pass_aq). So a frame is rendered by a SORTED build only if its uniforms are the last frame's, bit for bit.
-        vx_uniforms last_u = {};
-        bool last_u_valid = false;
-        bool live = false;    // the last frame here was a SORTED build's: its records and passes are there
-        uint32_t width = 0, height = 0, tile_rank = 0, tile_count = 0;  // the view (0 = none)
-    };
-    SortState sorted_state[kFrameStreams + 1];  // [slot + 1]
-    bool sorted_passes = true;                  // VX_SORTED=0: the unsorted builds everywhere (A/B)
-    bool sorted_always = false;                 // VX_SORTED=2: sorted passes also for views that move (measurement)
-    uint32_t sort_mask = 3;                     // VX_SORT_PERIOD (a power of two, default 4): a block is re-sorted every so many frames of its stream
     bool hot_first = true;            // VX_HOT_FIRST=0: sub-tiles in plain order (A/B)
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
     hipEvent_t pending_gather = nullptr;  // vx_wait_gather: the gather that still reads the tile list the next render overwrites
