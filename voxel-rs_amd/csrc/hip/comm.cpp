@@ -136,20 +136,28 @@ int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank,
         }
         HIP_TRY(hipEventRecord(ev.start, ctx->comm_stream));
     }
-    if (ctx->comm_rank == root) {
-        uint8_t* dst = static_cast<uint8_t*>(gathered);
-        // its own share (nothing to move when the root renders straight into its place in `gathered`)
-        if (tiles != dst + size_t(root) * bytes_per_rank)
-            HIP_TRY(hipMemcpyAsync(dst + size_t(root) * bytes_per_rank, tiles, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->comm_stream));
-        if (ctx->comm_ranks > 1) {
-            // one receive per peer, grouped: every peer sends over its own xGMI link at the same time
-            NCCL_TRY(g_rccl.GroupStart());
-            for (int r = 0; r < ctx->comm_ranks; ++r)
-                if (r != root) NCCL_TRY(g_rccl.Recv(dst + size_t(r) * bytes_per_rank, words, ncclUint32, r, ctx->comm, ctx->comm_stream));
-            NCCL_TRY(g_rccl.GroupEnd());
+    // (an error between the two records hands the pair back to the pool)
+    auto exchange = [&]() -> int {
+        if (ctx->comm_rank == root) {
+            uint8_t* dst = static_cast<uint8_t*>(gathered);
+            // its own share (nothing to move when the root renders straight into its place in `gathered`)
+            if (tiles != dst + size_t(root) * bytes_per_rank)
+                HIP_TRY(hipMemcpyAsync(dst + size_t(root) * bytes_per_rank, tiles, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->comm_stream));
+            if (ctx->comm_ranks > 1) {
+                // one receive per peer, grouped: every peer sends over its own xGMI link at the same time
+                NCCL_TRY(g_rccl.GroupStart());
+                for (int r = 0; r < ctx->comm_ranks; ++r)
+                    if (r != root) NCCL_TRY(g_rccl.Recv(dst + size_t(r) * bytes_per_rank, words, ncclUint32, r, ctx->comm, ctx->comm_stream));
+                NCCL_TRY(g_rccl.GroupEnd());
+            }
+        } else {
+            NCCL_TRY(g_rccl.Send(tiles, words, ncclUint32, root, ctx->comm, ctx->comm_stream));
         }
-    } else {
-        NCCL_TRY(g_rccl.Send(tiles, words, ncclUint32, root, ctx->comm, ctx->comm_stream));
+        return VX_OK;
+    };
+    if (const int rc = exchange()) {
+        if (ctx->profile) ctx->event_pool.push_back(ev);
+        return rc;
     }
     if (ctx->profile) {
         HIP_TRY(hipEventRecord(ev.stop, ctx->comm_stream));

@@ -167,44 +167,51 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint64_t* __restrict
     if (t < tail) d[head + body * 16 + t] = s[head + body * 16 + t];
 }
 
-// Scatters gathered compact tile lists back into a row-major image: ONE workgroup per 32x32 tile, a thread moves four neighbouring pixels
-// of a row (RGBA8: one 16-byte word; RGBA32F: four) -- whole 4 KB / 16 KB tiles are read in order, whole 128- / 512-byte row segments
-// written. (Round 2's version, a thread per pixel in 16x16 blocks, was 8160 workgroups at 1080p and took 230 us beside the render kernel's
-// persistent waves: the next frame on its stream waits for it.) `inverse` = place of every tile in the Morton sequence the ranks share out
-// (place j: rank j % tile_count, its local tile j / tile_count).
-__global__ __launch_bounds__(256) void assemble_kernel(const float4* __restrict__ tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width,
-                                                       uint32_t height, uint32_t tiles_x, const uint32_t* __restrict__ inverse, float4* __restrict__ out) {
+// Scatters gathered compact tile lists back into a row-major image: ONE WAVE per 32x32 tile -- a workgroup of 64 threads needs one free wave slot
+// on a compute unit, which a context that renders tile lists keeps free everywhere (runtime.cpp: fifteen persistent waves a CU instead of sixteen,
+// -0.8 %): the assembly starts when it is issued instead of when a frame has drained (a 256-thread workgroup needs four slots on ONE unit, and
+// with frames in flight the render kernels' queued waves take every slot the moment it is free: measured 190 us late, profiles/round3/pass_t).
+// Four times, a lane moves four neighbouring pixels of a row (RGBA8: one 16-byte word; RGBA32F: four): whole 4 KB / 16 KB tiles are read in
+// order, whole 128- / 512-byte row segments written. `inverse` = place of every tile in the Morton sequence the ranks share out (place j: rank
+// j % tile_count, its local tile j / tile_count). (Any base and stride: 16-byte accesses only where source and destination are aligned.)
+__global__ __launch_bounds__(64) void assemble_kernel(const float4* __restrict__ tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width,
+                                                      uint32_t height, uint32_t tiles_x, const uint32_t* __restrict__ inverse, float4* __restrict__ out) {
     const uint32_t tile = blockIdx.x, tx = tile % tiles_x, ty = tile / tiles_x;
     const uint32_t j = inverse[tile];
     const float4* src = tiles + (j % tile_count) * stride_px + size_t(j / tile_count) * (kTile * kTile);
-    const uint32_t row = threadIdx.x >> 3, x4 = (threadIdx.x & 7u) * 4u;  // 32 rows x 8 groups of four pixels
-    const uint32_t y = ty * kTile + row, x = tx * kTile + x4;
-    if (y >= height) return;
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k)
-        if (x + k < width) out[size_t(y) * width + x + k] = src[row * kTile + x4 + k];
-}
-
-// the same for RGBA8 tile lists and image (vx_target.format = VX_FORMAT_RGBA8; an RGBA8 image has its top row first)
-__global__ __launch_bounds__(256) void assemble_kernel_rgba8(const uint32_t* __restrict__ tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width,
-                                                             uint32_t height, uint32_t tiles_x, const uint32_t* __restrict__ inverse, uint32_t* __restrict__ out) {
-    const uint32_t tile = blockIdx.x, tx = tile % tiles_x, ty = tile / tiles_x;
-    const uint32_t j = inverse[tile];
-    const uint32_t* src = tiles + (j % tile_count) * stride_px + size_t(j / tile_count) * (kTile * kTile);
-    const uint32_t row = threadIdx.x >> 3, x4 = (threadIdx.x & 7u) * 4u;
-    const uint32_t y = ty * kTile + row, x = tx * kTile + x4;
-    if (y >= height) return;
-    uint32_t* dst = out + size_t(height - 1u - y) * width + x;
-    const uint4 v = *reinterpret_cast<const uint4*>(src + row * kTile + x4);  // (16-byte aligned: tiles are 4 KB, x4 a multiple of 4)
-    if (x + 3 < width && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
-        *reinterpret_cast<uint4*>(dst) = v;
-    } else {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for (uint32_t part = 0; part < 4; ++part) {
+        const uint32_t t = part * 64u + threadIdx.x, row = t >> 3, x4 = (t & 7u) * 4u;  // 32 rows x 8 groups of four pixels
+        const uint32_t y = ty * kTile + row, x = tx * kTile + x4;
+        if (y >= height) continue;
+#pragma unroll
         for (uint32_t k = 0; k < 4; ++k)
-            if (x + k < width) dst[k] = w[k];
+            if (x + k < width) out[size_t(y) * width + x + k] = src[row * kTile + x4 + k];
     }
 }
 
+// the same for RGBA8 tile lists and image (vx_target.format = VX_FORMAT_RGBA8; an RGBA8 image has its top row first)
+__global__ __launch_bounds__(64) void assemble_kernel_rgba8(const uint32_t* __restrict__ tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width,
+                                                            uint32_t height, uint32_t tiles_x, const uint32_t* __restrict__ inverse, uint32_t* __restrict__ out) {
+    const uint32_t tile = blockIdx.x, tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t j = inverse[tile];
+    const uint32_t* src = tiles + (j % tile_count) * stride_px + size_t(j / tile_count) * (kTile * kTile);
+    const bool src_aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+#pragma unroll
+    for (uint32_t part = 0; part < 4; ++part) {
+        const uint32_t t = part * 64u + threadIdx.x, row = t >> 3, x4 = (t & 7u) * 4u;
+        const uint32_t y = ty * kTile + row, x = tx * kTile + x4;
+        if (y >= height) continue;
+        uint32_t* dst = out + size_t(height - 1u - y) * width + x;
+        const uint32_t* from = src + row * kTile + x4;
+        if (src_aligned && x + 3 < width && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(from);
+        } else {
+            for (uint32_t k = 0; k < 4; ++k)
+                if (x + k < width) dst[k] = from[k];
+        }
+    }
+}
 
 }  // namespace
 
@@ -247,7 +254,7 @@ hipError_t launch_scatter(hipStream_t stream, uint32_t pieces, const uint64_t* t
 hipError_t launch_assemble(hipStream_t stream, int format, const void* tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width, uint32_t height, uint32_t tiles_x,
                            const uint32_t* inverse, void* out) {
     const uint32_t tiles_y = (height + kTile - 1) / kTile;
-    const dim3 grid(tiles_x * tiles_y), block(256);  // a workgroup per tile
+    const dim3 grid(tiles_x * tiles_y), block(64);  // a wave per tile
     if (format == VX_FORMAT_RGBA8)
         hipLaunchKernelGGL(assemble_kernel_rgba8, grid, block, 0, stream, static_cast<const uint32_t*>(tiles), stride_px, tile_count, width, height, tiles_x, inverse, static_cast<uint32_t*>(out));
     else

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "vx_context.hpp"
 
@@ -257,9 +258,13 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // Persistent waves per CU: all that fit -- the stacks fill a CU's LDS to the last hundred bytes. A context that gathers its tiles over
         // RCCL leaves `comm_headroom` of them out: LDS of every CU stays free, in one piece, for the communication kernels' workgroups, which
         // otherwise find room only when a whole frame has drained.
+        // A tile-list render (a rank's share, also of a forced one-rank run) leaves ONE slot out: what a one-wave workgroup needs -- the assembly of
+        // the gathered lists on rank 0 (assemble_kernel) then starts when it is issued (-0.8 % for the fifteen waves, against 5.8 % for an
+        // assembly that waits for a frame to drain: profiles/round4/pass_o).
         int per_cu_used = per_cu;
         if (ctx->waves_per_cu_cap > 0 && ctx->waves_per_cu_cap < per_cu) per_cu_used = ctx->waves_per_cu_cap;
         else if (ctx->comm_ranks > 1 && ctx->comm_headroom > 0 && per_cu > ctx->comm_headroom + 4) per_cu_used = per_cu - ctx->comm_headroom;
+        else if (p.tile_count > 1 || ctx->comm) per_cu_used = per_cu > 4 ? per_cu - 1 : per_cu;
         uint32_t waves = uint32_t(ctx->cu_count) * uint32_t(per_cu_used);
         if (waves > a.total_subtiles) waves = a.total_subtiles;
         if (waves > 8192) a.timeline = nullptr;
@@ -373,6 +378,66 @@ struct Upload {
 };
 constexpr uint64_t kDeltaLimit = 64ull << 20;  // commits up to this size travel packed (one transfer, one scatter kernel)
 constexpr uint64_t kPiece = 32768;             // bytes one workgroup of the scatter kernel moves
+
+// A whole world (gigabytes): the staging mirror is pinned and travels as it is; the traversal image and its origin table live in pageable
+// memory, from which a copy command crawls (2.8 GB/s measured: 2.5 s for the depth-14 terrain's 7 GB) -- they go through a ring of pinned
+// bounce buffers instead, filled by a handful of threads while the previous ones are in flight. Returns when everything has been read.
+int upload_big(vx_context* ctx, const std::vector<Upload>& up) {
+    constexpr size_t kSlot = size_t(32) << 20;
+    constexpr int kSlots = 4;
+    struct Bounce { uint8_t* host = nullptr; hipEvent_t done = nullptr; bool used = false; } ring[kSlots];
+    auto release = [&]() {
+        for (Bounce& b : ring) {
+            if (b.host) (void)hipHostFree(b.host);
+            if (b.done) (void)hipEventDestroy(b.done);
+        }
+    };
+    const unsigned workers = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    int next = 0;
+    for (const Upload& u : up) {
+        if (!u.bytes) continue;
+        const bool pinned = u.src >= ctx->staging && u.src + u.bytes <= ctx->staging + ctx->capacity + kStagingSlack;
+        if (pinned) {
+            if (hipMemcpyAsync(u.dst, u.src, u.bytes, hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess) {
+                release();
+                return fail(VX_ERR_HIP, std::string("commit: upload failed: ") + hipGetErrorString(hipGetLastError()));
+            }
+            continue;
+        }
+        for (uint64_t off = 0; off < u.bytes; off += kSlot) {
+            Bounce& b = ring[next];
+            next = (next + 1) % kSlots;
+            if (!b.host) {
+                if (hipHostMalloc(reinterpret_cast<void**>(&b.host), kSlot, hipHostMallocDefault) != hipSuccess ||
+                    hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) {
+                    release();
+                    return fail(VX_ERR_OUT_OF_MEMORY, "commit: no pinned memory for the upload");
+                }
+            }
+            if (b.used && hipEventSynchronize(b.done) != hipSuccess) {
+                release();
+                return fail(VX_ERR_HIP, "commit: upload failed");
+            }
+            const size_t n = size_t(std::min<uint64_t>(kSlot, u.bytes - off));
+            const size_t share = (n / workers + 4095) & ~size_t(4095);
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < workers && t * share < n; ++t)
+                pool.emplace_back([&, t] { std::memcpy(b.host + t * share, u.src + off + t * share, std::min(share, n - t * share)); });
+            std::memcpy(b.host, u.src + off, std::min(share, n));
+            for (auto& t : pool) t.join();
+            if (hipMemcpyAsync(u.dst + off, b.host, n, hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess ||
+                hipEventRecord(b.done, ctx->upload_stream) != hipSuccess) {
+                release();
+                return fail(VX_ERR_HIP, std::string("commit: upload failed: ") + hipGetErrorString(hipGetLastError()));
+            }
+            b.used = true;
+        }
+    }
+    // the caller may rewrite the staging mirror as soon as we return, and the bounce buffers go: wait for the copies to have read them
+    const hipError_t e = hipStreamSynchronize(ctx->upload_stream);
+    release();
+    return e == hipSuccess ? VX_OK : fail(VX_ERR_HIP, "commit: upload failed");
+}
 
 template <class WAIT>
 int upload_packed(vx_context* ctx, const std::vector<Upload>& up, WAIT&& wait_for_frames) {
@@ -551,7 +616,10 @@ void vx_destroy(vx_context* c) {
     (void)drain_streams(c);  // nothing may still be reading what is freed below
     for (auto& l : c->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     for (auto& l : c->event_pool) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
+    for (auto& l : c->gathers) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     if (c->staging) (void)hipHostFree(c->staging);
+    if (c->h_pick_tasks) (void)hipHostFree(c->h_pick_tasks);
+    if (c->h_pick_results) (void)hipHostFree(c->h_pick_results);
     void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_frame, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
                    c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin, c->d_excursions, c->d_main_todo, c->d_timeline};
     for (void* p : dev)
@@ -761,7 +829,9 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         // re-lay the changed chunks (and the root octree, which every commit rewrites) out as octants
         std::vector<vximg::Range> changed(count);
         for (uint32_t i = 0; i < count; ++i) changed[i] = vximg::Range{ranges[i].start, ranges[i].length};
-        const unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        // (a whole world: every core up to 64 -- the depth-14 terrain's image, 5.7 GB from 418 K chunks, took 4.2 s on 16; WorldImage::update takes
+        // no more workers than a sixteenth of the chunks it has to walk, so an incremental commit stays on a few)
+        const unsigned threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
         // A world whose image will not fit 32-bit byte offsets starts in the wide layout instead of finding that out at the end of a whole
         // build (an image is about 0.84 x the bytes of an ESVO world, 3.9 x those of a CSVO world; the wide layout serves any size)
         if (ctx->image.chunk_count() == 0 && ctx->image.layout() == vximg::kOct64 &&
@@ -848,11 +918,7 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         rc = upload_packed(ctx, up, wait_for_frames);
     } else {
         rc = wait_for_frames();
-        for (size_t i = 0; i < up.size() && rc == VX_OK; ++i)
-            if (up[i].bytes && hipMemcpyAsync(up[i].dst, up[i].src, up[i].bytes, hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess)
-                rc = fail(VX_ERR_HIP, std::string("commit: upload failed: ") + hipGetErrorString(hipGetLastError()));
-        // the caller may rewrite the staging mirror as soon as we return: wait for the copies to have read it
-        if (rc == VX_OK && hipStreamSynchronize(ctx->upload_stream) != hipSuccess) rc = fail(VX_ERR_HIP, "commit: upload failed");
+        if (rc == VX_OK) rc = upload_big(ctx, up);
     }
     if (rc != VX_OK) {
         // the device copy of the image can no longer be trusted; the world's own bytes may be incomplete too, which the caller
@@ -1106,21 +1172,37 @@ int vx_raycast(vx_context* ctx, const vx_picker_task* tasks, uint32_t count, vx_
     VX_LOCK(ctx);
     if (count == 0) return VX_OK;
     if (!tasks || !results) return fail(VX_ERR_INVALID_ARGUMENT, "raycast: null argument");
+    const int svo = ctx->big ? VX_SVO_ESVO_BIG : ctx->svo_type;
+    // The game's batches are small (80 tasks for an entity's AABB fan, svo_picker.rs:311-536; the reference sizes its buffers for 100, svo.rs:138-139)
+    // and a call is synchronous, 250 times a second: what it costs is its round trips, not its rays. Up to kPickerDirect tasks the kernel reads
+    // the tasks from, and writes the results to, pinned host memory the device sees (no copy commands: one launch, one wait); larger batches
+    // (C1's 65,536 rays: 3 MB each way) travel by DMA.
+    if (count <= vx_context::kPickerDirect) {
+        if (!ctx->h_pick_tasks) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pick_tasks), vx_context::kPickerDirect * sizeof(vx_picker_task), hipHostMallocMapped));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pick_results), vx_context::kPickerDirect * sizeof(vx_picker_result), hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_pick_tasks), ctx->h_pick_tasks, 0));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_pick_results), ctx->h_pick_results, 0));
+        }
+        std::memcpy(ctx->h_pick_tasks, tasks, size_t(count) * sizeof(vx_picker_task));
+        HIP_TRY(vxk::launch_picker(svo, ctx->stream, scene_of(ctx), ctx->d_pick_tasks, count, ctx->d_pick_results));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));  // the reference blocks on its fence too (svo.rs:248-249)
+        std::memcpy(results, ctx->h_pick_results, size_t(count) * sizeof(vx_picker_result));
+        return VX_OK;
+    }
     if (ctx->picker_cap < count) {
         if (ctx->d_tasks) (void)hipFree(ctx->d_tasks);
         if (ctx->d_results) (void)hipFree(ctx->d_results);
         ctx->d_tasks = nullptr; ctx->d_results = nullptr; ctx->picker_cap = 0;
-        const uint32_t cap = count < 128 ? 128 : count;  // the reference sizes these for 100 tasks (svo.rs:138-139)
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_tasks), size_t(cap) * sizeof(vx_picker_task)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_results), size_t(cap) * sizeof(vx_picker_result)));
-        ctx->picker_cap = cap;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_tasks), size_t(count) * sizeof(vx_picker_task)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_results), size_t(count) * sizeof(vx_picker_result)));
+        ctx->picker_cap = count;
     }
     HIP_TRY(hipMemcpyAsync(ctx->d_tasks, tasks, size_t(count) * sizeof(vx_picker_task), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(vxk::launch_picker(ctx->big ? VX_SVO_ESVO_BIG : ctx->svo_type, ctx->stream, scene_of(ctx), ctx->d_tasks, count, ctx->d_results));
-    HIP_TRY(hipEventRecord(ctx->render_done, ctx->stream));
-    ctx->render_recorded = true;
+    HIP_TRY(vxk::launch_picker(svo, ctx->stream, scene_of(ctx), ctx->d_tasks, count, ctx->d_results));
     HIP_TRY(hipMemcpyAsync(results, ctx->d_results, size_t(count) * sizeof(vx_picker_result), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the reference blocks on its fence too (svo.rs:248-249)
+    // (no event for later commits to wait for: the call returns when the stream has drained -- the reference blocks on its fence too)
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VX_OK;
 }
 
@@ -1224,18 +1306,25 @@ int vx_assemble_tiles_format(vx_context* ctx, const void* tiles, uint64_t stride
                              int format, void* stream) {
     if (!ctx || !tiles || !out || !tile_count || !width || !height || (format != VX_FORMAT_RGBA32F && format != VX_FORMAT_RGBA8))
         return fail(VX_ERR_INVALID_ARGUMENT, "assemble_tiles: bad argument");
+    // (pixels are moved as 16-byte words where they can be: RGBA32F lists and images are arrays of float4, RGBA8 ones of u32)
+    const uintptr_t align = format == VX_FORMAT_RGBA32F ? 15u : 3u;
+    if ((reinterpret_cast<uintptr_t>(tiles) & align) || (reinterpret_cast<uintptr_t>(out) & align))
+        return fail(VX_ERR_INVALID_ARGUMENT, "assemble_tiles: tile lists and image must be aligned to a pixel (16 bytes RGBA32F, 4 bytes RGBA8)");
     VX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t tiles_x = (width + kTile - 1) / kTile, tiles_y = (height + kTile - 1) / kTile;
     const vx_context::TileTable* t = nullptr;
     if (int rc = tile_table(ctx, tiles_x, tiles_y, &t)) return rc;
     HIP_TRY(vxk::launch_assemble(static_cast<hipStream_t>(stream), format, tiles, stride_pixels, tile_count, width, height, tiles_x, t->d_inverse, out));
-    // On the communicator's stream the assembly reads the gathered lists -- the root's own among them, which the root renders straight
-    // into (vx_gather_tiles). The newest gather's ticket therefore covers the assembly too: whoever waits for the ticket before
-    // rendering into a list again (vx_wait_gather) waits for the kernel that still reads it.
-    if (stream && static_cast<hipStream_t>(stream) == ctx->comm_stream && ctx->gather_index > 0) {
-        const int ticket = int((ctx->gather_index - 1) % unsigned(vx_context::kGatherEvents));
-        HIP_TRY(hipEventRecord(ctx->gather_done[ticket], ctx->comm_stream));
+    // On the communicator's stream the assembly reads gathered lists -- the root's own among them, which the root renders straight into
+    // (vx_gather_tiles). The tickets of every gather issued since the last assembly therefore cover this assembly too: whoever waits for
+    // one of them before rendering into a list again (vx_wait_gather) waits for the kernel that may still read it. (Round 3 re-recorded the
+    // newest ticket only: a caller that queued two gathers before assembling the first could overwrite a list under the assembly.)
+    if (stream && static_cast<hipStream_t>(stream) == ctx->comm_stream) {
+        for (unsigned g = ctx->assembled_index; g < ctx->gather_index; ++g)
+            if (ctx->gather_index - g <= unsigned(vx_context::kGatherEvents))
+                HIP_TRY(hipEventRecord(ctx->gather_done[g % unsigned(vx_context::kGatherEvents)], ctx->comm_stream));
+        ctx->assembled_index = ctx->gather_index;
     }
     return VX_OK;
 }
@@ -1254,7 +1343,7 @@ uint64_t vx_traversal_image_with_origin(int svo_type, const uint8_t* world_frame
                                         uint64_t capacity_words, uint32_t* out_origin_words, uint64_t origin_capacity_words) {
     if (!world_frame || layout < 0 || layout > 2 || (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO)) return 0;
     vximg::WorldImage img(svo_type, layout == 0 ? vximg::kEsvo48 : (layout == 1 ? vximg::kOct64 : vximg::kOct64Wide));
-    if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(16u, std::thread::hardware_concurrency())))) return 0;
+    if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(64u, std::thread::hardware_concurrency())))) return 0;
     const vximg::ZeroedWords& f = img.frame();
     if (out_words && capacity_words >= f.size()) std::memcpy(out_words, f.data(), f.size() * 4);
     const vximg::ZeroedWords& o = img.origin();

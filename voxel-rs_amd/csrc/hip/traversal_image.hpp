@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -87,6 +88,8 @@ public:
             if (q == MAP_FAILED) throw std::bad_alloc();
             p_ = static_cast<uint32_t*>(q);
             cap_ = want;
+            // (gigabytes that the encoding threads touch for the first time: as huge pages where the system gives them -- a hint, ignored otherwise)
+            (void)::madvise(p_, cap_ * 4, MADV_HUGEPAGE);
         }
         n_ = n;
     }
@@ -450,6 +453,8 @@ public:
     Layout layout() const { return layout_; }
     // the last update() failed only because the image outgrew what this layout's pointers can reach
     bool too_big() const { return too_big_; }
+    // seconds the last update() spent: [0] walking the root, [1] walking the chunks (workers), [2] placing them, [3] encoding them (workers), [4] the root and the header
+    const double* last_timing() const { return timing_; }
 
     // Is the point (x, y, z), in the octree's [1, 2)^3 coordinates, inside a voxel of the imaged world? A walk down the host
     // mirror, one child per level by the coordinates' mantissa bits. (The renderer asks this about the eye: every primary ray of
@@ -480,6 +485,9 @@ public:
     bool update(const uint8_t* world, uint64_t used, const Range* changed, size_t n_changed, unsigned threads) {
         dirty_.clear();
         too_big_ = false;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
+        auto t_step = now();
         if (used < 2) return false;
         const Bytes b{world + 8, size_t(used)};                                                        // CSVO arena
         const Words w{reinterpret_cast<const uint32_t*>(world + 4), size_t(used / 4 + 5)};             // ESVO descriptors[]
@@ -510,6 +518,8 @@ public:
         depth_ = depth;
         last_root_octants_ = root.octants.size();
 
+        timing_[0] = since(t_step);
+        t_step = now();
         // 2. drop images of chunks whose bytes were rewritten, note which of the others are still referenced (and whether they
         //    still hang in the same kind of slot), drop the rest; what is referenced and has no image is to be walked
         for (auto it = chunks_.begin(); n_changed && it != chunks_.end();) {
@@ -552,30 +562,50 @@ public:
         for (size_t i = 1; i < todo.size(); ++i)
             if (todo[i].key == todo[i - 1].key && (todo[i].masks != todo[i - 1].masks || todo[i].levels != todo[i - 1].levels)) return fail();
         todo.erase(std::unique(todo.begin(), todo.end(), [](const ChunkRef& x, const ChunkRef& y) { return x.key == y.key; }), todo.end());
-        std::vector<Tree> built(todo.size());
-        parallel(todo.size(), threads, [&](size_t i) {
-            if (esvo_) EsvoWalker(w, built[i], nullptr).run(todo[i].key, todo[i].masks, todo[i].levels);
-            else ChunkWalker(b, built[i]).run(todo[i].key);
-        });
-        std::vector<Placed> placed(todo.size());
+        // In batches: a tree is ~60 bytes an octant until it is encoded -- all of a whole world's at once were 9 GB of first-touched memory for the
+        // depth-14 terrain, and the workers' heap growth serialised them (the first build of a process walked its chunks no faster on sixteen
+        // threads than on one). A batch's trees are walked into vectors that keep their capacity, placed, encoded in place, and reused.
+        const size_t batch = 4096;
+        std::vector<Tree> built(std::min(todo.size(), batch));
+        std::vector<Placed> placed(built.size());
+        chunks_.reserve(chunks_.size() + todo.size());
         uint64_t top = frame_.size();
-        for (size_t i = 0; i < todo.size(); ++i) {
-            if (built[i].too_deep) return fail();
-            Placed& pl = placed[i];
-            pl.words = tree_words(built[i]);
-            pl.at = alloc_.alloc(pl.words);
-            pl.masks = built[i].root.packed();
-            pl.levels = todo[i].levels;
-            pl.seen = epoch_;
-            pl.src_begin = built[i].src_begin;
-            pl.src_end = built[i].src_end;
-            top = std::max(top, pl.at + pl.words);
-            dirty_.push_back(Range{pl.at * 4, pl.words * 4});
-            chunks_[todo[i].key] = pl;
+        double t_walk = since(t_step), t_place = 0.0, t_encode = 0.0;
+        for (size_t base = 0; base < todo.size(); base += batch) {
+            const size_t n = std::min(batch, todo.size() - base);
+            t_step = now();
+            parallel(n, threads, [&](size_t i) {
+                built[i].too_deep = false;
+                if (esvo_) EsvoWalker(w, built[i], nullptr).run(todo[base + i].key, todo[base + i].masks, todo[base + i].levels);
+                else ChunkWalker(b, built[i]).run(todo[base + i].key);
+                placed[i].words = tree_words(built[i]);  // (here, not in the placing loop: it looks at every octant)
+            });
+            t_walk += since(t_step);
+            t_step = now();
+            for (size_t i = 0; i < n; ++i) {
+                if (built[i].too_deep) return fail();
+                Placed& pl = placed[i];
+                pl.at = alloc_.alloc(pl.words);
+                pl.masks = built[i].root.packed();
+                pl.levels = todo[base + i].levels;
+                pl.seen = epoch_;
+                pl.src_begin = built[i].src_begin;
+                pl.src_end = built[i].src_end;
+                top = std::max(top, pl.at + pl.words);
+                dirty_.push_back(Range{pl.at * 4, pl.words * 4});
+                chunks_[todo[base + i].key] = pl;
+            }
+            if (frame_.size() < top) frame_.resize(top, 0u);
+            if (has_origin() && origin_.size() < frame_.size() / 4) origin_.resize(frame_.size() / 4, 0u);
+            t_place += since(t_step);
+            t_step = now();
+            parallel(n, threads, [&](size_t i) { encode(built[i], placed[i].at); });
+            t_encode += since(t_step);
         }
-        if (frame_.size() < top) frame_.resize(top, 0u);
-        if (has_origin() && origin_.size() < frame_.size() / 4) origin_.resize(frame_.size() / 4, 0u);
-        parallel(todo.size(), threads, [&](size_t i) { encode(built[i], placed[i].at); });
+        timing_[1] = t_walk;
+        timing_[2] = t_place;
+        timing_[3] = t_encode;
+        t_step = now();
 
         // 4. the root octree is rewritten by every commit (csvo.rs:68-139 re-serializes it): so is its image
         alloc_.release(root_at_, root_words_);
@@ -606,6 +636,7 @@ public:
         dirty_.push_back(Range{0, header_words() * 4});
         // what the pointers can reach: 32-bit byte offsets (and the buffer resource's) / 32-bit octant indices / 31-bit word offsets
         const uint64_t end = alloc_.end();
+        timing_[4] = since(t_step);
         too_big_ = layout_ == kOct64 ? end * 4 + 4096 >= (uint64_t(1) << 32) : (layout_ == kOct64Wide ? end / 8 >= (uint64_t(1) << 32) : end >= (uint64_t(1) << 31));
         return !too_big_;
     }
@@ -724,6 +755,7 @@ private:
     size_t last_root_octants_ = 0;
     uint32_t epoch_ = 0;
     bool too_big_ = false;
+    double timing_[5] = {};
 };
 
 }  // namespace vximg

@@ -97,6 +97,10 @@ struct vx_context {
     float* d_frame = nullptr;  size_t d_frame_bytes = 0;
     vx_hit* d_hits = nullptr;  size_t d_hits_bytes = 0;
     vx_picker_task* d_tasks = nullptr;  vx_picker_result* d_results = nullptr;  uint32_t picker_cap = 0;
+    // small picker batches: pinned host memory the kernel reads and writes directly (vx_raycast)
+    static constexpr uint32_t kPickerDirect = 2048;
+    vx_picker_task* h_pick_tasks = nullptr;  vx_picker_result* h_pick_results = nullptr;
+    vx_picker_task* d_pick_tasks = nullptr;  vx_picker_result* d_pick_results = nullptr;
     vx_result* d_trace_result = nullptr;  vx_frame* d_trace_frames = nullptr;  uint32_t* d_trace_count = nullptr;  uint32_t trace_cap = 0;
     unsigned long long* d_counters = nullptr;
 
@@ -150,7 +154,8 @@ struct vx_context {
     hipStream_t comm_stream = nullptr;
     static constexpr int kGatherEvents = 16;
     hipEvent_t gather_done[kGatherEvents] = {};
-    unsigned gather_index = 0;
+    unsigned gather_index = 0;      // gathers issued so far (ticket = index % kGatherEvents)
+    unsigned assembled_index = 0;   // ... of which an assembly on the communicator's stream has been issued behind
     std::vector<vxrt::ProfiledLaunch> gathers;  // vx_profile_enable: the exchanges' event pairs (vx_comm_profile_read)
 
     // pipelined presentation (vx_present_begin / vx_present_wait): per slot a device frame and its pinned host twin; the read-back
