@@ -8,8 +8,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[2]
 cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
-       "-fno-fast-math", f"-I{ROOT}/include", f"-I{ROOT}/voxel-rs_amd/csrc/hip", "-shared", "-o", "/tmp/vx_resource_usage.so",
-       str(ROOT / "voxel-rs_amd/csrc/hip/vx_api.hip"), "-Rpass-analysis=kernel-resource-usage"]
+       "-fno-fast-math", f"-I{ROOT}/include", f"-I{ROOT}/voxel-rs_amd/csrc/hip", "-c", "-o", "/tmp/vx_resource_usage.o",
+       str(ROOT / "voxel-rs_amd/csrc/hip/kernels_render.hip"), "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
 rows, cur = [], None
 for line in out.splitlines():

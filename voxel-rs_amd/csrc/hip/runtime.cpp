@@ -829,9 +829,9 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         // re-lay the changed chunks (and the root octree, which every commit rewrites) out as octants
         std::vector<vximg::Range> changed(count);
         for (uint32_t i = 0; i < count; ++i) changed[i] = vximg::Range{ranges[i].start, ranges[i].length};
-        // (a whole world: every core up to 64 -- the depth-14 terrain's image, 5.7 GB from 418 K chunks, took 4.2 s on 16; WorldImage::update takes
-        // no more workers than a sixteenth of the chunks it has to walk, so an incremental commit stays on a few)
-        const unsigned threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        // (up to 32 workers for the chunk walk of a whole world, 16 for its encoding; WorldImage::update takes no more than a sixteenth of the chunks
+        // it has to walk, so an incremental commit stays on a few)
+        const unsigned threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
         // A world whose image will not fit 32-bit byte offsets starts in the wide layout instead of finding that out at the end of a whole
         // build (an image is about 0.84 x the bytes of an ESVO world, 3.9 x those of a CSVO world; the wide layout serves any size)
         if (ctx->image.chunk_count() == 0 && ctx->image.layout() == vximg::kOct64 &&
@@ -1343,7 +1343,7 @@ uint64_t vx_traversal_image_with_origin(int svo_type, const uint8_t* world_frame
                                         uint64_t capacity_words, uint32_t* out_origin_words, uint64_t origin_capacity_words) {
     if (!world_frame || layout < 0 || layout > 2 || (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO)) return 0;
     vximg::WorldImage img(svo_type, layout == 0 ? vximg::kEsvo48 : (layout == 1 ? vximg::kOct64 : vximg::kOct64Wide));
-    if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(64u, std::thread::hardware_concurrency())))) return 0;
+    if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(32u, std::thread::hardware_concurrency())))) return 0;
     const vximg::ZeroedWords& f = img.frame();
     if (out_words && capacity_words >= f.size()) std::memcpy(out_words, f.data(), f.size() * 4);
     const vximg::ZeroedWords& o = img.origin();

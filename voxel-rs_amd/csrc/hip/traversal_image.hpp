@@ -27,6 +27,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -416,6 +419,76 @@ private:
     uint64_t end_ = 0;
 };
 
+// Worker threads that live as long as one update(): a whole world is walked and encoded in a hundred batches, and a thread per worker and batch
+// was a fifth of a second of thread creation on 48 workers.
+class Workers {
+public:
+    explicit Workers(unsigned n) {
+        for (unsigned t = 1; t < n; ++t) pool_.emplace_back([this] { loop(); });
+    }
+    ~Workers() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : pool_) t.join();
+    }
+    unsigned size() const { return unsigned(pool_.size()) + 1u; }
+    // f(i) for i in [0, n), on at most `limit` of the workers (the caller's thread is one of them)
+    void run(size_t n, unsigned limit, const std::function<void(size_t)>& f) {
+        if (n == 0) return;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            f_ = &f;
+            n_ = n;
+            next_.store(0);
+            active_ = 0;
+            slots_ = limit > 1 ? limit - 1 : 0;
+            ++generation_;
+        }
+        cv_.notify_all();
+        for (size_t i; (i = next_.fetch_add(1)) < n;) f(i);
+        std::unique_lock<std::mutex> lk(m_);
+        slots_ = 0;  // (nobody else joins this round)
+        done_.wait(lk, [&] { return active_ == 0; });
+        f_ = nullptr;
+    }
+
+private:
+    void loop() {
+        unsigned seen = 0;
+        for (;;) {
+            const std::function<void(size_t)>* f = nullptr;
+            size_t n = 0;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (generation_ != seen && slots_ > 0); });
+                if (stop_) return;
+                seen = generation_;
+                --slots_;
+                ++active_;
+                f = f_;
+                n = n_;
+            }
+            for (size_t i; (i = next_.fetch_add(1)) < n;) (*f)(i);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                --active_;
+            }
+            done_.notify_one();
+        }
+    }
+    std::vector<std::thread> pool_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* f_ = nullptr;
+    size_t n_ = 0;
+    std::atomic<size_t> next_{0};
+    unsigned generation_ = 0, slots_ = 0, active_ = 0;
+    bool stop_ = false;
+};
+
 // The image of a whole world, kept up to date commit by commit.
 class WorldImage {
 public:
@@ -566,6 +639,10 @@ public:
         // depth-14 terrain, and the workers' heap growth serialised them (the first build of a process walked its chunks no faster on sixteen
         // threads than on one). A batch's trees are walked into vectors that keep their capacity, placed, encoded in place, and reused.
         const size_t batch = 4096;
+        // (workers: a sixteenth of the chunks at most -- an incremental commit stays on a few --; the encoding, whose first touch of the frame's
+        // pages contends in the kernel, on sixteen at most: measured on the depth-14 terrain, profiles/round4/pass_p)
+        Workers workers(std::max(1u, std::min<unsigned>(threads, unsigned(todo.size() / 16 + 1))));
+        const unsigned encoders = std::min(16u, workers.size());
         std::vector<Tree> built(std::min(todo.size(), batch));
         std::vector<Placed> placed(built.size());
         chunks_.reserve(chunks_.size() + todo.size());
@@ -574,7 +651,7 @@ public:
         for (size_t base = 0; base < todo.size(); base += batch) {
             const size_t n = std::min(batch, todo.size() - base);
             t_step = now();
-            parallel(n, threads, [&](size_t i) {
+            workers.run(n, workers.size(), [&](size_t i) {
                 built[i].too_deep = false;
                 if (esvo_) EsvoWalker(w, built[i], nullptr).run(todo[base + i].key, todo[base + i].masks, todo[base + i].levels);
                 else ChunkWalker(b, built[i]).run(todo[base + i].key);
@@ -599,7 +676,7 @@ public:
             if (has_origin() && origin_.size() < frame_.size() / 4) origin_.resize(frame_.size() / 4, 0u);
             t_place += since(t_step);
             t_step = now();
-            parallel(n, threads, [&](size_t i) { encode(built[i], placed[i].at); });
+            workers.run(n, encoders, [&](size_t i) { encode(built[i], placed[i].at); });
             t_encode += since(t_step);
         }
         timing_[1] = t_walk;
@@ -666,19 +743,6 @@ private:
         uint64_t n = 0;
         for (const Octant& o : t.octants) n += oct64_words(o);
         return n;
-    }
-
-    template <class F>
-    static void parallel(size_t n, unsigned threads, F f) {
-        std::atomic<size_t> next{0};
-        auto worker = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
-        };
-        const unsigned n_workers = std::max(1u, std::min<unsigned>(threads, unsigned(n / 16 + 1)));
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < n_workers; ++t) pool.emplace_back(worker);
-        worker();
-        for (auto& t : pool) t.join();
     }
 
     // writes the tree's octants at frame word `at` (in walk order, each as large as its layout makes it); chunk children hold
