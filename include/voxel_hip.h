@@ -301,8 +301,9 @@ int vx_wait_gather(vx_context* ctx, int ticket);
 int vx_gather_query(vx_context* ctx, int ticket);
 void* vx_comm_stream(vx_context* ctx);
 /* vx_assemble_tiles for either pixel format: stride in PIXELS between the ranks' lists; an RGBA8 image comes out top row first.
- * Issued on vx_comm_stream(ctx), it extends the newest gather's ticket: vx_wait_gather(ticket) then also waits for this kernel,
- * which reads every rank's list -- the root's own included, which the root renders into in place. */
+ * Issued on vx_comm_stream(ctx), it extends the ticket of every gather issued since the last assembly on that stream: vx_wait_gather(ticket)
+ * then also waits for this kernel, which reads every rank's list -- the root's own included, which the root renders into in place. Lists and
+ * image must be aligned to a pixel (16 bytes RGBA32F, 4 bytes RGBA8). */
 int vx_assemble_tiles_format(vx_context* ctx, const void* tiles, uint64_t stride_pixels, uint32_t tile_count, uint32_t width, uint32_t height, void* out,
                              int format, void* stream);
 
@@ -348,7 +349,7 @@ int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches);
 /* The same for the exchanges (vx_gather_tiles calls made while profiling was enabled): time on the communicator's stream from the
  * first send / receive to the last, i.e. including the wait for the slowest peer. Synchronises the communicator's stream. */
 int vx_comm_profile_read(vx_context* ctx, double* gather_ms_sum, uint32_t* gathers);
-/* Measurement (contexts created with VX_TIMELINE=1 in the environment; else returns 0): per wave of the most recent render launch
+/* Measurement (contexts created with VX_TIMELINE=1 in the environment by the library's timeline build, lib/lib_tl; else returns 0): per wave of the most recent render launch
  * EIGHT words -- [0] when it started, [1] when it found the sub-tile queue empty, [2] when it left (all in 10 ns ticks of the device's
  * constant clock), [3] sub-tiles taken | service phases << 20 | ticks spent in them << 32, [4] its life in shader-clock cycles
  * (s_memtime: [4] / ([2] - [0]) x 100 MHz is the clock the kernel ran at), [5] the cycles of it spent in the traversal loop, [6] the
