@@ -54,6 +54,9 @@ def main():
     t0 = t[:, 0].min()
     start, empty, leave = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0  # microseconds
     q = lambda a: [round(float(np.percentile(a, p)), 1) for p in (0, 10, 50, 90, 99, 100)]
+    r7 = t[:, 7].astype(np.uint64)
+    wp, wt, wc = (r7 >> np.uint64(52)).astype(np.float64), ((r7 >> np.uint64(32)) & np.uint64(0xfffff)).astype(np.float64), (r7 & np.uint64(0xffffffff)).astype(np.float64)
+    fit = [round(float(v), 1) for v in np.linalg.lstsq(np.stack([wp, wt], axis=1), wc, rcond=None)[0]] if wp.sum() > 0 else None
     print(json.dumps({"format": args.format, "hot_first": args.hot, "waves": int(len(t)), "percentiles": [0, 10, 50, 90, 99, 100],
                       "start_us": q(start), "queue_empty_us": q(empty[t[:, 1] > 0]), "exit_us": q(leave), "tail_us_per_wave": q((leave - empty)[t[:, 1] > 0]),
                       "subtiles_taken": q(t[:, 3].astype(np.uint64) & np.uint64(0xfffff)),
@@ -67,7 +70,10 @@ def main():
                       "loop_trips_per_wave": q(t[:, 6]),
                       "cycles_per_trip_as_a_wave_sees_it": q(t[:, 5] / np.maximum(t[:, 6], 1.0)),
                       "cycles_per_trip_mean": round(float(t[:, 5].sum() / max(t[:, 6].sum(), 1.0)), 1),
-                      "simd_cycles_per_trip_at_4_waves": round(float(t[:, 5].sum() / max(t[:, 6].sum(), 1.0)) / 4.0, 1)}))
+                      "simd_cycles_per_trip_at_4_waves": round(float(t[:, 5].sum() / max(t[:, 6].sum(), 1.0)) / 4.0, 1),
+                      # the walks inside voxels (CSVO worlds): phases per wave, trips of the walk's loop (the slowest lane's iterations, summed over the
+                      # phases), shader-clock cycles in the walks -- and the least-squares fit cycles = a * phases + b * trips over the waves
+                      "walk_phases_per_wave": q(wp), "walk_trips_per_wave": q(wt), "walk_cycles_per_wave": q(wc), "walk_fit_cycles_per_phase_and_per_trip": fit}))
 
 
 if __name__ == "__main__":

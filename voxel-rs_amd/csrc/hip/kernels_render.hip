@@ -289,6 +289,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
         return t;
     };
     if (blockIdx.x == 0 && lane < kQueues) a.next_counter[lane * kQueueStride] = 0u;
+    uint32_t walk_cycles = 0, walk_trips = 0, walk_phases = 0;  // timeline only, wave-uniform: the walks inside voxels -- shader-clock cycles, trips of the walk's loop (its slowest lane's iterations), phases
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
 
     for (;;) {
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                 uint32_t on_bytes = 0;
                 bool given_up = false;
                 walk_phase = true;
+                const unsigned long long c_walk = a.timeline ? __builtin_amdgcn_s_memtime() : 0ull;
                 if (state == kForeign) {
                     walked = true;
                     tr.iter &= ~kParked;
@@ -445,6 +447,13 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                         held_t = state == kDone ? res.t : -1.0f;
                         state = kHeld;
                     }
+                }
+                if (a.timeline) {
+                    uint32_t most = on_bytes;
+                    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(most, off, 64); most = o > most ? o : most; }
+                    walk_cycles += uint32_t(__builtin_amdgcn_s_memtime() - c_walk);
+                    walk_trips += uint32_t(__builtin_amdgcn_readfirstlane(most));
+                    ++walk_phases;
                 }
                 // What the walk gave up on (a phantom chunk boundary, a phantom leaf of a block with holes, a straggler: walk_voxel_on_bytes) is run on the
                 // world's own bytes at the end of the wave's life: image-only renders list the RAY (a shadow ray: only the shadow ray); renders
@@ -657,7 +666,8 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
         unsigned long long* row = a.timeline + size_t(blockIdx.x) * 8;
         row[0] = t_start; row[1] = t_empty; row[2] = __builtin_amdgcn_s_memrealtime();
         row[3] = taken | ((unsigned long long)(service_phases & 0xfffu) << 20) | ((unsigned long long)in_service << 32);  // sub-tiles, service phases, ticks spent in them
-        row[4] = __builtin_amdgcn_s_memtime() - c_start; row[5] = loop_cycles; row[6] = loop_trips; row[7] = 0;
+        row[4] = __builtin_amdgcn_s_memtime() - c_start; row[5] = loop_cycles; row[6] = loop_trips;
+        row[7] = ((unsigned long long)(walk_phases & 0xfffu) << 52) | ((unsigned long long)(walk_trips & 0xfffffu) << 32) | walk_cycles;  // the walks inside voxels: phases, trips of their loop, cycles
     }
     // ---- second phase (image-only renders of a CSVO world): the rays this wave listed, on the world's own bytes ----
     if (FOREIGN == kForeignRerun || (FOREIGN == VX_SVO_CSVO && !HITS)) {

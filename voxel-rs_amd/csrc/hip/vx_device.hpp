@@ -1075,11 +1075,14 @@ struct Trav {
 // entry inside the voxel is {byte pointer, t_max, 16-bit header}: it fits the image cursor's own LDS slots below the voxel's parent --
 // which this ray's image cursor never uses -- 16-bit third plane included. The cursor's floats live in the image cursor `tr`
 // throughout (nothing is copied), and the voxel's parent takes part as a byte node whose header is the image node's child mask.
-// What a walk phase costs is its slowest lane: the lanes of a wave walk together, a walk is 3 iterations long on average and 15 for the
-// slowest of a sub-tile's rays, and an iteration is ~150 instructions at a quarter of a SIMD's issue slots -- the loads matter less than that
-// (tried, profiles/round4/pass_i: the voxels' N0 bytes kept beside the origin entry so that two walks in three read nothing of the world --
-// no gain; nodes below N0 fetched as 16 bytes, a PUSH's table entry taken from them -- 3 % slower; a cap on the stragglers of a phase, the
-// capped rays run on the bytes -- the rerun costs what the cap saves, pass_d).
+// What a walk phase costs is its slowest lane. Measured (the timeline build's walk probe, 4K depth-14 frame, profiles/round4/pass_q): a wave
+// makes 16 walk phases, 31 walkers each, whose loop makes 10 trips a phase -- a walk is 3 iterations long on average, but the slowest of 31
+// decides -- and cycles = 3,700 a phase + 2,700 a trip: a trip is two or three memory accesses one after the other (table entry, child
+// header, a stack slot below the LDS-resident levels), not its instructions -- with half as many waves on a CU it still takes 2,200.
+// Tried and not kept: the voxels' N0 bytes kept beside the origin entry so that two walks in three read nothing of the world (no gain:
+// the stragglers decide); nodes below N0 fetched as 16 bytes, a PUSH's table entry taken from them (3 % slower, pass_i); a cap on a
+// shadow ray's walk, the capped rays run on the world's bytes at the end of the wave's life (what the cap saves the rerun costs: 4K
+// depth 13 -2 %, 8K +2 %, pass_d / pass_q) or on the image again, walking together there (slower than on the bytes, pass_q).
 // It ends when a POP brings the ray back to the voxel's parent or above: from there on every node is a real one again and the ray
 // continues on the image (the stack slots at and above the parent's scale hold image entries, the walk only ever writes below them).
 // One loop, whose iterations are the reference's iterations (`tr.iter` counts them; the iteration `tr` stopped in is the first one
@@ -1102,12 +1105,20 @@ __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, b
     uint32_t bp = o0;  // the byte node the cursor examines: L first
     // its header in the 2-bits-per-child form (tag 01 per present child of a 1-bit level, csvo_header()): L's is the image node's child mask
     // (child c at bit 31 - c there)
-    uint32_t hd = rev_bits32(img_node) & 0xffu;
-    hd = (hd | (hd << 4)) & 0x0f0fu;
-    hd = (hd | (hd << 2)) & 0x3333u;
-    hd = (hd | (hd << 1)) & 0x5555u;
+    auto spread8 = [](uint32_t x) -> uint32_t {
+        x = (x | (x << 4)) & 0x0f0fu;
+        x = (x | (x << 2)) & 0x3333u;
+        return (x | (x << 1)) & 0x5555u;
+    };
+    uint32_t hd = spread8(rev_bits32(img_node) & 0xffu);
+    if (tr.iter >= uint32_t(kMaxSteps)) return kTravFinished;
+    // One iteration is ONE stretch of code for every lane: the PUSH's and the ADVANCE / POP's values are both worked out and the cursor takes one set
+    // or the other by selects; only the memory operations (table entry, child header, stack slot) sit under their lanes' predicate, and a lane whose
+    // walk ends notes how (`status`) and leaves at the bottom. Round 4's first form -- the reference's if / else if tree with a return wherever
+    // a walk can end -- compiled to ~490 instructions an iteration, 170 of them mask bookkeeping and register copies at the joins
+    // (profiles/round4/pass_q); a walk phase costs the iterations of its slowest lane, so that is what counts.
+    TravStatus status = kTravContinue;
     for (;;) {
-        if (tr.iter >= uint32_t(kMaxSteps)) return kTravFinished;
         if (LIMIT && tr.max_dst >= 0.0f && tr.t_min > tr.max_dst) return kTravFinished;
         ++tr.iter;
         const int dp = tr.scale - parent_scale + 1;  // the node's depth (svo.csvo.glsl:254): 1 = L, 0 = N0, below: wrapped
@@ -1118,91 +1129,89 @@ __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, b
         const bool is_child = tag != 0u, is_leaf = is_child && dp >= 0;
         const bool descend = is_child && tr.t_min <= tr.t_max;
         if (!descend) tr.flags &= ~T::kHasAdjacentLeaf;
-        bool advance = true;
-        if (descend && is_leaf && tr.t_min > 0.0f) {
+        bool out = false;  // this lane's walk ends with this iteration
+        const bool leaf_case = descend && is_leaf && tr.t_min > 0.0f;
+        if (leaf_case) {
             // a phantom leaf (a child of N0: the voxel's parent is left for the image as soon as the cursor is back at it), svo.csvo.glsl:296-372
             const uint32_t value = csvo_read_leaf_at(world, o0 - (o1 & 0x1fffffffu), o0 - 3u - (o1 >> 29), bp, oct);
-            bool decided = false;
+            bool hit = false;
             if constexpr (OPAQUE) {
                 const uint32_t set = value < 32u ? opaque_lo : opaque_hi;
                 if (value < 64u && ((set >> (value & 31u)) & 1u) != 0u && !(tr.flags & T::kHasAdjacentLeaf)) {
                     tr.leaf_hit_opaque(img, value, res);
                     *color_pending = true;
-                    return kTravAtLeaf;
+                    hit = true;
                 }
             }
             if constexpr (FULL_LEAF) {
-                if (tr.leaf_test_value(img, value, cast_translucent, res)) return kTravAtLeaf;
-                decided = true;  // passed: a translucent leaf, recorded; the rest of the iteration is the ADVANCE
+                if (!hit && tr.leaf_test_value(img, value, cast_translucent, res)) hit = true;
+                // (else passed: a translucent leaf, recorded; the rest of the iteration is the ADVANCE)
             }
-            if (!decided) return kTravForeign;
-        } else if (descend) {
-            if (is_leaf && tr.t_min == 0.0f) tr.flags |= T::kInsideVoxel;
-            const float tv_max = gmin(tr.t_max, tc_max);
-            if (tr.t_min <= tv_max) {
-                // ---- PUSH (svo.csvo.glsl:387-426) ----
-                if (tr.scale == 0) return kTravForeign;  // (below scale 0 the child index is no longer a mantissa bit)
-                const uint32_t offset = csvo_tag_bytes(hd & ((1u << (oct * 2u)) - 1u));
-                uint32_t next = bp + 3u + offset;  // out of L or N0 (read_next_ptr's leaf-node case)
-                if (dp < 0) {
-                    const uint32_t table = bp + 2u;
-                    const uint32_t word = u32_at(table + offset);
-                    const uint32_t e = word & (0xffffffffu >> ((0x001018u >> ((tag - 1u) * 8u)) & 0xffu));
-                    if (e & 0x80000000u) return kTravForeign;  // a phantom chunk boundary
-                    next = table + csvo_tag_bytes(hd) + e;
-                }
-                if (tr.scale == parent_scale) st.push(tr.scale, img_ptr, tr.t_max, img_node);  // (the way back needs the image's entry; written whether or not tc_max < h: harmless, the slot holds nothing else the ray could pop)
-                else if (tc_max < tr.h) st.push(tr.scale, bp, tr.t_max, hd << 16);
-                const float half = tr.scale_exp2 * 0.5f;
-                const float tcenx = __builtin_fmaf(half, tr.tcx, tcrx), tceny = __builtin_fmaf(half, tr.tcy, tcry), tcenz = __builtin_fmaf(half, tr.tcz, tcrz);
-                tr.h = tc_max;
-                --tr.scale;
-                tr.scale_exp2 = half;
-                if (tr.t_min < tcenx) tr.px += half;
-                if (tr.t_min < tceny) tr.py += half;
-                if (tr.t_min < tcenz) tr.pz += half;
-                tr.t_max = tv_max;
-                bp = next;
-                // the child's header: N0's one byte spread to tags, a u16 below it
-                const uint32_t raw = u32_at(bp);
-                uint32_t x = raw & 0xffu;
-                x = (x | (x << 4)) & 0x0f0fu;
-                x = (x | (x << 2)) & 0x3333u;
-                x = (x | (x << 1)) & 0x5555u;
-                hd = dp == 1 ? x : (raw & 0xffffu);
-                advance = false;
-            }
+            if (hit) { status = kTravAtLeaf; out = true; }
+            else if (!FULL_LEAF) { status = kTravForeign; out = true; }
         }
-        if (advance) {
-            // ---- ADVANCE, POP (svo.csvo.glsl:432-506; the child index is the position's bit at `scale`: see Trav::advance) ----
-            const float ax = tc_max >= tcrx ? tr.scale_exp2 : 0.0f, ay = tc_max >= tcry ? tr.scale_exp2 : 0.0f, az = tc_max >= tcrz ? tr.scale_exp2 : 0.0f;
-            tr.t_min = tc_max;
-            tr.px -= ax; tr.py -= ay; tr.pz -= az;
-            const uint32_t differing_bits = (__float_as_uint(tr.px + ax) ^ __float_as_uint(tr.px)) | (__float_as_uint(tr.py + ay) ^ __float_as_uint(tr.py)) |
-                                            (__float_as_uint(tr.pz + az) ^ __float_as_uint(tr.pz));
-            if (differing_bits >= (2u << tr.scale)) {
-                tr.scale = 31 - __builtin_clz(differing_bits);
-                if (uint32_t(tr.scale) >= uint32_t(kMaxScale)) return kTravFinished;
-                tr.scale_exp2 = pow2i(tr.scale - kMaxScale);
-                uint32_t p, a;
-                st.pop(tr.scale, p, tr.t_max, a);
-                const uint32_t keep = 0xffffffffu << tr.scale;
-                tr.px = __uint_as_float(__float_as_uint(tr.px) & keep);
-                tr.py = __uint_as_float(__float_as_uint(tr.py) & keep);
-                tr.pz = __uint_as_float(__float_as_uint(tr.pz) & keep);
-                tr.h = 0.0f;
-                if (tr.scale >= parent_scale) {  // back among real nodes: the slot holds an image entry
-                    tr.ptr = p;
-                    tr.node = a;
-                    return kTravContinue;
-                }
-                bp = p;
-                hd = a >> 16;
-            } else if (tr.scale == parent_scale) {
-                return kTravContinue;  // (the voxel's span was empty: a step to a sibling voxel, still at the voxel's parent -- ptr and node untouched)
-            }
+        const bool to_voxel = descend && !leaf_case;  // (a lane that is `out` already runs the rest of the iteration to no effect: it neither pushes nor pops)
+        if (to_voxel && is_leaf && tr.t_min == 0.0f) tr.flags |= T::kInsideVoxel;
+        const float tv_max = gmin(tr.t_max, tc_max);
+        const bool push = to_voxel && tr.t_min <= tv_max;
+
+        // ---- PUSH (svo.csvo.glsl:387-426): the child's node, the stack entry, the child cell ----
+        const bool wrapped = dp < 0;
+        const uint32_t offset = csvo_tag_bytes(hd & ((1u << (oct * 2u)) - 1u));
+        const uint32_t table = bp + 2u;
+        uint32_t word = 0u;
+        if (push && wrapped) word = u32_at(table + offset);
+        const uint32_t e = word & (0xffffffffu >> ((0x001018u >> ((tag - 1u) * 8u)) & 0xffu));
+        // out of L or N0: read_next_ptr's leaf-node case; below: the table entry's
+        const uint32_t next = wrapped ? table + csvo_tag_bytes(hd) + e : bp + 3u + offset;
+        // given up: below scale 0 the child index is no longer a mantissa bit; a phantom chunk boundary
+        if (push && (tr.scale == 0 || (wrapped && (e & 0x80000000u) != 0u))) { status = kTravForeign; out = true; }
+        // (the way back out of the voxel needs the image's entry: written whether or not tc_max < h -- harmless, the slot holds nothing else the ray could pop)
+        if (push && (dp == 1 || tc_max < tr.h)) st.push(tr.scale, dp == 1 ? img_ptr : bp, tr.t_max, dp == 1 ? img_node : hd << 16);
+        const float half = tr.scale_exp2 * 0.5f;
+        const float tcenx = __builtin_fmaf(half, tr.tcx, tcrx), tceny = __builtin_fmaf(half, tr.tcy, tcry), tcenz = __builtin_fmaf(half, tr.tcz, tcrz);
+        const float cx = tr.t_min < tcenx ? tr.px + half : tr.px, cy = tr.t_min < tceny ? tr.py + half : tr.py, cz = tr.t_min < tcenz ? tr.pz + half : tr.pz;
+        // the child's header: N0's one byte spread to tags, a u16 below it
+        uint32_t raw = 0u;
+        if (push) raw = u32_at(next);
+        const uint32_t child_hd = dp == 1 ? spread8(raw & 0xffu) : (raw & 0xffffu);
+
+        // ---- ADVANCE, POP (svo.csvo.glsl:432-506; the child index is the position's bit at `scale`: see Trav::advance) ----
+        const float ax = tc_max >= tcrx ? tr.scale_exp2 : 0.0f, ay = tc_max >= tcry ? tr.scale_exp2 : 0.0f, az = tc_max >= tcrz ? tr.scale_exp2 : 0.0f;
+        const float sx = tr.px - ax, sy = tr.py - ay, sz = tr.pz - az;
+        const uint32_t differing_bits = (__float_as_uint(sx + ax) ^ __float_as_uint(sx)) | (__float_as_uint(sy + ay) ^ __float_as_uint(sy)) |
+                                        (__float_as_uint(sz + az) ^ __float_as_uint(sz));
+        const bool pop = !push && !out && differing_bits >= (2u << tr.scale);
+        const int up = 31 - __builtin_clz(differing_bits | 1u);
+        const bool gone = pop && uint32_t(up) >= uint32_t(kMaxScale);
+        if (gone) { status = kTravFinished; out = true; }
+        uint32_t p = 0u, a = 0u;
+        float popped_t_max = 0.0f;
+        if (pop && !gone) st.pop(up, p, popped_t_max, a);
+        const uint32_t keep = 0xffffffffu << (up & 31);
+        if (pop && !gone && up >= parent_scale) {  // back among real nodes: the slot holds an image entry
+            tr.ptr = p;
+            tr.node = a;
+            out = true;
         }
+        // (the voxel's span was empty: a step to a sibling voxel, still at the voxel's parent -- ptr and node untouched)
+        if (!push && !pop && dp == 1) out = true;  // (status: kTravContinue, or what the leaf test above has set)
+
+        // ---- the cursor's next state ----
+        tr.t_min = push ? tr.t_min : tc_max;
+        tr.px = push ? cx : (pop ? __uint_as_float(__float_as_uint(sx) & keep) : sx);
+        tr.py = push ? cy : (pop ? __uint_as_float(__float_as_uint(sy) & keep) : sy);
+        tr.pz = push ? cz : (pop ? __uint_as_float(__float_as_uint(sz) & keep) : sz);
+        tr.h = push ? tc_max : (pop ? 0.0f : tr.h);
+        tr.t_max = push ? tv_max : (pop ? popped_t_max : tr.t_max);
+        tr.scale_exp2 = push ? half : (pop ? pow2i((up & 31) - kMaxScale) : tr.scale_exp2);
+        tr.scale = push ? tr.scale - 1 : (pop ? up : tr.scale);
+        bp = push ? next : (pop ? p : bp);
+        hd = push ? child_hd : (pop ? a >> 16 : hd);
+        if (!out && tr.iter >= uint32_t(kMaxSteps)) { status = kTravFinished; out = true; }
+        if (out) break;
     }
+    return status;
 }
 
 __device__ __forceinline__ void result_miss(Result& res, bool inside_voxel) {
