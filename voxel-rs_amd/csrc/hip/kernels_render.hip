@@ -258,8 +258,8 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
     unsigned long long loop_cycles = 0ull;
     uint32_t loop_trips = 0;
     // the sub-tile queue: a ticket is this launch's sub-tile number (lane 0's value counts)
-    // Wave w starts on sub-tile w without asking (a launch never has more waves than sub-tiles): 4096 waves do not open the frame by
-    // queueing at one counter. The counter hands out the sub-tiles from gridDim.x on.
+    // Wave w = 8 j + c starts on dispenser c's j-th sub-tile without asking: 4096 waves do not open the frame by queueing at the counters. The
+    // dispenser hands out its sub-tiles from there on.
     uint32_t my_queue = blockIdx.x & (kQueues - 1u);  // wave-uniform: the dispenser this wave draws from
     // A ticket is DRAWN (the atomic issued, its raw count -- lane 0's -- left in a vector register) and, later, SETTLED (the count waited for and
     // made the sub-tile's number). Nothing between the two may touch the raw value: round 2's draw did the arithmetic at once, so the wave
@@ -271,15 +271,17 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
         if (lane == 0) raw = atomicAdd(a.work_counter + my_queue * kQueueStride, 1u);
         return raw;
     };
-    // the n-th ticket of dispenser c is sub-tile (first_c + n) * 8 + c, first_c = how many of the waves' own first sub-tiles are c's
+    // the n-th ticket of dispenser c is its (first_c + n)-th sub-tile (queue_subtile), first_c = how many of the waves' own first sub-tiles are c's
+    // (beyond the launch's last sub-tile: the dispenser is dry -- its sub-tiles' numbers grow with k)
+    auto region_ticket = [&](uint32_t k, uint32_t queue) -> uint32_t { return queue_subtile(k, queue, a.stripe); };
     auto ticket_of = [&](uint32_t raw, uint32_t queue) -> uint32_t {
-        return (((gridDim.x + kQueues - 1u - queue) >> 3) + uint32_t(__builtin_amdgcn_readfirstlane(raw))) * kQueues + queue;
+        return region_ticket(((gridDim.x + kQueues - 1u - queue) >> 3) + uint32_t(__builtin_amdgcn_readfirstlane(raw)), queue);
     };
     uint32_t ticket_raw = 0, ticket_queue = my_queue;  // the ticket drawn ahead: its raw count and the dispenser it came from
     bool ticket_ahead = true, ticket_first = true;   // wave-uniform; the wave's first ticket is its own number: nothing was drawn
     // the ticket as the wave's value; a dispenser that has run dry sends the wave on to the next one (the frame's last stretch only)
     auto settle_ticket = [&]() -> uint32_t {
-        uint32_t t = ticket_ahead ? (ticket_first ? blockIdx.x : ticket_of(ticket_raw, ticket_queue)) : ticket_of(draw_raw(), my_queue);
+        uint32_t t = ticket_ahead ? (ticket_first ? region_ticket(blockIdx.x >> 3, my_queue) : ticket_of(ticket_raw, ticket_queue)) : ticket_of(draw_raw(), my_queue);
         ticket_ahead = false;
         ticket_first = false;
         for (uint32_t tried = 1; t >= a.total_subtiles && tried < kQueues; ++tried) {

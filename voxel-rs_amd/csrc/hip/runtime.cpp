@@ -255,6 +255,12 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             a.cur_tag = hs->tag;
             hs->width = p.width; hs->height = p.height; hs->tile_rank = p.tile_rank; hs->tile_count = p.tile_count;
         }
+        // The queue's stretches (queue_subtile). Frames in flight: an eighth of the launch each -- every XCD its own band of the screen, frame after
+        // frame (+3-4 % on the stretches of one sub-tile round 3 dealt out; a row of tiles each is 3 % WORSE than those). One frame at a time the
+        // XCDs have to finish together: a tile each (+1-2 %) -- or one sub-tile, where the tickets are places in the cost-ordered table
+        // (profiles/round4/pass_r).
+        a.stripe = 1;
+        if (!a.order) a.stripe = ctx->queue_stripe > 0 ? uint32_t(ctx->queue_stripe) : (slot >= 0 ? (a.total_subtiles + kQueues - 1u) / kQueues : 16u);
         // Persistent waves per CU: all that fit -- the stacks fill a CU's LDS to the last hundred bytes. A context that gathers its tiles over
         // RCCL leaves `comm_headroom` of them out: LDS of every CU stays free, in one piece, for the communication kernels' workgroups, which
         // otherwise find room only when a whole frame has drained.
@@ -594,6 +600,7 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_COMM_HEADROOM")) c->comm_headroom = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
+        if (const char* e = std::getenv("VX_QUEUE_STRIPE")) c->queue_stripe = std::atoi(e);
         if (c->refill_min < 1) c->refill_min = 1;
         if (c->refill_min > 64) c->refill_min = 64;
         if (c->service_min < 1) c->service_min = 1;

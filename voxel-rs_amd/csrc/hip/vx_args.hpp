@@ -75,17 +75,27 @@ constexpr uint32_t kBlockEdge = 16;    // the one-thread-per-pixel kernel: a 256
 constexpr uint32_t kBlockThreads = 256;
 
 constexpr uint32_t kQueues = 8, kQueueStride = 64;  // dispensers of the sub-tile queue, words between them
+// The k-th sub-tile of dispenser c is sub-tile ((k / S) * 8 + c) * S + k % S: the launch's sub-tiles in stretches of S (`stripe`), dealt
+// out to the dispensers in turn. Workgroups b and b + 8 run on the same XCD and wave b draws from dispenser b & 7, so with long stretches (a
+// band of the screen; a compact piece of a tile list's Morton order) what an XCD's waves traverse is the part of the world behind its own
+// stretches, and that is what its L2 holds -- not, eight times over, the nodes behind the whole screen, as with S = 1 (round 3: sub-tiles c,
+// c + 8, c + 16, ... to dispenser c). S = 1 is still what a cost-ordered launch uses: its tickets are places in a table sorted by cost.
+VX_HOST_DEVICE inline uint32_t queue_subtile(uint32_t k, uint32_t c, uint32_t stripe) {
+    const uint32_t q = k / stripe;  // (once per sub-tile and wave)
+    return (q * kQueues + c) * stripe + (k - q * stripe);
+}
 
 struct PersistentArgs {
     // The sub-tile queue: eight dispensers (kQueueStride words apart: one memory-side atomic unit each), dispenser c hands out the sub-tiles
-    // c, c + 8, c + 16, ... beyond the waves' first ones (wave w starts on sub-tile w without asking). A wave draws from dispenser
-    // (w & 7) and, when that one is empty, from the next. One dispenser for 4096 waves is 70 M atomic adds per second on one address:
+    // queue_subtile(k, c) beyond its waves' first ones (wave w = 8 j + c starts on dispenser c's j-th sub-tile without asking). A
+    // wave draws from dispenser (w & 7) and, when that one is empty, from the next. One dispenser for 4096 waves is 70 M atomic adds per second on one address:
     // more than the memory side carries out there -- a ticket took tens of microseconds. A stream has two sets: a launch uses one and
     // clears the other for its successor (which does not start before this one has ended).
     uint32_t* work_counter;   // this launch's set
     uint32_t* next_counter;   // the set to clear
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
+    uint32_t stripe;          // the length of the stretches the sub-tiles are dealt out to the dispensers in (queue_subtile), at least 1
     // Expensive sub-tiles first. A ray is a chain of dependent steps -- about 0.8 us per iteration on a busy device -- so a frame cannot
     // end before its longest rays do (up to ~300 iterations against a mean of ~30): handed out in screen order they start in mid-frame
     // and the frame ends with a long tail of waves that wait for a few of them (profiles/timeline.py). So every ray that ends notes
