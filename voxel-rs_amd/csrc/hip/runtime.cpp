@@ -255,12 +255,11 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             a.cur_tag = hs->tag;
             hs->width = p.width; hs->height = p.height; hs->tile_rank = p.tile_rank; hs->tile_count = p.tile_count;
         }
-        // The queue's stretches (queue_subtile). Frames in flight: an eighth of the launch each -- every XCD its own band of the screen, frame after
-        // frame (+3-4 % on the stretches of one sub-tile round 3 dealt out; a row of tiles each is 3 % WORSE than those). One frame at a time the
-        // XCDs have to finish together: a tile each (+1-2 %) -- or one sub-tile, where the tickets are places in the cost-ordered table
-        // (profiles/round4/pass_r).
+        // The queue's stretches (queue_subtile): a tile each -- or one sub-tile, where the tickets are places in the cost-ordered table. (With the
+        // tiles numbered along the rows an eighth of the launch per dispenser -- every XCD its own band of the screen -- was worth 3-4 % with
+        // frames in flight and cost 7 % one frame at a time; numbered in strips it is worth nothing: profiles/round4/pass_r.)
         a.stripe = 1;
-        if (!a.order) a.stripe = ctx->queue_stripe > 0 ? uint32_t(ctx->queue_stripe) : (slot >= 0 ? (a.total_subtiles + kQueues - 1u) / kQueues : 16u);
+        if (!a.order) a.stripe = ctx->queue_stripe > 0 ? uint32_t(ctx->queue_stripe) : 16u;
         // Persistent waves per CU: all that fit -- the stacks fill a CU's LDS to the last hundred bytes. A context that gathers its tiles over
         // RCCL leaves `comm_headroom` of them out: LDS of every CU stays free, in one piece, for the communication kernels' workgroups, which
         // otherwise find room only when a whole frame has drained.
@@ -361,6 +360,26 @@ int fill_params(vx_context* ctx, const vx_uniforms* u, uint32_t w, uint32_t h, u
     p.height = h;
     p.tiles_x = (w + kTile - 1) / kTile;
     p.tiles_y = (h + kTile - 1) / kTile;
+    p.n_local_tiles = vx_local_tile_count(w, h, tile_rank, tile_count);
+    p.tile_numbering = uint32_t(ctx->tile_numbering);
+    if (p.tile_numbering == 1u && tile_count > 1) p.tile_numbering = 2u;  // (a tile list has no columns)
+    p.tile_stride = p.tile_stride_inv = 1;
+    p.strip_w = ctx->tile_strip > 0 ? uint32_t(ctx->tile_strip) : 1u;
+    if (p.strip_w > p.tiles_x) p.strip_w = p.tiles_x ? p.tiles_x : 1u;
+    if (p.tile_numbering == 2u && p.n_local_tiles < 3) p.tile_numbering = 0u;
+    if (p.tile_numbering == 2u) {
+        const uint64_t n = p.n_local_tiles;
+        auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+        uint64_t g = uint64_t(double(n) * 0.6180339887498949);
+        if (g < 1) g = 1;
+        while (gcd(g, n) != 1) ++g;  // (n - 1 is prime to n: the search ends)
+        // the inverse of g modulo n (extended Euclid)
+        long long t0 = 0, t1 = 1, r0 = (long long)n, r1 = (long long)g;
+        while (r1 > 0) { const long long q = r0 / r1; long long t = t0 - q * t1; t0 = t1; t1 = t; t = r0 - q * r1; r0 = r1; r1 = t; }
+        if (t0 < 0) t0 += (long long)n;
+        p.tile_stride = uint32_t(g);
+        p.tile_stride_inv = uint32_t(t0);
+    }
     p.tile_rank = tile_rank;
     p.tile_count = tile_count;
     p.n_local_tiles = vx_local_tile_count(w, h, tile_rank, tile_count);
@@ -601,6 +620,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_QUEUE_STRIPE")) c->queue_stripe = std::atoi(e);
+        if (const char* e = std::getenv("VX_TILE_NUMBERING")) c->tile_numbering = std::atoi(e);
+        if (const char* e = std::getenv("VX_TILE_STRIP")) c->tile_strip = std::atoi(e);
         if (c->refill_min < 1) c->refill_min = 1;
         if (c->refill_min > 64) c->refill_min = 64;
         if (c->service_min < 1) c->service_min = 1;

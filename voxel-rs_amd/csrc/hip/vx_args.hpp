@@ -50,6 +50,13 @@ struct RenderParams {
     uint32_t affine_view;  // the view matrix's last row is (0,0,0,1): the per-pixel perspective divide is a division by exactly 1
     uint32_t width, height;
     uint32_t tiles_x, tiles_y;
+    // How the queue's tile numbers i lie in the launch's list of n_local_tiles tiles (a whole image: its tiles in row-major order) -- 0: number =
+    // place; 1 (whole images): strips of strip_w columns one after the other, a strip's tiles along its rows (1: down the columns); 2: place (i * tile_stride) % n_local_tiles,
+    // tile_stride prime to the number of tiles and about 0.618 of it -- consecutive numbers lie far apart in both directions (the tile at place
+    // t has number (t * tile_stride_inv) % n_local_tiles). What a frame costs depends on the ORDER its tiles are handed out in: along the rows
+    // all waves are in the sky first and on the ground last -- the memory side idles, then queues -- and the frame ends on its dearest tiles
+    // (profiles/round4/pass_r: C3 0.261 -> 0.239 ms with frames in flight, 0.367 -> 0.348 one at a time, for either of 1 and 2).
+    uint32_t tile_numbering, tile_stride, tile_stride_inv, strip_w;
     uint32_t tile_rank, tile_count, n_local_tiles;
     // screen sharding (tile_count > 1): the image's 32x32 tiles in Morton order of their (x, y) -- this context renders the tiles
     // tile_order[k * tile_count + tile_rank], k = 0 .. n_local_tiles - 1 (device memory; null when the whole image is rendered)
