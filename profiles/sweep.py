@@ -17,9 +17,8 @@ from _pkg import load_package  # noqa: E402
 vra = load_package()
 from voxel_rs_amd import hip, scenes  # noqa: E402
 
-KEYS = {"k": "VX_RENDER_KERNEL", "r": "VX_REFILL_MIN", "s": "VX_SERVICE_MIN", "m": "VX_MIN_WAVES", "w": "VX_WAVES_PER_CU", "f": "VX_FRAMES_IN_FLIGHT",
-        "e": "VX_FOREIGN_MIN", "x": "VX_NO_EXCURSION", "d": "VX_DEEP_STACK", "h": "VX_HOT_FIRST", "X": "VX_HOT_LEVELS", "L": "VX_HIP_LIB", "v": "VX_VARIANT", "W": "VX_FIVE_WAVES", "B": "VX_BATCH", "T": "VX_TICKET_AHEAD", "R": "VX_FOREIGN_RERUN", "G": "VX_AHEAD_GUARD"}
-
+KEYS = {"k": "VX_RENDER_KERNEL", "r": "VX_REFILL_MIN", "s": "VX_SERVICE_MIN", "w": "VX_WAVES_PER_CU", "f": "VX_FRAMES_IN_FLIGHT", "h": "VX_HOT_FIRST", "X": "VX_HOT_LEVELS",
+        "L": "VX_LIB_DIR", "R": "VX_FOREIGN_RERUN", "n": "VX_TILE_NUMBERING", "t": "VX_TILE_STRIP", "q": "VX_QUEUE_STRIPE", "i": "VX_TRAVERSAL_IMAGE"}
 
 def main():
     ap = argparse.ArgumentParser()

@@ -8,12 +8,12 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[2]
-want = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "render_persistentILi3ELb0ELb0ELi4ELi0ELb1ELi13ELb0E"
+want = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "render_persistentILi3ELb0ELb0ELi0ELi13ELb0E"  # <IMAGE, image-only, no counters, no walks, 13 stack levels>: the ESVO image kernel
 show = "--asm" in sys.argv
 out = "/tmp/vx_hot_loop.s"
 cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
        "-fno-fast-math", "-gline-tables-only", f"-I{ROOT}/include", f"-I{ROOT}/voxel-rs_amd/csrc/hip", "-S", "--cuda-device-only", "-o", out,
-       str(ROOT / "voxel-rs_amd/csrc/hip/vx_api.hip")]
+       str(ROOT / "voxel-rs_amd/csrc/hip/kernels_render.hip")]
 subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 s = open(out).read().split("\n")
 files = {}
@@ -21,8 +21,8 @@ for l in s:
     m = re.match(r'\s+\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
     if m:
         files[int(m.group(1))] = (m.group(3) or m.group(2)).split("/")[-1]
-start = [i for i, l in enumerate(s) if want in l and l.rstrip().endswith(":") or (want in l and ": ;" in l and l.startswith("_Z"))][0]
-end = [i for i in range(start, len(s)) if s[i].strip().startswith("s_endpgm")][0]
+start = [i for i, l in enumerate(s) if want in l and l.startswith("_Z")][0]
+end = [i for i in range(start, len(s)) if s[i].strip().startswith(".Lfunc_end")][0]
 k = s[start:end + 1]
 loads = [i for i, l in enumerate(k) if "buffer_load_dwordx2" in l or "global_load_dwordx2" in l]
 i0 = loads[0]
