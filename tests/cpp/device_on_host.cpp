@@ -30,6 +30,39 @@ static inline float __int_as_float(int32_t u) { float f; std::memcpy(&f, &u, 4);
 namespace vxd { unsigned char* vx_smem = nullptr; }
 static uint32_t g_opaque_lo = 0, g_opaque_hi = 0;  // walk mode 3: the block ids whose textures are opaque throughout (RenderParams::opaque_*)
 extern "C" void devhost_set_opaque(uint32_t lo, uint32_t hi) { g_opaque_lo = lo; g_opaque_hi = hi; }
+
+// The sub-tile queue's arithmetic (vx_args.hpp), as the kernel and the runtime use it.
+// queue_subtile: the numbers dispenser c hands out, k = 0, 1, ... until the first beyond the launch -- every sub-tile of the launch exactly once? Returns 1 / 0.
+extern "C" int devhost_queue_covers(uint32_t total, uint32_t stripe) {
+    std::vector<uint8_t> seen(total, 0);
+    uint32_t n = 0;
+    for (uint32_t c = 0; c < vxk::kQueues; ++c) {
+        uint32_t last = 0;
+        for (uint32_t k = 0;; ++k) {
+            const uint32_t t = vxk::queue_subtile(k, c, stripe);
+            if (k && t <= last) return 0;  // (a dispenser's numbers grow: the first beyond the launch means it is dry)
+            last = t;
+            if (t >= total) break;
+            if (seen[t]++) return 0;
+            ++n;
+        }
+    }
+    return n == total ? 1 : 0;
+}
+// tile_place / tile_number (RenderParams::tile_numbering) as launch_render sets them up: a permutation of the launch's tiles and its inverse? Returns 1 / 0;
+// `place_of` (n_local entries, may be null) receives the places in queue order.
+extern "C" int devhost_tile_numbering(uint32_t tiles_x, uint32_t tiles_y, uint32_t tile_count, uint32_t n_local, int numbering, int strip, uint32_t* place_of) {
+    vxd::RenderParams p = {};
+    p.tiles_x = tiles_x; p.tiles_y = tiles_y; p.tile_count = tile_count; p.n_local_tiles = n_local;
+    vxd::set_tile_numbering(p, numbering, strip);
+    std::vector<uint8_t> seen(n_local, 0);
+    for (uint32_t i = 0; i < n_local; ++i) {
+        const uint32_t place = vxd::tile_place(p, i);
+        if (place >= n_local || seen[place]++ || vxd::tile_number(p, place) != i) return 0;
+        if (place_of) place_of[i] = place;
+    }
+    return 1;
+}
 using namespace vxd;
 
 extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t world_bytes, const vx_material* mats, uint32_t n_mats,

@@ -21,8 +21,9 @@ def devhost():
     so = BUILD / "libdevice_on_host.so"
     src = Path(ROOT) / "tests" / "cpp" / "device_on_host.cpp"
     hdr = Path(ROOT) / "voxel-rs_amd" / "csrc" / "hip" / "vx_device.hpp"
+    args_hdr = Path(ROOT) / "voxel-rs_amd" / "csrc" / "hip" / "vx_args.hpp"
     shim = Path(ROOT) / "tests" / "cpp" / "shims" / "vx_platform.hpp"
-    if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime, shim.stat().st_mtime):
+    if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime, args_hdr.stat().st_mtime, shim.stat().st_mtime):
         # tests/cpp/shims comes first: its vx_platform.hpp (plain C++) is found instead of the product's (gfx950 built-ins)
         cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", f"-I{ROOT}/include", f"-I{ROOT}/tests/cpp/shims",
                f"-I{ROOT}/voxel-rs_amd/csrc/hip", str(src), "-o", str(so)]
@@ -247,3 +248,36 @@ def test_image_traversal_in_deep_worlds(devhost, golden, fmt, base, depth):
     for layout in (1, 2):
         got, gsteps = image_cast(devhost, fmt, world, mats, tex, mips, tasks, 1, layout, shallow=2)
         assert_same_casts(got, gsteps, exp, esteps)
+
+
+def test_the_sub_tile_queue_hands_out_every_sub_tile_once(devhost):
+    """queue_subtile (vx_args.hpp): the launch's sub-tiles are dealt out to the eight dispensers in stretches of `stripe`; a dispenser's numbers grow, the
+    first beyond the launch means it is dry, and between them the dispensers cover the launch exactly once -- for launches of a tile, of odd sizes, with
+    stretches of one sub-tile (the cost order), a tile, an eighth of the launch, more than the launch."""
+    for total in (16, 32, 48, 16 * 7, 16 * 90, 16 * 2040, 16 * 8160):
+        for stripe in (1, 2, 16, 48, 100, 960, (total + 7) // 8, total, total + 5):
+            assert devhost.devhost_queue_covers(total, stripe) == 1, (total, stripe)
+
+
+def test_tile_numberings_are_permutations(devhost):
+    """RenderParams::tile_numbering as launch_render sets it up (set_tile_numbering) and the kernel uses it both ways (tile_place for the refill, tile_number
+    for the cost notes): along the rows, in strips of W columns (the last strip narrower), with the 0.618 stride (what a tile list gets whatever is asked
+    for) -- each a permutation of the launch's tiles whose inverse is the inverse. The strips run down the screen: consecutive numbers of a strip are
+    neighbours in a row, then the next row."""
+    for tx, ty in ((1, 1), (2, 1), (1, 5), (3, 3), (10, 9), (60, 34), (120, 68), (7, 13)):
+        n = tx * ty
+        for numbering in (0, 1, 2):
+            for strip in (1, 2, 3, 4, 8, 100):
+                assert devhost.devhost_tile_numbering(tx, ty, 1, n, numbering, strip, None) == 1, (tx, ty, numbering, strip)
+        for count in (2, 3, 8):  # a rank's share of a tile list
+            for rank_n in {(n + count - 1) // count, n // count} - {0}:
+                for numbering in (0, 1, 2):
+                    assert devhost.devhost_tile_numbering(tx, ty, count, rank_n, numbering, 8, None) == 1, (tx, ty, count, rank_n, numbering)
+    place = (C.c_uint32 * (60 * 34))()
+    assert devhost.devhost_tile_numbering(60, 34, 1, 60 * 34, 1, 8, place) == 1
+    p = np.frombuffer(place, dtype=np.uint32)
+    assert list(p[:9]) == [0, 1, 2, 3, 4, 5, 6, 7, 60] and p[8 * 34] == 8  # a strip of eight columns from the top row down, then the next strip
+    assert p[7 * 8 * 34] == 56 and list(p[7 * 8 * 34:7 * 8 * 34 + 5]) == [56, 57, 58, 59, 116]  # the last strip: four columns
+    assert devhost.devhost_tile_numbering(60, 34, 1, 60 * 34, 2, 8, place) == 1
+    step = int(p[1]) - int(p[0])
+    assert 0.55 * 2040 < step < 0.68 * 2040  # the stride: about 0.618 of the tiles

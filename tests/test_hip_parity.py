@@ -757,6 +757,58 @@ def test_views_and_sizes_in_turn(hip, fmt):
     svo.close()
 
 
+@pytest.mark.parametrize("fmt", FMTS)
+def test_the_order_of_the_tiles_changes_no_pixel(hip, fmt, monkeypatch):
+    """Where on the screen the queue's tile numbers lie (VX_TILE_NUMBERING: rows, strips of VX_TILE_STRIP columns, the stride), and how many sub-tiles in
+    a row go to one dispenser (VX_QUEUE_STRIPE), is the ORDER a frame's work is done in and nothing else: a frame of an odd size -- a last strip narrower
+    than the others, edge tiles -- with hit records, image-only one frame at a time (cost order: seven frames) and on the frame streams, and a rank's
+    share of a tile list, under every setting, byte for byte the frame of the default."""
+    import torch
+    from voxel_rs_amd import scenes
+
+    world = vra.World(SVO_TYPES[fmt])
+    st = world.build_heightfield(8, threads=4)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    w, h = 333, 227
+    u = scenes.bench_camera(8, st["h_max"], w, h, shadow_distance=3.0e38)
+
+    def frames():
+        svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))  # (the knobs are read when a context is created)
+        svo.set_materials(mats)
+        svo.set_textures(tex, 6)
+        svo.update_full(world)  # (the world's change list went to the first context)
+        img, hits = svo.render(u, w, h, want_hits=True)
+        out = {"hits": img.tobytes() + hits.tobytes()}
+        for k in range(7):  # the context's own stream: from the third frame on through the cost-ordered table
+            out["own %d" % k] = svo.render(u, w, h)[0].tobytes()
+        t = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        torch.cuda.synchronize()
+        for k in range(4):
+            svo.render_device(u, w, h, t[k & 1].data_ptr())
+        svo.sync()
+        out["in flight"] = t[0].cpu().numpy().tobytes() + t[1].cpu().numpy().tobytes()
+        n = hip.local_tile_count(w, h, 1, 3)
+        lst = torch.zeros((n * 1024, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        svo.render_device(u, w, h, lst.data_ptr(), tile_rank=1, tile_count=3)
+        svo.sync()
+        out["rank 1 of 3"] = lst.cpu().numpy().tobytes()
+        svo.close()
+        return out
+
+    for name in ("VX_TILE_NUMBERING", "VX_TILE_STRIP", "VX_QUEUE_STRIPE"):
+        monkeypatch.delenv(name, raising=False)
+    ref = frames()
+    assert ref["own 0"] == ref["own 6"] and ref["in flight"][:len(ref["own 0"])] == ref["own 0"]
+    for numbering, strip, stripe in ((0, 8, 16), (1, 1, 16), (1, 3, 1), (1, 8, 100), (1, 100, 16), (2, 8, 16), (2, 8, 1), (0, 8, 100000)):
+        monkeypatch.setenv("VX_TILE_NUMBERING", str(numbering))
+        monkeypatch.setenv("VX_TILE_STRIP", str(strip))
+        monkeypatch.setenv("VX_QUEUE_STRIPE", str(stripe))
+        got = frames()
+        for key in ref:
+            assert got[key] == ref[key], (numbering, strip, stripe, key)
+
+
 # ---- output formats, presentation ring, lifetime, fall-back, the library's own gather ---------------------------------------------
 
 

@@ -122,15 +122,6 @@ __device__ __forceinline__ void out_index_to_xy(const RenderParams& p, uint32_t 
     }
 }
 
-// tile numbering 1: number -> row-major place (strips of strip_w columns, the tiles of a strip along its rows; the last strip is narrower)
-__device__ __forceinline__ uint32_t strip_place(const RenderParams& p, uint32_t number) {
-    const uint32_t per_strip = p.strip_w * p.tiles_y, full = p.tiles_x / p.strip_w;
-    const uint32_t strip = number / per_strip < full ? number / per_strip : full;
-    const uint32_t first = strip * p.strip_w, wide = p.tiles_x - first < p.strip_w ? p.tiles_x - first : p.strip_w;
-    const uint32_t in = number - first * p.tiles_y;
-    return (in / wide) * p.tiles_x + first + in % wide;
-}
-
 // the sub-tile (8x8 pixels: the unit of the queue) a pixel's output index lies in
 __device__ __forceinline__ uint32_t subtile_of(const RenderParams& p, uint32_t out_index) {
     uint32_t local_tile, in_x, in_y;  // local_tile: the tile's place in this launch's list (a whole image: its row-major number)
@@ -145,14 +136,7 @@ __device__ __forceinline__ uint32_t subtile_of(const RenderParams& p, uint32_t o
         in_x = x & 31u;
         in_y = y & 31u;
     }
-    // ... and its number in the queue (RenderParams::tile_numbering)
-    if (p.tile_numbering == 2u) local_tile = uint32_t((uint64_t(local_tile) * p.tile_stride_inv) % p.n_local_tiles);
-    else if (p.tile_numbering == 1u && p.tile_count <= 1) {
-        // strips of strip_w columns, the tiles of a strip along its rows (the last strip is narrower)
-        const uint32_t tcol = local_tile % p.tiles_x, trow = local_tile / p.tiles_x, strip = tcol / p.strip_w;
-        const uint32_t first = strip * p.strip_w, wide = p.tiles_x - first < p.strip_w ? p.tiles_x - first : p.strip_w;
-        local_tile = first * p.tiles_y + trow * wide + (tcol - first);
-    }
+    local_tile = tile_number(p, local_tile);  // ... and its number in the queue
     const uint32_t sx = in_x >> 3, sy = in_y >> 3;  // 4x4 sub-tiles in Morton order (see the refill)
     return local_tile * 16u + ((sx & 1u) | ((sy & 1u) << 1) | ((sx & 2u) << 1) | ((sy & 2u) << 2));
 }
@@ -640,8 +624,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                     // sub-tile -> pixel: 32x32 tile (sharding unit), 4x4 sub-tiles in Morton order, 8x8 pixels in Morton order
                     // (the queue's tile number -> the tile's place in the launch's list: RenderParams::tile_numbering)
                     const uint32_t number = sub >> 4, s = sub & 15u;
-                    const uint32_t local_tile = p.tile_numbering == 2u ? uint32_t((uint64_t(number) * p.tile_stride) % p.n_local_tiles)
-                                              : (p.tile_numbering == 1u && p.tile_count <= 1 ? strip_place(p, number) : number);
+                    const uint32_t local_tile = tile_place(p, number);
                     const uint32_t tile = p.tile_count > 1 ? p.tile_order[local_tile * p.tile_count + p.tile_rank] : local_tile;
                     const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
                     const uint32_t sx = (s & 1u) | ((s >> 1) & 2u), sy = ((s >> 1) & 1u) | ((s >> 2) & 2u);

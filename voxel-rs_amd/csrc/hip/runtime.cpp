@@ -360,29 +360,10 @@ int fill_params(vx_context* ctx, const vx_uniforms* u, uint32_t w, uint32_t h, u
     p.height = h;
     p.tiles_x = (w + kTile - 1) / kTile;
     p.tiles_y = (h + kTile - 1) / kTile;
-    p.n_local_tiles = vx_local_tile_count(w, h, tile_rank, tile_count);
-    p.tile_numbering = uint32_t(ctx->tile_numbering);
-    if (p.tile_numbering == 1u && tile_count > 1) p.tile_numbering = 2u;  // (a tile list has no columns)
-    p.tile_stride = p.tile_stride_inv = 1;
-    p.strip_w = ctx->tile_strip > 0 ? uint32_t(ctx->tile_strip) : 1u;
-    if (p.strip_w > p.tiles_x) p.strip_w = p.tiles_x ? p.tiles_x : 1u;
-    if (p.tile_numbering == 2u && p.n_local_tiles < 3) p.tile_numbering = 0u;
-    if (p.tile_numbering == 2u) {
-        const uint64_t n = p.n_local_tiles;
-        auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
-        uint64_t g = uint64_t(double(n) * 0.6180339887498949);
-        if (g < 1) g = 1;
-        while (gcd(g, n) != 1) ++g;  // (n - 1 is prime to n: the search ends)
-        // the inverse of g modulo n (extended Euclid)
-        long long t0 = 0, t1 = 1, r0 = (long long)n, r1 = (long long)g;
-        while (r1 > 0) { const long long q = r0 / r1; long long t = t0 - q * t1; t0 = t1; t1 = t; t = r0 - q * r1; r0 = r1; r1 = t; }
-        if (t0 < 0) t0 += (long long)n;
-        p.tile_stride = uint32_t(g);
-        p.tile_stride_inv = uint32_t(t0);
-    }
     p.tile_rank = tile_rank;
     p.tile_count = tile_count;
     p.n_local_tiles = vx_local_tile_count(w, h, tile_rank, tile_count);
+    set_tile_numbering(p, ctx->tile_numbering, ctx->tile_strip);
     p.tile_order = nullptr;
     p.rgba8 = format == VX_FORMAT_RGBA8 ? 1u : 0u;
     p.opaque_lo = uint32_t(ctx->opaque_blocks);

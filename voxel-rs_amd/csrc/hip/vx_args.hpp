@@ -73,6 +73,53 @@ VX_HOST_DEVICE inline void view_origin(const float* m, float ro[3]) {
     for (int r = 0; r < 3; ++r) ro[r] = (m[r] * 0.0f + m[4 + r] * 0.0f + m[8 + r] * 0.0f + m[12 + r] * 1.0f) / ow;
 }
 
+// RenderParams::tile_numbering, both ways: the place in the launch's list of the tile with queue number `number`, and back.
+VX_HOST_DEVICE inline uint32_t tile_place(const RenderParams& p, uint32_t number) {
+    if (p.tile_numbering == 2u) return uint32_t((uint64_t(number) * p.tile_stride) % p.n_local_tiles);
+    if (p.tile_numbering == 1u && p.tile_count <= 1) {
+        // strips of strip_w columns, the tiles of a strip along its rows (the last strip is narrower)
+        const uint32_t per_strip = p.strip_w * p.tiles_y, full = p.tiles_x / p.strip_w;
+        const uint32_t strip = number / per_strip < full ? number / per_strip : full;
+        const uint32_t first = strip * p.strip_w, wide = p.tiles_x - first < p.strip_w ? p.tiles_x - first : p.strip_w;
+        const uint32_t in = number - first * p.tiles_y;
+        return (in / wide) * p.tiles_x + first + in % wide;
+    }
+    return number;
+}
+VX_HOST_DEVICE inline uint32_t tile_number(const RenderParams& p, uint32_t place) {
+    if (p.tile_numbering == 2u) return uint32_t((uint64_t(place) * p.tile_stride_inv) % p.n_local_tiles);
+    if (p.tile_numbering == 1u && p.tile_count <= 1) {
+        const uint32_t tcol = place % p.tiles_x, trow = place / p.tiles_x, strip = tcol / p.strip_w;
+        const uint32_t first = strip * p.strip_w, wide = p.tiles_x - first < p.strip_w ? p.tiles_x - first : p.strip_w;
+        return first * p.tiles_y + trow * wide + (tcol - first);
+    }
+    return place;
+}
+// ... and what launch_render puts there: strips of `strip` columns for a whole image, the stride for a tile list (which has no columns) -- g prime to
+// the n tiles and about 0.618 n, and its inverse modulo n
+inline void set_tile_numbering(RenderParams& p, int numbering, int strip) {
+    p.tile_numbering = uint32_t(numbering < 0 || numbering > 2 ? 0 : numbering);
+    if (p.tile_numbering == 1u && p.tile_count > 1) p.tile_numbering = 2u;
+    p.tile_stride = p.tile_stride_inv = 1;
+    p.strip_w = strip > 0 ? uint32_t(strip) : 1u;
+    if (p.strip_w > p.tiles_x) p.strip_w = p.tiles_x ? p.tiles_x : 1u;
+    if (p.tile_numbering == 2u && p.n_local_tiles < 3) p.tile_numbering = 0u;
+    if (p.tile_numbering != 2u) return;
+    const uint64_t n = p.n_local_tiles;
+    uint64_t g = uint64_t(double(n) * 0.6180339887498949);
+    if (g < 1) g = 1;
+    for (;; ++g) {  // (n - 1 is prime to n: the search ends)
+        uint64_t a = g, b = n;
+        while (b) { const uint64_t t = a % b; a = b; b = t; }
+        if (a == 1) break;
+    }
+    long long t0 = 0, t1 = 1, r0 = (long long)n, r1 = (long long)g;  // extended Euclid: t0 = 1 / g modulo n
+    while (r1 > 0) { const long long q = r0 / r1; long long t = t0 - q * t1; t0 = t1; t1 = t; t = r0 - q * r1; r0 = r1; r1 = t; }
+    if (t0 < 0) t0 += (long long)n;
+    p.tile_stride = uint32_t(g);
+    p.tile_stride_inv = uint32_t(t0);
+}
+
 }  // namespace vxd
 
 namespace vxk {
