@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                         if (a.timeline) t_empty = __builtin_amdgcn_s_memrealtime();
                         break;
                     }
-                    sub = a.order ? uint32_t(__builtin_amdgcn_readfirstlane(a.order[t])) : t;  // most expensive first, or screen order
+                    sub = a.order ? uint32_t(__builtin_amdgcn_readfirstlane(a.order[t])) : t;  // most expensive first, or the order of their numbers
                     if (sub >= a.total_subtiles) sub = t;  // (never: a table of another view is not used)
                     cursor = 0;
                     ++taken;

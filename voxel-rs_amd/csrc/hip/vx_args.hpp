@@ -151,11 +151,11 @@ struct PersistentArgs {
     uint32_t refill_min, service_min;
     uint32_t stripe;          // the length of the stretches the sub-tiles are dealt out to the dispensers in (queue_subtile), at least 1
     // Expensive sub-tiles first. A ray is a chain of dependent steps -- about 0.8 us per iteration on a busy device -- so a frame cannot
-    // end before its longest rays do (up to ~300 iterations against a mean of ~30): handed out in screen order they start in mid-frame
+    // end before its longest rays do (up to ~300 iterations against a mean of ~30): handed out in the order of their numbers they start in mid-frame
     // and the frame ends with a long tail of waves that wait for a few of them (profiles/timeline.py). So every ray that ends notes
     // its iteration count in its sub-tile's entry of `cost_cur` (atomic max), a small kernel behind the frame sorts the sub-tiles into
-    // sixteen cost classes, most expensive first, screen order within a class (order_kernel), and the NEXT frame of the same view on this
-    // stream draws its tickets through that table: `order` (null: screen order). Order only: no pixel's value depends on it.
+    // sixteen cost classes, most expensive first, the order of their numbers within a class (order_kernel), and the NEXT frame of the same view on this
+    // stream draws its tickets through that table: `order` (null: the order of their numbers). Order only: no pixel's value depends on it.
     const uint32_t* order;          // [total_subtiles] sub-tile ids, or null
     uint32_t* cost_cur;             // [total_subtiles] tag << 12 | iterations of the sub-tile's longest ray this frame; null = do not note
     uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
