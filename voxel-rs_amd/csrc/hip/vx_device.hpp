@@ -394,6 +394,88 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
     for (int k = 0; k < 4; ++k) rgba[k] = (a[k] * (1.0f - frac) + b[k] * frac) * (1.0f / 255.0f);
 }
 
+// Two layers sampled at the same coordinates and level of detail -- a shaded hit's normal map and its colour: texture_lod twice, value for value, but
+// with the texels of BOTH samples (and of both mip levels of each) requested before any of them is looked at. A service phase lasts as long as its
+// longest chain of dependent memory accesses, and one sample after the other was six of them (level offsets, the four taps of the finer level, the
+// four of the coarser, twice over); side by side they are two. The layers of a texture array share their dimensions, so the taps' places within a
+// layer are worked out once. `want_a` / `want_b`: which of the two this lane wants at all (the other's result is left alone).
+__device__ __forceinline__ void texture_lod_pair(const DevTextures& t, float u, float v, float layer_a_f, float layer_b_f, float lod, bool want_a, bool want_b,
+                                                 float a_rgba[4], float b_rgba[4]) {
+    if (t.levels == 0 || t.layers == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (want_a) a_rgba[k] = 0.0f;
+            if (want_b) b_rgba[k] = 0.0f;
+        }
+        return;
+    }
+    auto layer_of = [&](float layer_f) -> uint32_t {
+        const float lf = floorf(layer_f + 0.5f);
+        return lf <= 0.0f ? 0u : (lf >= float(t.layers - 1) ? t.layers - 1 : uint32_t(lf));
+    };
+    const uint32_t layer_a = layer_of(layer_a_f), layer_b = layer_of(layer_b_f);
+    if (!(lod > 0.0f)) {  // magnification: NEAREST on the base level (exact texel values)
+        const TexLevel L(t, 0, 0);
+        const uint32_t texel = (uint32_t(L.repeat_t(int(floorf(v * float(L.h))))) * uint32_t(L.w) + uint32_t(L.clamp_s(int(floorf(u * float(L.w)))))) * 4u;
+        const uint32_t layer_bytes = uint32_t(L.h) * uint32_t(L.w) * 4u;
+        uint32_t ra = 0u, rb = 0u;
+        if (want_a) ra = buf_u32(t.buf, L.base + layer_a * layer_bytes + texel);
+        if (want_b) rb = buf_u32(t.buf, L.base + layer_b * layer_bytes + texel);
+        if (want_a) unpack_rgba8(ra, a_rgba);
+        if (want_b) unpack_rgba8(rb, b_rgba);
+        return;
+    }
+    const float q = float(t.levels - 1);
+    const float lam = lod > q ? q : lod;
+    const float fl = floorf(lam);
+    const uint32_t d1 = uint32_t(fl);
+    const uint32_t d2 = d1 + 1 > t.levels - 1 ? t.levels - 1 : d1 + 1;
+    const float frac = lam - fl;
+    // the four taps of a level: their places within a layer and their weights (sample_linear_bytes)
+    struct Taps { uint32_t base, layer_bytes, o00, o10, o01, o11; float ax, ay; };
+    auto taps_of = [&](uint32_t level) -> Taps {
+        const TexLevel L(t, level, 0);
+        const float x = u * float(L.w) - 0.5f, y = v * float(L.h) - 0.5f;
+        const float fx = floorf(x), fy = floorf(y);
+        const int i0 = int(fx), j0 = int(fy);
+        const int x0 = L.clamp_s(i0), x1 = L.clamp_s(i0 + 1), y0 = L.repeat_t(j0), y1 = y0 + 1 == L.h ? 0 : y0 + 1;
+        Taps tp;
+        tp.base = L.base;
+        tp.layer_bytes = uint32_t(L.h) * uint32_t(L.w) * 4u;
+        tp.o00 = (uint32_t(y0) * uint32_t(L.w) + uint32_t(x0)) * 4u; tp.o10 = (uint32_t(y0) * uint32_t(L.w) + uint32_t(x1)) * 4u;
+        tp.o01 = (uint32_t(y1) * uint32_t(L.w) + uint32_t(x0)) * 4u; tp.o11 = (uint32_t(y1) * uint32_t(L.w) + uint32_t(x1)) * 4u;
+        tp.ax = x - fx; tp.ay = y - fy;
+        return tp;
+    };
+    const Taps t1 = taps_of(d1), t2 = taps_of(d2);
+    uint32_t ra[8] = {}, rb[8] = {};  // [level][tap]
+    auto request = [&](uint32_t layer, uint32_t r[8]) {
+        const uint32_t b1 = t1.base + layer * t1.layer_bytes, b2 = t2.base + layer * t2.layer_bytes;
+        r[0] = buf_u32(t.buf, b1 + t1.o00); r[1] = buf_u32(t.buf, b1 + t1.o10); r[2] = buf_u32(t.buf, b1 + t1.o01); r[3] = buf_u32(t.buf, b1 + t1.o11);
+        r[4] = buf_u32(t.buf, b2 + t2.o00); r[5] = buf_u32(t.buf, b2 + t2.o10); r[6] = buf_u32(t.buf, b2 + t2.o01); r[7] = buf_u32(t.buf, b2 + t2.o11);
+    };
+    if (want_a) request(layer_a, ra);
+    if (want_b) request(layer_b, rb);
+    auto blend = [&](const uint32_t r[8], float rgba[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float lv[2];
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const float ax = l ? t2.ax : t1.ax, ay = l ? t2.ay : t1.ay;
+                const float c00 = float((r[4 * l] >> (8 * k)) & 0xffu), c10 = float((r[4 * l + 1] >> (8 * k)) & 0xffu);
+                const float c01 = float((r[4 * l + 2] >> (8 * k)) & 0xffu), c11 = float((r[4 * l + 3] >> (8 * k)) & 0xffu);
+                const float lo = c00 * (1.0f - ax) + c10 * ax;
+                const float hi = c01 * (1.0f - ax) + c11 * ax;
+                lv[l] = lo * (1.0f - ay) + hi * ay;
+            }
+            rgba[k] = (lv[0] * (1.0f - frac) + lv[1] * frac) * (1.0f / 255.0f);
+        }
+    };
+    if (want_a) blend(ra, a_rgba);
+    if (want_b) blend(rb, b_rgba);
+}
+
 // ---- intersect_octree as a resumable per-lane state machine ------------------------------------------------------
 //
 // The reference's loop body has three very different costs: the common descend/advance/pop step, the rare leaf test
@@ -1370,9 +1452,15 @@ __device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderPa
     else if (res.face_id == 2) tex_normal_id = mat.tex_bottom_normal;
 
     float normal[3] = {kFaceNormals[res.face_id][0], kFaceNormals[res.face_id][1], kFaceNormals[res.face_id][2]};
+    // the normal map's sample and -- where the hit was found without it (an opaque block) -- the colour's, side by side (texture_lod_pair)
+    int tex_id = mat.tex_side;
+    if (res.face_id == 3) tex_id = mat.tex_top;
+    else if (res.face_id == 2) tex_id = mat.tex_bottom;
+    const bool want_color = COLOR_PENDING && color_pending;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sampled_color[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (tex_normal_id != -1 || want_color)
+        texture_lod_pair(sc.tex, res.uv[0], res.uv[1], float(tex_normal_id), float(tex_id), res.lod, tex_normal_id != -1, want_color, s, sampled_color);
     if (tex_normal_id != -1) {
-        float s[4];
-        texture_lod(sc.tex, res.uv[0], res.uv[1], float(tex_normal_id), res.lod, s);
         const float tex[3] = {s[0] * 2.0f - 1.0f, s[2] * 2.0f - 1.0f, s[1] * 2.0f - 1.0f};  // .xzy
         float n[3];
         normalize3(tex, n);
@@ -1394,12 +1482,7 @@ __device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderPa
 
     o.ds = diffuse + specular;
     o.color[0] = res.color[0]; o.color[1] = res.color[1]; o.color[2] = res.color[2]; o.color[3] = res.color[3];
-    if (COLOR_PENDING && color_pending) {
-        int tex_id = mat.tex_side;
-        if (res.face_id == 3) tex_id = mat.tex_top;
-        else if (res.face_id == 2) tex_id = mat.tex_bottom;
-        texture_lod(sc.tex, res.uv[0], res.uv[1], float(tex_id), res.lod, o.color);
-    }
+    if (want_color) { o.color[0] = sampled_color[0]; o.color[1] = sampled_color[1]; o.color[2] = sampled_color[2]; o.color[3] = sampled_color[3]; }
     if (p.u.render_shadows && res.t < p.u.shadow_distance) {
         o.final_color = false;
         o.flags |= 2u;
