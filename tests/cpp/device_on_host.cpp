@@ -94,7 +94,7 @@ extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t worl
         if (res.t > 0.0f) {
             r.dst = res.t; r.inside_voxel = res.inside_voxel;
             std::memcpy(r.pos, res.pos, 12);
-            std::memcpy(r.normal, kFaceNormals[res.face_id], 12);
+            face_vector<0>(uint32_t(res.face_id), r.normal);
         } else r.dst = -1.0f;
         results[i] = r;
     }

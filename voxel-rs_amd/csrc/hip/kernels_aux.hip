@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void picker_kernel(SceneArgs sa, const vx_picke
         r.dst = res.t;
         r.inside_voxel = res.inside_voxel ? 1u : 0u;
         r.pos[0] = res.pos[0]; r.pos[1] = res.pos[1]; r.pos[2] = res.pos[2];
-        r.normal[0] = kFaceNormals[res.face_id][0]; r.normal[1] = kFaceNormals[res.face_id][1]; r.normal[2] = kFaceNormals[res.face_id][2];
+        face_vector<0>(uint32_t(res.face_id), r.normal);
     } else {
         r.dst = -1.0f;
     }

@@ -1404,9 +1404,26 @@ __device__ __forceinline__ void sky_color(const float rd[3], float out[3]) {
     }
 }
 
-__constant__ float kFaceNormals[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};    // svo.glsl:2-9
-__constant__ float kFaceTangents[6][3] = {{0, 0, 1}, {0, 0, -1}, {1, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {1, 0, 0}};    // svo.glsl:12-19
-__constant__ float kFaceBitangents[6][3] = {{0, 1, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 1}, {0, 1, 0}, {0, 1, 0}};    // svo.glsl:22-29
+// A face's normal, tangent and bitangent (svo.glsl:2-9, 12-19, 22-29): components of -1, 0 or 1, two bits each (1 = 1, 2 = -1), the six faces of a component in
+// one 12-bit constant -- arithmetic on the face's number instead of three look-ups in constant memory, each a round trip of its own in the middle of a
+// shading phase (profiles/round4/pass_t).
+constexpr int kFaceNormalsI[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+constexpr int kFaceTangentsI[6][3] = {{0, 0, 1}, {0, 0, -1}, {1, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {1, 0, 0}};
+constexpr int kFaceBitangentsI[6][3] = {{0, 1, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 1}, {0, 1, 0}, {0, 1, 0}};
+constexpr uint32_t face_pack(const int (&t)[6][3], int k) {
+    uint32_t v = 0;
+    for (int f = 0; f < 6; ++f) v |= uint32_t(t[f][k] == 1 ? 1 : (t[f][k] == -1 ? 2 : 0)) << (2 * f);
+    return v;
+}
+template <int TABLE>  // 0 normals, 1 tangents, 2 bitangents
+__device__ __forceinline__ void face_vector(uint32_t face, float out[3]) {
+    constexpr uint32_t px = TABLE == 0 ? face_pack(kFaceNormalsI, 0) : (TABLE == 1 ? face_pack(kFaceTangentsI, 0) : face_pack(kFaceBitangentsI, 0));
+    constexpr uint32_t py = TABLE == 0 ? face_pack(kFaceNormalsI, 1) : (TABLE == 1 ? face_pack(kFaceTangentsI, 1) : face_pack(kFaceBitangentsI, 1));
+    constexpr uint32_t pz = TABLE == 0 ? face_pack(kFaceNormalsI, 2) : (TABLE == 1 ? face_pack(kFaceTangentsI, 2) : face_pack(kFaceBitangentsI, 2));
+    const uint32_t sh = (face < 6u ? face : 5u) * 2u;
+    const uint32_t cx = (px >> sh) & 3u, cy = (py >> sh) & 3u, cz = (pz >> sh) & 3u;
+    out[0] = float(int(cx & 1u) - int(cx >> 1)); out[1] = float(int(cy & 1u) - int(cy >> 1)); out[2] = float(int(cz & 1u) - int(cz >> 1));
+}
 
 // world.glsl:87-88
 __device__ __forceinline__ void apply_light(const RenderParams& p, float color[4], float ds, float shadow) {
@@ -1451,7 +1468,8 @@ __device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderPa
     if (res.face_id == 3) tex_normal_id = mat.tex_top_normal;
     else if (res.face_id == 2) tex_normal_id = mat.tex_bottom_normal;
 
-    float normal[3] = {kFaceNormals[res.face_id][0], kFaceNormals[res.face_id][1], kFaceNormals[res.face_id][2]};
+    float normal[3];
+    face_vector<0>(uint32_t(res.face_id), normal);
     // the normal map's sample and -- where the hit was found without it (an opaque block) -- the colour's, side by side (texture_lod_pair)
     int tex_id = mat.tex_side;
     if (res.face_id == 3) tex_id = mat.tex_top;
@@ -1465,8 +1483,11 @@ __device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderPa
         float n[3];
         normalize3(tex, n);
         const float base[3] = {normal[0], normal[1], normal[2]};
+        float tangent[3], bitangent[3];
+        face_vector<1>(uint32_t(res.face_id), tangent);
+        face_vector<2>(uint32_t(res.face_id), bitangent);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) normal[k] = n[0] * kFaceTangents[res.face_id][k] + n[1] * base[k] + n[2] * kFaceBitangents[res.face_id][k];
+        for (int k = 0; k < 3; ++k) normal[k] = n[0] * tangent[k] + n[1] * base[k] + n[2] * bitangent[k];
     }
 
     const float neg_l[3] = {-p.u.light_dir[0], -p.u.light_dir[1], -p.u.light_dir[2]};
@@ -1529,7 +1550,8 @@ __device__ __forceinline__ void shade_pixel(const DevScene& sc, const RenderPara
         if (res.face_id == 3) tex_normal_id = mat.tex_top_normal;
         else if (res.face_id == 2) tex_normal_id = mat.tex_bottom_normal;
 
-        float normal[3] = {kFaceNormals[res.face_id][0], kFaceNormals[res.face_id][1], kFaceNormals[res.face_id][2]};
+        float normal[3];
+    face_vector<0>(uint32_t(res.face_id), normal);
         if (tex_normal_id != -1) {
             float s[4];
             texture_lod(sc.tex, res.uv[0], res.uv[1], float(tex_normal_id), res.lod, s);
@@ -1537,8 +1559,11 @@ __device__ __forceinline__ void shade_pixel(const DevScene& sc, const RenderPara
             float n[3];
             normalize3(tex, n);
             const float base[3] = {normal[0], normal[1], normal[2]};
+            float tangent[3], bitangent[3];
+            face_vector<1>(uint32_t(res.face_id), tangent);
+            face_vector<2>(uint32_t(res.face_id), bitangent);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) normal[k] = n[0] * kFaceTangents[res.face_id][k] + n[1] * base[k] + n[2] * kFaceBitangents[res.face_id][k];
+            for (int k = 0; k < 3; ++k) normal[k] = n[0] * tangent[k] + n[1] * base[k] + n[2] * bitangent[k];
         }
 
         const float neg_l[3] = {-p.u.light_dir[0], -p.u.light_dir[1], -p.u.light_dir[2]};
