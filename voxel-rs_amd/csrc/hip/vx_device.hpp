@@ -321,11 +321,13 @@ struct TexLevel {
     int w, h;
     uint32_t base;
     bool pow2_h;  // wave-uniform: REPEAT is a mask instead of a signed modulo
-    __device__ __forceinline__ TexLevel(const DevTextures& t, uint32_t level, uint32_t layer) {
+    __device__ __forceinline__ TexLevel(const DevTextures& t, uint32_t level, uint32_t layer) : TexLevel(t, level, layer, t.level_offset[level]) {}
+    // (the level's offset handed in: read ahead of the chain of accesses the sample hangs on, texture_lod_pair)
+    __device__ __forceinline__ TexLevel(const DevTextures& t, uint32_t level, uint32_t layer, uint32_t level_offset) {
         const uint32_t ww = t.width >> level, hh = t.height >> level;
         w = int(ww ? ww : 1);
         h = int(hh ? hh : 1);
-        base = t.level_offset[level] + layer * uint32_t(h) * uint32_t(w) * 4u;
+        base = level_offset + layer * uint32_t(h) * uint32_t(w) * 4u;
         pow2_h = t.pow2_height || (t.height & (t.height - 1)) == 0;
     }
     __device__ __forceinline__ int clamp_s(int x) const { x = x < 0 ? 0 : x; return x > w - 1 ? w - 1 : x; }
@@ -399,7 +401,31 @@ __device__ __forceinline__ void texture_lod(const DevTextures& t, float u, float
 // longest chain of dependent memory accesses, and one sample after the other was six of them (level offsets, the four taps of the finer level, the
 // four of the coarser, twice over); side by side they are two. The layers of a texture array share their dimensions, so the taps' places within a
 // layer are worked out once. `want_a` / `want_b`: which of the two this lane wants at all (the other's result is left alone).
-__device__ __forceinline__ void texture_lod_pair(const DevTextures& t, float u, float v, float layer_a_f, float layer_b_f, float lod, bool want_a, bool want_b,
+// the mip levels a sample at `lod` blends, and where they start in the chain (two words of the level table, indexed per lane: memory accesses -- made
+// where this is called, ahead of whatever the sample's layer still waits for)
+struct TexLod {
+    uint32_t d1, d2, offset1, offset2;
+    float frac;
+    bool nearest;
+};
+__device__ __forceinline__ TexLod texture_levels(const DevTextures& t, float lod) {
+    TexLod l = {0u, 0u, 0u, 0u, 0.0f, true};
+    if (t.levels == 0 || t.layers == 0) return l;
+    l.nearest = !(lod > 0.0f);
+    if (!l.nearest) {
+        const float q = float(t.levels - 1);
+        const float lam = lod > q ? q : lod;
+        const float fl = floorf(lam);
+        l.d1 = uint32_t(fl);
+        l.d2 = l.d1 + 1 > t.levels - 1 ? t.levels - 1 : l.d1 + 1;
+        l.frac = lam - fl;
+    }
+    l.offset1 = t.level_offset[l.d1];
+    l.offset2 = t.level_offset[l.d2];
+    return l;
+}
+
+__device__ __forceinline__ void texture_lod_pair(const DevTextures& t, const TexLod& lv, float u, float v, float layer_a_f, float layer_b_f, bool want_a, bool want_b,
                                                  float a_rgba[4], float b_rgba[4]) {
     if (t.levels == 0 || t.layers == 0) {
 #pragma unroll
@@ -414,27 +440,20 @@ __device__ __forceinline__ void texture_lod_pair(const DevTextures& t, float u, 
         return lf <= 0.0f ? 0u : (lf >= float(t.layers - 1) ? t.layers - 1 : uint32_t(lf));
     };
     const uint32_t layer_a = layer_of(layer_a_f), layer_b = layer_of(layer_b_f);
-    if (!(lod > 0.0f)) {  // magnification: NEAREST on the base level (exact texel values)
-        const TexLevel L(t, 0, 0);
+    if (lv.nearest) {  // magnification: NEAREST on the base level (exact texel values)
+        const TexLevel L(t, 0, 0, lv.offset1);
         const uint32_t texel = (uint32_t(L.repeat_t(int(floorf(v * float(L.h))))) * uint32_t(L.w) + uint32_t(L.clamp_s(int(floorf(u * float(L.w)))))) * 4u;
         const uint32_t layer_bytes = uint32_t(L.h) * uint32_t(L.w) * 4u;
-        uint32_t ra = 0u, rb = 0u;
-        if (want_a) ra = buf_u32(t.buf, L.base + layer_a * layer_bytes + texel);
-        if (want_b) rb = buf_u32(t.buf, L.base + layer_b * layer_bytes + texel);
+        const uint32_t ra = buf_u32(t.buf, L.base + layer_a * layer_bytes + texel), rb = buf_u32(t.buf, L.base + layer_b * layer_bytes + texel);
         if (want_a) unpack_rgba8(ra, a_rgba);
         if (want_b) unpack_rgba8(rb, b_rgba);
         return;
     }
-    const float q = float(t.levels - 1);
-    const float lam = lod > q ? q : lod;
-    const float fl = floorf(lam);
-    const uint32_t d1 = uint32_t(fl);
-    const uint32_t d2 = d1 + 1 > t.levels - 1 ? t.levels - 1 : d1 + 1;
-    const float frac = lam - fl;
+    const float frac = lv.frac;
     // the four taps of a level: their places within a layer and their weights (sample_linear_bytes)
     struct Taps { uint32_t base, layer_bytes, o00, o10, o01, o11; float ax, ay; };
-    auto taps_of = [&](uint32_t level) -> Taps {
-        const TexLevel L(t, level, 0);
+    auto taps_of = [&](uint32_t level, uint32_t level_offset) -> Taps {
+        const TexLevel L(t, level, 0, level_offset);
         const float x = u * float(L.w) - 0.5f, y = v * float(L.h) - 0.5f;
         const float fx = floorf(x), fy = floorf(y);
         const int i0 = int(fx), j0 = int(fy);
@@ -447,15 +466,17 @@ __device__ __forceinline__ void texture_lod_pair(const DevTextures& t, float u, 
         tp.ax = x - fx; tp.ay = y - fy;
         return tp;
     };
-    const Taps t1 = taps_of(d1), t2 = taps_of(d2);
+    const Taps t1 = taps_of(lv.d1, lv.offset1), t2 = taps_of(lv.d2, lv.offset2);
     uint32_t ra[8] = {}, rb[8] = {};  // [level][tap]
     auto request = [&](uint32_t layer, uint32_t r[8]) {
         const uint32_t b1 = t1.base + layer * t1.layer_bytes, b2 = t2.base + layer * t2.layer_bytes;
         r[0] = buf_u32(t.buf, b1 + t1.o00); r[1] = buf_u32(t.buf, b1 + t1.o10); r[2] = buf_u32(t.buf, b1 + t1.o01); r[3] = buf_u32(t.buf, b1 + t1.o11);
         r[4] = buf_u32(t.buf, b2 + t2.o00); r[5] = buf_u32(t.buf, b2 + t2.o10); r[6] = buf_u32(t.buf, b2 + t2.o01); r[7] = buf_u32(t.buf, b2 + t2.o11);
     };
-    if (want_a) request(layer_a, ra);
-    if (want_b) request(layer_b, rb);
+    // (both layers' texels are requested whether wanted or not -- an unwanted sample's sixteen bytes cost nothing beside its neighbour's, and a request
+    // under its own condition would be waited for before the other is made)
+    request(layer_a, ra);
+    request(layer_b, rb);
     auto blend = [&](const uint32_t r[8], float rgba[4]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1463,6 +1484,7 @@ __device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderPa
         }
     }
 
+    const TexLod levels = texture_levels(sc.tex, res.lod);  // (its two words requested beside the material's row)
     const vx_material mat = material_at(sc, res.value);
     int tex_normal_id = mat.tex_side_normal;
     if (res.face_id == 3) tex_normal_id = mat.tex_top_normal;
@@ -1477,7 +1499,7 @@ __device__ __forceinline__ void shade_primary(const DevScene& sc, const RenderPa
     const bool want_color = COLOR_PENDING && color_pending;
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sampled_color[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (tex_normal_id != -1 || want_color)
-        texture_lod_pair(sc.tex, res.uv[0], res.uv[1], float(tex_normal_id), float(tex_id), res.lod, tex_normal_id != -1, want_color, s, sampled_color);
+        texture_lod_pair(sc.tex, levels, res.uv[0], res.uv[1], float(tex_normal_id), float(tex_id), tex_normal_id != -1, want_color, s, sampled_color);
     if (tex_normal_id != -1) {
         const float tex[3] = {s[0] * 2.0f - 1.0f, s[2] * 2.0f - 1.0f, s[1] * 2.0f - 1.0f};  // .xzy
         float n[3];
