@@ -15,3 +15,16 @@ def load_package():
     sys.modules["voxel_rs_amd"] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def csrc_hash():
+    """sha256[:16] over the names and contents of the library's device and runtime sources (voxel-rs_amd/csrc/hip/*): what a stored counter file
+    (profiles/roundN/traffic.json) was measured on, checked by bench.py without git (the GPU box's snapshot has no history)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "voxel-rs_amd" / "csrc" / "hip").iterdir()):
+        if f.is_file():
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]

@@ -8,11 +8,15 @@ ray, shading, one shadow ray per lit pixel, sky) plus, for N > 1, the RCCL gathe
     python bench.py                      # 1 GPU, C3 workload (configs[2] of BASELINE.json)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line. `value` = the rays of the K timed frames / their time. `roofline.achieved` = algorithmic bytes per launch
-(step counters of the instrumented kernel variant x the byte model of DESIGN.md, averaged over the K views) / the render kernel's
-average duration, measured with HIP events on the stream it is launched on. `still_view` = the same with a camera that stands still
-(round 3's headline). `cpu_baseline` = the C oracle (restatement of the reference's GLSL; the reference has no CPU raycast) timed on
-this box's host cores over a bounded sample of the first view's frame.
+Rank 0 prints ONE JSON line. Two measurements of the same frames stand behind `value`: the MEDIAN of --repeats timed blocks of exactly --steps
+frames each (a block is a few milliseconds), and one SUSTAINED block of --sustained-seconds of the same path (the reference's own harness
+samples for 20 s, benchmark-ingame.py:37); `value` is the burst median unless the sustained figure is more than 2 % below it, then the sustained
+one (`value_source` says which). `roofline.achieved` = algorithmic bytes per launch (step counters of the instrumented kernel variant x the
+byte model of DESIGN.md, averaged over the K views) / the render kernel's average duration, measured with HIP events on the stream it is launched
+on. `roofline.issue.clock_mhz_in_kernel` is sampled in THIS run (vx_clock_probe, while the sustained block renders). `configs` = the other
+BASELINE configurations (C2, C4 static and streamed, C5) on this GPU; `forced_sharded` = the N > 1 code path on this one GPU (a child process).
+`cpu_baseline` = the C oracle (restatement of the reference's GLSL; the reference has no CPU raycast) timed on this box's host cores over
+whole frames of the first view at 1 / 8 / 32 / all threads, with what the box grants this process (affinity, cgroup quota) stated.
 """
 import argparse
 import json
@@ -27,7 +31,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s achievable)
-PROFILE_ROUNDS = ("round4", "round3", "round2", "round1")
+PROFILE_ROUNDS = ("round5", "round4", "round3", "round2", "round1")
 
 
 # ---- byte models ---------------------------------------------------------------------------------------------------
@@ -57,45 +61,48 @@ def image_model_bytes(c):
     return 8 * c["pushes"] + c["leaf_tests"] * (4 + 32) + nearest * 4 + c["leaf_tests_trilinear"] * 32 + 16 * c["pixels"] + c["lit_pixels"] * (32 + 4)
 
 
-def measured_traffic(fmt):
-    """HBM-side bytes per launch of the render kernel on this workload: a STORED artifact -- the committed rocprofv3 --pmc passes
-    of this same command (profiles/roundN/profile.sh -> profiles/roundN/traffic.json, which names the commit it was measured at); PMC
-    counters cannot be read from inside this run. Returns (bytes, source) or (None, None)."""
+def stored_counters(fmt):
+    """The committed rocprofv3 --pmc passes of this same command (profiles/roundN/profile*.sh -> profiles/roundN/traffic.json): PMC counters cannot
+    be read from inside this run, so they are a STORED artifact -- and only quoted when they were measured on the library sources this run uses:
+    traffic.json names the hash of voxel-rs_amd/csrc/hip (`csrc_sha16`, _pkg.csrc_hash), and any other hash makes `traffic` and `issue` null with a
+    note instead of stale numbers. Returns (row or None, source, note)."""
+    from _pkg import csrc_hash
+
+    here = csrc_hash()
     for rnd in PROFILE_ROUNDS:
         try:
             t = json.loads((ROOT / "profiles" / rnd / "traffic.json").read_text())
-            return t[fmt]["bytes_per_launch"], f"profiles/{rnd}/traffic.json" + (f" @ {t['commit']}" if "commit" in t else "")
-        except (OSError, KeyError, ValueError):
+        except (OSError, ValueError):
             continue
-    return None, None
+        src = f"profiles/{rnd}/traffic.json" + (f" @ {t['commit']}" if "commit" in t else "")
+        if t.get("csrc_sha16") != here:
+            return None, src, (f"{src} was measured on other library sources (csrc_sha16 {t.get('csrc_sha16', 'not recorded')}, this run {here}): "
+                               "not quoted; re-run the profile passes (profiles/round5/profile_r5.sh)")
+        return t.get(fmt), src, None
+    return None, None, "no stored counter file"
 
 
-def issue_model(fmt):
-    """What bounds the kernel in practice: instruction issue. STORED artifacts: the render kernel's instruction counts per launch from the
-    committed --pmc passes (traffic.json: SQ_INSTS_VALU / SALU / VMEM_RD / LDS / SMEM) and the measured cost of an instruction with four
-    waves on a SIMD (issue_model.json: profiles/tools/valu_issue.hip). Returns a dict or None."""
-    for rnd in PROFILE_ROUNDS:
-        try:
-            t = json.loads((ROOT / "profiles" / rnd / "traffic.json").read_text())
-            m = json.loads((ROOT / "profiles" / "round3" / "issue_model.json").read_text())
-            r = t[fmt]
-            insts = sum(float(r.get(k) or 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
-            clock = float(m["clock_mhz"][fmt])
-            bound_ms = insts * float(m["simd_cycles_per_instruction"]) / float(m["simds"]) / (clock * 1e3)
-            return {"bound": "instruction issue (every SIMD issuing its waves' instructions back to back)", "instructions_per_launch": int(insts),
-                    "valu_per_launch": int(r["SQ_INSTS_VALU"]), "salu_per_launch": int(r["SQ_INSTS_SALU"]), "valu_lane_utilisation": r.get("valu_lane_utilisation"),
-                    "wait_share_of_wave_cycles": (round(r["SQ_WAIT_ANY"] / r["SQ_WAVE_CYCLES"], 3) if r.get("SQ_WAIT_ANY") and r.get("SQ_WAVE_CYCLES") else None),
-                    "simd_cycles_per_instruction": m["simd_cycles_per_instruction"], "simds": m["simds"], "clock_mhz_in_kernel": clock,
-                    "issue_bound_ms": round(bound_ms, 4), "source": f"profiles/{rnd}/traffic.json @ {t.get('commit', '?')}, profiles/round3/issue_model.json"}
-        except (OSError, KeyError, ValueError, TypeError):
-            continue
-    return None
+def issue_model(row, source, clock_mhz, clock_source):
+    """What bounds the kernel in practice: instruction issue. The render kernel's instruction counts per launch from the stored --pmc passes
+    (SQ_INSTS_VALU / SALU / VMEM_RD / LDS / SMEM) x the measured cost of an instruction with four waves on a SIMD (profiles/round3/issue_model.json:
+    profiles/tools/valu_issue.hip) / 1024 SIMDs / the shader clock measured in this run."""
+    try:
+        m = json.loads((ROOT / "profiles" / "round3" / "issue_model.json").read_text())
+        insts = sum(float(row.get(k) or 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
+        bound_ms = insts * float(m["simd_cycles_per_instruction"]) / float(m["simds"]) / (clock_mhz * 1e3)
+        return {"bound": "instruction issue (every SIMD issuing its waves' instructions back to back)", "instructions_per_launch": int(insts),
+                "valu_per_launch": int(row["SQ_INSTS_VALU"]), "salu_per_launch": int(row["SQ_INSTS_SALU"]), "valu_lane_utilisation": row.get("valu_lane_utilisation"),
+                "wait_share_of_wave_cycles": (round(row["SQ_WAIT_ANY"] / row["SQ_WAVE_CYCLES"], 3) if row.get("SQ_WAIT_ANY") and row.get("SQ_WAVE_CYCLES") else None),
+                "simd_cycles_per_instruction": m["simd_cycles_per_instruction"], "simds": m["simds"], "clock_mhz_in_kernel": round(clock_mhz, 1),
+                "clock_source": clock_source, "issue_bound_ms": round(bound_ms, 4), "source": f"{source}, profiles/round3/issue_model.json"}
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 # ---- the workload -----------------------------------------------------------------------------------------------------------------
 
 
-def moving_uniforms(scenes, depth, h_max, W, H, i):
+def moving_uniforms(scenes, depth, h_max, W, H, i, shadows=True):
     """Frame i of the camera's path: the §8d view, turned by a quarter of a degree a frame about the vertical and walked forward at 5
     blocks a second (at 60 frames a second). Every primary hit casts its shadow ray ("primary + 1 shadow ray" of configs[2]): the game's
     default cut-off of 500 blocks would cast almost none from this altitude (the `shadow_distance_500` object)."""
@@ -103,7 +110,7 @@ def moving_uniforms(scenes, depth, h_max, W, H, i):
     a = math.radians(0.25 * i)
     fwd = (0.6 * math.cos(a) - 0.7 * math.sin(a), -0.35, 0.6 * math.sin(a) + 0.7 * math.cos(a))
     eye = (0.5 * n + 0.05 * i, h_max + 0.05 * n, 0.5 * n + 0.066 * i)
-    return scenes.render_params_to_uniforms(eye, fwd, (0.0, 1.0, 0.0), math.radians(72.0), W / H, 0.3, (-1.0, -1.0, -1.0), True, 3.0e38)
+    return scenes.render_params_to_uniforms(eye, fwd, (0.0, 1.0, 0.0), math.radians(72.0), W / H, 0.3, (-1.0, -1.0, -1.0), shadows, 3.0e38)
 
 
 class Workload:
@@ -131,6 +138,7 @@ class Workload:
         # work per frame: deterministic for a fixed scene / camera, counted by the instrumented kernel for this rank's tiles
         self.counters = [self.svo.render_counters(u, W, H, rank, world_size) for u in self.path]
         self.rays_per_block = sum(c["rays"] for c in self.counters)
+        self.iterations_per_block = sum(c["iterations"] for c in self.counters)
         self.bytes_per_frame = sum(algorithmic_bytes(args.format, c) for c in self.counters) / len(self.counters)
         self.image_bytes_per_frame = sum(image_model_bytes(c) for c in self.counters) / len(self.counters)
 
@@ -364,53 +372,179 @@ class Sharded:
 # ---- measurements -----------------------------------------------------------------------------------------------------------------
 
 
+def granted_cpus():
+    """What this process may run on: the affinity mask, the cgroup's CPU quota (v2 cpu.max, v1 cfs quota / period), the machine's logical CPUs."""
+    out = {"logical_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cgroup_cpu_max": None}
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        out["cgroup_cpu_max"] = None if quota == "max" else round(float(quota) / float(period), 2)
+    except (OSError, ValueError):
+        try:
+            quota = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            period = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            out["cgroup_cpu_max"] = round(quota / period, 2) if quota > 0 else None
+        except (OSError, ValueError):
+            pass
+    try:
+        out["loadavg_1min"] = round(os.getloadavg()[0], 1)
+    except OSError:
+        pass
+    return out
+
+
 def cpu_baseline(args, wl, orc):
-    """The C oracle on this box's host cores over a bounded sample of the path's first view: all cores (about --cpu-seconds) and one thread (about 4 s)."""
+    """The C oracle on this box's host cores: whole frames of the path's first view (the unit of its OpenMP loop is a 32x32 tile, handed out one
+    at a time) at 1, 8, 32 and all threads -- about 3 s each, --cpu-seconds for the last -- so that the line says how the restatement scales on
+    what this process is GRANTED. `value` / `cores` = the best point of the sweep and the threads it ran on."""
     W, H = args.width, args.height
     scene = orc.OracleScene(wl.fmt, wl.world.frame(), wl.mats.view(orc.MATERIAL_DTYPE), wl.tex, 6)
     ou = orc.Uniforms.from_buffer_copy(bytes(wl.path[0]))
-    cores = orc.lib().or_max_threads()
-    # warm up the thread pool and the page cache on a thin band, then time one band of a tenth of the frame to decide
-    # between whole frames and bands (a frame this size takes well under a second on a server CPU)
-    scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 8), want_hits=False, counters=orc.Counters(), threads=cores)
-    t0 = time.perf_counter()
-    scene.render(ou, W, H, rect=(0, H // 2 - H // 20, W, H // 2 + H // 20), want_hits=False, counters=orc.Counters(), threads=cores)
-    frame_estimate_s = 10.0 * (time.perf_counter() - t0)
-    cc = orc.Counters()
-    if frame_estimate_s <= args.cpu_seconds:
-        reps = 0
+    granted = granted_cpus()
+    omp_threads = orc.lib().or_max_threads()
+    every = omp_threads
+    points = sorted({t for t in (1, 8, 32, every) if t <= every})
+    scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 32), want_hits=False, counters=orc.Counters(), threads=every)  # (thread pool, page cache)
+    sweep = []
+    for t in points:
+        seconds = args.cpu_seconds if t == every else min(3.0, args.cpu_seconds)
+        cc = orc.Counters()
+        frames = 0
         t0 = time.perf_counter()
-        while reps < 400 and (reps == 0 or time.perf_counter() - t0 < args.cpu_seconds):
-            scene.render(ou, W, H, want_hits=False, counters=cc, threads=cores)
-            reps += 1
-        cpu_s = time.perf_counter() - t0
-        sample = f"{reps} x the whole {W}x{H} frame"
-    else:
-        bands = 8
-        band_h = max(int(H * args.cpu_seconds / frame_estimate_s) // bands, 1)
-        t0 = time.perf_counter()
-        for b in range(bands):
-            y0 = int((b + 0.5) * H / bands) - band_h // 2
-            scene.render(ou, W, H, rect=(0, max(y0, 0), W, min(y0 + band_h, H)), want_hits=False, counters=cc, threads=cores)
-        cpu_s = time.perf_counter() - t0
-        sample = f"{bands} bands x {band_h} rows of the {W}x{H} frame"
-    # and on ONE thread (BASELINE.md §2: "1 thread, and all host cores"): bands of rows spread over the frame, about 4 s of work
-    c1 = orc.Counters()
-    scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 2), want_hits=False, counters=c1, threads=1)  # (warm)
-    t0 = time.perf_counter()
-    scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 16), want_hits=False, counters=c1, threads=1)
-    per_row_s = (time.perf_counter() - t0) / 16
-    rows = max(2, min(H // 8, int(4.0 / max(per_row_s, 1e-6)) // 8))
-    c1 = orc.Counters()
-    t0 = time.perf_counter()
-    for b in range(8):
-        y0 = int((b + 0.5) * H / 8) - rows // 2
-        scene.render(ou, W, H, rect=(0, max(y0, 0), W, min(y0 + rows, H)), want_hits=False, counters=c1, threads=1)
-    one_s = time.perf_counter() - t0
-    return {"value": round(cc.rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{sample} (the path's first view): {cc.rays} rays in {cpu_s:.2f} s (C restatement of the GLSL path, OpenMP; the reference has no CPU raycast)",
-            "single_thread": {"value": round(c1.rays / one_s / 1e6, 4), "unit": "Mrays/s", "cores": 1,
-                              "sample": f"8 bands x {rows} rows of the {W}x{H} frame: {c1.rays} rays in {one_s:.2f} s"}}
+        while frames < 400 and (frames == 0 or time.perf_counter() - t0 < seconds):
+            scene.render(ou, W, H, want_hits=False, counters=cc, threads=t)
+            frames += 1
+        dt = time.perf_counter() - t0
+        sweep.append({"threads": t, "value": round(cc.rays / dt / 1e6, 4), "frames": frames, "seconds": round(dt, 2), "rays": int(cc.rays)})
+    best = max(sweep, key=lambda r: r["value"])
+    one = sweep[0]
+    return {"value": best["value"], "unit": "Mrays/s", "cores": best["threads"], "kind": "port",
+            "sample": f"{best['frames']} x the whole {W}x{H} frame (the path's first view): {best['rays']} rays in {best['seconds']:.2f} s on {best['threads']} threads "
+                      "(C restatement of the GLSL path, OpenMP over 32x32 tiles; the reference has no CPU raycast)",
+            "granted": granted, "omp_max_threads": omp_threads, "sweep": sweep, "speedup_best_over_one_thread": round(best["value"] / max(one["value"], 1e-9), 2),
+            "single_thread": {"value": one["value"], "unit": "Mrays/s", "cores": 1, "sample": f"{one['frames']} x the whole frame: {one['rays']} rays in {one['seconds']:.2f} s"}}
+
+
+# ---- the other BASELINE configurations on this GPU -----------------------------------------------------------------------------------
+
+
+def other_configs(args, vra, hip, scenes, torch, formats):
+    """C2 (1080p primary rays, depth 10), C4 (4K primary + shadow on the full-detail depth-14 terrain: static, and streamed by the chunk loader),
+    C5 (7680x4320 + 2x2 resolve on that terrain: one rank's share of eight, and the whole frame on this one GPU): the same moving camera, frames into
+    device memory with the library's two frames in flight, the median of five blocks. Rays and iterations from the instrumented kernel (first view)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("stream_bench", ROOT / "profiles" / "stream_bench.py")
+    stream_bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stream_bench)
+    out = {}
+    mats, tex = scenes.synthetic_materials(), scenes.asset_textures(ROOT / "tests" / "golden" / "textures")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timed(svo, frame, steps, repeats=5):
+        for i in range(4):
+            frame(i)
+        svo.sync()
+        torch.cuda.synchronize()
+        blocks = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                frame(i)
+            svo.sync()
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / steps * 1e3)
+        return sorted(blocks)[len(blocks) // 2]
+
+    def line(ms, c, extra=None):
+        return {"ms_per_step": round(ms, 4), "value": round(c["rays"] / ms / 1e3, 1), "unit": "Mrays/s", "rays_per_step": int(c["rays"]),
+                "iterations_per_s": round(c["iterations"] / ms * 1e3, 0), **(extra or {})}
+
+    for fmt_name in formats:
+        fmt = vra.SVO_ESVO if fmt_name == "esvo" else vra.SVO_CSVO
+        for depth in (10, 14):
+            t0 = time.perf_counter()
+            world = vra.World(fmt)
+            st = world.build_heightfield(depth)
+            build_s = time.perf_counter() - t0
+            svo = hip.Svo(fmt, world.size_in_bytes + (16 << 20))
+            svo.set_materials(mats)
+            svo.set_textures(tex, 6)
+            t0 = time.perf_counter()
+            svo.update(world)
+            svo.sync()
+            commit_s = time.perf_counter() - t0
+            about = {"svo_bytes": world.size_in_bytes, "leaves": st["leaves"], "scene_build_s": round(build_s, 2), "first_commit_s": round(commit_s, 2)}
+            if depth == 10:
+                W, H = 1920, 1080
+                path = [moving_uniforms(scenes, depth, st["h_max"], W, H, i, shadows=False) for i in range(20)]
+                imgs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+                torch.cuda.synchronize()
+                ms = timed(svo, lambda i: svo.render_device(path[i % 20], W, H, imgs[i % 2].data_ptr()), 200)
+                out.setdefault("C2", {})[fmt_name] = line(ms, svo.render_counters(path[0], W, H), {"workload": "1920x1080 primary rays only, depth-10 SVO", **about})
+            else:
+                w, h = 3840, 2160
+                path = [moving_uniforms(scenes, depth, st["h_max"], w, h, i) for i in range(20)]
+                imgs = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+                torch.cuda.synchronize()
+                ms = timed(svo, lambda i: svo.render_device(path[i % 20], w, h, imgs[i % 2].data_ptr()), 40)
+                out.setdefault("C4_static", {})[fmt_name] = line(ms, svo.render_counters(path[0], w, h),
+                                                                 {"workload": "3840x2160 primary + shadow, static full-detail depth-14 terrain", **about, "image": svo.image_info()})
+                del imgs
+                # C5: 2x2 supersamples of the 4K frame. One rank's share of eight (its tile list; the resolve of the assembled frame is rank 0's), and
+                # the whole supersampled frame + the resolve on this one GPU
+                W, H = 2 * w, 2 * h
+                u5 = moving_uniforms(scenes, depth, st["h_max"], W, H, 0)
+                per = hip.local_tile_count(W, H, 0, 8)
+                lists = [torch.zeros((per, 32, 32, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+                torch.cuda.synchronize()
+                ms = timed(svo, lambda i: svo.render_device(u5, W, H, lists[i % 2].data_ptr(), tile_rank=0, tile_count=8), 40)
+                out.setdefault("C5_rank_share", {})[fmt_name] = line(ms, svo.render_counters(u5, W, H, 0, 8),
+                                                                     {"workload": "rank 0's tiles (one in eight, Morton round-robin) of the 7680x4320 supersampled frame, depth-14 terrain"})
+                del lists
+                big = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+                small = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+
+                def whole(i):
+                    svo.render_device(u5, W, H, big[i % 2].data_ptr())
+                    svo.stream_wait_render(stream)
+                    svo.resolve_2x2(big[i % 2].data_ptr(), w, h, small.data_ptr(), stream=stream)
+
+                ms = timed(svo, whole, 12, 3)
+                out.setdefault("C5_whole_on_one_gpu", {})[fmt_name] = line(ms, svo.render_counters(u5, W, H), {"workload": "7680x4320 + 2x2 resolve to 3840x2160, depth-14 terrain, this GPU alone"})
+                del big, small
+            svo.close()
+            del world, svo
+        # C4 as the game produces it: the chunk loader streams the depth-14 terrain in around the camera (radius 40, <= 400 events a commit,
+        # pipelined commits) while frames render: the kernel in mid-stream and settled, and what the frame loop's thread pays per step
+        r = stream_bench.run(stream_bench.parse_args(["--format", fmt_name, "--scene-depth", "14", "--radius", "40", "--width", "3840", "--height", "2160", "--frames", "80"]))
+        out.setdefault("C4_streamed", {})[fmt_name] = {
+            "ms_per_step": r["kernel_ms_streaming_median"], "value": r["Mrays_per_s_settled"], "unit": "Mrays/s", "rays_per_step": r["rays_last_frame"],
+            "iterations_per_s": round(r["iterations_last_frame"] / max(r["kernel_ms_settled_median"], 1e-9) * 1e3, 0),
+            "ms_per_step_settled": r["kernel_ms_settled_median"], "host_ms_per_step_median": r["host_ms_per_step_median"], "host_ms_per_step_max": r["host_ms_per_step_max"],
+            "apply_ms_median": r["apply_ms_median"], "commit_ms_median": r["commit_ms_median"], "resident_chunks": r["resident_chunks"],
+            "initial_fill_s": r["initial_fill"]["seconds"], "workload": r["workload"]}
+    return out
+
+
+def forced_sharded_child(args):
+    """The N > 1 code path (tile lists, the library's RCCL gather on a one-rank communicator, rank 0's assembly) on this one GPU, in a child process of
+    its own (a fresh context and process group; this process has finished its GPU work and waits): `bench.py --force-sharded` at the same sizes."""
+    import subprocess
+
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--force-sharded", "--no-cpu-baseline", "--no-extras", "--sustained-seconds", "0", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--repeats", "9", "--depth", str(args.depth), "--width", str(args.width), "--height", str(args.height), "--format", args.format,
+           "--textures", args.textures]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return {"value": d["value"], "unit": "Mrays/s", "ms_per_step": d["ms_per_step"], "identical": d["config"].get("sharded_frame_identical_to_whole_render"),
+                "gather": d["config"].get("gather"), "gather_format": d["config"].get("gather_format"), "frames_in_flight": d["roofline"].get("frames_in_flight"),
+                "host_issue_ms_per_step": d["config"].get("host_issue_ms_per_step")}
+    except Exception as e:  # the record says so instead of failing the headline
+        return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def picker_latency(wl, hip, np):
@@ -457,11 +591,16 @@ def parse_args():
                     help="sharded: pixel format of the tile lists that travel and of rank 0's image (rgba8 = Framebuffer::as_image's bytes: a quarter of the link time)")
     ap.add_argument("--gather-timeout", type=float, default=30.0, help="sharded: seconds the first exchange may take before it is declared hung")
     ap.add_argument("--simulate-gather-failure", action="store_true", help="testing: make the library's exchange fail, to exercise the fall-back")
+    ap.add_argument("--sustained-seconds", type=float, default=3.0,
+                    help="after the median-of-blocks headline: one block of at least this many seconds of the same path (0 = none); it becomes `value` if more than 2 %% below the burst median")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (C2, C4 static / streamed, C5 on this GPU: about 40 s, most of it the depth-14 terrain's build)")
+    ap.add_argument("--config-formats", default="csvo,esvo", help="node formats the `configs` object is measured for")
+    ap.add_argument("--no-forced-sharded", action="store_true", help="skip the `forced_sharded` object (the N > 1 code path on this one GPU, a child process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary blocks (still view, shadow_distance 500, picker): profiler runs, whose per-kernel averages they would dilute")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary blocks (still view, shadow_distance 500, picker, configs, forced_sharded): profiler runs, whose per-kernel averages they would dilute")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (tile lists, RCCL gather, assembly) even with one rank; needs a torch.distributed.run launch")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock target for the cpu_baseline sample (all host cores)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall-clock target for the cpu_baseline sample on all threads (the sweep's other points: 3 s each)")
     ap.add_argument("--textures", choices=["assets", "procedural"], default="assets",
                     help="assets: the reference's own 64x64 textures (tests/golden/textures) for the blocks the terrain uses")
     return ap.parse_args()
@@ -542,6 +681,73 @@ def main():
     svo.profile_enable(False)
     enqueue_s = sorted(enqueue)[len(enqueue) // 2]
 
+    # The sustained block: the same path, again and again, for --sustained-seconds without a pause -- what the device holds over seconds (clock,
+    # power, temperature), which a 5 ms block cannot say. The host stays a few hundred frames ahead at most: every 100 frames an event is
+    # recorded behind the newest render (vx_stream_wait_render on torch's stream), and the host waits for the event four marks back and notes
+    # when it passed -- frames completed against time, from which the first and the last second's rates are read. Meanwhile a second thread
+    # samples the shader clock (vx_clock_probe: a one-lane kernel beside the render kernels).
+    sustained, clock = None, None
+    if args.sustained_seconds > 0:
+        import threading
+
+        probes, stop = [], threading.Event()
+
+        def sample_clock():
+            while not stop.is_set():
+                try:
+                    probes.append(svo.clock_probe(200))
+                except Exception:  # (the record then carries no clock)
+                    return
+                stop.wait(0.02)
+
+        ts = torch.cuda.current_stream()
+        MARK = 100
+        # (how many frames: fixed before the block from the burst rate, the same number on every rank -- a sharded frame is a collective)
+        burst = torch.tensor([sorted(blocks)[len(blocks) // 2] / args.steps], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(burst, op=dist.ReduceOp.MAX)
+        frames_target = max(MARK, int(math.ceil(args.sustained_seconds * 1.02 / max(float(burst[0]), 1e-6) / MARK)) * MARK)
+        barrier()
+        run.i = 0
+        sampler = threading.Thread(target=sample_clock, daemon=True)
+        sampler.start()
+        marks, passed, frames_issued = [], [], 0
+        t0 = time.perf_counter()
+        while frames_issued < frames_target:
+            for _ in range(MARK):
+                run.step()
+            frames_issued += MARK
+            svo.stream_wait_render(ts.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(ts)
+            marks.append((frames_issued, ev))
+            while len(marks) > 4:
+                f, e = marks.pop(0)
+                e.synchronize()
+                passed.append((f, time.perf_counter() - t0))
+        for f, e in marks:
+            e.synchronize()
+            passed.append((f, time.perf_counter() - t0))
+        barrier()
+        total_s = time.perf_counter() - t0
+        stop.set()
+        sampler.join(timeout=5.0)
+        if dist is not None:  # (the slowest rank's time stands)
+            slowest = torch.tensor([total_s], dtype=torch.float64, device="cuda")
+            dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+            total_s = float(slowest[0])
+
+        def rate_between(a, b):  # frames per second between two moments of the block, from the marks
+            inside = [(f, t) for f, t in passed if a <= t <= b]
+            return (inside[-1][0] - inside[0][0]) / (inside[-1][1] - inside[0][1]) if len(inside) >= 2 and inside[-1][1] > inside[0][1] else None
+
+        sustained = {"seconds": round(total_s, 3), "frames": frames_issued, "ms_per_step": round(total_s / frames_issued * 1e3, 4),
+                     "frames_per_s_first_second": rate_between(0.0, 1.0), "frames_per_s_last_second": rate_between(total_s - 1.0, total_s)}
+        if probes:
+            ps = sorted(probes)
+            clock = {"mhz_median": round(ps[len(ps) // 2], 1), "mhz_min": round(ps[0], 1), "mhz_max": round(ps[-1], 1), "samples": len(ps),
+                     "source": "vx_clock_probe (s_memtime against the 100 MHz counter over 200 us, a wave of its own) sampled every 20 ms while the sustained block's kernels run"}
+
     # One frame at a time (outside the timed region): with several frames in flight a kernel's HIP-event span includes the time it
     # shares the device with its neighbours, so the kernel's OWN duration -- what the roofline fraction is defined on -- is measured
     # with the device to itself, over the path's views, twice:
@@ -592,9 +798,21 @@ def main():
         sd500 = view_block(scenes.bench_camera(args.depth, wl.st["h_max"], W, H, shadow_distance=500.0, render_shadows=True), 5)
         sd500.update({"shadow_distance": 500.0, "note": "the timed frames cast a shadow ray from every primary hit (shadow_distance = inf); this is the game's default cut-off, a still view"})
         picker = picker_latency(wl, hip, np)
+    configs, forced = None, None
+    if not sharded and not args.no_extras and rank == 0:
+        if not args.no_configs:
+            try:
+                configs = other_configs(args, vra, hip, scenes, torch, [f for f in args.config_formats.split(",") if f in ("csvo", "esvo")])
+            except Exception as e:  # (a box without the memory for the depth-14 terrain: the headline still stands)
+                configs = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if not args.no_forced_sharded:
+            svo.sync()
+            torch.cuda.synchronize()
+            forced = forced_sharded_child(args)
 
     times = torch.tensor(blocks, dtype=torch.float64, device="cuda")
-    stats = torch.tensor([float(wl.rays_per_block), float(wl.bytes_per_frame), kernel_ms / max(launches, 1), kernel_exclusive_ms, gather_ms / max(gathers, 1)],
+    stats = torch.tensor([float(wl.rays_per_block), float(wl.bytes_per_frame), kernel_ms / max(launches, 1), kernel_exclusive_ms, gather_ms / max(gathers, 1),
+                          float(wl.iterations_per_block)],
                          dtype=torch.float64, device="cuda")
     per_rank = None
     if dist is not None:
@@ -602,12 +820,14 @@ def main():
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         total_rays_per_block = float(sm[0])
+        total_iterations_per_block = float(sm[5])
         every = [torch.zeros_like(stats) for _ in range(world_size)]
         dist.all_gather(every, stats)
         per_rank = [{"rank": r, "rays_per_block": int(e[0]), "kernel_span_ms_in_flight": round(float(e[2]), 4), "kernel_exclusive_ms": round(float(e[3]), 4),
                      "exchange_ms": round(float(e[4]), 4)} for r, e in enumerate(every)]
     else:
         total_rays_per_block = float(wl.rays_per_block)
+        total_iterations_per_block = float(wl.iterations_per_block)
     block_s = sorted(float(t) for t in times)
     elapsed = block_s[len(block_s) // 2]
     # sharded: the frame rank 0 assembled last against the same frame rendered whole on this GPU (outside the timed region)
@@ -623,13 +843,27 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays_per_block / elapsed / 1e6  # Mrays/s, whole job
+    burst = {"value": round(value, 3), "ms_per_step": round(ms_per_step, 4)}
+    value_source = f"median of {len(block_s)} timed blocks of {args.steps} frames"
+    if sustained:
+        # the same path's views in the same order: rays per frame as in the blocks. The sustained figure is the headline if it is more than 2 % lower.
+        rays_per_frame_all = total_rays_per_block / args.steps
+        sustained["value"] = round(rays_per_frame_all / (sustained["ms_per_step"] * 1e-3) / 1e6, 3)
+        for k in ("first", "last"):
+            fps = sustained.pop(f"frames_per_s_{k}_second")
+            sustained[f"block_{k}_s_value"] = round(rays_per_frame_all * fps / 1e6, 3) if fps else None
+        sustained["vs_burst_median"] = round(sustained["value"] / value, 4)
+        if sustained["value"] < 0.98 * value:
+            value, ms_per_step = sustained["value"], sustained["ms_per_step"]
+            value_source = f"the sustained block ({sustained['seconds']} s, {sustained['frames']} frames): more than 2 % below the burst median, so it is the headline"
     kernel_avg_ms = kernel_ms / max(launches, 1)
     my_bytes = wl.bytes_per_frame
     achieved = my_bytes / (kernel_exclusive_ms * 1e-3) / 1e9 if kernel_exclusive_ms > 0 else 0.0
     reference_shape = (W, H, args.depth, world_size) == (1920, 1080, 12, 1)
-    traffic, traffic_source = measured_traffic(args.format) if reference_shape else (None, None)
+    stored, traffic_source, stored_note = stored_counters(args.format) if reference_shape else (None, None, "not the reference shape (1920x1080, depth 12, one GPU)")
+    traffic = stored.get("bytes_per_launch") if stored else None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": traffic, "traffic_source": traffic_source, "kernel": "render_persistent",
+                "traffic": traffic, "traffic_source": traffic_source, **({"traffic_note": stored_note} if stored_note else {}), "kernel": "render_persistent",
                 # achieved = algorithmic bytes per launch / the kernel's own duration: one frame at a time on one stream, HIP events bracketing
                 # each launch (what rocprofv3's kernel duration is 6-8 % below: the bracket includes the launch's own start and end)
                 "kernel_exclusive_ms": round(kernel_exclusive_ms, 4), "kernel_exclusive_ms_is": "HIP-event bracket around each launch",
@@ -649,10 +883,12 @@ def main():
                 "sustained_GBps": round(my_bytes * args.steps / max(elapsed, 1e-9) / 1e9, 3)}
     # The HBM byte model is what the contract asks for, but this kernel's working set is cache resident and it is bound by instruction
     # issue: the second, practical bound, with the fraction of it the kernel reaches one frame at a time and in the timed mode.
-    issue = issue_model(args.format) if reference_shape else None
+    issue = issue_model(stored, traffic_source, clock["mhz_median"], "this run: " + clock["source"]) if (stored and clock) else None
+    if clock:
+        roofline["clock"] = clock
     if issue:
         issue["frac_of_bound_one_frame_at_a_time"] = round(issue["issue_bound_ms"] / kernel_exclusive_ms, 4) if kernel_exclusive_ms > 0 else None
-        issue["frac_of_bound_timed_mode"] = round(issue["issue_bound_ms"] / ms_per_step, 4)
+        issue["frac_of_bound_timed_mode"] = round(issue["issue_bound_ms"] / burst["ms_per_step"], 4)
         roofline["issue"] = issue
 
     cpu = None
@@ -666,7 +902,10 @@ def main():
         "metric": "Mrays/sec (primary+shadow) at 1920x1080, depth-12 SVO; achieved HBM GB/s",
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
         "repeats": len(block_s), "block_ms_min_median_max": [round(block_s[0] * 1e3, 3), round(elapsed * 1e3, 3), round(block_s[-1] * 1e3, 3)],
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": round(ms_per_step, 4), "value_source": value_source, "burst": burst, **({"sustained": sustained} if sustained else {}),
+        # a scene-independent rate: iterations of the traversal loop (the instrumented kernel's count for this path's views) per second
+        "iterations_per_s": round(total_iterations_per_block / args.steps / (ms_per_step * 1e-3), 0),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"C3: {W}x{H} primary + 1 shadow ray per lit pixel, textured + normal-mapped shading, depth-{args.depth} SVO "
                                f"({args.format.upper()} nodes), 1 frame per step, the camera moves every frame (0.25 degrees, 0.083 blocks)",
@@ -682,8 +921,10 @@ def main():
                    "scene_build_s": round(wl.build_s, 2), "upload_s": round(wl.upload_s, 3),
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4)},
         "roofline": roofline, "cpu_baseline": cpu, **({"still_view": still} if still else {}), **({"shadow_distance_500": sd500} if sd500 else {}),
-        **({"picker": picker} if picker else {}),
+        **({"picker": picker} if picker else {}), **({"configs": configs} if configs else {}), **({"forced_sharded": forced} if forced else {}),
     }
+    if forced and forced.get("value"):
+        forced["vs_plain_burst"] = round(forced["value"] / burst["value"], 4)
     # the JSON line is the LAST thing on stdout: tear the communicators down first (RCCL prints a banner through C stdio, which
     # is flushed at exit otherwise) and flush C's buffers before Python's
     if sharded and run.gather_used == "library":

@@ -346,6 +346,11 @@ int vx_render_counters(vx_context* ctx, const vx_uniforms* uniforms, uint32_t wi
 int vx_profile_enable(vx_context* ctx, int enabled);
 /* Sum of the bracketed kernel durations (ms) and their count since the last call; synchronises. */
 int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches);
+/* The shader clock the device runs at while this call lasts, in MHz: a one-lane kernel on a stream of its own, beside whatever the context
+ * has in flight, compares the shader-clock counter with the device's constant 100 MHz counter over `microseconds` (10 .. 100000). Blocks the
+ * calling thread until the probe has run; may be called from a second thread while the context's own thread renders (it takes the
+ * context's lock only to launch). No counterpart in the reference: bench.py samples it during its sustained block. */
+int vx_clock_probe(vx_context* ctx, uint32_t microseconds, double* shader_mhz);
 /* The same for the exchanges (vx_gather_tiles calls made while profiling was enabled): time on the communicator's stream from the
  * first send / receive to the last, i.e. including the wait for the slowest peer. Synchronises the communicator's stream. */
 int vx_comm_profile_read(vx_context* ctx, double* gather_ms_sum, uint32_t* gathers);

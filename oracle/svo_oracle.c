@@ -656,21 +656,30 @@ void or_render(const or_scene* scene, const or_uniforms* u, uint32_t w, uint32_t
     {
         or_counters local;
         memset(&local, 0, sizeof local);
+        /* the unit of work is a 32x32 tile of the rectangle ("all host cores ... over 32x32 tiles"), handed out one at a time: rows of
+         * the sky cost a fraction of rows of the ground, and 1080 rows in chunks of four were too few units for a hundred threads */
+        const int64_t tx0 = x0 / 32, ty0 = y0 / 32, ntx = ((int64_t)x1 + 31) / 32 - tx0, nty = ((int64_t)y1 + 31) / 32 - ty0;
+        const int64_t n_tiles = ntx > 0 && nty > 0 ? ntx * nty : 0;
 #ifdef _OPENMP
-#pragma omp for schedule(dynamic, 4)
+#pragma omp for schedule(dynamic, 1)
 #endif
-        for (int64_t y = (int64_t)y0; y < (int64_t)y1; ++y) {
-            for (uint32_t x = x0; x < x1; ++x) {
-                float ro[3], rd[3], color[4];
-                int hit = 0;
-                or_primary_ray(u, w, h, x, (uint32_t)y, ro, rd);
-                trace_ray(scene, u, ro, rd, color, &hit, hits ? &hits[(size_t)y * w + x] : NULL, ctr ? &local : NULL);
-                if (!hit) {
-                    float sky[3];
-                    sky_color(rd, sky);
-                    color[0] = sky[0]; color[1] = sky[1]; color[2] = sky[2]; color[3] = 1.0f;
+        for (int64_t t = 0; t < n_tiles; ++t) {
+            const uint32_t bx = (uint32_t)(tx0 + t % ntx) * 32u, by = (uint32_t)(ty0 + t / ntx) * 32u;
+            const uint32_t xa = bx > x0 ? bx : x0, xb = bx + 32u < x1 ? bx + 32u : x1;
+            const uint32_t ya = by > y0 ? by : y0, yb = by + 32u < y1 ? by + 32u : y1;
+            for (uint32_t y = ya; y < yb; ++y) {
+                for (uint32_t x = xa; x < xb; ++x) {
+                    float ro[3], rd[3], color[4];
+                    int hit = 0;
+                    or_primary_ray(u, w, h, x, y, ro, rd);
+                    trace_ray(scene, u, ro, rd, color, &hit, hits ? &hits[(size_t)y * w + x] : NULL, ctr ? &local : NULL);
+                    if (!hit) {
+                        float sky[3];
+                        sky_color(rd, sky);
+                        color[0] = sky[0]; color[1] = sky[1]; color[2] = sky[2]; color[3] = 1.0f;
+                    }
+                    memcpy(out_rgba + ((size_t)y * w + x) * 4, color, sizeof color);
                 }
-                memcpy(out_rgba + ((size_t)y * w + x) * 4, color, sizeof color);
             }
         }
         if (ctr) {

@@ -2,7 +2,7 @@
 # round 4: rocprofv3 evidence for the C3 bench, ONE FRAME AT A TIME (--frames-in-flight 1: every launch of the render kernel has the
 # device to itself, so the profiler's average duration is the kernel's own -- the figure bench.py reports as
 # roofline.kernel_exclusive_ms). Kernel trace and each PMC group are separate passes (never combined).
-#   usage: profiles/round4/profile_r3.sh <csvo|esvo>
+#   usage: profiles/round4/profile_r4.sh <csvo|esvo>
 set -u
 fmt=$1
 out=gpurun_out/prof_r4_$fmt

@@ -23,7 +23,7 @@ vra = load_package()
 from voxel_rs_amd import hip, host, scenes  # noqa: E402
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--format", default="csvo")
     ap.add_argument("--scene-depth", type=int, default=12)
@@ -35,7 +35,11 @@ def main():
     ap.add_argument("--events", type=int, default=400)
     ap.add_argument("--capacity-mb", type=int, default=2000)
     ap.add_argument("--pipelined", type=int, default=1, help="1 = VX_COMMIT_PIPELINED during the flight (the commit worker), 0 = inline commits")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run(args):
+    """The measurement, as a dict (bench.py calls this for its `configs.C4_streamed` object; `args` = parse_args([...]))."""
     import torch
 
     fmt = vra.SVO_ESVO if args.format == "esvo" else vra.SVO_CSVO
@@ -97,7 +101,8 @@ def main():
         ms, launches = svo.profile_read()
         settled.append(dict(kernel_ms=ms / max(launches, 1)))
     svo.profile_enable(False)
-    rays = svo.render_counters(u, W, H)["rays"]
+    last = svo.render_counters(u, W, H)
+    rays = last["rays"]
     streaming = [r for r in rows if r["events"] > 0]
     commits = [r for r in streaming if r["bytes"] > 0]
     out = {
@@ -106,7 +111,7 @@ def main():
                          "build_s": round(fill["build_us"] / 1e6, 2), "apply_s": round(fill["apply_us"] / 1e6, 2), "commit_s": round(fill["commit_us"] / 1e6, 3),
                          "commit_GBps": round(fill["bytes"] / max(fill["commit_us"], 1) / 1e3, 2)},
         "frames": len(rows), "streaming_frames": len(streaming), "pending_after_flight": rows[-1]["pending"], "resident_chunks": s.resident_chunks, "arena_MB": round(rows[-1]["arena_bytes"] / 1e6, 1),
-        "rays_last_frame": int(rays),
+        "rays_last_frame": int(rays), "iterations_last_frame": int(last["iterations"]),
         "kernel_ms_streaming_median": round(statistics.median(r["kernel_ms"] for r in streaming), 3) if streaming else None,
         "kernel_ms_settled_median": round(statistics.median(r["kernel_ms"] for r in settled), 3),
         "Mrays_per_s_settled": round(rays / statistics.median(r["kernel_ms"] for r in settled) / 1e3, 1),
@@ -122,8 +127,9 @@ def main():
         "commit_ms_median": round(statistics.median(r["commit_us"] for r in commits) / 1e3, 2) if commits else None,
         "commit_GBps_median": round(statistics.median(r["bytes"] / max(r["commit_us"], 1) / 1e3 for r in commits), 2) if commits else None,
     }
-    print(json.dumps(out))
+    svo.close()
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(run(parse_args())))

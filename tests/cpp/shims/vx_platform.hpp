@@ -12,10 +12,12 @@ namespace vxd {
 
 struct buf_t { const uint8_t* p; uint32_t bytes; };
 inline buf_t make_buf(const void* p, uint32_t bytes) { return buf_t{static_cast<const uint8_t*>(p), bytes}; }
-// like the V#'s range check with the zero padding the product keeps behind every buffer it reads unaligned: bytes beyond the end read as 0
+// like the V#'s range check: a read that does not fit the buffer's range WHOLE returns 0. (The product keeps zero padding behind every buffer
+// it reads unaligned, inside the descriptor's range -- kWorldPad, kImagePad in runtime.cpp --, so that a straddling read returns the real bytes
+// plus zeros; the harness pads the arrays it hands over the same way. A buffer made without its padding shows up here as it would on the GPU.)
 inline void buf_read(buf_t b, uint32_t off, void* out, uint32_t n) {
     std::memset(out, 0, n);
-    if (off < b.bytes) std::memcpy(out, b.p + off, b.bytes - off < n ? b.bytes - off : n);
+    if (uint64_t(off) + n <= b.bytes) std::memcpy(out, b.p + off, n);
 }
 inline uint32_t buf_u32(buf_t b, uint32_t off) { uint32_t v; buf_read(b, off, &v, 4); return v; }
 inline uint32_t buf_u8(buf_t b, uint32_t off) { return off < b.bytes ? b.p[off] : 0u; }

@@ -127,6 +127,49 @@ def test_full_size_frames(hip, fmt, config, textures, shadow_distance):
 
 
 @pytest.mark.parametrize("fmt", FMTS)
+def test_views_of_the_benchmarks_moving_camera(hip, fmt):
+    """The frames bench.py TIMES: its own twenty views (bench.moving_uniforms: 1920x1080, depth 12, the reference's textures, every primary hit casts
+    its shadow ray), rendered as it renders them -- image-only, device resident, two frames in flight, one after the other along the path -- and the
+    first, the eighth and the last of them against the oracle's frames (colour within 5e-6; the render with hit records of the same views: exact
+    records, and the image-only frame's pixels byte for byte)."""
+    import sys
+
+    import torch
+
+    root = Path(__file__).resolve().parent.parent
+    if str(root) not in sys.path:
+        sys.path.insert(0, str(root))
+    import bench
+
+    depth, w, h, steps = 12, 1920, 1080, 20
+    world = vra.World(FMTS[fmt])
+    st = world.build_heightfield(depth)
+    tex, mats = scenes.asset_textures(TEXTURE_DIR), scenes.synthetic_materials()
+    scene = orc.OracleScene(FMTS[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    svo = hip.Svo(FMTS[fmt], world.size_in_bytes + (16 << 20))
+    svo.set_materials(mats)
+    svo.set_textures(tex, 6)
+    svo.update(world)
+    svo.set_frames_in_flight(2)
+    path = [bench.moving_uniforms(scenes, depth, st["h_max"], w, h, i) for i in range(steps)]
+    frames = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(steps)]
+    torch.cuda.synchronize()
+    for _ in range(2):  # (twice along the path, like consecutive timed blocks)
+        for i, u in enumerate(path):
+            svo.render_device(u, w, h, frames[i].data_ptr())
+    svo.sync()
+    for i in (0, 7, 19):
+        got = frames[i].cpu().numpy()
+        cimg, chits = scene.render(orc.Uniforms.from_buffer_copy(bytes(path[i])), w, h)
+        assert np.array_equal(np.isnan(got), np.isnan(cimg)), f"view {i}"
+        assert np.nanmax(np.abs(got - cimg)) <= 5e-6, f"view {i}"
+        img, hits = svo.render(path[i], w, h, want_hits=True)
+        assert hits.tobytes() == chits.tobytes(), f"view {i}"
+        assert np.array_equal(np.isnan(got), np.isnan(img)) and np.nanmax(np.abs(got - img)) == 0.0, f"view {i}"
+        assert int((chits["flags"] & 1).sum()) > 0.3 * w * h
+
+
+@pytest.mark.parametrize("fmt", FMTS)
 def test_c5_supersampled_frame(hip, fmt):
     """2x2 ordered-grid supersampling: a (2w x 2h) render box-filtered down, against the oracle's (2w x 2h) frame filtered
     the same way in numpy (same association order: (a + b) + (c + d), then * 0.25)."""

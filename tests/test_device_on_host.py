@@ -52,6 +52,7 @@ def run(lib, golden, fmt, world, tasks, cast_translucent):
     mats = golden_materials(golden)
     out = np.zeros(len(tasks), dtype=orc.PICKER_RESULT_DTYPE)
     level_offset = (C.c_uint32 * 16)(0)
+    frame = np.concatenate([frame, np.zeros(4, dtype=np.uint32)])  # the 16 zero bytes a context keeps behind the world buffer, inside its range (kWorldPad)
     lib.devhost_picker(1 if fmt == "esvo" else 2, frame.ctypes.data_as(C.c_void_p), C.c_uint64(frame.size * 4), mats.ctypes.data_as(C.c_void_p),
                        mats.size, tex.ctypes.data_as(C.c_void_p), 4, 4, 4, 1, level_offset, tasks.ctypes.data_as(C.c_void_p), len(tasks),
                        out.ctypes.data_as(C.c_void_p), cast_translucent)
@@ -122,6 +123,7 @@ def image_cast(lib, fmt, world, mats, tex, mips, tasks, cast_translucent, layout
     level_offset = (C.c_uint32 * 16)(*[int(o) for o in offsets])
     out = np.zeros(len(tasks), dtype=RESULT_DTYPE)
     steps = np.zeros(len(tasks), dtype=np.uint32)
+    frame = np.concatenate([frame, np.zeros(4, dtype=np.uint32)])  # (kWorldPad, as above)
     lib.devhost_image_cast(1 if fmt == "esvo" else 2, layout, int(shallow), int(walk_mode), frame.ctypes.data_as(C.c_void_p), C.c_uint64(frame.size * 4),
                            image.ctypes.data_as(C.c_void_p), C.c_uint64(image.size * 4), origin.ctypes.data_as(C.c_void_p),
                            mats.ctypes.data_as(C.c_void_p), mats.size, chain.ctypes.data_as(C.c_void_p), tex.shape[2], tex.shape[1], tex.shape[0],

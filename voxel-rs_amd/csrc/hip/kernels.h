@@ -29,6 +29,7 @@ hipError_t launch_render_v1(int svo, uint32_t blocks, hipStream_t stream, const 
                             unsigned long long* counters);
 
 // kernels_aux.hip
+hipError_t launch_clock_probe(hipStream_t stream, uint32_t ticks_10ns, unsigned long long* out2);  // out2 (device-visible): {shader cycles, 10 ns ticks}
 hipError_t launch_resolve_2x2(hipStream_t stream, const void* src_rgba32f, uint32_t w, uint32_t h, void* dst_rgba32f);
 hipError_t launch_picker(int svo, hipStream_t stream, const vxd::SceneArgs& sc, const vx_picker_task* tasks, uint32_t n, vx_picker_result* results);
 hipError_t launch_trace(int svo, hipStream_t stream, const vxd::SceneArgs& sc, const TraceArgs& a, vx_result* result, vx_frame* frames, uint32_t max_frames, uint32_t* n_frames);

@@ -22,6 +22,22 @@ __global__ __launch_bounds__(256) void resolve_2x2_kernel(const float4* __restri
                                          ((a.w + b.w) + (c.w + d.w)) * 0.25f);
 }
 
+// Measurement: the shader clock this device runs at NOW -- one lane watches the constant 100 MHz counter (s_memrealtime) for `ticks` of it and
+// reports how far the shader-clock counter (s_memtime) moved meanwhile. A wave of its own beside whatever else runs (bench.py samples it
+// while the render kernels of its sustained block run: the clock those kernels hold over seconds).
+__global__ __launch_bounds__(64) void clock_probe_kernel(uint32_t ticks, unsigned long long* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1;
+    do {
+        __builtin_amdgcn_s_sleep(16);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    } while (r1 - r0 < ticks);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+
 template <int SVO>
 __global__ __launch_bounds__(64) void picker_kernel(SceneArgs sa, const vx_picker_task* __restrict__ tasks, uint32_t n,
                                                     vx_picker_result* __restrict__ results) {
@@ -216,6 +232,11 @@ __global__ __launch_bounds__(64) void assemble_kernel_rgba8(const uint32_t* __re
 }  // namespace
 
 namespace vxk {
+
+hipError_t launch_clock_probe(hipStream_t stream, uint32_t ticks, unsigned long long* out) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, ticks, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_resolve_2x2(hipStream_t stream, const void* src, uint32_t w, uint32_t h, void* dst) {
     hipLaunchKernelGGL(resolve_2x2_kernel, dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, stream, static_cast<const float4*>(src), w, h, static_cast<float4*>(dst));

@@ -260,6 +260,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // frames in flight and cost 7 % one frame at a time; numbered in strips it is worth nothing: profiles/round4/pass_r.)
         a.stripe = 1;
         if (!a.order) a.stripe = ctx->queue_stripe > 0 ? uint32_t(ctx->queue_stripe) : 16u;
+        // (a stretch longer than the launch behaves like one of its length; clamped so that queue_subtile's 32-bit products cannot wrap)
+        if (a.stripe > a.total_subtiles) a.stripe = a.total_subtiles;
+        if (a.stripe < 1u) a.stripe = 1u;
         // Persistent waves per CU: all that fit -- the stacks fill a CU's LDS to the last hundred bytes. A context that gathers its tiles over
         // RCCL leaves `comm_headroom` of them out: LDS of every CU stays free, in one piece, for the communication kernels' workgroups, which
         // otherwise find room only when a whole frame has drained.
@@ -657,6 +660,8 @@ void vx_destroy(vx_context* c) {
         if (ps.copied) (void)hipEventDestroy(ps.copied);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->probe_stream) (void)hipStreamDestroy(c->probe_stream);
+    if (c->h_probe) (void)hipHostFree(c->h_probe);
     for (auto& t : c->tile_tables) {
         if (t.d_order) (void)hipFree(t.d_order);
         if (t.d_inverse) (void)hipFree(t.d_inverse);
@@ -1395,6 +1400,28 @@ int vx_profile_read(vx_context* ctx, double* kernel_ms_sum, uint32_t* launches) 
     *kernel_ms_sum = sum;
     *launches = uint32_t(ctx->launches.size());
     ctx->launches.clear();
+    return VX_OK;
+}
+
+int vx_clock_probe(vx_context* ctx, uint32_t microseconds, double* shader_mhz) {
+    if (!ctx || !shader_mhz) return fail(VX_ERR_INVALID_ARGUMENT, "clock_probe: null argument");
+    if (microseconds < 10u || microseconds > 100000u) return fail(VX_ERR_INVALID_ARGUMENT, "clock_probe: 10 .. 100000 microseconds");
+    std::lock_guard<std::mutex> one(ctx->probe_mutex);
+    HIP_TRY(hipSetDevice(ctx->device));
+    {
+        VX_LOCK(ctx);  // (launching only: the wait below is outside, the context's own thread goes on rendering)
+        if (!ctx->probe_stream) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            HIP_TRY(hipStreamCreateWithPriority(&ctx->probe_stream, hipStreamNonBlocking, greatest));
+        }
+        if (!ctx->h_probe) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_probe), 2 * sizeof(unsigned long long), hipHostMallocDefault));
+        ctx->h_probe[0] = ctx->h_probe[1] = 0ull;
+        HIP_TRY(vxk::launch_clock_probe(ctx->probe_stream, microseconds * 100u, ctx->h_probe));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->probe_stream));
+    if (ctx->h_probe[1] == 0ull) return fail(VX_ERR_HIP, "clock_probe: the probe did not report");
+    *shader_mhz = double(ctx->h_probe[0]) / double(ctx->h_probe[1]) * 100.0;  // cycles per 10 ns tick x 100 = MHz
     return VX_OK;
 }
 

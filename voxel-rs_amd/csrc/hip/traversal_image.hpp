@@ -28,6 +28,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <cstdint>
@@ -448,11 +449,24 @@ public:
             ++generation_;
         }
         cv_.notify_all();
-        for (size_t i; (i = next_.fetch_add(1)) < n;) f(i);
-        std::unique_lock<std::mutex> lk(m_);
-        slots_ = 0;  // (nobody else joins this round)
-        done_.wait(lk, [&] { return active_ == 0; });
-        f_ = nullptr;
+        // An exception on any thread (bad_alloc while a walker grows its tree) ends the round early -- nobody takes another index -- and
+        // is rethrown HERE, on the caller's thread, once every worker has left f: the caller's vectors outlive the workers' use of them and a
+        // commit that runs out of memory fails with an error code instead of std::terminate.
+        try {
+            for (size_t i; (i = next_.fetch_add(1)) < n;) f(i);
+        } catch (...) {
+            note_failure(n);
+        }
+        std::exception_ptr thrown;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            slots_ = 0;  // (nobody else joins this round)
+            done_.wait(lk, [&] { return active_ == 0; });
+            f_ = nullptr;
+            thrown = failure_;
+            failure_ = nullptr;
+        }
+        if (thrown) std::rethrow_exception(thrown);
     }
 
 private:
@@ -471,7 +485,11 @@ private:
                 f = f_;
                 n = n_;
             }
-            for (size_t i; (i = next_.fetch_add(1)) < n;) (*f)(i);
+            try {
+                for (size_t i; (i = next_.fetch_add(1)) < n;) (*f)(i);
+            } catch (...) {
+                note_failure(n);
+            }
             {
                 std::lock_guard<std::mutex> lk(m_);
                 --active_;
@@ -479,9 +497,16 @@ private:
             done_.notify_one();
         }
     }
+    // (inside a catch block) keeps the first exception of the round and stops the hand-out of indices
+    void note_failure(size_t n) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!failure_) failure_ = std::current_exception();
+        next_.store(n);
+    }
     std::vector<std::thread> pool_;
     std::mutex m_;
     std::condition_variable cv_, done_;
+    std::exception_ptr failure_;
     const std::function<void(size_t)>* f_ = nullptr;
     size_t n_ = 0;
     std::atomic<size_t> next_{0};
@@ -556,6 +581,17 @@ public:
     // arena in use; `changed` = byte ranges (relative to the arena, like vx_commit's) rewritten since the last call.
     // Returns false when the world cannot be imaged (malformed or image beyond 4 GiB): the caller then traverses the world's bytes.
     bool update(const uint8_t* world, uint64_t used, const Range* changed, size_t n_changed, unsigned threads) {
+        // Nothing is thrown across the C ABI: running out of host memory in the middle of a build (a walker's tree, the frame's growth; on a
+        // worker thread: rethrown by Workers::run on this one) leaves no image, like any other failure, and the context renders from the world's bytes.
+        try {
+            return update_or_throw(world, used, changed, n_changed, threads);
+        } catch (const std::exception&) {
+            return fail();
+        }
+    }
+
+private:
+    bool update_or_throw(const uint8_t* world, uint64_t used, const Range* changed, size_t n_changed, unsigned threads) {
         dirty_.clear();
         too_big_ = false;
         auto now = [] { return std::chrono::steady_clock::now(); };

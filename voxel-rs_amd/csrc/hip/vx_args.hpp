@@ -8,7 +8,7 @@
 
 #include "voxel_hip.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VX_HOST_DEVICE __host__ __device__
 #else
 #define VX_HOST_DEVICE

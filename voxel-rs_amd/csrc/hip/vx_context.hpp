@@ -169,6 +169,11 @@ struct vx_context {
     unsigned present_next = 0;
     hipStream_t copy_stream = nullptr;
 
+    // vx_clock_probe: its stream and its two words of pinned host memory the kernel writes to
+    hipStream_t probe_stream = nullptr;
+    unsigned long long* h_probe = nullptr;
+    std::mutex probe_mutex;  // one probe at a time
+
     bool profile = false;
     std::vector<vxrt::ProfiledLaunch> launches;
     std::vector<vxrt::ProfiledLaunch> event_pool;

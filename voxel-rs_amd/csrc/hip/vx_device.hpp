@@ -480,7 +480,7 @@ __device__ __forceinline__ void texture_lod_pair(const DevTextures& t, const Tex
     auto blend = [&](const uint32_t r[8], float rgba[4]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float lv[2];
+            float level[2];
 #pragma unroll
             for (int l = 0; l < 2; ++l) {
                 const float ax = l ? t2.ax : t1.ax, ay = l ? t2.ay : t1.ay;
@@ -488,9 +488,9 @@ __device__ __forceinline__ void texture_lod_pair(const DevTextures& t, const Tex
                 const float c01 = float((r[4 * l + 2] >> (8 * k)) & 0xffu), c11 = float((r[4 * l + 3] >> (8 * k)) & 0xffu);
                 const float lo = c00 * (1.0f - ax) + c10 * ax;
                 const float hi = c01 * (1.0f - ax) + c11 * ax;
-                lv[l] = lo * (1.0f - ay) + hi * ay;
+                level[l] = lo * (1.0f - ay) + hi * ay;
             }
-            rgba[k] = (lv[0] * (1.0f - frac) + lv[1] * frac) * (1.0f / 255.0f);
+            rgba[k] = (level[0] * (1.0f - frac) + level[1] * frac) * (1.0f / 255.0f);
         }
     };
     if (want_a) blend(ra, a_rgba);

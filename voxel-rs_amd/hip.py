@@ -107,6 +107,7 @@ SYMBOLS = {
     "vx_timeline_read": (_u32, [_vp, _vp, _u32]),
     "vx_gather_query": (_int, [_vp, _int]),
     "vx_comm_profile_read": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32)]),
+    "vx_clock_probe": (_int, [_vp, _u32, C.POINTER(C.c_double)]),
     "vx_profile_enable": (_int, [_vp, _int]),
     "vx_profile_read": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32)]),
     "vx_stream": (_vp, [_vp]),
@@ -382,6 +383,12 @@ class Svo:
         out = (_u64 * 4)()
         _check(lib().vx_excursion_counters(self._h, C.byref(out), 2 if stop else int(reset)))
         return {"rays": int(out[0]), "started_over": int(out[1]), "service_phases": int(out[2]), "iterations_on_bytes": int(out[3])}
+
+    def clock_probe(self, microseconds=200):
+        """The shader clock (MHz) the device runs at during the call (vx_clock_probe); callable from a second thread while frames render."""
+        mhz = C.c_double(0)
+        _check(lib().vx_clock_probe(self._h, microseconds, C.byref(mhz)))
+        return mhz.value
 
     def profile_enable(self, on=True):
         _check(lib().vx_profile_enable(self._h, int(on)))
