@@ -255,13 +255,24 @@ class Sharded:
             if library_gather:
                 if args.simulate_gather_failure:
                     raise RuntimeError("simulated failure of the library's gather (--simulate-gather-failure)")
+                if args.simulate_absent_peer and rank != 0:
+                    return  # (this rank never joins the exchange: rank 0's receive waits, and its watchdog has to notice)
                 state["last_ticket"] = tickets[g] = svo.gather_tiles(tiles.data_ptr(), tiles.numel() * tiles.element_size(),
                                                                     gathered.data_ptr() if rank == 0 else None, root=0)
             else:
                 if self.profile_on:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
-                dist.gather(tiles, [gathered[r] for r in range(world_size)] if rank == 0 else None, dst=0)
+                if args.dist_backend == "gloo":
+                    # (the tests' control plane, several ranks on one GPU: gloo moves host memory)
+                    host_tiles = tiles.cpu()
+                    parts = [torch.empty_like(host_tiles) for _ in range(world_size)] if rank == 0 else None
+                    dist.gather(host_tiles, parts, dst=0)
+                    if rank == 0:
+                        for r in range(world_size):
+                            gathered[r].copy_(parts[r])
+                else:
+                    dist.gather(tiles, [gathered[r] for r in range(world_size)] if rank == 0 else None, dst=0)
                 if self.profile_on:
                     ev[1].record()
                     self.gather_events.append(ev)
@@ -326,7 +337,7 @@ class Sharded:
         except Exception as e:  # an error code from the library (VX_ERR_HIP with RCCL's message), or the simulated one
             print(f"[bench rank {self.rank}] exchange failed: {e}", file=sys.stderr)
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.args.ctl_device)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
         return bool(int(flag.item()))
 
@@ -344,7 +355,7 @@ class Sharded:
             except Exception as e:
                 print(f"[bench rank {self.rank}] vx_comm_init failed: {e}", file=sys.stderr)
                 init_ok = 0
-            flag = torch.tensor([init_ok], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([init_ok], dtype=torch.int32, device=args.ctl_device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) and self._first_frames_ok(args.gather_timeout):
                 self.gather_used = "library"
@@ -402,7 +413,8 @@ def cpu_baseline(args, wl, orc):
     granted = granted_cpus()
     omp_threads = orc.lib().or_max_threads()
     every = omp_threads
-    points = sorted({t for t in (1, 8, 32, every) if t <= every})
+    quota = int(granted["cgroup_cpu_max"]) if granted.get("cgroup_cpu_max") else 0  # (a thread per granted CPU, where a quota says how many those are)
+    points = sorted({t for t in (1, 8, quota, 32, every) if 1 <= t <= every})
     scene.render(ou, W, H, rect=(0, H // 2, W, H // 2 + 32), want_hits=False, counters=orc.Counters(), threads=every)  # (thread pool, page cache)
     sweep = []
     for t in points:
@@ -591,6 +603,10 @@ def parse_args():
                     help="sharded: pixel format of the tile lists that travel and of rank 0's image (rgba8 = Framebuffer::as_image's bytes: a quarter of the link time)")
     ap.add_argument("--gather-timeout", type=float, default=30.0, help="sharded: seconds the first exchange may take before it is declared hung")
     ap.add_argument("--simulate-gather-failure", action="store_true", help="testing: make the library's exchange fail, to exercise the fall-back")
+    ap.add_argument("--simulate-absent-peer", action="store_true", help="testing: the ranks other than 0 never join the library's exchange (the watchdog must end the wait)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed's backend for this script's barriers and statistics (gloo: the tests, where several ranks share one GPU and RCCL proper cannot run)")
+    ap.add_argument("--comm-library", default="", help="the RCCL build the render context opens (vx_comm_library); the tests name their stand-in (tests/stub_rccl)")
     ap.add_argument("--sustained-seconds", type=float, default=3.0,
                     help="after the median-of-blocks headline: one block of at least this many seconds of the same path (0 = none); it becomes `value` if more than 2 %% below the burst median")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (C2, C4 static / streamed, C5 on this GPU: about 40 s, most of it the depth-14 terrain's build)")
@@ -638,7 +654,13 @@ def main():
                 probe.bind(("127.0.0.1", 0))
                 port = probe.getsockname()[1]
             os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+    args.ctl_device = "cuda" if args.dist_backend == "nccl" else "cpu"
+    if args.comm_library:
+        hip.comm_library(args.comm_library)
 
     W, H = args.width, args.height
     wl = Workload(args, vra, hip, scenes, rank, world_size, local_rank)
@@ -703,7 +725,7 @@ def main():
         ts = torch.cuda.current_stream()
         MARK = 100
         # (how many frames: fixed before the block from the burst rate, the same number on every rank -- a sharded frame is a collective)
-        burst = torch.tensor([sorted(blocks)[len(blocks) // 2] / args.steps], dtype=torch.float64, device="cuda")
+        burst = torch.tensor([sorted(blocks)[len(blocks) // 2] / args.steps], dtype=torch.float64, device=args.ctl_device)
         if dist is not None:
             dist.all_reduce(burst, op=dist.ReduceOp.MAX)
         frames_target = max(MARK, int(math.ceil(args.sustained_seconds * 1.02 / max(float(burst[0]), 1e-6) / MARK)) * MARK)
@@ -733,7 +755,7 @@ def main():
         stop.set()
         sampler.join(timeout=5.0)
         if dist is not None:  # (the slowest rank's time stands)
-            slowest = torch.tensor([total_s], dtype=torch.float64, device="cuda")
+            slowest = torch.tensor([total_s], dtype=torch.float64, device=args.ctl_device)
             dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
             total_s = float(slowest[0])
 
@@ -810,10 +832,10 @@ def main():
             torch.cuda.synchronize()
             forced = forced_sharded_child(args)
 
-    times = torch.tensor(blocks, dtype=torch.float64, device="cuda")
+    times = torch.tensor(blocks, dtype=torch.float64, device=args.ctl_device)
     stats = torch.tensor([float(wl.rays_per_block), float(wl.bytes_per_frame), kernel_ms / max(launches, 1), kernel_exclusive_ms, gather_ms / max(gathers, 1),
                           float(wl.iterations_per_block)],
-                         dtype=torch.float64, device="cuda")
+                         dtype=torch.float64, device=args.ctl_device)
     per_rank = None
     if dist is not None:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)  # per block: the slowest rank

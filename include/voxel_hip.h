@@ -275,6 +275,10 @@ int vx_present_wait(vx_context* ctx, int slot, const void** pixels, size_t* byte
  * of the Morton order. Returns the number of tiles; fills `out` when capacity suffices. Pure host function. */
 uint32_t vx_tile_order(uint32_t width, uint32_t height, uint32_t* out, uint32_t capacity);
 
+/* Which RCCL to open: by default the library is opened by its soname (librccl.so.1: the copy the process already has loaded, if any) when the
+ * first communicator is asked for. A deployment that ships its own build -- and the tests, whose stand-in lets several ranks share one GPU
+ * (tests/stub_rccl) -- names the file here, before the first vx_comm_* call. Process-wide. No counterpart in the reference (one GL context). */
+int vx_comm_library(const char* path);
 /* The handle owns the RCCL communicator the finished tiles travel over (SURVEY.md 8b "Ownership"; one process per GPU):
  *   vx_comm_unique_id   on ONE rank: a fresh 128-byte id (ncclGetUniqueId), which the caller hands to every rank by its own means
  *   vx_comm_init        on every rank, collectively: ncclCommInitRank on this context's device

@@ -24,13 +24,19 @@ struct Rccl {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 Rccl g_rccl;
+std::string g_rccl_path;  // vx_comm_library: the library to open instead of librccl.so.1
 
 // RCCL is opened when the first communicator is asked for. By its soname: a process that already has one loaded (PyTorch brings
 // its own copy) shares that one.
 int rccl_open() {
     if (g_rccl.lib) return VX_OK;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    void* h = nullptr;
+    if (!g_rccl_path.empty()) {
+        h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);  // (a path: another build than the process may already have loaded by soname)
+    } else {
+        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    }
     if (!h) return fail(VX_ERR_STATE, std::string("RCCL is not available: ") + dlerror());
 #define VX_SYM(name)                                                                                  \
     g_rccl.name = reinterpret_cast<decltype(g_rccl.name)>(dlsym(h, "nccl" #name));                     \
@@ -58,6 +64,13 @@ void comm_release(vx_context* c) {
 extern "C" {
 
 // ---- multi-GPU: the gather of the finished tiles over RCCL ---------------------------------------------------------------------
+
+int vx_comm_library(const char* path) {
+    if (!path || !*path) return fail(VX_ERR_INVALID_ARGUMENT, "comm_library: empty path");
+    if (g_rccl.lib) return fail(VX_ERR_STATE, "comm_library: RCCL is already open (call this before the first vx_comm_* call)");
+    g_rccl_path = path;
+    return VX_OK;
+}
 
 int vx_comm_unique_id(void* out_id, size_t bytes) {
     if (!out_id || bytes < sizeof(ncclUniqueId)) return fail(VX_ERR_INVALID_ARGUMENT, "comm_unique_id: needs VX_COMM_ID_BYTES (128) bytes");

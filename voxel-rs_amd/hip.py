@@ -93,6 +93,7 @@ SYMBOLS = {
     "vx_tile_order": (_u32, [_u32, _u32, _vp, _u32]),
     "vx_present_begin": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, _int, C.POINTER(_int)]),
     "vx_present_wait": (_int, [_vp, _int, C.POINTER(_vp), C.POINTER(_sz)]),
+    "vx_comm_library": (_int, [C.c_char_p]),
     "vx_comm_unique_id": (_int, [_vp, _sz]),
     "vx_comm_init": (_int, [_vp, _int, _int, _vp]),
     "vx_comm_destroy": (_int, [_vp]),
@@ -164,6 +165,11 @@ def tile_order(width, height):
     out = np.zeros(n, dtype=np.uint32)
     lib().vx_tile_order(width, height, out.ctypes.data_as(_vp), n)
     return out
+
+
+def comm_library(path):
+    """The RCCL build to open instead of librccl.so.1 (vx_comm_library); before the first communicator."""
+    _check(lib().vx_comm_library(str(path).encode()))
 
 
 def comm_unique_id():
