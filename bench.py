@@ -582,7 +582,7 @@ def picker_latency(wl, hip, np):
     return out
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -619,7 +619,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall-clock target for the cpu_baseline sample on all threads (the sweep's other points: 3 s each)")
     ap.add_argument("--textures", choices=["assets", "procedural"], default="assets",
                     help="assets: the reference's own 64x64 textures (tests/golden/textures) for the blocks the terrain uses")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def main():
