@@ -61,7 +61,7 @@ def test_ranks_sharing_one_gpu_gather_the_whole_frame(tmp_path, world, fmt, gath
         assert rc == 0, f"rank {r} failed:\n{err[-3000:]}"
     d = json.loads(out.read_text())
     assert d["identical"] and d["world"] == world and d["checked"] == -(-30 // group), d
-    assert d["frames_in_flight"] >= 3
+    assert d["frames_in_flight"] >= 2  # (max(3, N), rounded down to whole groups)
 
 
 def bench_ranks(world, extra):
