@@ -136,7 +136,7 @@ __device__ __forceinline__ uint32_t subtile_of(const RenderParams& p, uint32_t o
         in_x = x & 31u;
         in_y = y & 31u;
     }
-    local_tile = tile_number(p, local_tile);  // ... and its number in the queue
+    local_tile = p.number_of_place[local_tile];  // ... and its number in the queue
     const uint32_t sx = in_x >> 3, sy = in_y >> 3;  // 4x4 sub-tiles in Morton order (see the refill)
     return local_tile * 16u + ((sx & 1u) | ((sy & 1u) << 1) | ((sx & 2u) << 1) | ((sy & 2u) << 2));
 }
@@ -624,9 +624,9 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                     // sub-tile -> pixel: 32x32 tile (sharding unit), 4x4 sub-tiles in Morton order, 8x8 pixels in Morton order
                     // (the queue's tile number -> the tile's place in the launch's list: RenderParams::tile_numbering)
                     const uint32_t number = sub >> 4, s = sub & 15u;
-                    const uint32_t local_tile = tile_place(p, number);
-                    const uint32_t tile = p.tile_count > 1 ? p.tile_order[local_tile * p.tile_count + p.tile_rank] : local_tile;
-                    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+                    const uint2 entry = p.tile_table[number];  // (wave-uniform: one scalar load)
+                    const uint32_t local_tile = entry.y;
+                    const uint32_t tx = entry.x & 0xffffu, ty = entry.x >> 16;
                     const uint32_t sx = (s & 1u) | ((s >> 1) & 2u), sy = ((s >> 1) & 1u) | ((s >> 2) & 2u);
                     uint32_t lx, ly;
                     lane_to_xy(k, lx, ly);

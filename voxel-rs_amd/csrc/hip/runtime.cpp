@@ -115,6 +115,36 @@ int tile_table(vx_context* ctx, uint32_t tiles_x, uint32_t tiles_y, const vx_con
     return VX_OK;
 }
 
+// RenderParams::tile_table / number_of_place for this launch shape: made once with tile_place / tile_number (vx_args.hpp) and kept
+int launch_table(vx_context* ctx, RenderParams& p) {
+    for (const auto& t : ctx->launch_tables)
+        if (t.tiles_x == p.tiles_x && t.tiles_y == p.tiles_y && t.rank == p.tile_rank && t.count == p.tile_count && t.numbering == p.tile_numbering && t.strip == p.strip_w) {
+            p.tile_table = t.d_table;
+            p.number_of_place = t.d_number;
+            return VX_OK;
+        }
+    std::vector<uint32_t> order, inverse;
+    if (p.tile_count > 1) tile_order_host(p.tiles_x, p.tiles_y, order, inverse);
+    std::vector<uint2> table(p.n_local_tiles);
+    std::vector<uint32_t> number(p.n_local_tiles);
+    for (uint32_t i = 0; i < p.n_local_tiles; ++i) {
+        const uint32_t place = tile_place(p, i);
+        const uint32_t tile = p.tile_count > 1 ? order[size_t(place) * p.tile_count + p.tile_rank] : place;
+        table[i] = make_uint2((tile % p.tiles_x) | ((tile / p.tiles_x) << 16), place);
+        number[place] = i;
+    }
+    vx_context::LaunchTable t;
+    t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y; t.rank = p.tile_rank; t.count = p.tile_count; t.numbering = p.tile_numbering; t.strip = p.strip_w;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d_table), table.size() * sizeof(uint2)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d_number), number.size() * 4));
+    HIP_TRY(hipMemcpy(t.d_table, table.data(), table.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_number, number.data(), number.size() * 4, hipMemcpyHostToDevice));
+    ctx->launch_tables.push_back(t);
+    p.tile_table = t.d_table;
+    p.number_of_place = t.d_number;
+    return VX_OK;
+}
+
 int ensure(void** p, size_t* have, size_t need) {
     if (*have >= need && *p) return VX_OK;
     if (*p) (void)hipFree(*p);
@@ -375,6 +405,12 @@ int fill_params(vx_context* ctx, const vx_uniforms* u, uint32_t w, uint32_t h, u
         const vx_context::TileTable* t = nullptr;
         if (int rc = tile_table(ctx, p.tiles_x, p.tiles_y, &t)) return rc;
         p.tile_order = t->d_order;
+    }
+    p.tile_table = nullptr;
+    p.number_of_place = nullptr;
+    if (p.n_local_tiles) {
+        if (p.tiles_x > 0xffffu || p.tiles_y > 0xffffu) return fail(VX_ERR_INVALID_ARGUMENT, "image too large (tile coordinates are 16 bits)");
+        if (int rc = launch_table(ctx, p)) return rc;
     }
     return VX_OK;
 }
@@ -641,6 +677,10 @@ void vx_destroy(vx_context* c) {
         if (c->d_frame_todo[i]) (void)hipFree(c->d_frame_todo[i]);
         if (c->frame_done[i]) (void)hipEventDestroy(c->frame_done[i]);
         if (c->frame_stream[i]) (void)hipStreamDestroy(c->frame_stream[i]);
+    }
+    for (auto& t : c->launch_tables) {
+        if (t.d_table) (void)hipFree(t.d_table);
+        if (t.d_number) (void)hipFree(t.d_number);
     }
     vxrt::comm_release(c);
     for (auto& hs : c->hot) {

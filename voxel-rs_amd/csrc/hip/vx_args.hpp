@@ -58,6 +58,12 @@ struct RenderParams {
     // (profiles/round4/pass_r: C3 0.261 -> 0.239 ms with frames in flight, 0.367 -> 0.348 one at a time, for either of 1 and 2).
     uint32_t tile_numbering, tile_stride, tile_stride_inv, strip_w;
     uint32_t tile_rank, tile_count, n_local_tiles;
+    // ... as two tables the HOST makes once per (image size, rank, numbering) with tile_place / tile_number below (device memory, n_local_tiles entries
+    // each): the kernel's refill reads one entry per sub-tile instead of working the place, the Morton look-up and two divisions by tiles_x out
+    // (a quarter of a refill's instructions, profiles/round5). tile_table[number] = {tile x | tile y << 16, place in the launch's list};
+    // number_of_place[place] = the tile's queue number (the cost notes).
+    const uint2* tile_table;
+    const uint32_t* number_of_place;
     // screen sharding (tile_count > 1): the image's 32x32 tiles in Morton order of their (x, y) -- this context renders the tiles
     // tile_order[k * tile_count + tile_rank], k = 0 .. n_local_tiles - 1 (device memory; null when the whole image is rendered)
     const uint32_t* tile_order;

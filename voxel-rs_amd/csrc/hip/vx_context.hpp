@@ -149,6 +149,9 @@ struct vx_context {
     // screen sharding: the Morton order of an image's tiles and its inverse, on the device, per image size seen
     struct TileTable { uint32_t tiles_x = 0, tiles_y = 0; uint32_t* d_order = nullptr; uint32_t* d_inverse = nullptr; };
     std::vector<TileTable> tile_tables;
+    // ... and what a launch's queue numbers mean on the screen (RenderParams::tile_table / number_of_place), per (image size, rank, numbering) seen
+    struct LaunchTable { uint32_t tiles_x = 0, tiles_y = 0, rank = 0, count = 0, numbering = 0, strip = 0; uint2* d_table = nullptr; uint32_t* d_number = nullptr; };
+    std::vector<LaunchTable> launch_tables;
 
     // multi-GPU: the RCCL communicator over which the finished tiles are gathered (vx_comm_init), its stream and the events that
     // say when a gather has read its tile list
