@@ -16,6 +16,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstring>
 #include <optional>
 #include <unordered_map>
 #include <unordered_set>
@@ -214,8 +215,9 @@ public:
             }
         }
 
-        const std::vector<uint8_t> root = serialize_root(*octree.root, octree.depth());
-        const size_t off = buffer.insert(UINT64_MAX, root.data(), root.size());
+        root_.clear();
+        serialize_root(*octree.root, octree.depth(), root_);
+        const size_t off = buffer.insert(UINT64_MAX, root_.data(), root_.size());
         root_info = LeafInfo{off};
     }
 
@@ -265,10 +267,18 @@ private:
         for (int b = 0; b < 4; ++b) dst[b] = uint8_t(p >> (8 * b));
     }
 
-    // csvo.rs:68-139
-    std::vector<uint8_t> serialize_root(OctantId octant_id, uint8_t depth) const {
+    // csvo.rs:68-139: the root octree as internal nodes, appended to `out` -- the node's header, its offset table (1/2/4-byte offsets by magnitude,
+    // relative to the table's end: detail::csvo_pack_internal's layout), its children back to back; the lowest level holds 4-byte absolute
+    // arena offsets with bit 31 set. Every commit rewrites the root (csvo.rs:237-249), and a vector per node and per child was a third of a
+    // streaming step's host time: the children are emitted straight behind a placeholder for the largest possible table and moved up once
+    // the table's size is known -- no allocation per node.
+    void serialize_root(OctantId octant_id, uint8_t depth, std::vector<uint8_t>& out) const {
         const Octant<CsvoSerializedChunk>& octant = octree.octants[octant_id];
-        std::vector<std::pair<uint32_t, std::vector<uint8_t>>> children;
+        constexpr size_t kMaxTable = 8 * 4;
+        const size_t start = out.size();
+        out.resize(start + 2 + kMaxTable);
+        size_t child_at[8];
+        uint32_t child_idx[8], n = 0;
         for (uint32_t idx = 0; idx < 8; ++idx) {
             const Child<CsvoSerializedChunk>& child = octant.children[idx];
             if (child.is_none()) continue;
@@ -277,32 +287,45 @@ private:
                     auto it = leaf_info.find(content->pos_hash);
                     if (it != leaf_info.end()) {
                         const uint32_t pointer = uint32_t(it->second.buf_offset) | (1u << 31);
-                        std::vector<uint8_t> bytes(4);
-                        for (int b = 0; b < 4; ++b) bytes[b] = uint8_t(pointer >> (8 * b));
-                        children.emplace_back(idx, std::move(bytes));
+                        child_at[n] = out.size();
+                        child_idx[n++] = idx;
+                        for (int b = 0; b < 4; ++b) out.push_back(uint8_t(pointer >> (8 * b)));
                     }
                 }
                 continue;
             }
             if (!child.is_octant()) continue;  // reference asserts uniform leaf level (csvo.rs:87)
-            children.emplace_back(idx, serialize_root(child.octant, uint8_t(depth - 1)));
+            child_at[n] = out.size();
+            child_idx[n++] = idx;
+            serialize_root(child.octant, uint8_t(depth - 1), out);
         }
-
-        std::vector<uint8_t> out;
+        const size_t body = start + 2 + kMaxTable;  // where the children's bytes begin for now
+        uint16_t header = 0;
+        size_t table = 0;
+        uint8_t entries[kMaxTable];
         if (depth == 1) {
-            uint16_t header = 0;
-            out.assign(2, 0);
-            for (const auto& c : children) {
-                header |= uint16_t(3u << (c.first * 2));
-                out.insert(out.end(), c.second.begin(), c.second.end());
-            }
-            out[0] = uint8_t(header & 0xff);
-            out[1] = uint8_t(header >> 8);
+            // (the entries ARE the pointers: tag 3 per present child, nothing behind the table)
+            for (uint32_t i = 0; i < n; ++i) header |= uint16_t(3u << (child_idx[i] * 2));
         } else {
-            detail::csvo_pack_internal(children, out);
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t offset = uint32_t(child_at[i] - body);
+                uint32_t v = offset > 1 ? offset : 1, bits = 0;
+                while (v >>= 1) ++bits;
+                const uint32_t tag = bits / 8 + 1;  // (an offset of 2^24 and more cannot occur: a root octree is kilobytes)
+                header |= uint16_t((tag > 3 ? 3u : tag) << (child_idx[i] * 2));
+                const uint32_t nbytes = tag >= 3 ? 4 : tag;
+                for (uint32_t b = 0; b < nbytes; ++b) entries[table++] = uint8_t(offset >> (8 * b));
+            }
         }
-        return out;
+        out[start] = uint8_t(header & 0xff);
+        out[start + 1] = uint8_t(header >> 8);
+        std::memcpy(out.data() + start + 2, entries, table);
+        const size_t body_bytes = out.size() - body;
+        std::memmove(out.data() + start + 2 + table, out.data() + body, body_bytes);
+        out.resize(start + 2 + table + body_bytes);
     }
+
+    std::vector<uint8_t> root_;  // serialize()'s scratch: the root octree's bytes
 };
 
 }  // namespace vx

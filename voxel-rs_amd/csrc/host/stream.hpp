@@ -31,19 +31,45 @@
 namespace vx {
 namespace systems {
 
-// One chunk of the heightfield scene at world chunk position `pos` (surface shell only, ids as scene.hpp); nullopt when the
-// chunk holds no voxel or lies outside the [0, 2^depth) domain.
-inline std::optional<Chunk> generate_heightfield_chunk(uint32_t depth, uint32_t seed, ChunkPos pos, uint8_t lod) {
-    const int64_t n = int64_t(1) << depth;
-    if (pos.x < 0 || pos.y < 0 || pos.z < 0 || int64_t(pos.x) * 32 >= n || int64_t(pos.y) * 32 >= n || int64_t(pos.z) * 32 >= n) return std::nullopt;
+// The terrain's heights under one (x, z) column of chunks and around it (34 x 34: the shell of a voxel looks at its four neighbours), shared by the
+// chunks of every layer of the column, and the span of layers that hold any voxel at all.
+struct ColumnHeights {
     uint32_t h[34 * 34];
+    uint32_t lowest = 0, highest = 0;  // world y of the lowest and the highest voxel of the column's shell
+};
+inline void heightfield_column(uint32_t depth, uint32_t seed, int32_t cx, int32_t cz, ColumnHeights& out) {
+    const int64_t n = int64_t(1) << depth;
     for (int dz = -1; dz <= 32; ++dz)
         for (int dx = -1; dx <= 32; ++dx) {
-            const int64_t wx = std::clamp<int64_t>(int64_t(pos.x) * 32 + dx, 0, n - 1), wz = std::clamp<int64_t>(int64_t(pos.z) * 32 + dz, 0, n - 1);
-            h[(dz + 1) * 34 + (dx + 1)] = heightfield_height(depth, seed, uint32_t(wx), uint32_t(wz));
+            const int64_t wx = std::clamp<int64_t>(int64_t(cx) * 32 + dx, 0, n - 1), wz = std::clamp<int64_t>(int64_t(cz) * 32 + dz, 0, n - 1);
+            out.h[(dz + 1) * 34 + (dx + 1)] = heightfield_height(depth, seed, uint32_t(wx), uint32_t(wz));
         }
-    Chunk chunk(pos, lod);
+    out.lowest = UINT32_MAX;
+    out.highest = 0;
+    for (uint32_t z = 0; z < 32; ++z)
+        for (uint32_t x = 0; x < 32; ++x) {
+            const uint32_t* h = out.h;
+            const uint32_t c = h[(z + 1) * 34 + (x + 1)];
+            const uint32_t m = std::min(std::min(h[(z + 1) * 34 + x], h[(z + 1) * 34 + x + 2]), std::min(h[z * 34 + x + 1], h[(z + 2) * 34 + x + 1]));
+            out.lowest = std::min(out.lowest, std::min(c, m + 1));
+            out.highest = std::max(out.highest, c);
+        }
+}
+
+// One chunk of the heightfield scene at world chunk position `pos` (surface shell only, ids as scene.hpp); nullopt when the
+// chunk holds no voxel or lies outside the [0, 2^depth) domain. `column` (optional): the heights of the chunk's column, made once for all its layers.
+inline std::optional<Chunk> generate_heightfield_chunk(uint32_t depth, uint32_t seed, ChunkPos pos, uint8_t lod, const ColumnHeights* column = nullptr) {
+    const int64_t n = int64_t(1) << depth;
+    if (pos.x < 0 || pos.y < 0 || pos.z < 0 || int64_t(pos.x) * 32 >= n || int64_t(pos.y) * 32 >= n || int64_t(pos.z) * 32 >= n) return std::nullopt;
+    ColumnHeights own;
+    if (!column) {
+        heightfield_column(depth, seed, pos.x, pos.z, own);
+        column = &own;
+    }
+    const uint32_t* h = column->h;
     const uint32_t y0 = uint32_t(pos.y) * 32;
+    if (column->highest < y0 || column->lowest > y0 + 31) return std::nullopt;  // (most chunks of a column: air above, rock below)
+    Chunk chunk(pos, lod);
     uint64_t count = 0;
     for (uint32_t z = 0; z < 32; ++z)
         for (uint32_t x = 0; x < 32; ++x) {
@@ -97,6 +123,9 @@ public:
     // returns the number of events the move produced
     // camera (optional): the view the events of this move are ordered by; its position is (x, y, z)
     size_t move_to(float x, float y, float z, const graphics::Camera* camera = nullptr) {
+        using clock = std::chrono::steady_clock;
+        auto ms_since = [](clock::time_point t0) { return std::chrono::duration<double, std::milli>(clock::now() - t0).count(); };
+        clock::time_point t0 = clock::now();
         const ChunkPos centre = ChunkPos::from_block_pos(int32_t(std::floor(x)), int32_t(std::floor(y)), int32_t(std::floor(z)));
         if (!(centre == cs_.center) || !has_centre_) {
             cs_.center = centre;
@@ -104,26 +133,35 @@ public:
             shift_chunks(cs_, leaf_ids_, world_);  // worldsvo.rs:161-196
             dirty_ = true;
         }
+        last_move_ms[0] = ms_since(t0);
+        t0 = clock::now();
         std::vector<ChunkEvent> events = loader_.update(x, y, z);
         // what the player looks at first, the rest from front to back (src/gamelogic/world.rs:132-137)
         if (camera) events = sort_chunks_by_view_frustum(events, *camera);
+        last_move_ms[1] = ms_since(t0);
+        t0 = clock::now();
         // Every event gets a slot in the queue; chunks are generated and serialized in the background from now on (the reference
         // hands them to its job system as soon as they are known, worldsvo.rs:90-99) and applied, in event order, by pump().
         {
+            // (a deque's elements stay where they are while others are pushed behind and popped in front of them: the workers hold plain pointers;
+            // a re-centre at radius 40 queues 25 K events, and an allocation per event was a millisecond of the frame loop's step)
             std::lock_guard<std::mutex> lock(m_);
             for (const ChunkEvent& e : events) {
-                auto slot = std::make_shared<Slot>();
-                slot->event = e;
-                if (e.kind == ChunkEvent::Unload) slot->ready = true;  // nothing to build
-                else jobs_.push_back(slot);
-                queue_.push_back(std::move(slot));
+                queue_.emplace_back();
+                Slot& slot = queue_.back();
+                slot.event = e;
+                if (e.kind == ChunkEvent::Unload) slot.ready = true;  // nothing to build
+                else jobs_.push_back(&slot);
             }
         }
         if (pool_.empty() && !events.empty())
             for (uint32_t t = 0; t < threads_; ++t) pool_.emplace_back([this]() { build_loop(); });
         cv_jobs_.notify_all();
+        last_move_ms[2] = ms_since(t0);
         return events.size();
     }
+    // what the last move_to spent, in ms: shifting the resident chunks (a new centre chunk only), the chunk loader's events, queueing them
+    double last_move_ms[3] = {0, 0, 0};
 
     // wait = true: the next max_events events are applied, whether their chunks are built yet or not (the call waits for them: what
     // the tests want, the same events per call whatever the machine). wait = false: only events whose chunks are ready are applied,
@@ -139,7 +177,7 @@ public:
         {
             std::unique_lock<std::mutex> lock(m_);
             while (!queue_.empty() && batch.size() < max_events) {
-                Slot& slot = *queue_.front();
+                Slot& slot = queue_.front();
                 if (!slot.ready) {
                     if (!wait) break;
                     cv_done_.wait(lock, [&]() { return slot.ready; });
@@ -224,18 +262,19 @@ private:
 
     void build_loop() {
         for (;;) {
-            std::shared_ptr<Slot> slot;
+            Slot* slot = nullptr;  // (pump() pops a slot only once it is ready, i.e. after this thread's last touch of it)
             {
                 std::unique_lock<std::mutex> lock(m_);
                 // not too far ahead of pump(): finished chunks wait in memory until they are applied
                 cv_jobs_.wait(lock, [&]() { return stop_ || (!jobs_.empty() && built_ahead_ < kMaxBuiltAhead); });
                 if (stop_) return;
-                slot = std::move(jobs_.front());
+                slot = jobs_.front();
                 jobs_.pop_front();
                 ++built_ahead_;
             }
             std::optional<SerializedT> built;
-            std::optional<Chunk> chunk = generate_heightfield_chunk(scene_depth_, seed_, slot->event.pos, slot->event.lod);
+            std::shared_ptr<const ColumnHeights> column = column_heights(slot->event.pos.x, slot->event.pos.z);
+            std::optional<Chunk> chunk = generate_heightfield_chunk(scene_depth_, seed_, slot->event.pos, slot->event.lod, column.get());
             if (chunk) built.emplace(*chunk);
             {
                 std::lock_guard<std::mutex> lock(m_);
@@ -244,6 +283,22 @@ private:
             }
             cv_done_.notify_all();
         }
+    }
+
+    // The heights of a column of chunks, evaluated once for its (up to 81) layers: a re-centre's events are mostly layers of the same few hundred
+    // columns, nine in ten of them air. Kept for the most recently used columns.
+    std::shared_ptr<const ColumnHeights> column_heights(int32_t cx, int32_t cz) {
+        const uint64_t key = (uint64_t(uint32_t(cx)) << 32) | uint32_t(cz);
+        {
+            std::lock_guard<std::mutex> lock(columns_m_);
+            auto it = columns_.find(key);
+            if (it != columns_.end()) return it->second;
+        }
+        auto made = std::make_shared<ColumnHeights>();
+        heightfield_column(scene_depth_, seed_, cx, cz, *made);  // (outside the lock; two workers may make the same column once in a while)
+        std::lock_guard<std::mutex> lock(columns_m_);
+        if (columns_.size() >= kMaxColumns) columns_.clear();  // (crude: the window moves on, what was made for the old one goes)
+        return columns_.emplace(key, std::move(made)).first->second;
     }
 
     void remove(ChunkPos pos) {
@@ -261,10 +316,14 @@ private:
     WorldT world_;
     std::unordered_map<ChunkPos, LeafId, ChunkPosHash> leaf_ids_;
     // events in arrival order; jobs_ = those of them no worker has taken yet
-    std::deque<std::shared_ptr<Slot>> queue_, jobs_;
+    std::deque<Slot> queue_;
+    std::deque<Slot*> jobs_;
     static constexpr size_t kMaxBuiltAhead = 16384;
     size_t built_ahead_ = 0;  // chunks taken by workers and not applied yet
     std::mutex m_;
+    std::mutex columns_m_;
+    std::unordered_map<uint64_t, std::shared_ptr<const ColumnHeights>> columns_;
+    static constexpr size_t kMaxColumns = 16384;
     std::condition_variable cv_jobs_, cv_done_;
     std::vector<std::thread> pool_;
     bool stop_ = false;
