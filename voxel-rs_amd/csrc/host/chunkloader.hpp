@@ -78,6 +78,8 @@ public:
                 const ChunkPos base{current.x + dx, 0, current.z + dz};
                 const uint8_t lod = calculate_lod(current, base);
                 Column& col = column_at(base.x, base.z);
+                // (what the last scan left in this column -- these layers, at this LOD, nothing else -- is what this one would: most columns, most times)
+                if (col.settled && col.settled_lod == lod && col.settled_lo == y_lo && col.settled_hi == y_hi) continue;
                 for (int32_t y = y_lo; y <= y_hi; ++y) {
                     uint8_t& at = col.lod[size_t(y - start_y_)];
                     if (at == lod) continue;
@@ -85,6 +87,9 @@ public:
                     if (!at) { ++col.loaded; ++loaded_count_; }
                     at = lod;
                 }
+                // settled if nothing of the column is loaded outside the window (the unload pass below removes such layers; it re-marks then)
+                col.settled = col.loaded == uint32_t(y_hi - y_lo + 1);
+                col.settled_lod = lod; col.settled_lo = y_lo; col.settled_hi = y_hi;
             }
         }
 
@@ -96,7 +101,12 @@ public:
             Column& col = it->second;
             const int64_t dx = int64_t(key.x) - current.x, dz = int64_t(key.z) - current.z;
             const bool outside = dx * dx + dz * dz > int64_t(r) * r;
+            if (col.loaded && !outside && col.settled && col.settled_lo == y_lo && col.settled_hi == y_hi) {
+                column_order_[kept++] = key;  // (exactly the window's layers are loaded: nothing to unload)
+                continue;
+            }
             if (col.loaded && (outside || col.first_layer() < y_lo - start_y_ || col.last_layer() > y_hi - start_y_)) {
+                col.settled = false;
                 for (int32_t y = start_y_; y < end_y_; ++y) {
                     uint8_t& at = col.lod[size_t(y - start_y_)];
                     if (!at || (!outside && y >= y_lo && y <= y_hi)) continue;
@@ -166,6 +176,7 @@ public:
             uint8_t& at = col.lod[size_t(pos.y - start_y_)];
             if (!at) { ++col.loaded; ++loaded_count_; }
             at = lod ? lod : uint8_t(255);  // (0 means "not loaded" in the table; the reference's LODs are 2..5)
+            col.settled = false;
         }
         rescan_ = true;  // the resident set changed behind update()'s back: the next call has to look again
     }
@@ -196,6 +207,10 @@ private:
     struct Column {
         std::vector<uint8_t> lod;
         uint32_t loaded = 0;
+        // update()'s short cut: the column holds exactly the layers [settled_lo, settled_hi], every one at settled_lod
+        bool settled = false;
+        uint8_t settled_lod = 0;
+        int32_t settled_lo = 0, settled_hi = 0;
         int32_t first_layer() const { for (size_t i = 0; i < lod.size(); ++i) if (lod[i]) return int32_t(i); return INT32_MAX; }
         int32_t last_layer() const { for (size_t i = lod.size(); i-- > 0;) if (lod[i]) return int32_t(i); return INT32_MIN; }
     };

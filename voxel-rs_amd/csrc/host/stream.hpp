@@ -173,7 +173,7 @@ public:
         auto ms_since = [](clock::time_point t0) { return std::chrono::duration<double, std::milli>(clock::now() - t0).count(); };
         clock::time_point t0 = clock::now();
         std::vector<ChunkEvent> batch;
-        std::vector<std::optional<SerializedT>> built;
+        std::vector<std::unique_ptr<SerializedT>> built;
         {
             std::unique_lock<std::mutex> lock(m_);
             while (!queue_.empty() && batch.size() < max_events) {
@@ -257,7 +257,7 @@ private:
     struct Slot {
         ChunkEvent event;
         bool ready = false;
-        std::optional<SerializedT> built;
+        std::unique_ptr<SerializedT> built;  // (a pointer: a re-centre queues 25 K slots, nine in ten of which never hold a chunk)
     };
 
     void build_loop() {
@@ -272,10 +272,10 @@ private:
                 jobs_.pop_front();
                 ++built_ahead_;
             }
-            std::optional<SerializedT> built;
+            std::unique_ptr<SerializedT> built;
             std::shared_ptr<const ColumnHeights> column = column_heights(slot->event.pos.x, slot->event.pos.z);
             std::optional<Chunk> chunk = generate_heightfield_chunk(scene_depth_, seed_, slot->event.pos, slot->event.lod, column.get());
-            if (chunk) built.emplace(*chunk);
+            if (chunk) built = std::make_unique<SerializedT>(*chunk);
             {
                 std::lock_guard<std::mutex> lock(m_);
                 slot->built = std::move(built);
