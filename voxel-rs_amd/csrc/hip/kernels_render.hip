@@ -607,10 +607,6 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                         break;
                     }
                     sub = a.order ? uint32_t(__builtin_amdgcn_readfirstlane(a.order[t])) : t;  // most expensive first, or the order of their numbers
-                    if (a.hot_tickets) {  // (wave-uniform; the immediate operand makes it two instructions under a scalar branch)
-                        if (t < a.hot_tickets) __builtin_amdgcn_s_setprio(3);
-                        else __builtin_amdgcn_s_setprio(0);
-                    }
                     if (sub >= a.total_subtiles) sub = t;  // (never: a table of another view is not used)
                     cursor = 0;
                     ++taken;

@@ -235,7 +235,6 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.timeline_part = ctx->timeline_part;
         a.ticket_ahead = 1u + 2u;  // (the frame's last two quarter-grids of tickets are not drawn ahead)
         a.order = nullptr;
-        a.hot_tickets = 0;
         a.cost_cur = nullptr;
         a.cur_tag = 0xfffffu;
         vx_context::HotState* hs = nullptr;
@@ -277,7 +276,6 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
                 const uint32_t g = (hs->frames - 2) % 3;
                 HIP_TRY(hipStreamWaitEvent(stream, hs->order_done[g], 0));
                 a.order = hs->order[g];
-                a.hot_tickets = ctx->hot_prio_share > 0 ? a.total_subtiles / uint32_t(ctx->hot_prio_share) : 0u;
             } else if (hs->frames == 0 && hs->order_done[0]) {
                 // a new view starts over in generation 0: what the old view's order kernels still have to write comes first
                 for (int g = 0; g < 3; ++g) HIP_TRY(hipStreamWaitEvent(stream, hs->order_done[g], 0));
@@ -628,7 +626,6 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_FOREIGN_RERUN")) c->foreign_rerun = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VX_HOT_LEVELS")) c->hot_levels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_HOT_FIRST")) c->hot_first = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VX_HOT_PRIO")) c->hot_prio_share = std::atoi(e);
         if (const char* e = std::getenv("VX_TIMELINE"))
             if (std::atoi(e) != 0 && vxk::timeline_build()) CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_timeline), 8192 * 8 * sizeof(unsigned long long)));
         if (const char* e = std::getenv("VX_TIMELINE_PART")) c->timeline_part = uint32_t(std::atoi(e));

@@ -165,10 +165,6 @@ struct PersistentArgs {
     const uint32_t* order;          // [total_subtiles] sub-tile ids, or null
     uint32_t* cost_cur;             // [total_subtiles] tag << 12 | iterations of the sub-tile's longest ray this frame; null = do not note
     uint32_t cur_tag;               // frame tag (20 bits, never 0): entries with another tag are stale (no clearing between frames)
-    // Cost-ordered launches: a wave that starts on one of the table's first `hot_tickets` sub-tiles (the dearest of the frame before last: the rays
-    // whose chains of dependent iterations decide when the frame can end) raises its issue priority (s_setprio) until it takes a cheaper one -- the
-    // SIMD's four waves issue the same instructions in all, but the frame's critical path gets them first (0 = never).
-    uint32_t hot_tickets;
     uint32_t ticket_ahead;          // 1 + g: waves draw their next sub-tile's ticket when they start on one (its round trip runs under the traversal),
                                     // except for the frame's last g quarter-grids of tickets
     uint32_t timeline_part;         // measurement: which part of the service phases the timeline's tick count covers (0 all, 1 leaf tests, 2 finished rays, 3 refill, 4 ray set-up, 5 walks inside voxels)

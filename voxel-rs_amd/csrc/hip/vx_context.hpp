@@ -80,7 +80,6 @@ struct vx_context {
     hipStream_t order_stream = nullptr;
     HotState hot[kFrameStreams + 1];  // [slot + 1]
     bool hot_first = true;            // VX_HOT_FIRST=0: sub-tiles in plain order (A/B)
-    int hot_prio_share = 0;           // (experiment, VX_HOT_PRIO=n) waves on the dearest 1/n of a cost-ordered launch's sub-tiles run at raised priority; 0 = off
     hipEvent_t pending_wait = nullptr;  // vx_wait_event: what the next pipelined render has to wait for
     hipEvent_t pending_gather = nullptr;  // vx_wait_gather: the gather that still reads the tile list the next render overwrites
     int frames_in_flight = 2;           // 1 serialises frames on `stream` again (vx_set_frames_in_flight / VX_FRAMES_IN_FLIGHT)
