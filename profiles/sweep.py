@@ -11,6 +11,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+# (the knobs of experiments -- r, w, h, t, q -- are read by the library's measurement build only: make tl)
+os.environ.setdefault("VX_LIB_DIR", str(ROOT / "voxel-rs_amd" / "lib" / "lib_tl"))
 sys.path.insert(0, str(ROOT))
 from _pkg import load_package  # noqa: E402
 

@@ -580,10 +580,10 @@ OCCUPANCY_COUNTERS = ("wave_steps", "services", "refills", "tail_wave_steps", "t
 @pytest.mark.parametrize("fmt", FMTS)
 def test_kernel_versions_agree(hip, fmt, monkeypatch):
     """The persistent wavefront kernel (default) and the one-thread-per-pixel kernel write identical images and hit
-    records, for several refill/service thresholds (they only reorder work between lanes), from the traversal image (default),
+    records, for several service thresholds (they only reorder work between lanes), from the traversal image (default),
     from the world's own bytes, from the image layout for more than 4 GiB (octant indices behind a 64-bit pointer), with the LDS copy of
-    the top levels, with and without the order table, with the walk inside voxels in the render loop of a small world,
-    with three frames in flight. (The library's timeline build: test_timeline_build_renders_the_same_frames.)"""
+    the top levels, with the walk inside voxels in the render loop of a small world, with three frames in flight. (The library's
+    measurement build and its knobs: test_timeline_build_renders_the_same_frames, test_knobs_of_the_measurement_build_change_no_pixel.)"""
     from voxel_rs_amd import scenes
 
     world = vra.World(SVO_TYPES[fmt])
@@ -592,10 +592,11 @@ def test_kernel_versions_agree(hip, fmt, monkeypatch):
     w, h = 250, 130
     u = scenes.bench_camera(8, st["h_max"], w, h)
     results = []
-    knobs = ("VX_RENDER_KERNEL", "VX_REFILL_MIN", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_HOT_LEVELS", "VX_HOT_FIRST", "VX_FRAMES_IN_FLIGHT",
-             "VX_FOREIGN_RERUN")
-    for env in ({"VX_RENDER_KERNEL": "1"}, {}, {"VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"}, {"VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"},
-                {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_HOT_LEVELS": "1"}, {"VX_HOT_FIRST": "0"}, {"VX_FOREIGN_RERUN": "0"},
+    knobs = ("VX_RENDER_KERNEL", "VX_SERVICE_MIN", "VX_TRAVERSAL_IMAGE", "VX_WIDE_IMAGE", "VX_HOT_LEVELS", "VX_FRAMES_IN_FLIGHT", "VX_FOREIGN_RERUN")
+    # (the knobs of experiments -- the refill threshold, the order table off -- exist in the library's measurement build only:
+    # test_knobs_of_the_measurement_build_change_no_pixel)
+    for env in ({"VX_RENDER_KERNEL": "1"}, {}, {"VX_SERVICE_MIN": "1"}, {"VX_SERVICE_MIN": "33"},
+                {"VX_TRAVERSAL_IMAGE": "0"}, {"VX_WIDE_IMAGE": "1"}, {"VX_HOT_LEVELS": "1"}, {"VX_FOREIGN_RERUN": "0"},
                 {"VX_FRAMES_IN_FLIGHT": "3"}):
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
@@ -757,56 +758,45 @@ def test_views_and_sizes_in_turn(hip, fmt):
     svo.close()
 
 
+def run_knob_worker(fmt, env, measurement_build):
+    """tests/knob_worker.py in a process of its own (a process loads one build of the library; the knobs are read when a context is created)."""
+    import json
+    import subprocess
+    import sys
+
+    e = {k: v for k, v in os.environ.items() if not k.startswith("VX_")}
+    e.update(env)
+    if measurement_build:
+        e["VX_LIB_DIR"] = str(Path(ROOT) / "voxel-rs_amd" / "lib" / "lib_tl")
+    r = subprocess.run([sys.executable, str(Path(ROOT) / "tests" / "knob_worker.py"), fmt], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
 @pytest.mark.parametrize("fmt", FMTS)
-def test_the_order_of_the_tiles_changes_no_pixel(hip, fmt, monkeypatch):
-    """Where on the screen the queue's tile numbers lie (VX_TILE_NUMBERING: rows, strips of VX_TILE_STRIP columns, the stride), and how many sub-tiles in
-    a row go to one dispenser (VX_QUEUE_STRIPE), is the ORDER a frame's work is done in and nothing else: a frame of an odd size -- a last strip narrower
-    than the others, edge tiles -- with hit records, image-only one frame at a time (cost order: seven frames) and on the frame streams, and a rank's
-    share of a tile list, under every setting, byte for byte the frame of the default."""
-    import torch
-    from voxel_rs_amd import scenes
+def test_the_order_of_the_tiles_changes_no_pixel(hip, fmt):
+    """Where on the screen the queue's tile numbers lie (VX_TILE_NUMBERING: rows, strips of eight columns, the stride) is the ORDER a frame's work is done in
+    and nothing else: a frame of an odd size -- a last strip narrower than the others, edge tiles -- with hit records, image-only one frame at a time (cost
+    order: seven frames) and on the frame streams, and a rank's share of a tile list, under every numbering, byte for byte the frame of the default. In the
+    library's measurement build also the width of the strips (VX_TILE_STRIP) and how many sub-tiles in a row go to one dispenser (VX_QUEUE_STRIPE)."""
+    ref = run_knob_worker(fmt, {}, False)
+    assert ref["own 0"] == ref["own 6"]
+    for numbering in (0, 2):
+        assert run_knob_worker(fmt, {"VX_TILE_NUMBERING": str(numbering)}, False) == ref, numbering
+    for numbering, strip, stripe in ((1, 1, 16), (1, 3, 1), (1, 8, 100), (1, 100, 16), (2, 8, 1), (0, 8, 100000)):
+        got = run_knob_worker(fmt, {"VX_TILE_NUMBERING": str(numbering), "VX_TILE_STRIP": str(strip), "VX_QUEUE_STRIPE": str(stripe)}, True)
+        assert got == ref, (numbering, strip, stripe)
 
-    world = vra.World(SVO_TYPES[fmt])
-    st = world.build_heightfield(8, threads=4)
-    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
-    w, h = 333, 227
-    u = scenes.bench_camera(8, st["h_max"], w, h, shadow_distance=3.0e38)
 
-    def frames():
-        svo = hip.Svo(SVO_TYPES[fmt], world.size_in_bytes + (1 << 20))  # (the knobs are read when a context is created)
-        svo.set_materials(mats)
-        svo.set_textures(tex, 6)
-        svo.update_full(world)  # (the world's change list went to the first context)
-        img, hits = svo.render(u, w, h, want_hits=True)
-        out = {"hits": img.tobytes() + hits.tobytes()}
-        for k in range(7):  # the context's own stream: from the third frame on through the cost-ordered table
-            out["own %d" % k] = svo.render(u, w, h)[0].tobytes()
-        t = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-        torch.cuda.synchronize()
-        for k in range(4):
-            svo.render_device(u, w, h, t[k & 1].data_ptr())
-        svo.sync()
-        out["in flight"] = t[0].cpu().numpy().tobytes() + t[1].cpu().numpy().tobytes()
-        n = hip.local_tile_count(w, h, 1, 3)
-        lst = torch.zeros((n * 1024, 4), dtype=torch.float32, device="cuda")
-        torch.cuda.synchronize()
-        svo.render_device(u, w, h, lst.data_ptr(), tile_rank=1, tile_count=3)
-        svo.sync()
-        out["rank 1 of 3"] = lst.cpu().numpy().tobytes()
-        svo.close()
-        return out
-
-    for name in ("VX_TILE_NUMBERING", "VX_TILE_STRIP", "VX_QUEUE_STRIPE"):
-        monkeypatch.delenv(name, raising=False)
-    ref = frames()
-    assert ref["own 0"] == ref["own 6"] and ref["in flight"][:len(ref["own 0"])] == ref["own 0"]
-    for numbering, strip, stripe in ((0, 8, 16), (1, 1, 16), (1, 3, 1), (1, 8, 100), (1, 100, 16), (2, 8, 16), (2, 8, 1), (0, 8, 100000)):
-        monkeypatch.setenv("VX_TILE_NUMBERING", str(numbering))
-        monkeypatch.setenv("VX_TILE_STRIP", str(strip))
-        monkeypatch.setenv("VX_QUEUE_STRIPE", str(stripe))
-        got = frames()
-        for key in ref:
-            assert got[key] == ref[key], (numbering, strip, stripe, key)
+@pytest.mark.parametrize("fmt", FMTS)
+def test_knobs_of_the_measurement_build_change_no_pixel(hip, fmt):
+    """The knobs of experiments -- honoured by the library's measurement build only (lib/lib_tl; the product build ignores them) -- reorder work and nothing
+    else: the refill and service thresholds, the order table off, a cap on the resident waves. Frames, hit records and step counters of the product build."""
+    ref = run_knob_worker(fmt, {}, False)
+    for env in ({"VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"}, {"VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"}, {"VX_HOT_FIRST": "0"}, {"VX_WAVES_PER_CU": "3"}):
+        assert run_knob_worker(fmt, env, True) == ref, env
+    # ... and the product build does not read them
+    assert run_knob_worker(fmt, {"VX_REFILL_MIN": "64", "VX_WAVES_PER_CU": "1", "VX_QUEUE_STRIPE": "3"}, False) == ref
 
 
 # ---- output formats, presentation ring, lifetime, fall-back, the library's own gather ---------------------------------------------

@@ -616,8 +616,9 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_excursions), 8 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(c->d_excursions, 0, 8 * sizeof(unsigned long long)));
     {
-        // The knobs that stay (tests and measurements; none of them changes a pixel): which kernel, how many frames in flight, the image
-        // on / off / wide / capped, the order table, the LDS copy of the top levels, the lockstep thresholds.
+        // The environment knobs of the product build (ten; none of them changes a pixel): which kernel, how many frames in flight, the image on /
+        // off / wide / capped, where a CSVO world's inside-voxel rays go, the LDS copy of the top levels, the wave slots left to a communicator,
+        // the lockstep threshold, how the tiles are numbered.
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("VX_FRAMES_IN_FLIGHT")) c->frames_in_flight = std::atoi(e);
         if (c->frames_in_flight < 1) c->frames_in_flight = 1;
@@ -625,23 +626,28 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FOREIGN_RERUN")) c->foreign_rerun = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VX_HOT_LEVELS")) c->hot_levels = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VX_HOT_FIRST")) c->hot_first = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VX_TIMELINE"))
-            if (std::atoi(e) != 0 && vxk::timeline_build()) CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_timeline), 8192 * 8 * sizeof(unsigned long long)));
-        if (const char* e = std::getenv("VX_TIMELINE_PART")) c->timeline_part = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_IMAGE_CAP_BYTES")) c->image_cap_bytes = size_t(std::strtoull(e, nullptr, 10));
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)
         int wide_image = 0;
         if (const char* e = std::getenv("VX_WIDE_IMAGE")) wide_image = std::atoi(e);
         c->image = vximg::WorldImage(svo_type, wide_image ? vximg::kOct64Wide : vximg::kOct64, wide_image == 2 ? (uint64_t(5) << 30) / 4 : 0);
-        if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
         if (const char* e = std::getenv("VX_COMM_HEADROOM")) c->comm_headroom = std::max(0, std::atoi(e));
-        if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
-        if (const char* e = std::getenv("VX_QUEUE_STRIPE")) c->queue_stripe = std::atoi(e);
         if (const char* e = std::getenv("VX_TILE_NUMBERING")) c->tile_numbering = std::atoi(e);
-        if (const char* e = std::getenv("VX_TILE_STRIP")) c->tile_strip = std::atoi(e);
+        // The knobs of experiments exist in the library's MEASUREMENT build only (make tl: lib/lib_tl, loaded through VX_LIB_DIR by
+        // profiles/timeline.py, profiles/sweep.py and the tests that vary them): the wave timeline, the order table off, the refill threshold,
+        // a cap on the resident waves, the queue's stretches, the width of the tile strips.
+        if (vxk::timeline_build()) {
+            if (const char* e = std::getenv("VX_HOT_FIRST")) c->hot_first = std::atoi(e) != 0;
+            if (const char* e = std::getenv("VX_TIMELINE"))
+                if (std::atoi(e) != 0) CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_timeline), 8192 * 8 * sizeof(unsigned long long)));
+            if (const char* e = std::getenv("VX_TIMELINE_PART")) c->timeline_part = uint32_t(std::atoi(e));
+            if (const char* e = std::getenv("VX_WAVES_PER_CU")) c->waves_per_cu_cap = std::atoi(e);
+            if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
+            if (const char* e = std::getenv("VX_QUEUE_STRIPE")) c->queue_stripe = std::atoi(e);
+            if (const char* e = std::getenv("VX_TILE_STRIP")) c->tile_strip = std::atoi(e);
+        }
         if (c->refill_min < 1) c->refill_min = 1;
         if (c->refill_min > 64) c->refill_min = 64;
         if (c->service_min < 1) c->service_min = 1;
