@@ -277,8 +277,18 @@ class Sharded:
                     ev[1].record()
                     self.gather_events.append(ev)
 
+        def fused(g, tiles, gathered, image):
+            # the library's exchange, frame by frame: one call per frame (vx_render_gather) instead of four
+            u = self.view if self.view is not None else self.wl.path[self.i % len(self.wl.path)]
+            self.last_view = u
+            self.i += 1
+            state["last_ticket"] = tickets[g] = svo.render_gather(u, W, H, tiles.data_ptr(), tiles.numel() * tiles.element_size(), gathered.data_ptr() if rank == 0 else None,
+                                                                  image.data_ptr() if rank == 0 else None, tickets.get(g, -1), rank, world_size, vx_fmt)
+
+        plain_library = library_gather and not (args.simulate_gather_failure or args.simulate_absent_peer or args.separate_calls)
         sh = self.FrameSharder(W, H, rank, world_size, dist, "cuda", self._render_tiles, assemble, before_render=before_render, after_render=after_render,
-                               after_exchange=after_exchange, buffers=FRAMES, group=GROUP, gather=gather, pixel_format=args.gather_format)
+                               after_exchange=after_exchange, buffers=FRAMES, group=GROUP, gather=gather, pixel_format=args.gather_format,
+                               fused=fused if plain_library else None)
         if not library_gather:
             # (torch's gather wants its own send buffer: the root's list is not rendered in place)
             sh.tiles = [torch.zeros((GROUP, sh.n_max, 32, 32, 4), dtype=sh.dtype, device="cuda") for _ in range(FRAMES // GROUP)]
@@ -603,6 +613,7 @@ def parse_args(argv=None):
                     help="sharded: pixel format of the tile lists that travel and of rank 0's image (rgba8 = Framebuffer::as_image's bytes: a quarter of the link time)")
     ap.add_argument("--gather-timeout", type=float, default=30.0, help="sharded: seconds the first exchange may take before it is declared hung")
     ap.add_argument("--simulate-gather-failure", action="store_true", help="testing: make the library's exchange fail, to exercise the fall-back")
+    ap.add_argument("--separate-calls", action="store_true", help="sharded, the library's exchange: wait / render / gather / assemble as four calls per frame instead of vx_render_gather's one (A/B)")
     ap.add_argument("--simulate-absent-peer", action="store_true", help="testing: the ranks other than 0 never join the library's exchange (the watchdog must end the wait)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed's backend for this script's barriers and statistics (gloo: the tests, where several ranks share one GPU and RCCL proper cannot run)")

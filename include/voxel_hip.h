@@ -304,6 +304,15 @@ int vx_wait_gather(vx_context* ctx, int ticket);
  * this against a deadline instead of calling vx_sync. */
 int vx_gather_query(vx_context* ctx, int ticket);
 void* vx_comm_stream(vx_context* ctx);
+/* One sharded frame in ONE call -- what a rank does per frame, in the order it has to be done: vx_wait_gather(wait_ticket) unless wait_ticket < 0 (the
+ * exchange that last read this tile list), vx_render of this rank's tiles into `target` (device memory; tile_rank / tile_count / format as for
+ * vx_render), vx_gather_tiles of the list (bytes_per_rank of it) to `root`, and, on the root, vx_assemble_tiles_format of the gathered lists
+ * (`gathered`: [ranks][bytes_per_rank]; the root's own list should be target->rgba32f = gathered + root * bytes_per_rank: rendered in place)
+ * into `image` on the communicator's stream (image NULL: no assembly). *out_ticket names the exchange (and covers the assembly). Saves the
+ * caller three of four trips through the ABI: at eight ranks a rank's share of a 1080p frame is 0.03 ms of GPU time, and a frame loop
+ * that spends longer than that per frame on calls is the bound (bench.py's host_issue_ms_per_step). The reference has no counterpart. */
+int vx_render_gather(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, const vx_target* target, uint64_t bytes_per_rank,
+                     void* gathered, int root, void* image, int wait_ticket, int* out_ticket);
 /* vx_assemble_tiles for either pixel format: stride in PIXELS between the ranks' lists; an RGBA8 image comes out top row first.
  * Issued on vx_comm_stream(ctx), it extends the ticket of every gather issued since the last assembly on that stream: vx_wait_gather(ticket)
  * then also waits for this kernel, which reads every rank's list -- the root's own included, which the root renders into in place. Lists and

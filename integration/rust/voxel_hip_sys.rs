@@ -125,6 +125,7 @@ extern "C" {
     // ---- multi-GPU: one process per GPU, screen tiles, RCCL gather --------------------------------------------------------------
     pub fn vx_tile_order(width: u32, height: u32, out: *mut u32, capacity: u32) -> u32;
     pub fn vx_local_tile_count(width: u32, height: u32, tile_rank: u32, tile_count: u32) -> u32;
+    pub fn vx_comm_library(path: *const c_char) -> c_int;
     pub fn vx_comm_unique_id(out_id: *mut c_void, bytes: usize) -> c_int;
     pub fn vx_comm_init(ctx: *mut vx_context, nranks: c_int, rank: c_int, unique_id: *const c_void) -> c_int;
     pub fn vx_comm_destroy(ctx: *mut vx_context) -> c_int;
@@ -132,6 +133,8 @@ extern "C" {
     pub fn vx_gather_tiles(ctx: *mut vx_context, tiles: *const c_void, bytes_per_rank: u64, gathered: *mut c_void, root: c_int, out_ticket: *mut c_int) -> c_int;
     pub fn vx_wait_gather(ctx: *mut vx_context, ticket: c_int) -> c_int;
     pub fn vx_gather_query(ctx: *mut vx_context, ticket: c_int) -> c_int;
+    pub fn vx_render_gather(ctx: *mut vx_context, uniforms: *const vx_uniforms, width: u32, height: u32, target: *const vx_target, bytes_per_rank: u64,
+                            gathered: *mut c_void, root: c_int, image: *mut c_void, wait_ticket: c_int, out_ticket: *mut c_int) -> c_int;
     pub fn vx_comm_stream(ctx: *mut vx_context) -> *mut c_void;
     pub fn vx_assemble_tiles(ctx: *mut vx_context, tiles: *const f32, stride_floats: u64, tile_count: u32, width: u32, height: u32, out_rgba32f: *mut f32) -> c_int;
     pub fn vx_assemble_tiles_format(ctx: *mut vx_context, tiles: *const c_void, stride_pixels: u64, tile_count: u32, width: u32, height: u32, out: *mut c_void,

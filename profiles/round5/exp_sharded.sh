@@ -13,3 +13,4 @@ $B --force-sharded --frames-in-flight 4 2>/dev/null | j sharded_fif4
 $B --force-sharded --gather-format rgba32f 2>/dev/null | j sharded_rgba32f
 $B --force-sharded --gather torch 2>/dev/null | j sharded_torch
 $B --force-sharded --gather-group 2 --frames-in-flight 4 2>/dev/null | j sharded_group2
+$B --force-sharded --separate-calls 2>/dev/null | j sharded_separate_calls

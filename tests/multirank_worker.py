@@ -5,7 +5,7 @@ Runs the multi-rank code path bench.py runs on a node -- bench.Sharded: tile-lis
 still reads, rank 0's assembly on the communicator's stream -- with tests/stub_rccl standing in for RCCL (which refuses two ranks on one device) and
 gloo carrying the unique id and the barriers. Rank 0 compares EVERY assembled frame of a moving camera with the same frame rendered whole.
 
-    RANK=r LOCAL_RANK=0 WORLD_SIZE=N MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/multirank_worker.py <out.json> <format> <gather-format> <frames> <group>
+    RANK=r LOCAL_RANK=0 WORLD_SIZE=N MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/multirank_worker.py <out.json> <format> <gather-format> <frames> <group> [separate]
 """
 import json
 import os
@@ -35,7 +35,7 @@ def main():
     hip.comm_library(stub)
     args = bench.parse_args(["--gpus", str(world), "--steps", str(n_frames), "--depth", "9", "--width", "640", "--height", "360", "--format", fmt_name,
                              "--gather", "library", "--gather-format", gather_format, "--gather-group", str(group), "--gather-timeout", "60",
-                             "--dist-backend", "gloo", "--textures", "procedural"])
+                             "--dist-backend", "gloo", "--textures", "procedural"] + (["--separate-calls"] if len(sys.argv) > 6 and sys.argv[6] == "separate" else []))
     args.ctl_device = "cpu"
     wl = bench.Workload(args, vra, hip, scenes, rank, world, 0)
     run = bench.Sharded(args, wl, torch, dist, hip, rank, world)  # (its first frames are already checked against the whole render, on every rank's verdict)

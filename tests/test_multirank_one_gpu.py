@@ -50,13 +50,14 @@ def launch(world, argv, extra_env=None, timeout=420):
     return out
 
 
-@pytest.mark.parametrize("world,fmt,gather_format,headroom,group", [
-    (2, "csvo", "rgba8", "4", 1), (2, "esvo", "rgba32f", "0", 1), (3, "csvo", "rgba32f", "4", 1), (3, "esvo", "rgba8", "0", 2),
-], ids=["2ranks-csvo-rgba8-headroom4", "2ranks-esvo-rgba32f-headroom0", "3ranks-csvo-rgba32f-headroom4", "3ranks-esvo-rgba8-headroom0-group2"])
-def test_ranks_sharing_one_gpu_gather_the_whole_frame(tmp_path, world, fmt, gather_format, headroom, group):
-    """Thirty frames of a moving camera through vx_gather_tiles with `world` ranks: every frame rank 0 assembles is, byte for byte, the frame rendered whole."""
+@pytest.mark.parametrize("world,fmt,gather_format,headroom,group,calls", [
+    (2, "csvo", "rgba8", "4", 1, "one"), (2, "esvo", "rgba32f", "0", 1, "separate"), (3, "csvo", "rgba32f", "4", 1, "one"), (3, "esvo", "rgba8", "0", 2, "separate"),
+], ids=["2ranks-csvo-rgba8-headroom4", "2ranks-esvo-rgba32f-headroom0-separate-calls", "3ranks-csvo-rgba32f-headroom4", "3ranks-esvo-rgba8-headroom0-group2"])
+def test_ranks_sharing_one_gpu_gather_the_whole_frame(tmp_path, world, fmt, gather_format, headroom, group, calls):
+    """Thirty frames of a moving camera through the library's exchange with `world` ranks -- a frame per call (vx_render_gather) or as wait / render /
+    gather / assemble --: every frame rank 0 assembles is, byte for byte, the frame rendered whole."""
     out = tmp_path / "result.json"
-    res = launch(world, [str(ROOT / "tests" / "multirank_worker.py"), str(out), fmt, gather_format, "30", str(group)], {"VX_COMM_HEADROOM": headroom})
+    res = launch(world, [str(ROOT / "tests" / "multirank_worker.py"), str(out), fmt, gather_format, "30", str(group), calls], {"VX_COMM_HEADROOM": headroom})
     for r, (rc, _, err) in enumerate(res):
         assert rc == 0, f"rank {r} failed:\n{err[-3000:]}"
     d = json.loads(out.read_text())

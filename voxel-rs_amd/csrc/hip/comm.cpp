@@ -219,5 +219,25 @@ int vx_wait_gather(vx_context* ctx, int ticket) {
 
 void* vx_comm_stream(vx_context* ctx) { return ctx ? static_cast<void*>(ctx->comm_stream) : nullptr; }
 
+int vx_render_gather(vx_context* ctx, const vx_uniforms* uniforms, uint32_t width, uint32_t height, const vx_target* target, uint64_t bytes_per_rank,
+                     void* gathered, int root, void* image, int wait_ticket, int* out_ticket) {
+    if (!ctx || !target || !target->rgba32f) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: null argument");
+    if (target->memory != VX_MEM_DEVICE) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: the tile list lives in device memory");
+    VX_LOCK(ctx);  // (one frame's four steps as one: nothing of another thread's in between)
+    if (wait_ticket >= 0)
+        if (int rc = vx_wait_gather(ctx, wait_ticket)) return rc;
+    if (int rc = vx_render(ctx, uniforms, width, height, target)) return rc;
+    int ticket = -1;
+    if (int rc = vx_gather_tiles(ctx, target->rgba32f, bytes_per_rank, gathered, root, &ticket)) return rc;
+    if (image && ctx->comm_rank == root) {
+        const uint64_t pixel = target->format == VX_FORMAT_RGBA8 ? 4u : 16u;
+        if (bytes_per_rank % pixel) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: bytes_per_rank must be whole pixels");
+        // (vx_render with tile_count 1 writes the whole frame: the "list" of a one-rank run is the frame, and the assembly runs for its cost)
+        if (int rc = vx_assemble_tiles_format(ctx, gathered, bytes_per_rank / pixel, uint32_t(ctx->comm_ranks), width, height, image, target->format, ctx->comm_stream)) return rc;
+    }
+    if (out_ticket) *out_ticket = ticket;
+    return VX_OK;
+}
+
 
 }  // extern "C"

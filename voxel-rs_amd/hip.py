@@ -100,6 +100,7 @@ SYMBOLS = {
     "vx_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "vx_gather_tiles": (_int, [_vp, _vp, _u64, _vp, _int, C.POINTER(_int)]),
     "vx_wait_gather": (_int, [_vp, _int]),
+    "vx_render_gather": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, C.POINTER(Target), _u64, _vp, _int, _vp, _int, C.POINTER(_int)]),
     "vx_comm_stream": (_vp, [_vp]),
     "vx_local_tile_count": (_u32, [_u32, _u32, _u32, _u32]),
     "vx_render_counters": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, _u32, _u32, C.POINTER(Counters)]),
@@ -303,6 +304,14 @@ class Svo:
     def gather_tiles(self, tiles_ptr, bytes_per_rank, gathered_ptr, root=0):
         ticket = _int(-1)
         _check(lib().vx_gather_tiles(self._h, tiles_ptr, bytes_per_rank, gathered_ptr, root, C.byref(ticket)))
+        return ticket.value
+
+    def render_gather(self, uniforms, width, height, tiles_ptr, bytes_per_rank, gathered_ptr, image_ptr, wait_ticket=-1, tile_rank=0, tile_count=1, fmt=VX_FORMAT_RGBA32F, root=0):
+        """One sharded frame in one call (vx_render_gather): wait for the exchange that last read the list, render this rank's tiles, gather them to
+        `root`, and assemble on the root. Returns the exchange's ticket."""
+        t = Target(tiles_ptr, None, VX_MEM_DEVICE, tile_rank, tile_count, fmt)
+        ticket = _int(-1)
+        _check(lib().vx_render_gather(self._h, C.byref(uniforms), width, height, C.byref(t), bytes_per_rank, gathered_ptr, root, image_ptr, wait_ticket, C.byref(ticket)))
         return ticket.value
 
     def wait_gather(self, ticket):

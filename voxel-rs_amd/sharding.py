@@ -85,7 +85,7 @@ class FrameSharder:
     """
 
     def __init__(self, width, height, rank, world, dist, device, render_tiles, assemble, before_render=None, after_render=None,
-                 after_exchange=None, buffers=2, group=1, gather=None, pixel_format="rgba32f"):
+                 after_exchange=None, buffers=2, group=1, gather=None, pixel_format="rgba32f", fused=None):
         import torch
 
         # rgba32f: the reference's framebuffer; rgba8: what Framebuffer::as_image reads back from it (vx_format) -- a quarter of the
@@ -106,6 +106,10 @@ class FrameSharder:
         # gather(tiles, gathered_or_None): the exchange step. Default: torch.distributed's gather (what the CPU tests run, on gloo);
         # bench.py hands in the library's own (vx_gather_tiles: RCCL send/receive owned by the render context)
         self.gather = gather
+        # fused(g, tiles, gathered_or_None, image_or_None): the whole frame -- wait for the exchange that last read buffer g's list, render, gather,
+        # assemble on rank 0 -- as ONE call of the renderer (vx_render_gather), for frames that are exchanged one by one (group 1): a rank's
+        # share of a frame is tens of microseconds of GPU time at eight ranks, and so are four separate calls from a Python loop
+        self.fused = fused if group == 1 else None
         self.n_local = len(local_tile_ids(width, height, rank, world))
         self.n_max = max(len(local_tile_ids(width, height, r, world)) for r in range(world))
         n_groups = buffers // group
@@ -131,6 +135,15 @@ class FrameSharder:
         return self.images[self._last] if self.rank == 0 and self._last is not None else None
 
     def step(self):
+        if self.fused is not None:
+            g = self._g
+            self.fused(g, self.tiles[g][0], self.gathered[g], self.images[0] if self.rank == 0 else None)
+            self.frame += 1
+            if self.rank == 0:
+                self._last = 0
+                self.last_gathered = self.gathered[g][:, 0]
+            self._g = (g + 1) % len(self.tiles)
+            return self.image
         g, j = self._g, self._slot
         self.before_render(g)
         self.render_tiles(self.tiles[g][j])
