@@ -125,7 +125,18 @@ int vx_comm_info(const vx_context* ctx, int* nranks, int* rank) {
     return VX_OK;
 }
 
+namespace {
+// the exchange; only_slot >= 0: the list was rendered by the frame just issued on that frame stream (vx_render_gather knows) -- one event to wait for
+// instead of every stream's (a HIP call each: a third of what a sharded frame costs its host thread)
+int gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank, void* gathered, int root, int* out_ticket, int only_slot);
+}  // namespace
+
 int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank, void* gathered, int root, int* out_ticket) {
+    return gather_tiles(ctx, tiles, bytes_per_rank, gathered, root, out_ticket, -1);
+}
+
+namespace {
+int gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank, void* gathered, int root, int* out_ticket, int only_slot) {
     if (!ctx || !tiles || !bytes_per_rank || (bytes_per_rank & 3)) return fail(VX_ERR_INVALID_ARGUMENT, "gather_tiles: bad argument");
     VX_LOCK(ctx);
     if (!ctx->comm) return fail(VX_ERR_STATE, "gather_tiles: no communicator (vx_comm_init)");
@@ -134,9 +145,13 @@ int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank,
     HIP_TRY(hipSetDevice(ctx->device));
     // behind the renders issued so far (the list's among them), on the communicator's own stream: the frame streams go on with the
     // next frames meanwhile
-    if (ctx->render_recorded) HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->render_done, 0));
-    for (int i = 0; i < vx_context::kFrameStreams; ++i)  // (every frame issued so far: a list may hold a group of frames)
-        if (ctx->frame_recorded[i]) HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->frame_done[i], 0));
+    if (only_slot >= 0 && only_slot < vx_context::kFrameStreams && ctx->frame_recorded[only_slot]) {
+        HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->frame_done[only_slot], 0));
+    } else {
+        if (ctx->render_recorded) HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->render_done, 0));
+        for (int i = 0; i < vx_context::kFrameStreams; ++i)  // (every frame issued so far: a list may hold a group of frames)
+            if (ctx->frame_recorded[i]) HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->frame_done[i], 0));
+    }
     const size_t words = size_t(bytes_per_rank / 4);
     ProfiledLaunch ev{};
     if (ctx->profile) {  // (vx_profile_enable: the exchange bracketed by events on the communicator's stream, vx_comm_profile_read)
@@ -181,6 +196,7 @@ int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank,
     if (out_ticket) *out_ticket = ticket;
     return VX_OK;
 }
+}  // namespace
 
 int vx_gather_query(vx_context* ctx, int ticket) {
     if (!ctx || ticket < 0 || ticket >= vx_context::kGatherEvents || !ctx->gather_done[ticket]) return -1;
@@ -228,7 +244,8 @@ int vx_render_gather(vx_context* ctx, const vx_uniforms* uniforms, uint32_t widt
         if (int rc = vx_wait_gather(ctx, wait_ticket)) return rc;
     if (int rc = vx_render(ctx, uniforms, width, height, target)) return rc;
     int ticket = -1;
-    if (int rc = vx_gather_tiles(ctx, target->rgba32f, bytes_per_rank, gathered, root, &ticket)) return rc;
+    // (the list was written by the render just issued: behind that frame's event alone -- a render on the context's own stream: behind everything)
+    if (int rc = gather_tiles(ctx, target->rgba32f, bytes_per_rank, gathered, root, &ticket, ctx->last_frame_slot)) return rc;
     if (image && ctx->comm_rank == root) {
         const uint64_t pixel = target->format == VX_FORMAT_RGBA8 ? 4u : 16u;
         if (bytes_per_rank % pixel) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: bytes_per_rank must be whole pixels");
