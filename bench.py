@@ -192,7 +192,10 @@ class Sharded:
         # frames per collective (1: every frame is gathered as soon as it is rendered; more: fewer, larger messages)
         self.group = max(1, min(args.gather_group if args.gather_group else 1, frames))
         self.frames = frames - frames % self.group
-        self.svo.set_frames_in_flight(self.frames)
+        # (the library's frame streams -- kernels that can run side by side -- are a choice of their own: a list that is still being exchanged needs a
+        # buffer, not a stream)
+        self.streams = min(8, max(1, args.streams)) if args.streams else self.frames
+        self.svo.set_frames_in_flight(self.streams)
         self.i = 0
         self.view = None
         self.last_view = None
@@ -606,6 +609,7 @@ def parse_args(argv=None):
                     help="frames the renderer keeps in flight (1..8); default: the library's own (2) on one GPU, max(3, N) when the frame is sharded over N "
                          "(a sharded frame's next render waits for the exchange and rank 0's assembly of the frame before last on its stream)")
     ap.add_argument("--gather-group", type=int, default=0, help="sharded: frames per gather (default 1)")
+    ap.add_argument("--streams", type=int, default=0, help="sharded: the library's frame streams (default: as many as frames in flight, i.e. tile-list buffers)")
     ap.add_argument("--gather", choices=["auto", "library", "torch"], default="auto",
                     help="sharded: the exchange step -- library: vx_gather_tiles (RCCL send/receive owned by the render context); torch: torch.distributed.gather; "
                          "auto: the library's, checked on its first frames (watchdog + the assembled frame against the whole render), torch's if that fails")
