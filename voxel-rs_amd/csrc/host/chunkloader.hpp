@@ -120,11 +120,16 @@ public:
             else columns_.erase(it);
         }
         column_order_.resize(kept);
-        // (chunks outside [start_y, end_y) only ever get here through add_loaded_chunk: they are never in reach)
+        // (chunks outside [start_y, end_y) only ever get here through add_loaded_chunk: the scan above never visits them, the reach test does)
         for (auto it = stray_.begin(); it != stray_.end();) {
-            events.push_back(ChunkEvent{ChunkEvent::Unload, it->first, 0});
-            it = stray_.erase(it);
-            --loaded_count_;
+            const int64_t dx = int64_t(it->first.x) - current.x, dy = std::abs(int64_t(it->first.y) - current.y), dz = int64_t(it->first.z) - current.z;
+            if (dy > r || dx * dx + dz * dz > int64_t(r) * r) {
+                events.push_back(ChunkEvent{ChunkEvent::Unload, it->first, 0});
+                it = stray_.erase(it);
+                --loaded_count_;
+            } else {
+                ++it;
+            }
         }
 
         sort_by_distance(events, current);
