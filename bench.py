@@ -843,8 +843,13 @@ def main():
             except Exception as e:  # (a box without the memory for the depth-14 terrain: the headline still stands)
                 configs = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_forced_sharded:
+            # (this process is through with the GPU: its context goes first -- ten streams of an idle context still hold hardware queues, and with
+            # them mapped the child's frame streams were time-sliced: 10 % below what the same command does on its own)
             svo.sync()
             torch.cuda.synchronize()
+            run.images = None
+            svo.close()
+            torch.cuda.empty_cache()
             forced = forced_sharded_child(args)
 
     times = torch.tensor(blocks, dtype=torch.float64, device=args.ctl_device)
