@@ -639,6 +639,12 @@ def parse_args(argv=None):
 
 def main():
     args = parse_args()
+    # `forced_sharded` first, while this process holds nothing of the GPU: measured after its own work -- with the parent's idle context still
+    # mapped (a dozen streams = hardware queues) -- the child's frame streams were time-sliced and the figure was 7-10 % below what the same
+    # command does on its own.
+    args.forced_sharded_result = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.force_sharded and not args.no_extras and not args.no_forced_sharded):
+        args.forced_sharded_result = forced_sharded_child(args)
     import numpy as np
     import torch
 
@@ -842,15 +848,7 @@ def main():
                 configs = other_configs(args, vra, hip, scenes, torch, [f for f in args.config_formats.split(",") if f in ("csvo", "esvo")])
             except Exception as e:  # (a box without the memory for the depth-14 terrain: the headline still stands)
                 configs = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if not args.no_forced_sharded:
-            # (this process is through with the GPU: its context goes first -- ten streams of an idle context still hold hardware queues, and with
-            # them mapped the child's frame streams were time-sliced: 10 % below what the same command does on its own)
-            svo.sync()
-            torch.cuda.synchronize()
-            run.images = None
-            svo.close()
-            torch.cuda.empty_cache()
-            forced = forced_sharded_child(args)
+        forced = args.forced_sharded_result  # (measured before this process touched the GPU: see main())
 
     times = torch.tensor(blocks, dtype=torch.float64, device=args.ctl_device)
     stats = torch.tensor([float(wl.rays_per_block), float(wl.bytes_per_frame), kernel_ms / max(launches, 1), kernel_exclusive_ms, gather_ms / max(gathers, 1),
