@@ -189,8 +189,10 @@ class Sharded:
         # frames in flight: the smaller a rank's share of the frame, the longer its tail relative to its body (a frame cannot
         # finish before its longest ray) and the more frames it takes to keep the device full
         frames = min(8, max(1, args.frames_in_flight)) if args.frames_in_flight else min(8, max(3, world_size))
-        # frames per collective (1: every frame is gathered as soon as it is rendered; more: fewer, larger messages)
-        self.group = max(1, min(args.gather_group if args.gather_group else 1, frames))
+        # frames per collective (1: every frame is gathered as soon as it is rendered; more: fewer, larger messages). From six ranks on two by
+        # default: a rank's share of a 1080p frame is then 0.03-0.04 ms of GPU time, what one exchange costs its host thread (0.03 ms measured on
+        # one rank: profiles/round5/pass_a) and its communicator stream -- by analysis only: no run with more than one GPU has been possible
+        self.group = max(1, min(args.gather_group if args.gather_group else (2 if world_size >= 6 else 1), frames))
         self.frames = frames - frames % self.group
         # (the library's frame streams -- kernels that can run side by side -- are a choice of their own: a list that is still being exchanged needs a
         # buffer, not a stream)
@@ -608,7 +610,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames the renderer keeps in flight (1..8); default: the library's own (2) on one GPU, max(3, N) when the frame is sharded over N "
                          "(a sharded frame's next render waits for the exchange and rank 0's assembly of the frame before last on its stream)")
-    ap.add_argument("--gather-group", type=int, default=0, help="sharded: frames per gather (default 1)")
+    ap.add_argument("--gather-group", type=int, default=0, help="sharded: frames per gather (default 1; 2 from six ranks on)")
     ap.add_argument("--streams", type=int, default=0, help="sharded: the library's frame streams (default: as many as frames in flight, i.e. tile-list buffers)")
     ap.add_argument("--gather", choices=["auto", "library", "torch"], default="auto",
                     help="sharded: the exchange step -- library: vx_gather_tiles (RCCL send/receive owned by the render context); torch: torch.distributed.gather; "
