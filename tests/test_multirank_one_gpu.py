@@ -87,6 +87,17 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert d["value"] > 0 and d["sustained"]["frames"] >= 100
 
 
+def test_bench_with_eight_ranks_on_one_gpu():
+    """... and for N = 8, the size of the node the scaling run uses: eight processes, eight frames in flight in groups of two (bench.py's default from six
+    ranks on), seven receives per exchange on rank 0."""
+    d = bench_ranks(8, ["--gather", "library"])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["rccl_ranks"] == 8 and c["gather"].startswith("vx_gather_tiles") and "gather_note" not in c
+    assert c["sharded_frame_identical_to_whole_render"] is True
+    assert len(c["per_rank"]) == 8 and all(r["rays_per_block"] > 0 for r in c["per_rank"])
+    assert d["roofline"]["frames_in_flight"] == 8 and d["roofline"]["frames_per_gather"] == 2
+
+
 def test_bench_watchdog_when_a_peer_never_joins():
     """A peer that never joins the exchange: rank 0's receive waits on the device, vx_gather_query stays at 'not yet', the watchdog's deadline passes, every
     rank switches IN THE SAME PROCESS to torch.distributed's gather, whose frames are checked the same way -- the run ends, with a line that says what ran."""
