@@ -295,17 +295,14 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
     uint32_t walk_cycles = 0, walk_trips = 0, walk_phases = 0;  // timeline only, wave-uniform: the walks inside voxels -- shader-clock cycles, trips of the walk's loop (its slowest lane's iterations), phases
     uint32_t my_chunk = 0, my_fill = 0;  // FOREIGN, wave-uniform: newest chunk of this wave's list (+ 1) and its fill
 
-    unsigned long long carried = 0ull;  // wave-uniform: the lanes that were still traversing when the loop was last left (PersistentArgs::carry)
     for (;;) {
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
         // idle lanes are not waiting for anything; lanes that wait for company before their excursion (FOREIGN) are not waiting for service
         const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle || (FOREIGN == VX_SVO_CSVO && state == kForeign))));
         // the loop goes on while more than this many lanes traverse (64 - popcount(trav) < park_limit, and trav != 0)
-        const uint32_t keep_going = a.carry ? a.carry : (park_limit >= 64u ? 0u : 64u - park_limit);
+        const uint32_t keep_going = park_limit >= 64u ? 0u : 64u - park_limit;
         // (the lanes that traverse, as the wave's mask: one compare per trip serves the loop's exit test and the next trip's execution mask)
         unsigned long long trav = __ballot(tr.iter < uint32_t(kMaxSteps));
-        // (carry: rays that were already traversing at the last exit have to end before the next one -- a ray is carried once)
-        const unsigned long long old_lanes = a.carry ? (carried & trav) : 0ull;
         const unsigned long long c_loop = a.timeline ? __builtin_amdgcn_s_memtime() : 0ull;
         // The hand-scheduled loop (vx_loop_gfx950.hpp) for cursors on a byte-offset image that the resident stack levels cover. It does not
         // clear kHasAdjacentLeaf: a wave with a traversing ray that has just passed a translucent voxel takes the compiler's loop this time.
@@ -326,8 +323,8 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                 // in the same trip; the build that lists such rays instead never waits for anything)
                 const uint32_t f_waiting = FOREIGN == VX_SVO_CSVO ? uint32_t(__popcll(__ballot(state == kForeign))) : 0u;
                 const uint32_t f_min = FOREIGN == VX_SVO_CSVO ? 1u : 0xffffffffu;
-                if (a.timeline) traverse_loop_gfx950<SVO, FOREIGN != 0, true, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips, old_lanes);
-                else traverse_loop_gfx950<SVO, FOREIGN != 0, false, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips, old_lanes);
+                if (a.timeline) traverse_loop_gfx950<SVO, FOREIGN != 0, true, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips);
+                else traverse_loop_gfx950<SVO, FOREIGN != 0, false, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips);
                 // a lane the loop parked says why in bits 28..30 of its iteration count
                 const uint32_t why = (tr.iter >> 28) & 7u;
                 if (why) {
@@ -349,9 +346,8 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                 ++wave_steps;
                 if (queue_empty) { ++tail_wave_steps; tail_iterations += uint32_t(__popcll(trav)); }
             }
-            if ((trav & old_lanes) == 0ull && uint32_t(__popcll(trav)) <= keep_going) break;
+            if (uint32_t(__popcll(trav)) <= keep_going) break;
         }
-        if (a.carry) carried = __ballot(tr.iter < uint32_t(kMaxSteps));
         if (a.timeline) loop_cycles += __builtin_amdgcn_s_memtime() - c_loop;
         if (STATS) ++services;
         const unsigned long long t_service = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;

@@ -155,10 +155,6 @@ struct PersistentArgs {
     uint32_t* next_counter;   // the set to clear
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
-    // Lockstep with ONE early exit per batch (0 = plain lockstep): the wave leaves its loop when every ray that was already traversing when it last left
-    // has ended AND at most `carry` others still traverse. Those stragglers are carried into the next batch -- each ray once at most -- instead of
-    // idling the other lanes while they end: as many service phases as in lockstep, fewer trips (profiles/round5/tools/carry_stragglers_sim.py).
-    uint32_t carry;
     uint32_t stripe;          // the length of the stretches the sub-tiles are dealt out to the dispensers in (queue_subtile), at least 1
     // Expensive sub-tiles first. A ray is a chain of dependent steps -- about 0.8 us per iteration on a busy device -- so a frame cannot
     // end before its longest rays do (up to ~300 iterations against a mean of ~30): handed out in the order of their numbers they start in mid-frame

@@ -73,8 +73,6 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "s_mov_b64 exec, %[s_trav]\n"                                                                                              \
         COUNT    /* (also carries the FOREIGN builds' second exit) */                                                              \
         "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
-        "s_and_b64 %[s_save], vcc, %[s_old]\n"                   /* a ray carried over from the batch before still traverses: go on */      \
-        "s_cbranch_scc1 1b\n"                                                                                                      \
         "s_bcnt1_i32_b64 %[s_n], vcc\n"                                                                                            \
         "s_cmp_gt_u32 %[s_n], %[keep]\n"                                                                                           \
         "s_cbranch_scc1 1b\n"
@@ -245,7 +243,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 // passed a translucent voxel -- are rare and take the compiler's loop); kInsideVoxel is not maintained (nothing in a render reads it).
 template <int SVO, bool FOREIGN, bool COUNT, int LEVELS>
 __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image, const uint8_t* image_base, uint32_t lds_slot0, uint32_t lds_aux0, uint32_t keep_going,
-                                                     uint32_t foreign_waiting, uint32_t foreign_min, uint32_t& trips, unsigned long long carried_lanes = 0ull) {
+                                                     uint32_t foreign_waiting, uint32_t foreign_min, uint32_t& trips) {
     static_assert(SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE, "cursors on a traversal image");
     static_assert(LEVELS == 13 || LEVELS == 16, "stack layouts: Stack<64, true, true, 13>, Stack<64, true, true, 16, true>");
     constexpr bool UNITS = SVO == VX_SVO_IMAGE_WIDE;
@@ -271,7 +269,7 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
           [s_save] "=&s"(s_save), [s_n] "=&s"(s_n)                                                                                                         \
         : [tcx] "v"(tr.tcx), [tcy] "v"(tr.tcy), [tcz] "v"(tr.tcz), [tbx] "v"(tr.tbx), [tby] "v"(tr.tby), [tbz] "v"(tr.tbz), [om] "v"(uint32_t(tr.octant_mask)), \
           [lds] "v"(lds_slot0), [lds16] "v"(lds_aux0), [inf] "v"(0x7f800000u), [rsrc] "s"(image), [base] "s"(image_base), [keep] "s"(keep_going), [k_cell] "s"(k_cell),           \
-          [k_half] "s"(k_half), [entry_exec] "s"(entry_exec), [fmin] "s"(foreign_min), [s_old] "s"(carried_lanes)                                                                                               \
+          [k_half] "s"(k_half), [entry_exec] "s"(entry_exec), [fmin] "s"(foreign_min)                                                                                               \
         : "v" VX_A0, "v" VX_A1, "v" VX_E0, "v" VX_E1, "vcc", "scc", "memory"
 #define VX_LOOP_VARIANT(F, C, U, L)                                                                                                                        \
     if constexpr (FOREIGN == F && COUNT == C && UNITS == U && LEVELS == L)                                                                                  \
