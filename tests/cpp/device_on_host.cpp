@@ -144,16 +144,9 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
                 // the lean walk (walk_voxel_on_bytes): what it gives up on is run whole on the world's own bytes, like the render kernel does
                 // (3: the image-only render kernels' build -- phantom leaves of opaque blocks are hits without their sample, whose colour
                 // is sampled when the hit is shaded; any other phantom leaf is given up)
-                // (4, 5: the same two in instalments of two / one iterations -- the render kernel caps a walk per service phase and resumes it in the next)
                 bool color_pending = false;
-                WalkState ws = {};
-                const uint32_t cap = walk_mode == 4 ? 2u : (walk_mode == 5 ? 1u : 0u);
-                bool resume = false;
-                if (walk_mode == 3 || walk_mode == 5) {
-                    do {
-                        s = walk_voxel_on_bytes<IMG, FullStack, true, true, false>(sc, sc_bytes.world, tr, st, cast_translucent, res, g_opaque_lo, g_opaque_hi, &color_pending, &ws, cap, resume);
-                        resume = true;
-                    } while (s == kTravWalking);
+                if (walk_mode == 3) {
+                    s = walk_voxel_on_bytes<IMG, FullStack, true, true, false>(sc, sc_bytes.world, tr, st, cast_translucent, res, g_opaque_lo, g_opaque_hi, &color_pending);
                     if (s == kTravAtLeaf && color_pending) {
                         const vx_material mat = material_at(sc, res.value);
                         int tex_id = mat.tex_side;
@@ -162,10 +155,7 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
                         texture_lod(sc.tex, res.uv[0], res.uv[1], float(tex_id), res.lod, res.color);
                     }
                 } else {
-                    do {
-                        s = walk_voxel_on_bytes<IMG, FullStack, true, false, true>(sc, sc_bytes.world, tr, st, cast_translucent, res, 0u, 0u, nullptr, &ws, cap, resume);
-                        resume = true;
-                    } while (s == kTravWalking);
+                    s = walk_voxel_on_bytes<IMG, FullStack, true, false, true>(sc, sc_bytes.world, tr, st, cast_translucent, res);
                 }
                 if (given_up && s == kTravForeign) ++*given_up;
                 if (s == kTravForeign) {

@@ -207,7 +207,7 @@ def test_lean_walk_as_the_image_only_kernels_run_it(devhost, golden):
             opaque |= 1 << b
     devhost.devhost_set_opaque(opaque & 0xffffffff, opaque >> 32)
     devhost.devhost_given_up.restype = C.c_uint32
-    for walk_mode in (2, 3, 4, 5):  # (4, 5: the walks of 2 and 3 in instalments, as the render kernel makes them)
+    for walk_mode in (2, 3):
         for layout, shallow in ((1, True), (1, 2), (2, 2)):
             got, gsteps = image_cast(devhost, "csvo", world, mats.view(orc.MATERIAL_DTYPE), tex, 6, tasks, 1, layout, shallow, walk_mode=walk_mode)
             assert_same_casts(got, gsteps, exp, esteps)

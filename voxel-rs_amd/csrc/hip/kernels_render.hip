@@ -103,10 +103,7 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(SceneArgs sa, Ren
 // shows that `service_min` lanes are waiting (or nobody is left traversing); idle lanes are re-filled with new pixels
 // when `refill_min` of them are free. The common descend/advance/pop step therefore runs with most lanes active
 // instead of the ~30 % the one-thread-per-pixel kernel reached (profiles/round1/v1_*).
-enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4, kDeep = 5, kForeign = 6, kHeld = 7, kWalking = 8 };
-// (FOREIGN = VX_SVO_CSVO, kWalking: a walk inside a voxel that PersistentArgs::walk_cap put off to the next service phase. A phase costs what its slowest
-// walker costs -- a trip of the walk's loop is 3,000 cycles of dependent accesses --, two walks in three are over after two iterations, one in twenty takes
-// ten: without the cap a phase of 31 walkers made 11 trips.)
+enum LaneState : int { kIdle = 0, kTrav = 1, kLeaf = 2, kDone = 3, kMissed = 4, kDeep = 5, kForeign = 6, kHeld = 7 };
 static_assert(int(kTrav) == int(vxd::kTravContinue) && int(kLeaf) == int(vxd::kTravAtLeaf) && int(kMissed) == int(vxd::kTravFinished) &&
                   int(kDeep) == int(vxd::kTravDeep) && int(kForeign) == int(vxd::kTravForeign),
               "a TravStatus is stored as the lane's state");
@@ -245,7 +242,6 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
     float primary_rd[3] = {0, 0, 0};  // kept while a primary ray is in flight: the sky needs it if the ray misses (world.glsl:135-138)
     float keep_color[4] = {0, 0, 0, 0}, keep_ds = 0.0f;
     float held_t = -1.0f;  // FOREIGN = VX_SVO_CSVO: the distance of a shadow ray that ended inside its voxel (kHeld)
-    uint32_t walk_bp = 0, walk_hd = 0;  // FOREIGN = VX_SVO_CSVO: a walk that was put off (kWalking): its byte node, parent scale << 16 | header (WalkState)
     vx_hit rec;            // HITS only
     uint32_t steps = 0;    // HITS only
     Counters ctr = {};
@@ -302,7 +298,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
     for (;;) {
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
         // idle lanes are not waiting for anything; lanes that wait for company before their excursion (FOREIGN) are not waiting for service
-        const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle || (FOREIGN == VX_SVO_CSVO && (state == kForeign || state == kWalking)))));
+        const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle || (FOREIGN == VX_SVO_CSVO && state == kForeign))));
         // the loop goes on while more than this many lanes traverse (64 - popcount(trav) < park_limit, and trav != 0)
         const uint32_t keep_going = park_limit >= 64u ? 0u : 64u - park_limit;
         // (the lanes that traverse, as the wave's mask: one compare per trip serves the loop's exit test and the next trip's execution mask)
@@ -431,40 +427,28 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
         bool walk_phase = false;
         bool walked = false;  // this lane made a walk in this phase
         if (FOREIGN == VX_SVO_CSVO) {
-            // new walkers: the phase is theirs (below); walks that the cap put off go on in ANY phase and make none of their own
             const unsigned long long fm = __ballot(state == kForeign);
-            const unsigned long long wm = __ballot(state == kWalking);
             // (unlikely: tells the register allocator that what the walk needs may be spilled around it, not across the phase)
-            if (__builtin_expect((fm | wm) != 0ull, 0)) {
+            if (__builtin_expect(fm != 0ull, 0)) {
                 uint32_t on_bytes = 0;
                 bool given_up = false;
-                walk_phase = fm != 0ull;
+                walk_phase = true;
                 const unsigned long long c_walk = a.timeline ? __builtin_amdgcn_s_memtime() : 0ull;
-                if (state == kForeign || state == kWalking) {
-                    const bool resume = state == kWalking;
+                if (state == kForeign) {
                     walked = true;
                     tr.iter &= ~kParked;
                     const uint32_t before = tr.iter;
-                    WalkState ws = {walk_bp, walk_hd & 0xffffu, int(walk_hd >> 16)};
                     const TravStatus s = walk_voxel_on_bytes<SVO, FullStack, false, kOpaqueFastPath, !kOpaqueFastPath>(sc, make_buf(sa.world, clamp_u32(sa.world_bytes)), tr, st, true, res,
-                                                                                                                        p.opaque_lo, p.opaque_hi, &color_pending, &ws, a.walk_cap, resume);
+                                                                                                                        p.opaque_lo, p.opaque_hi, &color_pending);
                     on_bytes = tr.iter - before;
-                    if (s == kTravWalking) {  // to be continued in the next phase, whichever it is
-                        walk_bp = ws.bp;
-                        walk_hd = (uint32_t(ws.parent_scale) << 16) | (ws.hd & 0xffffu);
-                        state = kWalking;
-                        tr.iter |= kParked;
-                    } else {
-                        // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there / given up (the pixel's turn comes later)
-                        given_up = s == kTravForeign;
-                        state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep)
-                                                   : (s == kTravAtLeaf ? kDone : (s == kTravFinished ? kMissed : kIdle));
-                        if (state != kTrav) tr.iter |= kParked;
-                        // (in a phase of the walkers' own a shadow ray that ended in its voxel is held for the phase in which everybody is)
-                        if (walk_phase && shadow_ray && (state == kDone || state == kMissed)) {
-                            held_t = state == kDone ? res.t : -1.0f;
-                            state = kHeld;
-                        }
+                    // back on the image / a phantom leaf inside the voxel was hit / the ray ended in there / given up (the pixel's turn comes later)
+                    given_up = s == kTravForeign;
+                    state = s == kTravContinue ? (SHALLOW || tr.scale >= kFastFloor ? kTrav : kDeep)
+                                               : (s == kTravAtLeaf ? kDone : (s == kTravFinished ? kMissed : kIdle));
+                    if (state != kTrav) tr.iter |= kParked;
+                    if (shadow_ray && (state == kDone || state == kMissed)) {
+                        held_t = state == kDone ? res.t : -1.0f;
+                        state = kHeld;
                     }
                 }
                 if (a.timeline) {
@@ -502,7 +486,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                     unsigned long long sum = on_bytes;
                     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
                     if (lane == 0) {
-                        atomicAdd(&a.excursions[0], (unsigned long long)__popcll(fm));  // (rays led into a voxel: counted when their walk starts)
+                        atomicAdd(&a.excursions[0], (unsigned long long)__popcll(fm));
                         if (HITS && gm) atomicAdd(&a.excursions[1], (unsigned long long)__popcll(gm));  // (image-only renders: counted by list_rays)
                         atomicAdd(&a.excursions[2], 1ull);
                         atomicAdd(&a.excursions[3], sum);

@@ -155,7 +155,6 @@ struct PersistentArgs {
     uint32_t* next_counter;   // the set to clear
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
-    uint32_t walk_cap;        // images of deep CSVO worlds: iterations a walk inside a voxel makes per service phase before it is put off to the next (0: no cap)
     uint32_t stripe;          // the length of the stretches the sub-tiles are dealt out to the dispensers in (queue_subtile), at least 1
     // Expensive sub-tiles first. A ray is a chain of dependent steps -- about 0.8 us per iteration on a busy device -- so a frame cannot
     // end before its longest rays do (up to ~300 iterations against a mean of ~30): handed out in the order of their numbers they start in mid-frame

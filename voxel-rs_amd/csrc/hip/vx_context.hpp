@@ -133,7 +133,6 @@ struct vx_context {
     // served together (hits shaded, misses painted), then the shadow rays, then the pixels lit and stored and the next sub-tile taken (round 3:
     // 9.2 -> 10.9 Grays/s from 63 to 64, profiles/round3/pass_m, pass_o). Smaller values (lanes served when that many wait) are kept for the tests.
     uint32_t refill_min = 4, service_min = 64;
-    uint32_t walk_cap = 4;  // PersistentArgs::walk_cap
     int tile_strip = 8;  // VX_TILE_STRIP: tile numbering 1's strips are this many tiles wide
     int tile_numbering = 1;  // VX_TILE_NUMBERING: how a whole-image render's tile numbers lie on the screen (RenderParams::tile_numbering)
     int queue_stripe = 0;  // VX_QUEUE_STRIPE: the length of the stretches the sub-tile queue deals out to its dispensers (0: by the launch, launch_render)

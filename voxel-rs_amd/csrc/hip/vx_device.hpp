@@ -524,8 +524,7 @@ __device__ __forceinline__ void texture_lod_pair(const DevTextures& t, const Tex
 // excursion on the world's own bytes and bring it back to the image (walk_voxel_on_bytes). The iteration is repeated there: the
 // caller takes `iter` back by one, as for kTravDeep. (An ESVO world's image needs none of this: see the PUSH in step_with.)
 // (the values are the render kernel's lane states -- kTrav, kLeaf, kMissed, kDeep, kForeign -- so that it can store a status as is)
-// kTravWalking (walk_voxel_on_bytes with a cap only): the walk inside the voxel is not over; its state is in the caller's WalkState.
-enum TravStatus : int { kTravContinue = 1, kTravAtLeaf = 2, kTravFinished = 4, kTravDeep = 5, kTravForeign = 6, kTravWalking = 8 };
+enum TravStatus : int { kTravContinue = 1, kTravAtLeaf = 2, kTravFinished = 4, kTravDeep = 5, kTravForeign = 6 };
 enum LeafOutcome : int { kLeafHit = 0, kLeafPassed = 1, kLeafPassedAndFinished = 2 };
 
 // Debug-trace state (trace kernel only): the output frames, and the reference's (ptr, parent_octant_idx) view of the
@@ -1195,31 +1194,18 @@ struct Trav {
 // whose value is in the host's set of blocks that are opaque throughout -- `opaque_lo/hi`, RenderParams -- is a hit without its sample,
 // as in the kernel's own leaf tests, and `*color_pending` says that its colour is still to be sampled), kTravFinished (a miss) or
 // kTravForeign (given up).
-// A walk in instalments (`max_trips` > 0; the render kernel: a service phase costs what its slowest walker costs, and two walks in three are over after
-// two iterations while one in twenty takes ten): after that many iterations the walk stops where it is -- kTravWalking, its byte cursor in `ws` -- and
-// the next call with `resume` goes on from there: the same iterations in the same order, across calls. (Everything else of the state is the image
-// cursor `tr` and the stack; the voxel's parent is found again in the stack slot the walk's first iteration wrote.)
-struct WalkState {
-    uint32_t bp, hd;   // the byte node the walk examines and its header (2 bits per child)
-    int parent_scale;  // the scale of the voxel's parent
-};
 template <int IMGSVO, class ST, bool LIMIT = false, bool OPAQUE = false, bool FULL_LEAF = true>
 __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, buf_t world, Trav<IMGSVO>& tr, const ST& st, bool cast_translucent,
-                                                          Result& res, uint32_t opaque_lo = 0u, uint32_t opaque_hi = 0u, bool* color_pending = nullptr,
-                                                          WalkState* ws = nullptr, uint32_t max_trips = 0u, bool resume = false) {
+                                                          Result& res, uint32_t opaque_lo = 0u, uint32_t opaque_hi = 0u, bool* color_pending = nullptr) {
     static_assert(!ST::kFast, "the walk needs the levels below the voxel");
     typedef Trav<IMGSVO> T;
     auto u32_at = [&](uint32_t p) -> uint32_t { return buf_u32(world, 8u + csvo_clamp(p)); };
-    const int parent_scale = resume ? ws->parent_scale : tr.scale;
-    uint32_t img_ptr = tr.ptr, img_node = tr.node;
-    if (resume) {  // (a resumed walk is below the voxel's parent: its image entry is what the first iteration left in the parent's slot)
-        float unused;
-        st.pop(parent_scale, img_ptr, unused, img_node);
-    }
+    const int parent_scale = tr.scale;
+    const uint32_t img_ptr = tr.ptr, img_node = tr.node;
     // origin table: [0] = byte pointer of L, [1] = k << 29 | (L - material section), k = L's place among its depth-2 parent's leaf-mask bytes
-    const uint64_t unit = T::WIDE ? uint64_t(img_ptr) : uint64_t(img_ptr >> 5);
+    const uint64_t unit = T::WIDE ? uint64_t(tr.ptr) : uint64_t(tr.ptr >> 5);
     const uint32_t o0 = mem_u32(img.origin + unit * 8u), o1 = mem_u32(img.origin + unit * 8u + 4u);
-    uint32_t bp = resume ? ws->bp : o0;  // the byte node the cursor examines: L first
+    uint32_t bp = o0;  // the byte node the cursor examines: L first
     // its header in the 2-bits-per-child form (tag 01 per present child of a 1-bit level, csvo_header()): L's is the image node's child mask
     // (child c at bit 31 - c there)
     auto spread8 = [](uint32_t x) -> uint32_t {
@@ -1227,9 +1213,8 @@ __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, b
         x = (x | (x << 2)) & 0x3333u;
         return (x | (x << 1)) & 0x5555u;
     };
-    uint32_t hd = resume ? ws->hd : spread8(rev_bits32(img_node) & 0xffu);
+    uint32_t hd = spread8(rev_bits32(img_node) & 0xffu);
     if (tr.iter >= uint32_t(kMaxSteps)) return kTravFinished;
-    uint32_t trips = 0;
     // One iteration is ONE stretch of code for every lane: the PUSH's and the ADVANCE / POP's values are both worked out and the cursor takes one set
     // or the other by selects; only the memory operations (table entry, child header, stack slot) sit under their lanes' predicate, and a lane whose
     // walk ends notes how (`status`) and leaves at the bottom. Round 4's first form -- the reference's if / else if tree with a return wherever
@@ -1328,12 +1313,6 @@ __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, b
         hd = push ? child_hd : (pop ? a >> 16 : hd);
         if (!out && tr.iter >= uint32_t(kMaxSteps)) { status = kTravFinished; out = true; }
         if (out) break;
-        if (max_trips && ++trips >= max_trips) {  // to be continued
-            ws->bp = bp;
-            ws->hd = hd;
-            ws->parent_scale = parent_scale;
-            return kTravWalking;
-        }
     }
     return status;
 }
