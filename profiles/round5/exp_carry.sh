@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the code this script drove was built in commit e67b562 and reverted: profiles/round5/pass_a/carry.txt)
 # lockstep with one early exit per batch: VX_CARRY = stragglers carried into the next batch (0 = plain lockstep)
 B="python bench.py --steps 20 --warmup 5 --repeats 9 --no-cpu-baseline --no-extras --sustained-seconds 1"
 j() { python -c "

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the code this script drove was built in commit 00107c1 and reverted: profiles/round5/pass_a/walk_cap.txt)
 # deep CSVO worlds: walks inside voxels in instalments of VX_EXP_WALK_CAP iterations per service phase (0 = whole, as round 4)
 for cap in 0 2 3 4 6 8; do
   VX_EXP_WALK_CAP=$cap python profiles/configs_bench.py --format csvo --configs C4-d13 C4 C5 2>/dev/null | python -c "
