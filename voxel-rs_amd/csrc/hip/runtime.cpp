@@ -437,7 +437,7 @@ int upload_big(vx_context* ctx, const std::vector<Upload>& up) {
             if (b.done) (void)hipEventDestroy(b.done);
         }
     };
-    const unsigned workers = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const unsigned workers = std::max(1u, std::min(8u, vximg::granted_cpus()));
     int next = 0;
     for (const Upload& u : up) {
         if (!u.bytes) continue;
@@ -884,6 +884,22 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         }
     }
 
+    // A context's FIRST commit of a large world: the world's own bytes leave for the device now -- the staging mirror is pinned, the copies are the
+    // DMA engine's -- and travel while the image is built below (a second of host work for the depth-14 terrain), instead of queueing behind it.
+    // (No frame can be in flight before the first commit; the caller's mirror stays untouched until upload_big's final wait.)
+    bool world_sent_ahead = false;
+    if (!ctx->committed) {
+        uint64_t world_total = 0;
+        for (const Upload& u : up) world_total += u.bytes;
+        if (world_total > kDeltaLimit) {
+            VX_LOCK(ctx);
+            for (const Upload& u : up)
+                if (u.bytes) HIP_TRY(hipMemcpyAsync(u.dst, u.src, u.bytes, hipMemcpyHostToDevice, ctx->upload_stream));
+            up.clear();
+            world_sent_ahead = true;
+        }
+    }
+
     bool image_ok = false;
     if (ctx->image_enabled && ctx->kernel_version != 1) {
         // re-lay the changed chunks (and the root octree, which every commit rewrites) out as octants
@@ -891,7 +907,7 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         for (uint32_t i = 0; i < count; ++i) changed[i] = vximg::Range{ranges[i].start, ranges[i].length};
         // (up to 32 workers for the chunk walk of a whole world, 16 for its encoding; WorldImage::update takes no more than a sixteenth of the chunks
         // it has to walk, so an incremental commit stays on a few)
-        const unsigned threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        const unsigned threads = std::max(1u, std::min(32u, vximg::granted_cpus()));
         // A world whose image will not fit 32-bit byte offsets starts in the wide layout instead of finding that out at the end of a whole
         // build (an image is about 0.84 x the bytes of an ESVO world, 3.9 x those of a CSVO world; the wide layout serves any size)
         if (ctx->image.chunk_count() == 0 && ctx->image.layout() == vximg::kOct64 &&
@@ -980,6 +996,8 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         rc = wait_for_frames();
         if (rc == VX_OK) rc = upload_big(ctx, up);
     }
+    // (the copies out of the caller's mirror that were sent ahead must have read it before the caller may write it again; upload_big has waited)
+    if (rc == VX_OK && world_sent_ahead && total <= kDeltaLimit && hipStreamSynchronize(ctx->upload_stream) != hipSuccess) rc = fail(VX_ERR_HIP, "commit: upload failed");
     if (rc != VX_OK) {
         // the device copy of the image can no longer be trusted; the world's own bytes may be incomplete too, which the caller
         // learns from the error -- a later commit of the same ranges repairs both
@@ -1403,7 +1421,7 @@ uint64_t vx_traversal_image_with_origin(int svo_type, const uint8_t* world_frame
                                         uint64_t capacity_words, uint32_t* out_origin_words, uint64_t origin_capacity_words) {
     if (!world_frame || layout < 0 || layout > 2 || (svo_type != VX_SVO_ESVO && svo_type != VX_SVO_CSVO)) return 0;
     vximg::WorldImage img(svo_type, layout == 0 ? vximg::kEsvo48 : (layout == 1 ? vximg::kOct64 : vximg::kOct64Wide));
-    if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(32u, std::thread::hardware_concurrency())))) return 0;
+    if (!img.update(world_frame, used_bytes, nullptr, 0, std::max(1u, std::min(32u, vximg::granted_cpus())))) return 0;
     const vximg::ZeroedWords& f = img.frame();
     if (out_words && capacity_words >= f.size()) std::memcpy(out_words, f.data(), f.size() * 4);
     const vximg::ZeroedWords& o = img.origin();
