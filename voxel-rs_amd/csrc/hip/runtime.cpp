@@ -884,22 +884,6 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         }
     }
 
-    // A context's FIRST commit of a large world: the world's own bytes leave for the device now -- the staging mirror is pinned, the copies are the
-    // DMA engine's -- and travel while the image is built below (a second of host work for the depth-14 terrain), instead of queueing behind it.
-    // (No frame can be in flight before the first commit; the caller's mirror stays untouched until upload_big's final wait.)
-    bool world_sent_ahead = false;
-    if (!ctx->committed) {
-        uint64_t world_total = 0;
-        for (const Upload& u : up) world_total += u.bytes;
-        if (world_total > kDeltaLimit) {
-            VX_LOCK(ctx);
-            for (const Upload& u : up)
-                if (u.bytes) HIP_TRY(hipMemcpyAsync(u.dst, u.src, u.bytes, hipMemcpyHostToDevice, ctx->upload_stream));
-            up.clear();
-            world_sent_ahead = true;
-        }
-    }
-
     bool image_ok = false;
     if (ctx->image_enabled && ctx->kernel_version != 1) {
         // re-lay the changed chunks (and the root octree, which every commit rewrites) out as octants
@@ -996,8 +980,6 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         rc = wait_for_frames();
         if (rc == VX_OK) rc = upload_big(ctx, up);
     }
-    // (the copies out of the caller's mirror that were sent ahead must have read it before the caller may write it again; upload_big has waited)
-    if (rc == VX_OK && world_sent_ahead && total <= kDeltaLimit && hipStreamSynchronize(ctx->upload_stream) != hipSuccess) rc = fail(VX_ERR_HIP, "commit: upload failed");
     if (rc != VX_OK) {
         // the device copy of the image can no longer be trusted; the world's own bytes may be incomplete too, which the caller
         // learns from the error -- a later commit of the same ranges repairs both
