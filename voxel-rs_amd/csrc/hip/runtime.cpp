@@ -634,7 +634,6 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         c->image = vximg::WorldImage(svo_type, wide_image ? vximg::kOct64Wide : vximg::kOct64, wide_image == 2 ? (uint64_t(5) << 30) / 4 : 0);
         if (const char* e = std::getenv("VX_COMM_HEADROOM")) c->comm_headroom = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("VX_SERVICE_MIN")) c->service_min = uint32_t(std::atoi(e));
-        if (const char* e = std::getenv("VX_EXP_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));  // (experiment)
         if (const char* e = std::getenv("VX_TILE_NUMBERING")) c->tile_numbering = std::atoi(e);
         // The knobs of experiments exist in the library's MEASUREMENT build only (make tl: lib/lib_tl, loaded through VX_LIB_DIR by
         // profiles/timeline.py, profiles/sweep.py and the tests that vary them): the wave timeline, the order table off, the refill threshold,
