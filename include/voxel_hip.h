@@ -371,7 +371,7 @@ int vx_comm_profile_read(vx_context* ctx, double* gather_ms_sum, uint32_t* gathe
  * EIGHT words -- [0] when it started, [1] when it found the sub-tile queue empty, [2] when it left (all in 10 ns ticks of the device's
  * constant clock), [3] sub-tiles taken | service phases << 20 | ticks spent in them << 32, [4] its life in shader-clock cycles
  * (s_memtime: [4] / ([2] - [0]) x 100 MHz is the clock the kernel ran at), [5] the cycles of it spent in the traversal loop, [6] the
- * loop's trips, [7] the walks inside voxels (images of CSVO worlds): walk phases << 52 | trips of the walk's loop << 32 | shader-clock cycles
+ * loop's trips | those in which every traversing lane ADVANCEd << 20 | those in which every one PUSHed << 40 (20 bits each), [7] the walks inside voxels (images of CSVO worlds): walk phases << 52 | trips of the walk's loop << 32 | shader-clock cycles
  * in the walks. `out` holds capacity_waves x 8 words. Returns the number of waves copied. Waits for every frame in flight. */
 uint32_t vx_timeline_read(vx_context* ctx, uint64_t* out, uint32_t capacity_waves);
 /* What vx_render walks after the last commit: [0] 0 = the world's own bytes (no image: switched off, or the world cannot be

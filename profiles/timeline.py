@@ -50,7 +50,12 @@ def main():
     svo.sync()
     ms, launches = svo.profile_read()
     svo.profile_enable(False)
-    t = svo.timeline().astype(np.float64)
+    raw = svo.timeline()
+    # row[6]: trips | ADVANCE-only trips << 20 | PUSH-only trips << 40 (the hand-scheduled loop's cheap tails)
+    r6 = raw[:, 6].copy()
+    adv_only, push_only = ((r6 >> np.uint64(20)) & np.uint64(0xfffff)).astype(np.float64), ((r6 >> np.uint64(40)) & np.uint64(0xfffff)).astype(np.float64)
+    raw[:, 6] = r6 & np.uint64(0xfffff)
+    t = raw.astype(np.float64)
     t0 = t[:, 0].min()
     start, empty, leave = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0  # microseconds
     q = lambda a: [round(float(np.percentile(a, p)), 1) for p in (0, 10, 50, 90, 99, 100)]
@@ -68,6 +73,9 @@ def main():
                       "clock_mhz": q(t[:, 4] / np.maximum(t[:, 2] - t[:, 0], 1.0) * 100.0),
                       "loop_share_of_wave_life": q(t[:, 5] / np.maximum(t[:, 4], 1.0)),
                       "loop_trips_per_wave": q(t[:, 6]),
+                      # of a frame's trips: every traversing lane ADVANCEs / every one PUSHes / both kinds (the merged tail, 22-31 instructions longer)
+                      "trips_by_tail_advance_only_push_only_merged": [round(float(adv_only.sum() / max(t[:, 6].sum(), 1.0)), 3), round(float(push_only.sum() / max(t[:, 6].sum(), 1.0)), 3),
+                                                                      round(float(1.0 - (adv_only.sum() + push_only.sum()) / max(t[:, 6].sum(), 1.0)), 3)],
                       "cycles_per_trip_as_a_wave_sees_it": q(t[:, 5] / np.maximum(t[:, 6], 1.0)),
                       "cycles_per_trip_mean": round(float(t[:, 5].sum() / max(t[:, 6].sum(), 1.0)), 1),
                       "simd_cycles_per_trip_at_4_waves": round(float(t[:, 5].sum() / max(t[:, 6].sum(), 1.0)) / 4.0, 1),

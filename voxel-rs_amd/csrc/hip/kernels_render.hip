@@ -258,6 +258,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
     const unsigned long long c_start = a.timeline ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long loop_cycles = 0ull;
     uint32_t loop_trips = 0;
+    unsigned long long loop_tails = 0ull;  // timeline only: of the hand-scheduled loop's trips, those that took its ADVANCE-only tail | its PUSH-only tail << 32
     // the sub-tile queue: a ticket is this launch's sub-tile number (lane 0's value counts)
     // Wave w = 8 j + c starts on dispenser c's j-th sub-tile without asking: 4096 waves do not open the frame by queueing at the counters. The
     // dispenser hands out its sub-tiles from there on.
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                 // in the same trip; the build that lists such rays instead never waits for anything)
                 const uint32_t f_waiting = FOREIGN == VX_SVO_CSVO ? uint32_t(__popcll(__ballot(state == kForeign))) : 0u;
                 const uint32_t f_min = FOREIGN == VX_SVO_CSVO ? 1u : 0xffffffffu;
-                if (a.timeline) traverse_loop_gfx950<SVO, FOREIGN != 0, true, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips);
+                if (a.timeline) traverse_loop_gfx950<SVO, FOREIGN != 0, true, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips, &loop_tails);
                 else traverse_loop_gfx950<SVO, FOREIGN != 0, false, LV>(tr, sc.world, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips);
                 // a lane the loop parked says why in bits 28..30 of its iteration count
                 const uint32_t why = (tr.iter >> 28) & 7u;
@@ -671,7 +672,9 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
         unsigned long long* row = a.timeline + size_t(blockIdx.x) * 8;
         row[0] = t_start; row[1] = t_empty; row[2] = __builtin_amdgcn_s_memrealtime();
         row[3] = taken | ((unsigned long long)(service_phases & 0xfffu) << 20) | ((unsigned long long)in_service << 32);  // sub-tiles, service phases, ticks spent in them
-        row[4] = __builtin_amdgcn_s_memtime() - c_start; row[5] = loop_cycles; row[6] = loop_trips;
+        row[4] = __builtin_amdgcn_s_memtime() - c_start; row[5] = loop_cycles;
+        // trips of the loop | of which every lane ADVANCEd << 20 | of which every lane PUSHed << 40 (the hand-scheduled loop's cheap tails)
+        row[6] = (unsigned long long)(loop_trips & 0xfffffu) | ((loop_tails & 0xfffffull) << 20) | (((loop_tails >> 32) & 0xfffffull) << 40);
         row[7] = ((unsigned long long)(walk_phases & 0xfffu) << 52) | ((unsigned long long)(walk_trips & 0xfffffu) << 32) | walk_cycles;  // the walks inside voxels: phases, trips of their loop, cycles
     }
     // ---- second phase (image-only renders of a CSVO world): the rays this wave listed, on the world's own bytes ----

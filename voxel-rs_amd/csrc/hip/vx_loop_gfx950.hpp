@@ -55,6 +55,9 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 #define VX_TAKE_ENTRY_ESVO_UNITS "v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[ptr], 0, v" VX_E0 ", vcc\n v_cndmask_b32_e32 %[node], 0, v" VX_E1 ", vcc\n"
 #define VX_TAKE_ENTRY_CSVO "v_mov_b32_e32 %[ptr], v" VX_E0 "\n v_mov_b32_e32 %[node], v" VX_E1 "\n"
 #define VX_COUNT_TRIP "s_add_u32 %[trips], %[trips], 1\n"
+// (measurement build: which tail a trip took, in ten-bit fields of the same counter -- a loop call makes at most kMaxSteps = 1000 trips)
+#define VX_COUNT_TRIP_ADVANCE_ONLY "s_add_u32 %[trips], %[trips], 0x401\n"
+#define VX_COUNT_TRIP_PUSH_ONLY "s_add_u32 %[trips], %[trips], 0x100001\n"
 // the entry of child `oct` of the octant at `ptr`: a byte offset through a raw buffer resource (out of range reads 0: any `ptr` is
 // harmless) | (images beyond 4 GiB, which no buffer resource reaches -- a structured one wraps at 4 GiB too, measured) an octant index in
 // 32-byte units: entry 4 * ptr + oct (the image is smaller than 32 GiB) behind a 64-bit base, so `ptr` has to stay a valid octant
@@ -93,7 +96,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 // one ADVANCEs. The trip therefore has three tails behind its common part (the child, the entry request, the plane distances, the leaf
 // exits, the PUSH mask): the merged one (both kinds of lane), and the two it degenerates to when the mask is all or none -- 31 and 22
 // instructions shorter, the ADVANCE-only one without the wait for the entry it requested for nothing.
-#define VX_LOOP_ASM(LEAF_EXITS, TAKE_MASKS, COUNT, LOAD_ENTRY, STACK_WRITE, STACK_READ)                                            \
+#define VX_LOOP_ASM(LEAF_EXITS, TAKE_MASKS, COUNT, COUNT_A, COUNT_P, LOAD_ENTRY, STACK_WRITE, STACK_READ)                          \
         "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
         "s_cmp_eq_u64 vcc, 0\n"                                                                                                    \
         "s_cbranch_scc1 9f\n"                                                                                                      \
@@ -201,7 +204,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         VX_TRIP_POP(STACK_READ)                                                                                                    \
         "s_waitcnt lgkmcnt(0)\n"                                                                                                   \
         "6:\n"                                                                                                                     \
-        VX_LOOP_CONTROL(COUNT)                                                                                                     \
+        VX_LOOP_CONTROL(COUNT_A)                                                                                                   \
         "s_branch 9f\n"                                                                                                            \
         /* ======== every lane PUSHes ======== */                                                                                  \
         "5:\n"                                                                                                                     \
@@ -227,7 +230,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
         TAKE_MASKS                                                                                                                 \
-        VX_LOOP_CONTROL(COUNT)                                                                                                     \
+        VX_LOOP_CONTROL(COUNT_P)                                                                                                   \
         "9:\n"                                                                                                                     \
         /* (the ADVANCE-only tail leaves its entry request in flight: it must have landed before the compiler's code reuses the pair -- */ \
         /* where every register is in use it did not always: one pixel in a few frames differed) */                                    \
@@ -243,7 +246,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 // passed a translucent voxel -- are rare and take the compiler's loop); kInsideVoxel is not maintained (nothing in a render reads it).
 template <int SVO, bool FOREIGN, bool COUNT, int LEVELS>
 __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image, const uint8_t* image_base, uint32_t lds_slot0, uint32_t lds_aux0, uint32_t keep_going,
-                                                     uint32_t foreign_waiting, uint32_t foreign_min, uint32_t& trips) {
+                                                     uint32_t foreign_waiting, uint32_t foreign_min, uint32_t& trips, unsigned long long* tails = nullptr) {
     static_assert(SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE, "cursors on a traversal image");
     static_assert(LEVELS == 13 || LEVELS == 16, "stack layouts: Stack<64, true, true, 13>, Stack<64, true, true, 16, true>");
     constexpr bool UNITS = SVO == VX_SVO_IMAGE_WIDE;
@@ -274,7 +277,8 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
 #define VX_LOOP_VARIANT(F, C, U, L)                                                                                                                        \
     if constexpr (FOREIGN == F && COUNT == C && UNITS == U && LEVELS == L)                                                                                  \
         asm volatile(VX_LOOP_ASM(VX_LOOP_PICK_##F(VX_LEAF_EXITS_CSVO, VX_LEAF_EXITS_ESVO), VX_LOOP_PICK_##F(VX_TAKE_ENTRY_CSVO, VX_LOOP_PICK_##U(VX_TAKE_ENTRY_ESVO_UNITS, VX_TAKE_ENTRY_ESVO_BYTES)),          \
-                                 VX_LOOP_PICK_##C(VX_COUNT_TRIP, "") VX_LOOP_PICK_##F(VX_FOREIGN_EXIT, ""), VX_LOOP_PICK_##U(VX_LOAD_ENTRY_UNITS, VX_LOAD_ENTRY_BYTES),                          \
+                                 VX_LOOP_PICK_##C(VX_COUNT_TRIP, "") VX_LOOP_PICK_##F(VX_FOREIGN_EXIT, ""), VX_LOOP_PICK_##C(VX_COUNT_TRIP_ADVANCE_ONLY, "") VX_LOOP_PICK_##F(VX_FOREIGN_EXIT, ""),     \
+                                 VX_LOOP_PICK_##C(VX_COUNT_TRIP_PUSH_ONLY, "") VX_LOOP_PICK_##F(VX_FOREIGN_EXIT, ""), VX_LOOP_PICK_##U(VX_LOAD_ENTRY_UNITS, VX_LOAD_ENTRY_BYTES),                 \
                                  VX_STACK_WRITE_##L, VX_STACK_READ_##L) VX_LOOP_OPERANDS)
 #define VX_LOOP_PICK_true(a, b) a
 #define VX_LOOP_PICK_false(a, b) b
@@ -296,7 +300,13 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
 #undef VX_LOOP_PICK_true
 #undef VX_LOOP_PICK_false
 #undef VX_LOOP_OPERANDS
-    trips += n_trips;
+    if constexpr (COUNT) {
+        // (measurement build) n_trips = trips | ADVANCE-only trips << 10 | PUSH-only trips << 20 of this call; *tails accumulates the two kinds in 32-bit halves
+        trips += n_trips & 0x3ffu;
+        if (tails) *tails += (unsigned long long)((n_trips >> 10) & 0x3ffu) | ((unsigned long long)((n_trips >> 20) & 0x3ffu) << 32);
+    } else {
+        trips += n_trips;
+    }
     tr.px = __uint_as_float(px); tr.py = __uint_as_float(py); tr.pz = __uint_as_float(pz);
     tr.scale = int(scale);
     tr.scale_exp2 = pow2i(tr.scale - kMaxScale);  // (the loop derives the cell size from the scale; the service phases read the member)
