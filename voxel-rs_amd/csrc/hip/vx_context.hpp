@@ -133,8 +133,8 @@ struct vx_context {
     // served together (hits shaded, misses painted), then the shadow rays, then the pixels lit and stored and the next sub-tile taken (round 3:
     // 9.2 -> 10.9 Grays/s from 63 to 64, profiles/round3/pass_m, pass_o). Smaller values (lanes served when that many wait) are kept for the tests.
     // refill_min = 64 (round 5): idle lanes are refilled when ALL of the wave's lanes are -- a sub-tile at a time, so that no batch mixes the next
-    // sub-tile's primary rays with this one's shadow rays: the lanes of a pure batch walk the tree together and most trips of the loop take its
-    // PUSH-only or ADVANCE-only tail (4 -> 64: C3 -1.1 %, 4K depth 13 -1.6 %, profiles/round5/pass_a/refill.txt). Smaller: the measurement build's VX_REFILL_MIN.
+    // sub-tile's primary rays with this one's shadow rays, and no service phase has to shade AND light (4 -> 64: C3 -1.1 %, 4K depth 13 -1.6 %,
+    // profiles/round5/pass_a/refill.txt, tails_detail.txt). Smaller: the measurement build's VX_REFILL_MIN.
     uint32_t refill_min = 64, service_min = 64;
     int tile_strip = 8;  // VX_TILE_STRIP: tile numbering 1's strips are this many tiles wide
     int tile_numbering = 1;  // VX_TILE_NUMBERING: how a whole-image render's tile numbers lie on the screen (RenderParams::tile_numbering)

@@ -92,8 +92,8 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_mov_b32_e32 %[h], 0\n"                                                                                                  \
         "v_cmpx_lt_u32_e32 vcc, 22, %[sc]\n"                     /* out of the octree */                                           \
         "v_add_u32_e32 %[iter], 0xc0000000, %[iter]\n"           /* parked | kTravFinished << 28 */
-// The rays of a sub-tile's 64 pixels walk the upper levels of the tree together: in most trips every traversing lane PUSHes, or every
-// one ADVANCEs. The trip therefore has three tails behind its common part (the child, the entry request, the plane distances, the leaf
+// The rays of a sub-tile's 64 pixels walk the upper levels of the tree together: in a fifth of the trips every traversing lane PUSHes, or every
+// one ADVANCEs (measured, C3 in lockstep: 11.4 % / 10.7 %, profiles/round5/pass_a/tails.txt). The trip therefore has three tails behind its common part (the child, the entry request, the plane distances, the leaf
 // exits, the PUSH mask): the merged one (both kinds of lane), and the two it degenerates to when the mask is all or none -- 31 and 22
 // instructions shorter, the ADVANCE-only one without the wait for the entry it requested for nothing.
 #define VX_LOOP_ASM(LEAF_EXITS, TAKE_MASKS, COUNT, COUNT_A, COUNT_P, LOAD_ENTRY, STACK_WRITE, STACK_READ)                          \
