@@ -1,4 +1,5 @@
 #!/bin/bash
+# (drove code that was built, measured and reverted: commit 7f12221 -- check it out to run this)
 # shadow rays deferred against lockstep, wave by wave (measurement build, C3 ESVO, one frame at a time): trips, phases, where the time is
 for cfg in "0 192 32" "1 256 32" "1 256 16" "1 128 32"; do
   set -- $cfg

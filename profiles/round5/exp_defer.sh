@@ -1,4 +1,5 @@
 #!/bin/bash
+# (drove code that was built, measured and reverted: commit 7f12221 -- check it out to run this)
 # shadow rays deferred (PersistentArgs::shadow_queue): off / on, the number of records a wave collects before it traces them, the lanes that must
 # have ended before it serves / refills. The measurement build reads the knobs.
 export VX_LIB_DIR=$PWD/voxel-rs_amd/lib/lib_tl

@@ -250,18 +250,6 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
 
     uint32_t cursor = 64, sub = 0;  // wave-uniform: position inside the current sub-tile
     bool queue_empty = false;
-    // Shadow rays deferred (PersistentArgs::shadow_queue). Lockstep keeps a sub-tile's 64 lanes together until its slowest ray has ended, and a sub-tile's
-    // SHADOW rays are the worst case of that: more than half of them are occluded and end within 14 iterations, the others march 50 -- 47 % of
-    // the lane slots of those batches do anything (profiles/round5/pass_a/trips_sim.txt). Refilling freed lanes with the next sub-tile's primary
-    // rays costs more than it gives (a wave out of step runs every service path in every phase, each for a fraction of its lanes); refilling them
-    // with MORE SHADOW RAYS does not mix anything: a shaded pixel's lane notes the pixel and is free, the wave goes on with the next sub-tile's
-    // primary rays in lockstep, and when enough records have come together it traces shadow rays only -- 64 at a time, the lanes of rays that
-    // have ended refilled from the queue -- whose service phases run the one path of a shadow ray that has ended. Which lane traces a ray changes
-    // nothing of it: pixels are bit for bit those of the lockstep build (the kernels with hit records keep a pixel's two rays in its lane).
-    constexpr bool DEFER = IMAGE && !HITS && !STATS && !HOT && FOREIGN != VX_SVO_CSVO;
-    uint32_t* const shadow_q = DEFER && a.shadow_queue ? a.shadow_queue + size_t(blockIdx.x) * (kShadowQueueCap * kRayRecordDwords) : nullptr;
-    uint32_t q_count = 0, q_head = 0;  // wave-uniform: records noted / handed to lanes
-    bool shadow_mode = false;          // wave-uniform: the wave is tracing its queue
     const unsigned long long t_start = a.timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long t_empty = 0ull;
     uint32_t taken = 0;
@@ -311,7 +299,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
     for (;;) {
         // ---- traverse until enough lanes wait for service (none are traversing on the first trip) ----
         // idle lanes are not waiting for anything; lanes that wait for company before their excursion (FOREIGN) are not waiting for service
-        const uint32_t park_limit = ((DEFER && shadow_mode) ? a.defer_service : a.service_min) + uint32_t(__popcll(__ballot(state == kIdle || (FOREIGN == VX_SVO_CSVO && state == kForeign))));
+        const uint32_t park_limit = a.service_min + uint32_t(__popcll(__ballot(state == kIdle || (FOREIGN == VX_SVO_CSVO && state == kForeign))));
         // the loop goes on while more than this many lanes traverse (64 - popcount(trav) < park_limit, and trav != 0)
         const uint32_t keep_going = park_limit >= 64u ? 0u : 64u - park_limit;
         // (the lanes that traverse, as the wave's mask: one compare per trip serves the loop's exit test and the next trip's execution mask)
@@ -552,9 +540,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
 
         // ---- finished rays ----
         VX_PART_BEGIN(2);
-        // (deferred shadow rays end among rays of other sub-tiles: a sub-tile's cost is its primary rays' then)
-        note_cost_wave(a, p, state == kDone && serve && !(DEFER && shadow_q && shadow_ray), out_index, tr.iter & ~kParked);
-        bool deferred = false;  // DEFER: this lane's pixel was shaded in this phase and its shadow ray goes to the wave's queue
+        note_cost_wave(a, p, state == kDone && serve, out_index, tr.iter & ~kParked);
         if (state == kDone && serve) {
             float color[4];
             bool write = true;
@@ -580,14 +566,9 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                         keep_ds = o.ds;
                         new_ro[0] = o.shadow_origin[0]; new_ro[1] = o.shadow_origin[1]; new_ro[2] = o.shadow_origin[2];
                         new_rd[0] = -p.u.light_dir[0]; new_rd[1] = -p.u.light_dir[1]; new_rd[2] = -p.u.light_dir[2];
+                        new_ray = true;
+                        shadow_ray = true;
                         write = false;
-                        if (DEFER && shadow_q) {
-                            deferred = true;
-                            state = kIdle;
-                        } else {
-                            new_ray = true;
-                            shadow_ray = true;
-                        }
                         if (STATS) { ctr.rays++; ++shadow_rays; }
                     }
                 }
@@ -610,30 +591,11 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
             }
         }
 
-        if (DEFER && shadow_q) {
-            const unsigned long long dm = __ballot(deferred);
-            if (dm) {
-                if (deferred) {
-                    uint4* w = reinterpret_cast<uint4*>(shadow_q + size_t(q_count + rank_in(dm)) * kRayRecordDwords);
-                    w[0] = make_uint4(out_index, fbits(new_ro[0]), fbits(new_ro[1]), fbits(new_ro[2]));
-                    w[1] = make_uint4(fbits(keep_color[0]), fbits(keep_color[1]), fbits(keep_color[2]), fbits(keep_color[3]));
-                    w[2] = make_uint4(fbits(keep_ds), 0u, 0u, 0u);
-                }
-                q_count += uint32_t(__popcll(dm));
-            }
-            // the wave's queue has been traced to its end: primary rays again, from this phase on -- or enough has come together: shadow rays from here
-            const bool all_idle = __ballot(state != kIdle) == 0ull;
-            if (shadow_mode && q_head == q_count && all_idle) {
-                shadow_mode = false;
-                q_count = q_head = 0;
-            }
-            if (!shadow_mode && all_idle && q_count >= a.defer_switch) shadow_mode = true;
-        }
         VX_PART_END(2);
         // ---- refill idle lanes from the sub-tile queue ----
         VX_PART_BEGIN(3);
         unsigned long long idle_mask = __ballot(state == kIdle);
-        if (!queue_empty && idle_mask && !walk_phase && !(DEFER && shadow_mode) && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
+        if (!queue_empty && idle_mask && !walk_phase && (uint32_t(__popcll(idle_mask)) >= a.refill_min || idle_mask == ~0ull)) {
             if (STATS) ++refills;
             for (int round = 0; round < 2 && idle_mask && !queue_empty; ++round) {
                 if (cursor >= 64) {
@@ -692,30 +654,6 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
             }
         }
 
-        // ---- ... or (shadow rays deferred) from the wave's own queue of shadow rays ----
-        if (DEFER && shadow_q) {
-            // (the sub-tile queue is empty and nothing is in flight: what the wave has noted is all that is left for it)
-            if (!shadow_mode && queue_empty && q_count != 0 && __ballot(state != kIdle || new_ray) == 0ull) shadow_mode = true;
-            if (shadow_mode && q_head != q_count) {
-                const unsigned long long im = __ballot(state == kIdle);
-                const uint32_t n_idle = uint32_t(__popcll(im)), left = q_count - q_head;
-                if (n_idle >= a.defer_service || im == ~0ull) {
-                    const uint32_t k = q_head + rank_in(im);
-                    if (state == kIdle && k < q_count) {
-                        const uint4* w = reinterpret_cast<const uint4*>(shadow_q + size_t(k) * kRayRecordDwords);
-                        const uint4 w0 = w[0], w1 = w[1];
-                        out_index = w0.x;
-                        new_ro[0] = bitsf(w0.y); new_ro[1] = bitsf(w0.z); new_ro[2] = bitsf(w0.w);
-                        new_rd[0] = -p.u.light_dir[0]; new_rd[1] = -p.u.light_dir[1]; new_rd[2] = -p.u.light_dir[2];
-                        keep_color[0] = bitsf(w1.x); keep_color[1] = bitsf(w1.y); keep_color[2] = bitsf(w1.z); keep_color[3] = bitsf(w1.w);
-                        keep_ds = bitsf(w[2].x);
-                        new_ray = true;
-                        shadow_ray = true;
-                    }
-                    q_head += n_idle < left ? n_idle : left;
-                }
-            }
-        }
         VX_PART_END(3);
         // ---- ray set-up (svo.esvo.glsl:50-150) for every lane that got a ray above ----
         VX_PART_BEGIN(4);
@@ -727,7 +665,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
 #undef VX_PART_BEGIN
 #undef VX_PART_END
         if (a.timeline) { if (a.timeline_part == 0) in_service += uint32_t(__builtin_amdgcn_s_memrealtime() - t_service); ++service_phases; }
-        if (__ballot(state != kIdle) == 0 && queue_empty && !(DEFER && q_count != 0)) break;
+        if (__ballot(state != kIdle) == 0 && queue_empty) break;
     }
 
     if (a.timeline && lane == 0) {

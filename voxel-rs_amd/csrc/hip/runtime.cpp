@@ -336,25 +336,6 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
             todo.chunks = ring + 32;
             todo.mask = uint32_t((ray_list ? have / (kRayChunkDwords / kChunkDwords) : have) - 1);
         }
-        // shadow rays deferred: the image-only builds whose rays never walk a voxel in a service phase (render_persistent's DEFER), when shadows are on
-        a.shadow_queue = nullptr;
-        a.defer_switch = ctx->defer_switch;
-        a.defer_service = ctx->defer_service;
-        if (ctx->defer_shadows && imaged && !HITS && !STATS && !build.hot && build.foreign != VX_SVO_CSVO && p.u.render_shadows) {
-            uint32_t*& q = ctx->d_shadow_queue[slot + 1];
-            size_t& have = ctx->shadow_queue_waves[slot + 1];
-            if (have < waves) {
-                if (q) {
-                    HIP_TRY(hipStreamSynchronize(stream));
-                    (void)hipFree(q);
-                    q = nullptr;
-                    have = 0;
-                }
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q), size_t(waves) * kShadowQueueCap * kRayRecordDwords * sizeof(uint32_t)));
-                have = waves;
-            }
-            a.shadow_queue = q;
-        }
         void* kargs[] = {const_cast<SceneArgs*>(&sc), const_cast<RenderParams*>(&p), &a, &out, &hits, &counters, &todo};
         HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(64), kargs, wave_lds, stream));
         tickets += 1u;
@@ -666,18 +647,11 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
             if (const char* e = std::getenv("VX_REFILL_MIN")) c->refill_min = uint32_t(std::atoi(e));
             if (const char* e = std::getenv("VX_QUEUE_STRIPE")) c->queue_stripe = std::atoi(e);
             if (const char* e = std::getenv("VX_TILE_STRIP")) c->tile_strip = std::atoi(e);
-            if (const char* e = std::getenv("VX_DEFER_SHADOWS")) c->defer_shadows = std::atoi(e) != 0;
-            if (const char* e = std::getenv("VX_DEFER_SWITCH")) c->defer_switch = uint32_t(std::atoi(e));
-            if (const char* e = std::getenv("VX_DEFER_SERVICE")) c->defer_service = uint32_t(std::atoi(e));
         }
         if (c->refill_min < 1) c->refill_min = 1;
         if (c->refill_min > 64) c->refill_min = 64;
         if (c->service_min < 1) c->service_min = 1;
         if (c->service_min > 64) c->service_min = 64;
-        if (c->defer_switch < 1) c->defer_switch = 1;
-        if (c->defer_switch > kShadowQueueCap - 64) c->defer_switch = kShadowQueueCap - 64;
-        if (c->defer_service < 1) c->defer_service = 1;
-        if (c->defer_service > 64) c->defer_service = 64;
     }
     // one all-zero material and a 1x1 transparent-black texture so that rendering works before any registry is set
     const vx_material zero_mat = {0, 0, -1, -1, -1, -1, -1, -1};
@@ -707,11 +681,9 @@ void vx_destroy(vx_context* c) {
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
         if (c->d_frame_counter[i]) (void)hipFree(c->d_frame_counter[i]);
         if (c->d_frame_todo[i]) (void)hipFree(c->d_frame_todo[i]);
-        if (c->d_shadow_queue[i + 1]) (void)hipFree(c->d_shadow_queue[i + 1]);
         if (c->frame_done[i]) (void)hipEventDestroy(c->frame_done[i]);
         if (c->frame_stream[i]) (void)hipStreamDestroy(c->frame_stream[i]);
     }
-    if (c->d_shadow_queue[0]) (void)hipFree(c->d_shadow_queue[0]);
     for (auto& t : c->launch_tables) {
         if (t.d_table) (void)hipFree(t.d_table);
         if (t.d_number) (void)hipFree(t.d_number);

@@ -169,12 +169,6 @@ struct PersistentArgs {
                                     // except for the frame's last g quarter-grids of tickets
     uint32_t timeline_part;         // measurement: which part of the service phases the timeline's tick count covers (0 all, 1 leaf tests, 2 finished rays, 3 refill, 4 ray set-up, 5 walks inside voxels)
     unsigned long long* timeline;   // measurement (the timeline build of the library), else null: per wave {start, queue found empty, exit} in 10 ns ticks, pixels taken
-    // Shadow rays deferred (image-only renders whose rays never walk a voxel in a service phase): a pixel that was shaded does not start its shadow ray
-    // in its lane -- the wave notes it (pixel, origin, the colour to be lit, diffuse + specular: a record as in PixelList's ray chunks) in a queue of
-    // its own, goes on with the next sub-tile's primary rays, and when `defer_switch` records have come together traces them 64 at a time, refilling
-    // from the queue whenever `defer_service` lanes have ended (render_persistent). Null: a pixel's shadow ray starts in its lane.
-    uint32_t* shadow_queue;         // [waves][kShadowQueueCap records of kRayRecordDwords dwords]
-    uint32_t defer_switch, defer_service;
     unsigned long long* excursions;  // counted on request only (vx_excursion_counters), else null: [0] rays that walked inside a voxel on the world's bytes, [1] of which were given up and run on the bytes, [2] service phases that ran such walks, [3] loop iterations made on the bytes
 };
 
@@ -193,7 +187,6 @@ struct PixelList {
 };
 constexpr uint32_t kChunkDwords = 128, kChunkEntries = 126;
 constexpr uint32_t kRayChunkDwords = 1024, kRayChunkRecords = 64, kRayRecordDwords = 12, kRayChunkHeader = 16;
-constexpr uint32_t kShadowQueueCap = 320;  // PersistentArgs::shadow_queue: records per wave (defer_switch <= kShadowQueueCap - 64)
 // render_persistent's FOREIGN: 0 = no ray of this image is ever led into a voxel's own bytes (ESVO worlds), VX_SVO_CSVO = such rays walk the
 // voxel on the world's bytes in a service phase (walk_voxel_on_bytes), kForeignRerun = they are listed and run on the bytes afterwards
 constexpr int kForeignRerun = 3;

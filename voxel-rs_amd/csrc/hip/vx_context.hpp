@@ -136,13 +136,6 @@ struct vx_context {
     // sub-tile's primary rays with this one's shadow rays, and no service phase has to shade AND light (4 -> 64: C3 -1.1 %, 4K depth 13 -1.6 %,
     // profiles/round5/pass_a/refill.txt, tails_detail.txt). Smaller: the measurement build's VX_REFILL_MIN.
     uint32_t refill_min = 64, service_min = 64;
-    // Shadow rays deferred (PersistentArgs::shadow_queue; render_persistent): on for the image-only builds that can (VX_DEFER_SHADOWS=0 in the
-    // measurement build: a pixel's shadow ray starts in its lane); a wave switches to its shadow rays when `defer_switch` of them have come
-    // together (<= kShadowQueueCap - 64) and serves / refills their lanes when `defer_service` have ended.
-    bool defer_shadows = true;
-    uint32_t defer_switch = 192, defer_service = 32;
-    uint32_t* d_shadow_queue[kFrameStreams + 1] = {};  // per stream ([0]: the context's own): waves x kShadowQueueCap records
-    size_t shadow_queue_waves[kFrameStreams + 1] = {};
     int tile_strip = 8;  // VX_TILE_STRIP: tile numbering 1's strips are this many tiles wide
     int tile_numbering = 1;  // VX_TILE_NUMBERING: how a whole-image render's tile numbers lie on the screen (RenderParams::tile_numbering)
     int queue_stripe = 0;  // VX_QUEUE_STRIPE: the length of the stretches the sub-tile queue deals out to its dispensers (0: by the launch, launch_render)
