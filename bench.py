@@ -31,7 +31,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s achievable)
-PROFILE_ROUNDS = ("round5", "round4", "round3", "round2", "round1")
+PROFILE_ROUNDS = ("round6", "round5", "round4", "round3", "round2", "round1")
 
 
 # ---- byte models ---------------------------------------------------------------------------------------------------
@@ -800,27 +800,31 @@ def main():
     #  (b) the library's one-frame-at-a-time mode (set_frames_in_flight(1): the context's own stream): what a consumer that presents
     #      every frame runs, and the same command rocprofv3 is run on for profiles/ (--frames-in-flight 1).
     def exclusive(n):
+        """(the kernel's own event span, the host's wall clock) per frame, every frame waited for before the next is issued -- the wall clock is what
+        a consumer that presents every frame sees (the reference's loop: svo.rs:220-228), order kernel, launch and wait included"""
         barrier()
         run.i = 0
         svo.profile_enable(True)
+        t0 = time.perf_counter()
         for _ in range(n):
             run.step()
             run.flush()
             svo.sync()
+        wall_ms = (time.perf_counter() - t0) / n * 1e3
         barrier()
         ms, k = svo.profile_read()
         if sharded and run.gather_used == "library":
             svo.comm_profile_read()
         svo.profile_enable(False)
-        return ms / max(k, 1)
+        return ms / max(k, 1), wall_ms
 
-    kernel_exclusive_frame_stream_ms = exclusive(min(args.steps, 25))
+    kernel_exclusive_frame_stream_ms, one_frame_wall_ms = exclusive(min(args.steps, 25))
     kernel_exclusive_ms = kernel_exclusive_frame_stream_ms
     if not sharded:
         svo.set_frames_in_flight(1)
         for _ in range(4):
             run.step()
-        kernel_exclusive_ms = exclusive(min(args.steps, 25))
+        kernel_exclusive_ms, one_frame_wall_ms = exclusive(min(args.steps, 25))
         svo.set_frames_in_flight(run.frames)
 
     # Secondary blocks (one GPU): the camera standing still (round 3's headline: the same view again and again), the game's own shadow
@@ -885,6 +889,7 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays_per_block / elapsed / 1e6  # Mrays/s, whole job
+    timed_region_s = sum(block_s) + (sustained["seconds"] if sustained else 0.0)  # every timed block and the sustained one: what `value` stands on
     burst = {"value": round(value, 3), "ms_per_step": round(ms_per_step, 4)}
     value_source = f"median of {len(block_s)} timed blocks of {args.steps} frames"
     if sustained:
@@ -930,8 +935,19 @@ def main():
         roofline["clock"] = clock
     if issue:
         issue["frac_of_bound_one_frame_at_a_time"] = round(issue["issue_bound_ms"] / kernel_exclusive_ms, 4) if kernel_exclusive_ms > 0 else None
-        issue["frac_of_bound_timed_mode"] = round(issue["issue_bound_ms"] / burst["ms_per_step"], 4)
+        # (against the ms_per_step this line reports: the sustained block's where that is the headline)
+        issue["frac_of_bound_timed_mode"] = round(issue["issue_bound_ms"] / ms_per_step, 4)
         roofline["issue"] = issue
+    elif reference_shape:
+        roofline["issue_note"] = (stored_note if not stored else
+                                  "no shader-clock sample in this run (--sustained-seconds 0: the clock is probed while the sustained block renders): the issue bound is not quoted")
+    # the same as flat scalars (a record that keeps only the scalars of `roofline` still carries them)
+    roofline.update({"clock_mhz_median": clock["mhz_median"] if clock else None, "issue_bound_ms": issue["issue_bound_ms"] if issue else None,
+                     "issue_frac_one_frame_at_a_time": issue["frac_of_bound_one_frame_at_a_time"] if issue else None,
+                     "issue_frac_timed_mode": issue["frac_of_bound_timed_mode"] if issue else None,
+                     "instructions_per_launch": issue["instructions_per_launch"] if issue else None,
+                     "wait_share_of_wave_cycles": issue["wait_share_of_wave_cycles"] if issue else None,
+                     "valu_lane_utilisation": issue["valu_lane_utilisation"] if issue else None})
 
     cpu = None
     if not args.no_cpu_baseline and world_size == 1:  # rank 0 at N = 1 only: a baseline of the workload, not of the scaling run
@@ -940,6 +956,15 @@ def main():
         cpu = cpu_baseline(args, wl, orc)
 
     rays_per_frame = total_rays_per_block / args.steps
+    if cpu:  # flat scalars beside the nested sweep
+        cpu["granted_cpus"] = cpu["granted"].get("cgroup_cpu_max") or cpu["granted"].get("affinity")
+        cpu["one_thread_value"] = cpu["single_thread"]["value"]
+    # the other configurations' frames as flat scalars of `config` (the nested `configs` object holds the whole lines)
+    flat_configs = {}
+    if configs and "error" not in configs:
+        for name, short in (("C2", "c2"), ("C4_static", "c4_static"), ("C4_streamed", "c4_streamed"), ("C5_rank_share", "c5_rank_share"), ("C5_whole_on_one_gpu", "c5_whole")):
+            for f, r in (configs.get(name) or {}).items():
+                flat_configs[f"{short}_{f}_ms"] = r.get("ms_per_step")
     out = {
         "metric": "Mrays/sec (primary+shadow) at 1920x1080, depth-12 SVO; achieved HBM GB/s",
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -961,7 +986,17 @@ def main():
                        "exchange_ms_per_gather_rank0": round(gather_ms / max(gathers, 1), 4), "per_rank": per_rank,
                        "sharded_frame_identical_to_whole_render": sharded_frame_identical} if sharded else {}),
                    "scene_build_s": round(wl.build_s, 2), "upload_s": round(wl.upload_s, 3),
-                   "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4)},
+                   "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
+                   # flat copies of what the nested objects say (`sustained`, `burst`, `configs`, `forced_sharded`)
+                   "burst_value": burst["value"], "burst_ms_per_step": burst["ms_per_step"],
+                   "sustained_value": sustained["value"] if sustained else None, "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None,
+                   "sustained_seconds": sustained["seconds"] if sustained else None, "sustained_frames": sustained["frames"] if sustained else None,
+                   # every frame waited for before the next is issued, the host's wall clock per frame (kernel_exclusive_ms is the kernel's event span there)
+                   "one_frame_at_a_time_wall_ms": round(one_frame_wall_ms, 4),
+                   "forced_sharded_ms": forced.get("ms_per_step") if forced else None,
+                   "forced_sharded_vs_plain": round(forced["value"] / burst["value"], 4) if forced and forced.get("value") else None,
+                   **flat_configs, "timed_region_s": round(timed_region_s, 3)},
+        "timed_region_s": round(timed_region_s, 3),
         "roofline": roofline, "cpu_baseline": cpu, **({"still_view": still} if still else {}), **({"shadow_distance_500": sd500} if sd500 else {}),
         **({"picker": picker} if picker else {}), **({"configs": configs} if configs else {}), **({"forced_sharded": forced} if forced else {}),
     }

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (measured at commit 488851f, "experiment: refill threshold in the product build": VX_EXP_REFILL_MIN existed there and nowhere since -- at HEAD nothing
+# reads it and every setting prints the same numbers. To repeat the comparison today: VX_REFILL_MIN with VX_LIB_DIR=voxel-rs_amd/lib/lib_tl, the measurement build.)
 # pure batches: idle lanes are refilled only when VX_EXP_REFILL_MIN of them are free (4 = round 4's; 64 = a sub-tile at a time: no batch mixes the next
 # sub-tile's primary rays with this one's shadow rays)
 B="python bench.py --steps 20 --warmup 5 --repeats 15 --no-cpu-baseline --no-extras --sustained-seconds 2"

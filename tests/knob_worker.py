@@ -49,8 +49,13 @@ def main():
     svo.render_device(u, w, h, lst.data_ptr(), tile_rank=1, tile_count=3)
     svo.sync()
     out["rank 1 of 3"] = sha(lst.cpu().numpy().tobytes())
-    counters = svo.render_counters(u, w, h)
-    out["counters"] = {k: v for k, v in counters.items() if k not in ("wave_steps", "services", "refills", "tail_wave_steps", "tail_iterations")}
+    # (a frame of several sub-tiles per resident wave: only then do the refill and service thresholds show in the scheduling counters)
+    cw, ch = 1280, 720
+    counters = svo.render_counters(scenes.bench_camera(8, st["h_max"], cw, ch, shadow_distance=3.0e38), cw, ch)
+    occupancy = ("wave_steps", "services", "refills", "tail_wave_steps", "tail_iterations")
+    out["counters"] = {k: v for k, v in counters.items() if k not in occupancy}
+    # how the instrumented kernel scheduled its lanes (not what the rays did): moves with the refill / service thresholds wherever they are honoured
+    out["occupancy"] = {k: counters[k] for k in occupancy}
     print(json.dumps(out))
 
 

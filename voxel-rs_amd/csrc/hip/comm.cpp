@@ -240,19 +240,29 @@ int vx_render_gather(vx_context* ctx, const vx_uniforms* uniforms, uint32_t widt
     if (!ctx || !target || !target->rgba32f) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: null argument");
     if (target->memory != VX_MEM_DEVICE) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: the tile list lives in device memory");
     VX_LOCK(ctx);  // (one frame's four steps as one: nothing of another thread's in between)
+    // every argument is checked BEFORE anything is issued: an error below this block leaves a gather in flight, and its ticket is the
+    // caller's only handle on it
+    if (!ctx->comm) return fail(VX_ERR_STATE, "render_gather: no communicator (vx_comm_init)");
+    if (root < 0 || root >= ctx->comm_ranks) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: bad root");
+    if (!bytes_per_rank || (bytes_per_rank & 3)) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: bytes_per_rank must be a positive multiple of 4");
+    if (ctx->comm_rank == root && !gathered) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: the root needs a destination");
+    // the list is this rank's share of a frame cut for the communicator's ranks (a one-rank communicator: the frame itself, tile_count 0 or 1)
+    if ((target->tile_count > 1 || ctx->comm_ranks > 1) && target->tile_count != uint32_t(ctx->comm_ranks))
+        return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: target->tile_count must be the communicator's size");
+    const uint64_t pixel = target->format == VX_FORMAT_RGBA8 ? 4u : 16u;
+    const bool assemble = image && ctx->comm_rank == root;
+    if (assemble && bytes_per_rank % pixel) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: bytes_per_rank must be whole pixels");
     if (wait_ticket >= 0)
         if (int rc = vx_wait_gather(ctx, wait_ticket)) return rc;
     if (int rc = vx_render(ctx, uniforms, width, height, target)) return rc;
     int ticket = -1;
     // (the list was written by the render just issued: behind that frame's event alone -- a render on the context's own stream: behind everything)
     if (int rc = gather_tiles(ctx, target->rgba32f, bytes_per_rank, gathered, root, &ticket, ctx->last_frame_slot)) return rc;
-    if (image && ctx->comm_rank == root) {
-        const uint64_t pixel = target->format == VX_FORMAT_RGBA8 ? 4u : 16u;
-        if (bytes_per_rank % pixel) return fail(VX_ERR_INVALID_ARGUMENT, "render_gather: bytes_per_rank must be whole pixels");
+    if (out_ticket) *out_ticket = ticket;  // (the gather is recorded: whatever happens next, the caller can wait for it)
+    if (assemble) {
         // (vx_render with tile_count 1 writes the whole frame: the "list" of a one-rank run is the frame, and the assembly runs for its cost)
         if (int rc = vx_assemble_tiles_format(ctx, gathered, bytes_per_rank / pixel, uint32_t(ctx->comm_ranks), width, height, image, target->format, ctx->comm_stream)) return rc;
     }
-    if (out_ticket) *out_ticket = ticket;
     return VX_OK;
 }
 

@@ -115,31 +115,50 @@ int tile_table(vx_context* ctx, uint32_t tiles_x, uint32_t tiles_y, const vx_con
     return VX_OK;
 }
 
-// RenderParams::tile_table / number_of_place for this launch shape: made once with tile_place / tile_number (vx_args.hpp) and kept
+// RenderParams::tile_table / number_of_place for this launch shape: made once with tile_place / tile_number (vx_args.hpp) and kept -- the most
+// recently used first, at most kLaunchTables of them (a context sees a handful of shapes: image size x rank x numbering; a caller that keeps
+// resizing its window must not grow the list, and its search, without bound). Both arrays live in ONE allocation: nothing leaks when the
+// second half of a set-up fails.
 int launch_table(vx_context* ctx, RenderParams& p) {
-    for (const auto& t : ctx->launch_tables)
+    constexpr size_t kLaunchTables = 32;
+    auto& tables = ctx->launch_tables;
+    for (size_t i = 0; i < tables.size(); ++i) {
+        const auto& t = tables[i];
         if (t.tiles_x == p.tiles_x && t.tiles_y == p.tiles_y && t.rank == p.tile_rank && t.count == p.tile_count && t.numbering == p.tile_numbering && t.strip == p.strip_w) {
-            p.tile_table = t.d_table;
-            p.number_of_place = t.d_number;
+            if (i) std::rotate(tables.begin(), tables.begin() + i, tables.begin() + i + 1);
+            p.tile_table = tables[0].d_table;
+            p.number_of_place = tables[0].d_number;
             return VX_OK;
         }
+    }
     std::vector<uint32_t> order, inverse;
     if (p.tile_count > 1) tile_order_host(p.tiles_x, p.tiles_y, order, inverse);
-    std::vector<uint2> table(p.n_local_tiles);
-    std::vector<uint32_t> number(p.n_local_tiles);
-    for (uint32_t i = 0; i < p.n_local_tiles; ++i) {
+    // [n x uint2 table][n x u32 number]
+    const size_t n = p.n_local_tiles;
+    std::vector<uint32_t> host(n * 3);
+    for (uint32_t i = 0; i < n; ++i) {
         const uint32_t place = tile_place(p, i);
         const uint32_t tile = p.tile_count > 1 ? order[size_t(place) * p.tile_count + p.tile_rank] : place;
-        table[i] = make_uint2((tile % p.tiles_x) | ((tile / p.tiles_x) << 16), place);
-        number[place] = i;
+        host[2 * size_t(i)] = (tile % p.tiles_x) | ((tile / p.tiles_x) << 16);
+        host[2 * size_t(i) + 1] = place;
+        host[2 * n + place] = i;
+    }
+    if (tables.size() >= kLaunchTables) {  // the least recently used goes; launches in flight may still read it
+        if (int rc = drain_streams(ctx)) return rc;
+        (void)hipFree(tables.back().d_table);
+        tables.pop_back();
     }
     vx_context::LaunchTable t;
     t.tiles_x = p.tiles_x; t.tiles_y = p.tiles_y; t.rank = p.tile_rank; t.count = p.tile_count; t.numbering = p.tile_numbering; t.strip = p.strip_w;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d_table), table.size() * sizeof(uint2)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d_number), number.size() * 4));
-    HIP_TRY(hipMemcpy(t.d_table, table.data(), table.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t.d_number, number.data(), number.size() * 4, hipMemcpyHostToDevice));
-    ctx->launch_tables.push_back(t);
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, host.size() * 4));
+    if (const hipError_t e = hipMemcpy(d, host.data(), host.size() * 4, hipMemcpyHostToDevice); e != hipSuccess) {
+        (void)hipFree(d);
+        HIP_TRY(e);
+    }
+    t.d_table = static_cast<uint2*>(d);
+    t.d_number = static_cast<uint32_t*>(d) + 2 * n;
+    tables.insert(tables.begin(), t);
     p.tile_table = t.d_table;
     p.number_of_place = t.d_number;
     return VX_OK;
@@ -685,8 +704,7 @@ void vx_destroy(vx_context* c) {
         if (c->frame_stream[i]) (void)hipStreamDestroy(c->frame_stream[i]);
     }
     for (auto& t : c->launch_tables) {
-        if (t.d_table) (void)hipFree(t.d_table);
-        if (t.d_number) (void)hipFree(t.d_number);
+        if (t.d_table) (void)hipFree(t.d_table);  // (d_number lies in the same allocation)
     }
     vxrt::comm_release(c);
     for (auto& hs : c->hot) {

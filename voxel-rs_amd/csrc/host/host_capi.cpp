@@ -257,7 +257,9 @@ struct Streamer {
     systems::WorldStreamer<Esvo<EsvoSerializedChunk>, EsvoSerializedChunk> esvo;
     systems::WorldStreamer<Csvo, CsvoSerializedChunk> csvo;
     Streamer(int t, uint32_t depth, uint32_t seed, uint32_t radius, int32_t y0, int32_t y1)
-        : svo_type(t), esvo(depth, seed, radius, y0, y1), csvo(depth, seed, radius, y0, y1) {}
+        : svo_type(t), esvo(depth, seed, radius, y0, y1, workers()), csvo(depth, seed, radius, y0, y1, workers()) {}
+    // (what the process is GRANTED, not what the machine has: a cgroup quota of 16 on 256 logical CPUs throttles every thread beyond the sixteenth)
+    static uint32_t workers() { return std::max(1u, std::min(16u, vximg::granted_cpus())); }
     // tests: a host-side stand-in for the device world buffer and the traversal image vx_commit keeps next to it
     std::vector<uint8_t> mirror;
     std::unique_ptr<vximg::WorldImage> image;
