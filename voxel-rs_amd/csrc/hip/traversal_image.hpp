@@ -893,4 +893,35 @@ private:
     double timing_[5] = {};
 };
 
+// Do two kOct64 images ([64-byte header][octants]) hold the same tree -- same masks, same leaf values, same shape -- wherever their octants
+// were placed? 1 / 0; -1 = a pointer out of range. (Tests: an image kept up to date commit by commit against one built from scratch.)
+inline int oct64_same_tree(const uint32_t* a, uint64_t na, const uint32_t* b, uint64_t nb) {
+    if (na < 16 || nb < 16 || a[0] != b[0] || a[1] != b[1]) return 0;
+    struct Pair { uint32_t pa, pb, masks; };
+    std::vector<Pair> todo{{a[2], b[2], a[1]}};
+    while (!todo.empty()) {
+        const Pair p = todo.back();
+        todo.pop_back();
+        const uint32_t children = p.masks >> 24, leaves = (p.masks >> 16) & 0xffu;
+        if (!children) continue;  // an octant without children takes no room
+        const uint32_t words = children == leaves ? 8u : 16u;  // values only / {pointer | value, masks} entries
+        if (p.pa % 32 || p.pb % 32 || uint64_t(p.pa) / 4 + words > na || uint64_t(p.pb) / 4 + words > nb) return -1;
+        const uint32_t *oa = a + p.pa / 4, *ob = b + p.pb / 4;
+        for (uint32_t c = 0; c < 8; ++c) {
+            const bool exists = (children >> (7 - c)) & 1u, leaf = (leaves >> (7 - c)) & 1u;
+            if (words == 8) {
+                if (oa[c] != ob[c] || (!exists && oa[c])) return 0;
+            } else if (!exists) {
+                if (oa[2 * c] | oa[2 * c + 1] | ob[2 * c] | ob[2 * c + 1]) return 0;
+            } else if (leaf) {
+                if (oa[2 * c] != ob[2 * c]) return 0;
+            } else {
+                if (oa[2 * c + 1] != ob[2 * c + 1]) return 0;
+                todo.push_back(Pair{oa[2 * c], ob[2 * c], oa[2 * c + 1]});
+            }
+        }
+    }
+    return 1;
+}
+
 }  // namespace vximg

@@ -1264,7 +1264,8 @@ __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, b
         const uint32_t table = bp + 2u;
         uint32_t word = 0u;
         if (push && wrapped) word = u32_at(table + offset);
-        const uint32_t e = word & (0xffffffffu >> ((0x001018u >> ((tag - 1u) * 8u)) & 0xffu));
+        // (tag 0 -- no child, nothing is pushed and `e` is not looked at -- must still shift by less than 32: UBSan on the host harness, make sanitize)
+        const uint32_t e = word & (0xffffffffu >> ((0x001018u >> (((tag - 1u) & 3u) * 8u)) & 0xffu));
         // out of L or N0: read_next_ptr's leaf-node case; below: the table entry's
         const uint32_t next = wrapped ? table + csvo_tag_bytes(hd) + e : bp + 3u + offset;
         // given up: below scale 0 the child index is no longer a mantissa bit; a phantom chunk boundary

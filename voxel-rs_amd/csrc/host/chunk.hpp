@@ -59,9 +59,10 @@ struct BlockPos {
     }
 
     void to_point(float out[3]) const {
-        const int32_t bx = (chunk.x << 5) | (int32_t(rel_x) & 31);
-        const int32_t by = (chunk.y << 5) | (int32_t(rel_y) & 31);
-        const int32_t bz = (chunk.z << 5) | (int32_t(rel_z) & 31);
+        // (the shift on the unsigned value: a negative chunk coordinate shifted left is undefined before C++20 -- UBSan, make sanitize)
+        const int32_t bx = int32_t(uint32_t(chunk.x) << 5) | (int32_t(rel_x) & 31);
+        const int32_t by = int32_t(uint32_t(chunk.y) << 5) | (int32_t(rel_y) & 31);
+        const int32_t bz = int32_t(uint32_t(chunk.z) << 5) | (int32_t(rel_z) & 31);
         out[0] = float(bx) + (rel_x - std::trunc(rel_x));
         out[1] = float(by) + (rel_y - std::trunc(rel_y));
         out[2] = float(bz) + (rel_z - std::trunc(rel_z));

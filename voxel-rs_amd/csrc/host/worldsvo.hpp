@@ -46,7 +46,8 @@ struct SvoCoordSpace {
     // chunk position -> SVO chunk position, none outside the cylinder of radius dst (full height dst up and down)
     std::optional<Position> cnv_chunk_pos(ChunkPos pos) const {
         const float r = float(dst);
-        const Vec3 p = cnv_block_pos(Vec3{float(pos.x << 5), float(pos.y << 5), float(pos.z << 5)});
+        auto times32 = [](int32_t c) { return float(int32_t(uint32_t(c) << 5)); };  // (a negative coordinate shifted left is undefined before C++20)
+        const Vec3 p = cnv_block_pos(Vec3{times32(pos.x), times32(pos.y), times32(pos.z)});
         const float x = p.x / 32.0f, y = p.y / 32.0f, z = p.z / 32.0f;
         const float dcy = y - r;
         if (dcy < -r || dcy > r) return std::nullopt;
