@@ -385,6 +385,14 @@ class Sharded:
         if not self._first_frames_ok(args.gather_timeout):
             self.gather_note = (self.gather_note + "; " if self.gather_note else "") + "torch.distributed.gather's first frames did not reproduce the whole render"
 
+    def regroup(self, group):
+        """the same exchange with `group` frames per gather: new tile lists and tickets (the caller has drained the device)"""
+        frames = min(8, max(1, self.args.frames_in_flight)) if self.args.frames_in_flight else min(8, max(3, self.world_size))
+        self.group = max(1, min(group, frames))
+        self.frames = frames - frames % self.group
+        self.sharder = self._build(self.gather_used == "library")
+        self.i = 0
+
     def exchange_profile(self):
         """(ms summed, exchanges) of the timed region: time on the exchange's stream from the first send / receive to the last"""
         if self.gather_used == "library":
@@ -540,6 +548,10 @@ def other_configs(args, vra, hip, scenes, torch, formats):
                 ms = timed(svo, whole, 12, 3)
                 out.setdefault("C5_whole_on_one_gpu", {})[fmt_name] = line(ms, svo.render_counters(u5, W, H), {"workload": "7680x4320 + 2x2 resolve to 3840x2160, depth-14 terrain, this GPU alone"})
                 del big, small
+                try:  # every rank's share of the supersampled frame, rendered here in turn (a projection: scale_model)
+                    out.setdefault("C5_scale_model", {})[fmt_name] = scale_model(svo, hip, torch, [u5], W, H, ms, frames_per_share=10)
+                except Exception as e:
+                    out.setdefault("C5_scale_model", {})[fmt_name] = {"error": f"{type(e).__name__}: {e}"[:200]}
             svo.close()
             del world, svo
         # C4 as the game produces it: the chunk loader streams the depth-14 terrain in around the camera (radius 40, <= 400 events a commit,
@@ -551,6 +563,58 @@ def other_configs(args, vra, hip, scenes, torch, formats):
             "ms_per_step_settled": r["kernel_ms_settled_median"], "host_ms_per_step_median": r["host_ms_per_step_median"], "host_ms_per_step_max": r["host_ms_per_step_max"],
             "apply_ms_median": r["apply_ms_median"], "commit_ms_median": r["commit_ms_median"], "resident_chunks": r["resident_chunks"],
             "initial_fill_s": r["initial_fill"]["seconds"], "workload": r["workload"]}
+    return out
+
+
+def scale_model(svo, hip, torch, views, W, H, whole_ms, frames_per_share=30):
+    """A PROJECTION, not a measurement, of the N-GPU frame from this one GPU: every one of the N tile shares (N = 2, 4, 8: the tiles in Morton order, round-robin)
+    of the frame rendered here as the rank that owns it would render it (its RGBA8 tile list, max(3, N) frames in flight, the camera moving), rank 0's assembly
+    of N gathered lists timed on its own, and the link time of a share into rank 0 at 77 GB/s per xGMI direction. projected frame = max(the dearest other
+    rank's share, rank 0's share + its assembly, the link time); projected_speedup = this GPU's whole frame / that. It says how EVEN the shares are
+    (share_ms_max against share_ms_mean) and what a perfect overlap would give; no N > 1 run stands behind it."""
+    out = {}
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timed(frame, steps):
+        for i in range(4):
+            frame(i)
+        svo.sync()
+        torch.cuda.synchronize()
+        blocks, issue = [], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                frame(i)
+            issue.append((time.perf_counter() - t0) / steps * 1e3)
+            svo.sync()
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / steps * 1e3)
+        return sorted(blocks)[1], sorted(issue)[1]
+
+    for n in (2, 4, 8):
+        svo.set_frames_in_flight(min(8, max(3, n)))
+        per = max(hip.local_tile_count(W, H, r, n) for r in range(n))
+        lists = [torch.zeros((per, 32, 32, 4), dtype=torch.uint8, device="cuda") for _ in range(min(8, max(3, n)))]
+        torch.cuda.synchronize()
+        shares, issues = [], []
+        for r in range(n):
+            ms, issue = timed(lambda i, r=r: svo.render_device(views[i % len(views)], W, H, lists[i % len(lists)].data_ptr(), tile_rank=r, tile_count=n, fmt=hip.VX_FORMAT_RGBA8),
+                              frames_per_share)
+            shares.append(ms)
+            issues.append(issue)
+        gathered = torch.zeros((n, per, 32, 32, 4), dtype=torch.uint8, device="cuda")
+        image = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        asm, _ = timed(lambda i: svo.assemble_tiles_format(gathered.data_ptr(), gathered.stride(0) // 4, n, W, H, image.data_ptr(), hip.VX_FORMAT_RGBA8, stream), frames_per_share)
+        link_ms = per * 1024 * 4 / 77e9 * 1e3
+        frame_ms = max(max(shares[1:]), shares[0] + asm, link_ms)
+        out[str(n)] = {"share_ms_max": round(max(shares), 4), "share_ms_mean": round(sum(shares) / n, 4), "share_ms_min": round(min(shares), 4),
+                       "host_issue_ms": round(max(issues), 4), "assembly_ms": round(asm, 4), "link_ms": round(link_ms, 4),
+                       "projected_frame_ms": round(frame_ms, 4), "projected_speedup": round(whole_ms / frame_ms, 2)}
+        del lists, gathered, image
+    svo.set_frames_in_flight(2)
+    out["whole_frame_ms_on_this_gpu"] = round(whole_ms, 4)
+    out["note"] = "a projection from one GPU (every rank's share rendered here in turn); no scaling curve was measured"
     return out
 
 
@@ -611,6 +675,9 @@ def parse_args(argv=None):
                     help="frames the renderer keeps in flight (1..8); default: the library's own (2) on one GPU, max(3, N) when the frame is sharded over N "
                          "(a sharded frame's next render waits for the exchange and rank 0's assembly of the frame before last on its stream)")
     ap.add_argument("--gather-group", type=int, default=0, help="sharded: frames per gather (default 1; 2 from six ranks on)")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="sharded, more than one rank: skip the self-calibration (two warm-up blocks at comm headroom {0, 2, 4} x frames per gather {1, 2}, the best kept "
+                         "on every rank; --gather-group pins the frames per gather)")
     ap.add_argument("--streams", type=int, default=0, help="sharded: the library's frame streams (default: as many as frames in flight, i.e. tile-list buffers)")
     ap.add_argument("--gather", choices=["auto", "library", "torch"], default="auto",
                     help="sharded: the exchange step -- library: vx_gather_tiles (RCCL send/receive owned by the render context); torch: torch.distributed.gather; "
@@ -715,6 +782,32 @@ def main():
     for _ in range(args.warmup):
         run.step()
     barrier()
+    # Self-calibration (more than one rank): what RCCL's kernels need beside persistent render waves (the wave slots per CU a context leaves them:
+    # vx_set_comm_headroom) and whether two frames per gather pay could only be guessed without a multi-GPU run, so the first such run measures them:
+    # two untimed blocks at every setting, the block times reduced to the slowest rank's, the best setting kept by every rank. Outside the timed region.
+    calibration = None
+    if sharded and world_size > 1 and not args.no_calibration:
+        trials = []
+        groups = [args.gather_group] if args.gather_group else [1, 2]
+        for group in groups:
+            barrier()
+            run.regroup(group)
+            for headroom in (0, 2, 4):
+                svo.set_comm_headroom(headroom)
+                for _ in range(max(run.frames, 4)):  # (the first frames of a setting: new buffers, another grid)
+                    run.step()
+                b, _ = timed_blocks(2)
+                t = torch.tensor([min(b)], dtype=torch.float64, device=args.ctl_device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                trials.append({"comm_headroom": headroom, "frames_per_gather": run.group, "ms_per_step": round(float(t[0]) / args.steps * 1e3, 4)})
+        best = min(trials, key=lambda r: r["ms_per_step"])  # (the reduced times are the same on every rank: so is the choice)
+        barrier()
+        run.regroup(best["frames_per_gather"])
+        svo.set_comm_headroom(best["comm_headroom"])
+        for _ in range(args.warmup):
+            run.step()
+        barrier()
+        calibration = {"chosen": best, "trials": trials, "note": "two untimed blocks per setting, slowest rank's time; outside the timed region"}
     # The timed block -- exactly --steps frames between two barriers -- is run --repeats times back to back and the MEDIAN block is
     # what is reported: 50 frames are 25 ms of GPU time, too little for one sample to stand on.
     svo.profile_enable(True)
@@ -847,6 +940,13 @@ def main():
         sd500 = view_block(scenes.bench_camera(args.depth, wl.st["h_max"], W, H, shadow_distance=500.0, render_shadows=True), 5)
         sd500.update({"shadow_distance": 500.0, "note": "the timed frames cast a shadow ray from every primary hit (shadow_distance = inf); this is the game's default cut-off, a still view"})
         picker = picker_latency(wl, hip, np)
+    scale = None
+    if not sharded and not args.no_extras and rank == 0:
+        try:
+            scale = scale_model(svo, hip, torch, wl.path, W, H, sorted(blocks)[len(blocks) // 2] / args.steps * 1e3)
+        except Exception as e:
+            scale = {"error": f"{type(e).__name__}: {e}"[:200]}
+        svo.set_frames_in_flight(run.frames)
     configs, forced = None, None
     if not sharded and not args.no_extras and rank == 0:
         if not args.no_configs:
@@ -984,7 +1084,8 @@ def main():
                        else "torch.distributed.gather (nccl backend)", "gather_requested": args.gather, **({"gather_note": run.gather_note} if run.gather_note else {}),
                        "gather_format": args.gather_format, "bytes_gathered_per_frame": int((world_size - 1) * run.sharder.n_max * 1024 * (4 if args.gather_format == "rgba8" else 16)),
                        "exchange_ms_per_gather_rank0": round(gather_ms / max(gathers, 1), 4), "per_rank": per_rank,
-                       "sharded_frame_identical_to_whole_render": sharded_frame_identical} if sharded else {}),
+                       "sharded_frame_identical_to_whole_render": sharded_frame_identical,
+                       **({"calibration": calibration, "comm_headroom": calibration["chosen"]["comm_headroom"]} if calibration else {})} if sharded else {}),
                    "scene_build_s": round(wl.build_s, 2), "upload_s": round(wl.upload_s, 3),
                    "host_issue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
                    # flat copies of what the nested objects say (`sustained`, `burst`, `configs`, `forced_sharded`)
@@ -995,10 +1096,14 @@ def main():
                    "one_frame_at_a_time_wall_ms": round(one_frame_wall_ms, 4),
                    "forced_sharded_ms": forced.get("ms_per_step") if forced else None,
                    "forced_sharded_vs_plain": round(forced["value"] / burst["value"], 4) if forced and forced.get("value") else None,
-                   **flat_configs, "timed_region_s": round(timed_region_s, 3)},
+                   **flat_configs,
+                   **({f"projected_speedup_{n}_gpus": scale[n]["projected_speedup"] for n in ("2", "4", "8")} if scale and "error" not in scale else {}),
+                   **({"share_ms_max_over_mean_8_gpus": round(scale["8"]["share_ms_max"] / max(scale["8"]["share_ms_mean"], 1e-9), 3)} if scale and "error" not in scale else {}),
+                   "timed_region_s": round(timed_region_s, 3)},
         "timed_region_s": round(timed_region_s, 3),
         "roofline": roofline, "cpu_baseline": cpu, **({"still_view": still} if still else {}), **({"shadow_distance_500": sd500} if sd500 else {}),
-        **({"picker": picker} if picker else {}), **({"configs": configs} if configs else {}), **({"forced_sharded": forced} if forced else {}),
+        **({"picker": picker} if picker else {}), **({"scale_model": scale} if scale else {}), **({"configs": configs} if configs else {}),
+        **({"forced_sharded": forced} if forced else {}),
     }
     if forced and forced.get("value"):
         forced["vs_plain_burst"] = round(forced["value"] / burst["value"], 4)

@@ -297,6 +297,11 @@ int vx_comm_unique_id(void* out_id, size_t bytes);
 int vx_comm_init(vx_context* ctx, int nranks, int rank, const void* unique_id);
 int vx_comm_destroy(vx_context* ctx);
 int vx_comm_info(const vx_context* ctx, int* nranks, int* rank);
+/* Wave slots per CU that a context with a communicator of more than one rank leaves to RCCL's own workgroups (its persistent render waves would
+ * otherwise fill every CU's LDS, and a communication kernel would find room only when a whole frame has drained). 0 .. 8; default 4 (or
+ * VX_COMM_HEADROOM at vx_create). Read by the next render: a caller can time a few frames at each setting and keep the best (bench.py does,
+ * at world_size > 1). No counterpart in the reference (one GL context, src/graphics/svo.rs:196-229). */
+int vx_set_comm_headroom(vx_context* ctx, int waves_per_cu);
 int vx_gather_tiles(vx_context* ctx, const void* tiles, uint64_t bytes_per_rank, void* gathered, int root, int* out_ticket);
 int vx_wait_gather(vx_context* ctx, int ticket);
 /* Has that gather (and an assembly issued behind it on the communicator's stream: see vx_assemble_tiles_format) finished? 1 = yes,

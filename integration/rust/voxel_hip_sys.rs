@@ -130,6 +130,7 @@ extern "C" {
     pub fn vx_comm_init(ctx: *mut vx_context, nranks: c_int, rank: c_int, unique_id: *const c_void) -> c_int;
     pub fn vx_comm_destroy(ctx: *mut vx_context) -> c_int;
     pub fn vx_comm_info(ctx: *const vx_context, nranks: *mut c_int, rank: *mut c_int) -> c_int;
+    pub fn vx_set_comm_headroom(ctx: *mut vx_context, waves_per_cu: c_int) -> c_int;
     pub fn vx_gather_tiles(ctx: *mut vx_context, tiles: *const c_void, bytes_per_rank: u64, gathered: *mut c_void, root: c_int, out_ticket: *mut c_int) -> c_int;
     pub fn vx_wait_gather(ctx: *mut vx_context, ticket: c_int) -> c_int;
     pub fn vx_gather_query(ctx: *mut vx_context, ticket: c_int) -> c_int;

@@ -52,7 +52,7 @@ def main():
         svo.set_materials(scenes.synthetic_materials())
         svo.set_textures(scenes.synthetic_textures(), 6)
         t0 = time.perf_counter()
-        svo.update(world)
+        svo.update_full(world)  # (a fresh context each time: the world's dirty ranges were consumed by the first update)
         commit_s = time.perf_counter() - t0
         for i in range(args.warmup):
             svo.render_device(u, W, H, out[i % 4].data_ptr())

@@ -85,23 +85,30 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert c["sharded_frame_identical_to_whole_render"] is True
     assert len(c["per_rank"]) == 2 and all(r["rays_per_block"] > 0 for r in c["per_rank"])
     assert d["value"] > 0 and d["sustained"]["frames"] >= 100
+    # the self-calibration of a first real N > 1 run (functional here: the ranks share one GPU): comm headroom {0, 2, 4} x frames per gather {1, 2}, the
+    # same choice on every rank, and the timed region ran with it
+    cal = c["calibration"]
+    assert len(cal["trials"]) == 6 and {(t["comm_headroom"], t["frames_per_gather"]) for t in cal["trials"]} == {(h, g) for h in (0, 2, 4) for g in (1, 2)}
+    assert cal["chosen"] in cal["trials"] and cal["chosen"]["ms_per_step"] == min(t["ms_per_step"] for t in cal["trials"])
+    assert d["roofline"]["frames_per_gather"] == cal["chosen"]["frames_per_gather"] and c["comm_headroom"] == cal["chosen"]["comm_headroom"]
 
 
 def test_bench_with_eight_ranks_on_one_gpu():
-    """... and for N = 8, the size of the node the scaling run uses: eight processes, eight frames in flight in groups of two (bench.py's default from six
-    ranks on), seven receives per exchange on rank 0."""
-    d = bench_ranks(8, ["--gather", "library"])
+    """... and for N = 8, the size of the node the scaling run uses: eight processes, eight frames in flight in groups of two (pinned here; the calibration
+    then tries the three headrooms only), seven receives per exchange on rank 0."""
+    d = bench_ranks(8, ["--gather", "library", "--gather-group", "2"])
     c = d["config"]
     assert d["n_gpus"] == 8 and c["rccl_ranks"] == 8 and c["gather"].startswith("vx_gather_tiles") and "gather_note" not in c
     assert c["sharded_frame_identical_to_whole_render"] is True
     assert len(c["per_rank"]) == 8 and all(r["rays_per_block"] > 0 for r in c["per_rank"])
     assert d["roofline"]["frames_in_flight"] == 8 and d["roofline"]["frames_per_gather"] == 2
+    assert [t["comm_headroom"] for t in c["calibration"]["trials"]] == [0, 2, 4] and all(t["frames_per_gather"] == 2 for t in c["calibration"]["trials"])
 
 
 def test_bench_watchdog_when_a_peer_never_joins():
     """A peer that never joins the exchange: rank 0's receive waits on the device, vx_gather_query stays at 'not yet', the watchdog's deadline passes, every
     rank switches IN THE SAME PROCESS to torch.distributed's gather, whose frames are checked the same way -- the run ends, with a line that says what ran."""
-    d = bench_ranks(2, ["--gather", "auto", "--gather-timeout", "3", "--simulate-absent-peer"])
+    d = bench_ranks(2, ["--gather", "auto", "--gather-timeout", "3", "--simulate-absent-peer", "--no-calibration"])
     c = d["config"]
     assert c["gather"].startswith("torch.distributed.gather") and "failed its first frames" in c["gather_note"]
     assert c["sharded_frame_identical_to_whole_render"] is True

@@ -125,6 +125,13 @@ int vx_comm_info(const vx_context* ctx, int* nranks, int* rank) {
     return VX_OK;
 }
 
+int vx_set_comm_headroom(vx_context* ctx, int waves_per_cu) {
+    if (!ctx || waves_per_cu < 0 || waves_per_cu > 8) return fail(VX_ERR_INVALID_ARGUMENT, "comm headroom: 0..8 waves per CU");
+    VX_LOCK(ctx);
+    ctx->comm_headroom = waves_per_cu;  // (launch_render reads it per launch)
+    return VX_OK;
+}
+
 namespace {
 // the exchange; only_slot >= 0: the list was rendered by the frame just issued on that frame stream (vx_render_gather knows) -- one event to wait for
 // instead of every stream's (a HIP call each: a third of what a sharded frame costs its host thread)

@@ -98,6 +98,7 @@ SYMBOLS = {
     "vx_comm_init": (_int, [_vp, _int, _int, _vp]),
     "vx_comm_destroy": (_int, [_vp]),
     "vx_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
+    "vx_set_comm_headroom": (_int, [_vp, _int]),
     "vx_gather_tiles": (_int, [_vp, _vp, _u64, _vp, _int, C.POINTER(_int)]),
     "vx_wait_gather": (_int, [_vp, _int]),
     "vx_render_gather": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, C.POINTER(Target), _u64, _vp, _int, _vp, _int, C.POINTER(_int)]),
@@ -300,6 +301,10 @@ class Svo:
 
     def comm_destroy(self):
         _check(lib().vx_comm_destroy(self._h))
+
+    def set_comm_headroom(self, waves_per_cu):
+        """Wave slots per CU left to RCCL's workgroups by a context whose communicator has more than one rank (vx_set_comm_headroom)."""
+        _check(lib().vx_set_comm_headroom(self._h, int(waves_per_cu)))
 
     def gather_tiles(self, tiles_ptr, bytes_per_rank, gathered_ptr, root=0):
         ticket = _int(-1)
