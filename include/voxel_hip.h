@@ -383,6 +383,11 @@ uint32_t vx_timeline_read(vx_context* ctx, uint64_t* out, uint32_t capacity_wave
  * imaged), 1 = the traversal image with byte offsets, 2 = its layout for more than 4 GiB (32-byte units behind a 64-bit pointer);
  * [1] bytes of the image, [2] bytes of its origin table (CSVO worlds), [3] chunks it holds. */
 int vx_image_info(const vx_context* ctx, uint64_t out[4]);
+/* The scheduling knobs this context runs with (they reorder a frame's work and change no pixel): [0] refill threshold, [1] service threshold, [2] cap on
+ * the persistent waves per CU (0 = none), [3] length of the sub-tile queue's stretches (0 = by the launch), [4] width of the tile numbering's strips, [5] cost-ordered
+ * queue on / off, [6] wave slots per CU left to RCCL (vx_set_comm_headroom), [7] 1 = this is the library's measurement build (the only one that reads the
+ * VX_REFILL_MIN / VX_WAVES_PER_CU / VX_QUEUE_STRIPE / VX_TILE_STRIP / VX_HOT_FIRST environment variables). For the tests. */
+int vx_debug_knobs(const vx_context* ctx, uint32_t out[8]);
 /* CSVO worlds rendered from their traversal image: since creation (or the last reset), [0] rays that were led into the voxel they
  * started in and made that walk on the world's own bytes, [1] those of them whose pixel was rendered again on the bytes (the walk
  * overwrote cursor state the rest of the ray depends on), [2] service phases of the render kernel that ran such walks (the rays of a

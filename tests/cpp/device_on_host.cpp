@@ -105,9 +105,13 @@ extern "C" void devhost_picker(int svo_type, const uint8_t* world, uint64_t worl
 // the loop, the hand-over to the full stack below the LDS-resident levels, leaf tests, and -- for the image of a CSVO world --
 // the excursion onto the world's own bytes when the ray is led into a voxel. Returns the reference's OctreeResult and the
 // number of loop iterations.
+// `along` (optional): the ray is the shadow ray of a primary that has just hit a voxel on THIS stack -- {un-mirrored corner of the voxel (3 floats as bits), the
+// parent's octant, masks, scale}: the cursor takes the levels down to the voxel's parent in one go (Trav::descend_along), as render_persistent's set-up does;
+// *along_taken says whether it took any level that way. `leaf_state` (optional): where the cursor stood when the ray hit, in the same form, for the next ray.
 template <int IMG, int FOREIGN, bool SHALLOW, int LV = kLdsLevels>
 static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float pos[3], const float dir[3], float max_dst, bool cast_translucent,
-                       int walk_mode, vx_result* out, uint32_t* steps, uint32_t* given_up = nullptr) {
+                       int walk_mode, vx_result* out, uint32_t* steps, uint32_t* given_up = nullptr, const uint32_t* along = nullptr, bool* along_taken = nullptr,
+                       uint32_t* leaf_state = nullptr) {
     StackSpill spill;
     typedef Stack<1, false, false, LV, (LV > kLdsLevels)> FullStack;  // (16 levels: the 16-bit third plane, like the kernel's)
     typedef Stack<1, true, SHALLOW, LV, (LV > kLdsLevels)> FastStack;
@@ -118,6 +122,15 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
     constexpr int kFastFloor = FullStack::kBaseScale - 1;
     Trav<IMG> tr;
     tr.init(sc, pos, dir, max_dst);
+    bool walked = false;  // the hit (if any) was found by a walk inside a voxel: the cursor does not stand at a voxel of the image
+    if (along) {
+        float q[3];
+        std::memcpy(q, along, 12);
+        // (the primary's cursor stood in the voxel's parent when it hit: the parent joins its ancestors on the stack, as render_persistent does at the hit)
+        fast_st.push(int(along[5]), along[3], 0.0f, along[4]);
+        tr.descend_along(fast_st, int(along[5]), q);
+        if (along_taken) *along_taken = tr.iter > 0;  // (levels taken in one go)
+    }
     Result res;
     bool hit = false;
     TravStatus s = kTravContinue;
@@ -157,6 +170,7 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
                 } else {
                     s = walk_voxel_on_bytes<IMG, FullStack, true, false, true>(sc, sc_bytes.world, tr, st, cast_translucent, res);
                 }
+                walked = true;
                 if (given_up && s == kTravForeign) ++*given_up;
                 if (s == kTravForeign) {
                     uint32_t n = 0;
@@ -186,6 +200,13 @@ static void image_cast(const DevScene& sc, const DevScene& sc_bytes, const float
     std::memcpy(out->pos, res.pos, 12); std::memcpy(out->uv, res.uv, 8); std::memcpy(out->color, res.color, 16);
     out->lod = res.lod; out->inside_voxel = res.inside_voxel ? 1 : 0;
     *steps = tr.iter;
+    if (leaf_state) {
+        leaf_state[6] = hit && !walked ? 1u : 0u;
+        float q[3];
+        tr.cell_corner(q);
+        std::memcpy(leaf_state, q, 12);
+        leaf_state[3] = tr.ptr; leaf_state[4] = tr.node; leaf_state[5] = uint32_t(tr.scale);
+    }
 }
 
 // layout: 1 = byte-offset image (VX_SVO_IMAGE), 2 = wide image (VX_SVO_IMAGE_WIDE); svo_type = the world's own format
@@ -230,4 +251,48 @@ extern "C" void devhost_image_cast(int svo_type, int layout, int shallow, int wa
 #undef CAST
 #undef CAST16
     }
+}
+
+
+// A pixel's two rays on the image of a world, the shadow ray both ways: from the root like any ray, and down the primary's path in one go (Trav::descend_along,
+// what render_persistent's ray set-up does). For every task: the primary ray; if it hits, the shadow ray from hit + normal * 0.001 (world.glsl:79-84) toward
+// `to_light` -- results[2 i] = the plain one, results[2 i + 1] = the one that started on the path, steps likewise. Returns how many shadow rays took at least one level
+// along the path. Byte-offset images, the stack build with 16 resident levels; walk_mode 3.
+extern "C" uint32_t devhost_image_shadow_pairs(int svo_type, const uint8_t* world, uint64_t world_bytes, const uint8_t* image, uint64_t image_bytes, const uint8_t* origin,
+                                               const vx_material* mats, uint32_t n_mats, const uint8_t* tex, uint32_t tw, uint32_t th, uint32_t layers, uint32_t levels,
+                                               const uint32_t* level_offset, const vx_picker_task* tasks, uint32_t n, const float* to_light, vx_result* results, uint32_t* steps) {
+    SceneArgs sa = {};
+    sa.world = world; sa.world_bytes = world_bytes; sa.materials = mats; sa.n_materials = n_mats;
+    sa.tex = tex; sa.tex_bytes = 0;
+    sa.width = tw; sa.height = th; sa.layers = layers; sa.levels = levels;
+    for (uint32_t l = 0; l < levels && l < 16; ++l) {
+        sa.level_offset[l] = level_offset[l];
+        const uint32_t w = (tw >> l) ? (tw >> l) : 1, h = (th >> l) ? (th >> l) : 1;
+        sa.tex_bytes = level_offset[l] + layers * w * h * 4;
+    }
+    sa.image = image; sa.image_bytes = image_bytes; sa.origin = origin;
+    const DevScene sc = make_image_scene(sa), sc_bytes = make_scene(sa);
+    std::vector<unsigned char> lds(Stack<1, false, false, 16, false>::kBytes + 64);
+    vx_smem = lds.data();
+    uint32_t taken = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        vx_result primary;
+        uint32_t primary_steps = 0, leaf[7] = {};
+        std::memset(&results[2 * i], 0, 2 * sizeof(vx_result));
+        steps[2 * i] = steps[2 * i + 1] = 0;
+        if (svo_type == 1) image_cast<VX_SVO_IMAGE, 0, true, 16>(sc, sc_bytes, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, true, 3, &primary, &primary_steps, nullptr, nullptr, nullptr, leaf);
+        else image_cast<VX_SVO_IMAGE, VX_SVO_CSVO, true, 16>(sc, sc_bytes, tasks[i].pos, tasks[i].dir, tasks[i].max_dst, true, 3, &primary, &primary_steps, nullptr, nullptr, nullptr, leaf);
+        if (!(primary.t >= 0.0f) || !leaf[6]) continue;
+        float normal[3];
+        face_vector<0>(uint32_t(primary.face_id), normal);
+        const float so[3] = {primary.pos[0] + normal[0] * 0.001f, primary.pos[1] + normal[1] * 0.001f, primary.pos[2] + normal[2] * 0.001f};
+        // the path first: the primary's stack is still in place
+        bool ok = false;
+        if (svo_type == 1) image_cast<VX_SVO_IMAGE, 0, true, 16>(sc, sc_bytes, so, to_light, -1.0f, true, 3, &results[2 * i + 1], &steps[2 * i + 1], nullptr, leaf, &ok);
+        else image_cast<VX_SVO_IMAGE, VX_SVO_CSVO, true, 16>(sc, sc_bytes, so, to_light, -1.0f, true, 3, &results[2 * i + 1], &steps[2 * i + 1], nullptr, leaf, &ok);
+        taken += ok ? 1u : 0u;
+        if (svo_type == 1) image_cast<VX_SVO_IMAGE, 0, true, 16>(sc, sc_bytes, so, to_light, -1.0f, true, 3, &results[2 * i], &steps[2 * i]);
+        else image_cast<VX_SVO_IMAGE, VX_SVO_CSVO, true, 16>(sc, sc_bytes, so, to_light, -1.0f, true, 3, &results[2 * i], &steps[2 * i]);
+    }
+    return taken;
 }

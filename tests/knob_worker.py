@@ -56,6 +56,7 @@ def main():
     out["counters"] = {k: v for k, v in counters.items() if k not in occupancy}
     # how the instrumented kernel scheduled its lanes (not what the rays did): moves with the refill / service thresholds wherever they are honoured
     out["occupancy"] = {k: counters[k] for k in occupancy}
+    out["knobs"] = svo.knobs()  # (what the context runs with: the measurement build reads the experiments' environment variables, the product build does not)
     print(json.dumps(out))
 
 

@@ -252,6 +252,119 @@ def test_image_traversal_in_deep_worlds(devhost, golden, fmt, base, depth):
         assert_same_casts(got, gsteps, exp, esteps)
 
 
+def shadow_pairs(lib, fmt, world, mats, tex, mips, tasks, to_light):
+    from voxel_rs_amd import hip
+
+    frame = world.frame(pad_words=0)
+    head = 4 + (20 if fmt == "esvo" else 4)
+    image, origin = hip.traversal_image(1 if fmt == "esvo" else 2, frame, frame.size * 4 - head, layout=1, with_origin=True)
+    image = np.concatenate([image, np.zeros(16, dtype=np.uint32)])
+    levels = orc.mip_chain(tex, mips)
+    chain = np.concatenate([lv.ravel() for lv in levels])
+    offsets = np.cumsum([0] + [lv.size for lv in levels[:-1]])
+    level_offset = (C.c_uint32 * 16)(*[int(o) for o in offsets])
+    out = np.zeros(2 * len(tasks), dtype=RESULT_DTYPE)
+    steps = np.zeros(2 * len(tasks), dtype=np.uint32)
+    frame = np.concatenate([frame, np.zeros(4, dtype=np.uint32)])
+    light = (C.c_float * 3)(*[float(v) for v in to_light])
+    lib.devhost_image_shadow_pairs.restype = C.c_uint32
+    taken = lib.devhost_image_shadow_pairs(1 if fmt == "esvo" else 2, frame.ctypes.data_as(C.c_void_p), C.c_uint64(frame.size * 4), image.ctypes.data_as(C.c_void_p),
+                                           C.c_uint64(image.size * 4), origin.ctypes.data_as(C.c_void_p), mats.ctypes.data_as(C.c_void_p), mats.size,
+                                           chain.ctypes.data_as(C.c_void_p), tex.shape[2], tex.shape[1], tex.shape[0], len(levels), level_offset,
+                                           tasks.ctypes.data_as(C.c_void_p), len(tasks), light, out.ctypes.data_as(C.c_void_p), steps.ctypes.data_as(C.c_void_p))
+    return taken, out, steps
+
+
+@pytest.mark.parametrize("fmt", ["esvo", "csvo"])
+@pytest.mark.parametrize("depth", [9, 11])
+def test_shadow_rays_that_start_on_their_primary_rays_path(devhost, fmt, depth):
+    """render_persistent's ray set-up lets a pixel's shadow ray take the levels down to the voxel its primary hit in one go, along the nodes the primary's stack
+    holds (Trav::descend_along: an image cursor writes its parent's entry at every push). The device code, driven the way the kernel drives it: for the
+    primary rays of a view of a terrain, the shadow ray (hit + normal * 0.001 towards the light, world.glsl:79-84) from the root like any ray and along the
+    path -- both must be the ORACLE's shadow ray, results and iteration counts, and most of them must in fact have taken the path."""
+    from voxel_rs_amd import scenes
+
+    svo_type = 1 if fmt == "esvo" else 2
+    world = vra.World(svo_type)
+    st = world.build_heightfield(depth, threads=4)
+    tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
+    scene = orc.OracleScene(svo_type, world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
+    w, h = 80, 45
+    u = scenes.bench_camera(depth, st["h_max"], w, h, shadow_distance=3.0e38)
+    eye = np.asarray(u.cam_pos[:], dtype=np.float32)
+    # the view's primary rays as picker tasks: towards the hit positions of an oracle render (any rays towards the terrain would do)
+    _, hits = scene.render(orc.Uniforms.from_buffer_copy(bytes(u)), w, h)
+    sel = hits[(hits["flags"] & 1) != 0]
+    tasks = np.zeros(len(sel), dtype=orc.PICKER_TASK_DTYPE)
+    d = sel["pos"] - eye
+    tasks["pos"] = eye
+    tasks["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tasks["max_dst"] = -1
+    opaque = 0
+    for b in range(len(mats)):
+        if all(tex[max(0, int(mats[b][k]))][:, :, 3].min() > 0 for k in ("tex_top", "tex_side", "tex_bottom")):
+            opaque |= 1 << b
+    devhost.devhost_set_opaque(opaque & 0xffffffff, opaque >> 32)
+    to_light = -np.asarray(u.light_dir[:], dtype=np.float32)
+    taken, out, steps = shadow_pairs(devhost, fmt, world, mats.view(orc.MATERIAL_DTYPE), tex, 6, tasks, to_light)
+    # the oracle's shadow rays: from ITS primary hits (the device's primaries are the oracle's: test_image_traversal_*)
+    prim, _ = oracle_cast(scene, tasks, 1)
+    normals = np.asarray(NORMALS, dtype=np.float32)
+    stasks = np.zeros(len(tasks), dtype=orc.PICKER_TASK_DTYPE)
+    stasks["pos"] = prim["pos"] + normals[np.clip(prim["face_id"], 0, 5)] * np.float32(0.001)
+    stasks["dir"] = to_light
+    stasks["max_dst"] = -1
+    exp, esteps = oracle_cast(scene, stasks, 1)
+    hit = prim["t"] >= 0
+    assert hit.sum() > 1000 and taken > 0.9 * hit.sum(), (int(hit.sum()), taken)
+    for k in (0, 1):  # from the root / along the path
+        got, gsteps = out[k::2][hit], steps[k::2][hit]
+        assert_same_casts(got, gsteps, exp[hit], esteps[hit])
+
+
+@pytest.mark.parametrize("fmt", ["esvo", "csvo"])
+def test_shadow_rays_on_the_path_in_a_deep_world(devhost, golden, fmt):
+    """... and at depth 14, where the shadow ray's offset falls below the clamp that keeps a hit inside its voxel: every shadow ray starts INSIDE the voxel its
+    primary hit (the result says so for those whose t_min is 0 there), takes the whole path down to the voxel's parent in one go and is led into the voxel from there (an empty node of an ESVO world; the walk on
+    the world's own bytes of a CSVO world)."""
+    rng = np.random.default_rng(5)
+    base = (400, 3, 401)
+    svo_type = 1 if fmt == "esvo" else 2
+    world = vra.World(svo_type)
+    for dx in range(2):
+        chunk = vra.Chunk(base[0] + dx, base[1], base[2], 5)
+        for x in range(32):
+            for z in range(32):
+                for y in range(6 + int(rng.integers(0, 6))):
+                    chunk.set_block(x, y, z, int(rng.choice([1, 2, 3, 4])))
+        chunk.compact()
+        world.set_chunk((base[0] + dx, base[1], base[2]), chunk)
+    world.serialize()
+    assert world.depth == 14
+    tex, mips = golden_textures(golden)
+    mats = golden_materials(golden)
+    scene = orc.OracleScene(svo_type, world.frame(), mats, tex, mips)
+    tasks = random_tasks(rng, 1500, 0, 1)
+    tasks["pos"] = (np.float32([32 * c for c in base]) + rng.uniform([0, 20, 0], [64, 30, 32], size=(len(tasks), 3))).astype(np.float32)
+    d = rng.normal(size=(len(tasks), 3)) * [1.0, 0.2, 1.0] - [0, 1.0, 0]
+    tasks["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tasks["max_dst"] = -1
+    devhost.devhost_set_opaque(0, 0)
+    to_light = np.float32([0.57735026, 0.57735026, 0.57735026])
+    taken, out, steps = shadow_pairs(devhost, fmt, world, mats, tex, mips, tasks, to_light)
+    prim, _ = oracle_cast(scene, tasks, 1)
+    hit = (prim["t"] >= 0) & (prim["inside_voxel"] == 0)
+    normals = np.asarray(NORMALS, dtype=np.float32)
+    stasks = np.zeros(len(tasks), dtype=orc.PICKER_TASK_DTYPE)
+    stasks["pos"] = prim["pos"] + normals[np.clip(prim["face_id"], 0, 5)] * np.float32(0.001)
+    stasks["dir"] = to_light
+    stasks["max_dst"] = -1
+    exp, esteps = oracle_cast(scene, stasks, 1)
+    assert hit.sum() > 500 and taken > 0.9 * hit.sum() and (exp["inside_voxel"][hit] != 0).mean() > 0.3, (int(hit.sum()), taken)
+    for k in (0, 1):
+        assert_same_casts(out[k::2][hit], steps[k::2][hit], exp[hit], esteps[hit])
+
+
 def test_the_sub_tile_queue_hands_out_every_sub_tile_once(devhost):
     """queue_subtile (vx_args.hpp): the launch's sub-tiles are dealt out to the eight dispensers in stretches of `stripe`; a dispenser's numbers grow, the
     first beyond the launch means it is dry, and between them the dispensers cover the launch exactly once -- for launches of a tile, of odd sizes, with

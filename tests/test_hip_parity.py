@@ -775,7 +775,7 @@ def test_views_and_sizes_in_turn(hip, fmt):
 
 def run_knob_worker(fmt, env, measurement_build, occupancy=False):
     """tests/knob_worker.py in a process of its own (a process loads one build of the library; the knobs are read when a context is created).
-    occupancy=True: also the instrumented kernel's scheduling counters (they vary a little from run to run: not part of the digest)."""
+    occupancy=True: also the scheduling knobs the worker's context says it runs with (vx_debug_knobs)."""
     import json
     import subprocess
     import sys
@@ -787,8 +787,9 @@ def run_knob_worker(fmt, env, measurement_build, occupancy=False):
     r = subprocess.run([sys.executable, str(Path(ROOT) / "tests" / "knob_worker.py"), fmt], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    occ = out.pop("occupancy")
-    return (out, occ) if occupancy else out
+    out.pop("occupancy")
+    knobs = out.pop("knobs")
+    return (out, knobs) if occupancy else out
 
 
 @pytest.mark.parametrize("fmt", FMTS)
@@ -813,15 +814,13 @@ def test_knobs_of_the_measurement_build_change_no_pixel(hip, fmt):
     ref = run_knob_worker(fmt, {}, False)
     for env in ({"VX_REFILL_MIN": "1", "VX_SERVICE_MIN": "1"}, {"VX_REFILL_MIN": "7", "VX_SERVICE_MIN": "33"}, {"VX_HOT_FIRST": "0"}, {"VX_WAVES_PER_CU": "3"}):
         assert run_knob_worker(fmt, env, True) == ref, env
-    # ... and the product build does not read them: a refill threshold of 1 multiplies the instrumented kernel's refills where it is honoured (the
-    # measurement build) and leaves them alone where it is not (they vary by a few per cent from run to run: which wave draws which ticket)
-    ref2, occ_ref = run_knob_worker(fmt, {}, False, occupancy=True)
-    got, occ_product = run_knob_worker(fmt, {"VX_REFILL_MIN": "1", "VX_WAVES_PER_CU": "1", "VX_QUEUE_STRIPE": "3"}, False, occupancy=True)
+    # ... and the product build does not read them: what each build's context says it runs with (vx_debug_knobs)
+    ref2, k_ref = run_knob_worker(fmt, {}, False, occupancy=True)
+    got, k_product = run_knob_worker(fmt, {"VX_REFILL_MIN": "1", "VX_WAVES_PER_CU": "1", "VX_QUEUE_STRIPE": "3", "VX_TILE_STRIP": "3", "VX_HOT_FIRST": "0"}, False, occupancy=True)
     assert got == ref and ref2 == ref
-    _, occ_measure = run_knob_worker(fmt, {"VX_REFILL_MIN": "1"}, True, occupancy=True)
-    print("refills: product default", occ_ref["refills"], "product with VX_REFILL_MIN=1", occ_product["refills"], "measurement build with it", occ_measure["refills"])
-    assert occ_measure["refills"] > 1.5 * occ_ref["refills"], "the measurement build honours VX_REFILL_MIN"
-    assert abs(occ_product["refills"] - occ_ref["refills"]) <= 0.1 * occ_ref["refills"], "the product build does not"
+    assert k_product == k_ref and k_ref["measurement_build"] == 0 and (k_ref["refill_min"], k_ref["waves_per_cu"], k_ref["queue_stripe"], k_ref["hot_first"]) == (64, 0, 0, 1), (k_ref, k_product)
+    _, k_measure = run_knob_worker(fmt, {"VX_REFILL_MIN": "1", "VX_WAVES_PER_CU": "3", "VX_QUEUE_STRIPE": "5", "VX_HOT_FIRST": "0"}, True, occupancy=True)
+    assert k_measure["measurement_build"] == 1 and (k_measure["refill_min"], k_measure["waves_per_cu"], k_measure["queue_stripe"], k_measure["hot_first"]) == (1, 3, 5, 0), k_measure
 
 
 # ---- output formats, presentation ring, lifetime, fall-back, the library's own gather ---------------------------------------------

@@ -28,7 +28,7 @@ C_SCALARS = {
 RUST_ALIASES = {"PickerTask": "vx_picker_task", "PickerResult": "vx_picker_result", "MaterialInstance": "vx_material"}
 # declared by the header for the test and measurement harness only: graphics::Svo has no use for them (everything else must be bound)
 NOT_BOUND = {"vx_debug_trace", "vx_render_counters", "vx_profile_enable", "vx_profile_read", "vx_timeline_read", "vx_excursion_counters",
-             "vx_traversal_image", "vx_traversal_image_with_origin", "vx_assemble_tiles_on", "vx_comm_profile_read", "vx_clock_probe"}
+             "vx_traversal_image", "vx_traversal_image_with_origin", "vx_assemble_tiles_on", "vx_comm_profile_read", "vx_clock_probe", "vx_debug_knobs"}
 
 
 def strip_c_comments(text):

@@ -242,6 +242,10 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
     float primary_rd[3] = {0, 0, 0};  // kept while a primary ray is in flight: the sky needs it if the ray misses (world.glsl:135-138)
     float keep_color[4] = {0, 0, 0, 0}, keep_ds = 0.0f;
     float held_t = -1.0f;  // FOREIGN = VX_SVO_CSVO: the distance of a shadow ray that ended inside its voxel (kHeld)
+    // A pixel's shadow ray starts in (or at) the voxel its primary ray hit, and the primary's stack holds that voxel's ancestors: the shadow ray takes
+    // the levels down to the voxel's parent in one go instead of a trip of the loop each (Trav::descend_along). Image cursors on the loop's own stack;
+    // the build with the LDS copy of the top levels keeps the plain descent (it is a cross-check).
+    constexpr bool kDescendAlong = IMAGE && !HOT;
     vx_hit rec;            // HITS only
     uint32_t steps = 0;    // HITS only
     Counters ctr = {};
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
     };
     // the n-th ticket of dispenser c is its (first_c + n)-th sub-tile (queue_subtile), first_c = how many of the waves' own first sub-tiles are c's
     // (beyond the launch's last sub-tile: the dispenser is dry -- its sub-tiles' numbers grow with k)
-    auto region_ticket = [&](uint32_t k, uint32_t queue) -> uint32_t { return queue_subtile(k, queue, a.stripe); };
+    auto region_ticket = [&](uint32_t k, uint32_t queue) -> uint32_t { return queue_subtile(k, queue, a.stripe, a.stripe_shift); };
     auto ticket_of = [&](uint32_t raw, uint32_t queue) -> uint32_t {
         return region_ticket(((gridDim.x + kQueues - 1u - queue) >> 3) + uint32_t(__builtin_amdgcn_readfirstlane(raw)), queue);
     };
@@ -537,6 +541,10 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
         // freshly assigned pixel -- only records origin and direction; one Trav::init below serves both kinds together.
         float new_ro[3] = {0, 0, 0}, new_rd[3] = {0, 0, 0};
         bool new_ray = false;
+        // (kDescendAlong) a shadow ray set up in this phase: the voxel its primary hit -- its un-mirrored corner, its parent's scale
+        bool along = false;
+        float along_q[3] = {0, 0, 0};
+        int along_scale = 0;
 
         // ---- finished rays ----
         VX_PART_BEGIN(2);
@@ -569,6 +577,14 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                         new_ray = true;
                         shadow_ray = true;
                         write = false;
+                        if constexpr (kDescendAlong) {
+                            // the primary's cursor still stands at the voxel (a hit found by a walk inside a voxel does not: its cursor is among phantom
+                            // nodes): the voxel's parent joins its ancestors on the stack, the voxel's corner says where the path leads
+                            along = !walked;
+                            tr.cell_corner(along_q);
+                            along_scale = tr.scale;
+                            if (along) fast_st.push(tr.scale, tr.ptr, tr.t_max, tr.node);
+                        }
                         if (STATS) { ctr.rays++; ++shadow_rays; }
                     }
                 }
@@ -660,6 +676,25 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
         if (new_ray) {
             tr.init(sc, new_ro, new_rd, -1.0f);  // iter = 0: not parked
             state = kTrav;
+        }
+        if constexpr (kDescendAlong) {
+            if (__ballot(along) != 0ull) {  // (wave-uniform: a batch of shadow rays)
+                if (along) {
+                    constexpr bool kByHand = VX_ASM_LOOP != 0 && (LV == kLdsLevels || LV == 16);
+                    if constexpr (kByHand) {
+                        if (along_scale >= FastStack::kBaseScale && along_scale < kMaxScale) {
+                            const int from = tr.scale;
+                            descend_along_gfx950<LV>(tr, uint32_t(reinterpret_cast<uintptr_t>(fast_st.at(0))) + fast_st.slot0, along_scale, along_q);
+                            if (tr.scale != from) {  // the node the cursor has reached: the path's at this scale
+                                float unused;
+                                fast_st.pop(tr.scale, tr.ptr, unused, tr.node);
+                            }
+                        }
+                    } else {
+                        tr.descend_along(fast_st, along_scale, along_q);
+                    }
+                }
+            }
         }
         VX_PART_END(4);
 #undef VX_PART_BEGIN

@@ -312,6 +312,9 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         // (a stretch longer than the launch behaves like one of its length; clamped so that queue_subtile's 32-bit products cannot wrap)
         if (a.stripe > a.total_subtiles) a.stripe = a.total_subtiles;
         if (a.stripe < 1u) a.stripe = 1u;
+        a.stripe_shift = 0xffffffffu;
+        for (uint32_t b = 0; b < 32u; ++b)
+            if (a.stripe == (1u << b)) a.stripe_shift = b;
         // Persistent waves per CU: all that fit -- the stacks fill a CU's LDS to the last hundred bytes. A context that gathers its tiles over
         // RCCL leaves `comm_headroom` of them out: LDS of every CU stays free, in one piece, for the communication kernels' workgroups, which
         // otherwise find room only when a whole frame has drained.
@@ -1505,6 +1508,14 @@ int vx_image_info(const vx_context* ctx, uint64_t out[4]) {
     out[1] = ctx->image_ok ? ctx->pub.frame_bytes : 0u;
     out[2] = ctx->image_ok ? ctx->pub.origin_bytes : 0u;
     out[3] = ctx->image_ok ? ctx->pub.chunks : 0u;
+    return VX_OK;
+}
+
+int vx_debug_knobs(const vx_context* ctx, uint32_t out[8]) {
+    if (!ctx || !out) return fail(VX_ERR_INVALID_ARGUMENT, "debug_knobs: null argument");
+    VX_LOCK(const_cast<vx_context*>(ctx));
+    out[0] = ctx->refill_min; out[1] = ctx->service_min; out[2] = uint32_t(ctx->waves_per_cu_cap); out[3] = uint32_t(ctx->queue_stripe);
+    out[4] = uint32_t(ctx->tile_strip); out[5] = ctx->hot_first ? 1u : 0u; out[6] = uint32_t(ctx->comm_headroom); out[7] = vxk::timeline_build() ? 1u : 0u;
     return VX_OK;
 }
 

@@ -140,8 +140,9 @@ constexpr uint32_t kQueues = 8, kQueueStride = 64;  // dispensers of the sub-til
 // band of the screen; a compact piece of a tile list's Morton order) what an XCD's waves traverse is the part of the world behind its own
 // stretches, and that is what its L2 holds -- not, eight times over, the nodes behind the whole screen, as with S = 1 (round 3: sub-tiles c,
 // c + 8, c + 16, ... to dispenser c). S = 1 is still what a cost-ordered launch uses: its tickets are places in a table sorted by cost.
-VX_HOST_DEVICE inline uint32_t queue_subtile(uint32_t k, uint32_t c, uint32_t stripe) {
-    const uint32_t q = k / stripe;  // (once per sub-tile and wave)
+// (`shift`: log2 of the stretch where it is a power of two -- the default 16 is --, else 0xffffffff: a 32-bit division is ~35 instructions, per ticket)
+VX_HOST_DEVICE inline uint32_t queue_subtile(uint32_t k, uint32_t c, uint32_t stripe, uint32_t shift = 0xffffffffu) {
+    const uint32_t q = shift < 32u ? k >> shift : k / stripe;  // (once per sub-tile and wave)
     return (q * kQueues + c) * stripe + (k - q * stripe);
 }
 
@@ -156,6 +157,7 @@ struct PersistentArgs {
     uint32_t total_subtiles;  // n_local_tiles * 16
     uint32_t refill_min, service_min;
     uint32_t stripe;          // the length of the stretches the sub-tiles are dealt out to the dispensers in (queue_subtile), at least 1
+    uint32_t stripe_shift;    // log2(stripe) where that is a power of two, else 0xffffffff
     // Expensive sub-tiles first. A ray is a chain of dependent steps -- about 0.8 us per iteration on a busy device -- so a frame cannot
     // end before its longest rays do (up to ~300 iterations against a mean of ~30): handed out in the order of their numbers they start in mid-frame
     // and the frame ends with a long tail of waves that wait for a few of them (profiles/timeline.py). So every ray that ends notes

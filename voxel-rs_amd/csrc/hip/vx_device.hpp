@@ -43,6 +43,7 @@ struct DevScene {
     buf_t materials;          // vx_material rows
     float octree_scale;       // = world[0]
     uint32_t root_ptr;        // CSVO: world[1]
+    uint32_t image_root_masks, image_root_octant;  // traversal images: the header's two words every ray starts from (read once, by make_image_scene)
     DevTextures tex;
     // buffers that outgrow a V#'s 32-bit offsets are read through a plain 64-bit pointer: the traversal image in its wide layout
     // (VX_SVO_IMAGE_WIDE), and an ESVO world of 4 GiB and more (VX_SVO_ESVO_BIG; descriptors[] indices stay 32 bits: 16 GiB)
@@ -68,6 +69,7 @@ __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
     sc.wide = a.world;
     sc.wide_bytes = a.world_bytes;
     sc.origin = nullptr;
+    sc.image_root_masks = sc.image_root_octant = 0;
     return sc;
 }
 
@@ -85,6 +87,9 @@ __device__ __forceinline__ DevScene make_image_scene(const SceneArgs& a) {
     sc.wide = a.image;
     sc.wide_bytes = a.image_bytes;
     sc.origin = a.origin;
+    // header of the image: root masks, root octant (byte offset / index). (A wide image's header is within the first 4 GiB: the resource reaches it.)
+    sc.image_root_masks = buf_u32(sc.world, 4);
+    sc.image_root_octant = buf_u32(sc.world, 8);
     return sc;
 }
 
@@ -187,6 +192,11 @@ struct Stack {
         } else if (uint32_t(scale) < uint32_t(kMaxScale)) {
             spill->ptr[scale] = p; spill->t_max[scale] = t; spill->aux[scale] = a;
         }
+    }
+    // the t_max of a resident slot alone: pointer and masks stay what they are (Trav::descend_along)
+    __device__ __forceinline__ void set_t_max(int scale, float t) const {
+        const uint32_t s = uint32_t(scale) * (THREADS * 4u) + slot0;
+        *at(s + kPlane) = __float_as_uint(t);
     }
     // scale is in [0, kMaxScale) here (the caller has already left the octree otherwise)
     __device__ __forceinline__ void pop(int scale, uint32_t& p, float& t, uint32_t& a) const {
@@ -651,8 +661,8 @@ struct Trav {
             if (depth == 2) pre_leaf_pointer = ptr;
         } else if (IMG) {
             depth = 0;
-            node = WIDE ? wide_u32(sc, 0, 4) : buf_u32(sc.world, 4);  // header of the image: root masks, root octant (byte offset / index)
-            ptr = WIDE ? wide_u32(sc, 0, 8) : buf_u32(sc.world, 8);
+            node = sc.image_root_masks;  // header of the image: root masks, root octant (byte offset / index) -- read once per kernel, not per ray
+            ptr = sc.image_root_octant;
         } else {
             // the reference starts at (ptr 0, parent_octant_idx 0): the preamble is an octant whose only child is the root
             depth = 0;
@@ -881,7 +891,12 @@ struct Trav {
                 }
             }
             sched_fence();
-            if (tc_max < h) {
+            // The reference writes the parent's entry only where the ray leaves the child before it leaves the parent (tc_max < h, svo.esvo.glsl:292-296). A
+            // write it skips is either of an entry that is never popped (tc_max == h: the ray leaves the parent with the child, the next POP goes above
+            // this level) or of the very entry the slot already holds (h == 0 after a POP to this parent: same pointer, same masks, the t_max that was
+            // just popped). So a cursor on an image writes at EVERY push and keeps no `h`: three instructions a trip of the render loop less, and a
+            // ray's stack holds every ancestor of its cell (the shadow ray's start relies on it: Trav::descend_along).
+            if (IMG || tc_max < h) {
                 st.push(scale, ptr, t_max, CSVO ? (depth << 16) | node : node);
                 if (TRACE && !CSVO) { tk->stack_ptr[scale] = tk->ref_ptr; tk->stack_aux[scale] = uint8_t(tk->ref_aux); }
             }
@@ -992,7 +1007,7 @@ struct Trav {
         const float hm = push ? half : 0.0f, other = push ? 0.0f : -scale_exp2;
         const float lhs = push ? t_min : tc_max;
         const float rx = __builtin_fmaf(hm, tcx, tcrx), ry = __builtin_fmaf(hm, tcy, tcry), rz = __builtin_fmaf(hm, tcz, tcrz);
-        if (push && tc_max < h) st.push(scale, ptr, t_max, node);
+        if (push) st.push(scale, ptr, t_max, node);  // (at every push, no `h`: see step_with)
         px += lhs < rx ? hm : other;
         py += lhs < ry ? hm : other;
         pz += lhs < rz ? hm : other;
@@ -1000,7 +1015,6 @@ struct Trav {
         const uint32_t differing_bits = (bx ^ __float_as_uint(px)) | (by ^ __float_as_uint(py)) | (bz ^ __float_as_uint(pz));
         const bool pop = !push && differing_bits >= (2u << scale);
         t_min = push ? t_min : tc_max;
-        h = push ? tc_max : h;
         t_max = push ? tv_max : t_max;
         scale_exp2 = push ? half : scale_exp2;
         scale = push ? scale - 1 : scale;
@@ -1017,7 +1031,6 @@ struct Trav {
                 px = __uint_as_float(__float_as_uint(px) & keep);
                 py = __uint_as_float(__float_as_uint(py) & keep);
                 pz = __uint_as_float(__float_as_uint(pz) & keep);
-                h = 0.0f;
             }
         }
         // the child's octant and masks. (A ray led into a voxel of an ESVO world walks it as an empty node whatever the entry holds, and
@@ -1025,6 +1038,60 @@ struct Trav {
         ptr = push ? ((WIDE && !FOREIGN && is_leaf) ? 0u : ahead.x) : ptr;
         node = push ? ((!FOREIGN && is_leaf) ? 0u : ahead.y) : node;
         if (!inside) return on_exit(kTravFinished);
+    }
+
+    // The un-mirrored corner of the cell the cursor is at (svo.esvo.glsl:205-207), in the octree's [1, 2)^3: for a ray at a leaf, the voxel's.
+    __device__ __forceinline__ void cell_corner(float q[3]) const {
+        q[0] = (octant_mask & 1) ? 3.0f - scale_exp2 - px : px;
+        q[1] = (octant_mask & 2) ? 3.0f - scale_exp2 - py : py;
+        q[2] = (octant_mask & 4) ? 3.0f - scale_exp2 - pz : pz;
+    }
+
+    // A ray that starts in or next to a voxel another ray of this lane has just hit -- a pixel's shadow ray (world.glsl:79-84: from the hit, 0.001 along the
+    // normal) -- descends from the root through nodes the first ray's stack still holds: every cursor on an image writes its parent's entry at EVERY push
+    // (step_with), so when the first ray stood at the voxel, slot s held the node at scale s on the voxel's path for every scale above the voxel's parent, and
+    // the caller has put the parent itself into its slot (`parent_scale`). The reference spends an iteration of its loop per level on that descent
+    // (svo.esvo.glsl:152-311: fetch the node, test the child, PUSH) -- 10 of a depth-12 shadow ray's ~30, each a trip of the render loop for the whole wave.
+    // Here the levels are run through in one go for as long as the ray stays ON the path: the child cell it is about to enter is the path's (`q`: the
+    // voxel's un-mirrored corner; cells are nested, so a cell is on the path iff its corner is q's prefix) -- that child exists and is a node, nothing need be
+    // fetched to know it -- and the reference would PUSH (t_min <= t_max, t_min <= min(t_max, tc_max)). Per level exactly the floats the PUSH computes: the
+    // cell's exit distances, tc_max, min(t_max, tc_max), the centre planes' distances, the child chosen by t_min against them; the stack gets this ray's t_max
+    // (pointer and masks are in place). Where the ray leaves the path (its origin lies in a neighbouring cell: at depth <= 12 the offset takes it out of the
+    // voxel; or the reference would ADVANCE) the cursor stands in the last node of the path it reached, about to examine its child -- an ordinary state of
+    // the traversal, and the loop takes over. Called on a cursor fresh from init().
+    template <class ST>
+    __device__ __forceinline__ void descend_along(const ST& st, int parent_scale, const float q[3]) {
+        static_assert(IMG && ST::kFast, "image cursors on the loop's stack");
+        if (!(parent_scale >= ST::kBaseScale && parent_scale < kMaxScale)) return;
+        const float cell = pow2i(parent_scale - kMaxScale);
+        // the voxel's corner in THIS ray's mirrored coordinates
+        const uint32_t ex = __float_as_uint((octant_mask & 1) ? 3.0f - cell - q[0] : q[0]);
+        const uint32_t ey = __float_as_uint((octant_mask & 2) ? 3.0f - cell - q[1] : q[1]);
+        const uint32_t ez = __float_as_uint((octant_mask & 4) ? 3.0f - cell - q[2] : q[2]);
+        const int from = scale;
+        while (scale > parent_scale) {
+            // the child cell the cursor is at: on the path? (its corner's bits from `scale` up are the voxel's)
+            const uint32_t off = (__float_as_uint(px) ^ ex) | (__float_as_uint(py) ^ ey) | (__float_as_uint(pz) ^ ez);
+            if ((off >> scale) != 0u) break;
+            const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
+            const float tc_max = gmin3(tcrx, tcry, tcrz);
+            const float tv_max = gmin(t_max, tc_max);
+            if (!(t_min <= t_max && t_min <= tv_max)) break;  // (the reference ADVANCEs here)
+            st.set_t_max(scale, t_max);
+            const float half = scale_exp2 * 0.5f;
+            const float rx = __builtin_fmaf(half, tcx, tcrx), ry = __builtin_fmaf(half, tcy, tcry), rz = __builtin_fmaf(half, tcz, tcrz);
+            px += t_min < rx ? half : 0.0f;
+            py += t_min < ry ? half : 0.0f;
+            pz += t_min < rz ? half : 0.0f;
+            t_max = tv_max;
+            scale_exp2 = half;
+            --scale;
+            ++iter;
+        }
+        if (scale != from) {  // the node the cursor has reached: the path's at this scale
+            float unused;
+            st.pop(scale, ptr, unused, node);
+        }
     }
 
     // image octants: bytes between the children's values -- an octant all of whose children are leaves (child bits 31..24 == leaf
@@ -1270,8 +1337,8 @@ __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, b
         const uint32_t next = wrapped ? table + csvo_tag_bytes(hd) + e : bp + 3u + offset;
         // given up: below scale 0 the child index is no longer a mantissa bit; a phantom chunk boundary
         if (push && (tr.scale == 0 || (wrapped && (e & 0x80000000u) != 0u))) { status = kTravForeign; out = true; }
-        // (the way back out of the voxel needs the image's entry: written whether or not tc_max < h -- harmless, the slot holds nothing else the ray could pop)
-        if (push && (dp == 1 || tc_max < tr.h)) st.push(tr.scale, dp == 1 ? img_ptr : bp, tr.t_max, dp == 1 ? img_node : hd << 16);
+        // (written at every push, like the image cursor's: it keeps no `h` -- step_with)
+        if (push) st.push(tr.scale, dp == 1 ? img_ptr : bp, tr.t_max, dp == 1 ? img_node : hd << 16);
         const float half = tr.scale_exp2 * 0.5f;
         const float tcenx = __builtin_fmaf(half, tr.tcx, tcrx), tceny = __builtin_fmaf(half, tr.tcy, tcry), tcenz = __builtin_fmaf(half, tr.tcz, tcrz);
         const float cx = tr.t_min < tcenx ? tr.px + half : tr.px, cy = tr.t_min < tceny ? tr.py + half : tr.py, cz = tr.t_min < tcenz ? tr.pz + half : tr.pz;
@@ -1306,7 +1373,6 @@ __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, b
         tr.px = push ? cx : (pop ? __uint_as_float(__float_as_uint(sx) & keep) : sx);
         tr.py = push ? cy : (pop ? __uint_as_float(__float_as_uint(sy) & keep) : sy);
         tr.pz = push ? cz : (pop ? __uint_as_float(__float_as_uint(sz) & keep) : sz);
-        tr.h = push ? tc_max : (pop ? 0.0f : tr.h);
         tr.t_max = push ? tv_max : (pop ? popped_t_max : tr.t_max);
         tr.scale_exp2 = push ? half : (pop ? pow2i((up & 31) - kMaxScale) : tr.scale_exp2);
         tr.scale = push ? tr.scale - 1 : (pop ? up : tr.scale);

@@ -89,7 +89,6 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_and_b32_e32 %[px], %[t1], %[px]\n"                                                                                      \
         "v_and_b32_e32 %[py], %[t1], %[py]\n"                                                                                      \
         "v_and_b32_e32 %[pz], %[t1], %[pz]\n"                                                                                      \
-        "v_mov_b32_e32 %[h], 0\n"                                                                                                  \
         "v_cmpx_lt_u32_e32 vcc, 22, %[sc]\n"                     /* out of the octree */                                           \
         "v_add_u32_e32 %[iter], 0xc0000000, %[iter]\n"           /* parked | kTravFinished << 28 */
 // The rays of a sub-tile's 64 pixels walk the upper levels of the tree together: in a fifth of the trips every traversing lane PUSHes, or every
@@ -140,10 +139,11 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_fmac_f32_e32 %[crx], %[hm], %[tcx]\n"                 /* a PUSH lane's centre planes, the others' corner planes still */ \
         "v_fmac_f32_e32 %[cry], %[hm], %[tcy]\n"                                                                                   \
         "v_fmac_f32_e32 %[crz], %[hm], %[tcz]\n"                                                                                   \
-        /* the parent's entry goes on the stack if the ray leaves the child before it leaves the parent (tc_max < h) */            \
+        /* the parent's entry goes on the stack -- at EVERY push (the reference writes it only where the ray leaves the child before it  */ \
+        /* leaves the parent, tc_max < h: the writes it skips are of entries that are never popped, or of the very entry the slot holds:  */ \
+        /* vx_device.hpp, step_image -- so the image cursor keeps no h at all)                                                             */ \
         "v_lshl_add_u32 %[t0], %[sc], 8, %[lds]\n"                                                                                 \
         "s_and_saveexec_b64 %[s_save], %[s_push]\n"                                                                                \
-        "v_cmpx_lt_f32_e32 vcc, %[tcm], %[h]\n"                                                                                    \
         STACK_WRITE                                                                                                                \
         "s_mov_b64 exec, %[s_save]\n"                                                                                              \
         /* the corner: += half a cell where t_min < t(centre) | -= a cell where tc_max >= t(corner) */                             \
@@ -172,7 +172,6 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         /* PUSH: the child becomes the node */                                                                                     \
         "s_and_b64 exec, %[s_save], %[s_push]\n"                                                                                   \
         "v_add_u32_e32 %[sc], -1, %[sc]\n"                                                                                         \
-        "v_mov_b32_e32 %[h], %[tcm]\n"                                                                                             \
         "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
         TAKE_MASKS                                                                                                                 \
@@ -212,10 +211,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_fmac_f32_e32 %[cry], %[hf], %[tcy]\n"                                                                                   \
         "v_fmac_f32_e32 %[crz], %[hf], %[tcz]\n"                                                                                   \
         "v_lshl_add_u32 %[t0], %[sc], 8, %[lds]\n"                                                                                 \
-        "s_mov_b64 %[s_save], exec\n"                                                                                              \
-        "v_cmpx_lt_f32_e32 vcc, %[tcm], %[h]\n"                                                                                    \
         STACK_WRITE                                                                                                                \
-        "s_mov_b64 exec, %[s_save]\n"                                                                                              \
         "v_cmp_lt_f32_e32 vcc, %[tmin], %[crx]\n"                                                                                  \
         "v_cndmask_b32_e32 %[t1], 0, %[hf], vcc\n"                                                                                 \
         "v_add_f32_e32 %[px], %[px], %[t1]\n"                                                                                      \
@@ -226,7 +222,6 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_cndmask_b32_e32 %[t1], 0, %[hf], vcc\n"                                                                                 \
         "v_add_f32_e32 %[pz], %[pz], %[t1]\n"                                                                                      \
         "v_add_u32_e32 %[sc], -1, %[sc]\n"                                                                                         \
-        "v_mov_b32_e32 %[h], %[tcm]\n"                                                                                             \
         "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
         TAKE_MASKS                                                                                                                 \
@@ -265,7 +260,7 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
     uint32_t waiting = uint32_t(__builtin_amdgcn_readfirstlane(int(foreign_waiting)));
     foreign_min = uint32_t(__builtin_amdgcn_readfirstlane(int(foreign_min)));
 #define VX_LOOP_OPERANDS                                                                                                                                   \
-        : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tmin] "+v"(tr.t_min), [tmax] "+v"(tr.t_max), [h] "+v"(tr.h), [sc] "+v"(scale), [ptr] "+v"(tr.ptr),  \
+        : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tmin] "+v"(tr.t_min), [tmax] "+v"(tr.t_max), [sc] "+v"(scale), [ptr] "+v"(tr.ptr),  \
           [node] "+v"(tr.node), [iter] "+v"(tr.iter), [trips] "+s"(n_trips), [waiting] "+s"(waiting), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [oct] "=&v"(oct), [m] "=&v"(m), \
           [nx] "=&v"(nx), [ny] "=&v"(ny), [nz] "=&v"(nz), [crx] "=&v"(crx), [cry] "=&v"(cry), [crz] "=&v"(crz), [tcm] "=&v"(tcm), [tvm] "=&v"(tvm),         \
           [tq] "=&v"(tq), [hf] "=&v"(hf), [hm] "=&v"(hm), [ot] "=&v"(ot), [sx] "=&v"(sx), [s_trav] "=&s"(s_trav), [s_push] "=&s"(s_push),                  \
@@ -310,6 +305,81 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
     tr.px = __uint_as_float(px); tr.py = __uint_as_float(py); tr.pz = __uint_as_float(pz);
     tr.scale = int(scale);
     tr.scale_exp2 = pow2i(tr.scale - kMaxScale);  // (the loop derives the cell size from the scale; the service phases read the member)
+}
+
+// Trav::descend_along (vx_device.hpp) by hand, for the same reason as the loop: as the compiler lays the per-level loop out -- three regions behind
+// execution-mask bookkeeping, three taken branches, packed fmas at 3.4 cycles each -- a level costs a wave ~150 cycles, 640 at four waves a SIMD, and the
+// levels saved (a trip of the render loop each) barely pay for it (measured: profiles/round6, timelines before / after). Here a level is 33
+// instructions and one taken branch. Bit for bit the C++ (the parity tests run this one on the GPU, the host harness steps the other against the oracle).
+// LEVELS: 13 (three-word slots) or 16 (16-bit third plane): where a slot's t_max lies behind its pointer. Called by the lanes whose shadow ray has a path
+// to follow (any execution mask); `lds_slot0` as for the loop. Leaves the cursor's pointer and masks to the caller (Stack::pop of the scale reached).
+template <int LEVELS, class TRAV>
+__device__ __forceinline__ void descend_along_gfx950(TRAV& tr, uint32_t lds_slot0, int parent_scale, const float q[3]) {
+    static_assert(LEVELS == 13 || LEVELS == 16, "stack layouts: Stack<64, true, true, 13>, Stack<64, true, true, 16, true>");
+    const float cell = pow2i(parent_scale - kMaxScale);
+    const uint32_t ex = __float_as_uint((tr.octant_mask & 1) ? 3.0f - cell - q[0] : q[0]);
+    const uint32_t ey = __float_as_uint((tr.octant_mask & 2) ? 3.0f - cell - q[1] : q[1]);
+    const uint32_t ez = __float_as_uint((tr.octant_mask & 4) ? 3.0f - cell - q[2] : q[2]);
+    uint32_t px = __float_as_uint(tr.px), py = __float_as_uint(tr.py), pz = __float_as_uint(tr.pz);
+    uint32_t scale = uint32_t(tr.scale);
+    uint32_t t0, t1, t2;
+    float crx, cry, crz, tcm, tvm, hf;
+    unsigned long long s_entry;
+    const uint32_t k_half = 0x33800000u;  // half a cell at `scale`: 2^(scale - 24) = (scale + 103) << 23
+#define VX_DESCEND_ASM(TMAX_OFFSET)                                                                                                 \
+        "s_mov_b64 %[s_entry], exec\n"                                                                                             \
+        "1:\n"                                                                                                                     \
+        "v_xor_b32_e32 %[t0], %[px], %[ex]\n"                                                                                      \
+        "v_xor_b32_e32 %[t1], %[py], %[ey]\n"                                                                                      \
+        "v_xor_b32_e32 %[t2], %[pz], %[ez]\n"                                                                                      \
+        "v_or3_b32 %[t0], %[t0], %[t1], %[t2]\n"                                                                                   \
+        "v_lshrrev_b32_e32 %[t0], %[sc], %[t0]\n"                                                                                  \
+        "v_cmpx_lt_i32_e32 vcc, %[ps], %[sc]\n"                  /* above the voxel's parent */                                    \
+        "v_cmpx_eq_u32_e32 vcc, 0, %[t0]\n"                      /* the cell the cursor is at is on the path */                    \
+        "v_fma_f32 %[crx], %[px], %[tcx], -%[tbx]\n"                                                                               \
+        "v_fma_f32 %[cry], %[py], %[tcy], -%[tby]\n"                                                                               \
+        "v_fma_f32 %[crz], %[pz], %[tcz], -%[tbz]\n"                                                                               \
+        "v_min3_f32 %[tcm], %[crx], %[cry], %[crz]\n"                                                                              \
+        "v_min_f32_e32 %[tvm], %[tmax], %[tcm]\n"                                                                                  \
+        "v_cmpx_le_f32_e32 vcc, %[tmin], %[tmax]\n"              /* the reference PUSHes: t_min <= t_max ... */                    \
+        "v_cmp_le_f32_e32 vcc, %[tmin], %[tvm]\n"                /* ... and t_min <= min(t_max, tc_max) */                         \
+        "s_and_b64 exec, exec, vcc\n"                                                                                              \
+        "s_cbranch_execz 9f\n"                                                                                                     \
+        "v_lshl_add_u32 %[t0], %[sc], 8, %[lds]\n"                                                                                 \
+        "ds_write_b32 %[t0], %[tmax] offset:" #TMAX_OFFSET "\n"  /* this ray's t_max in the parent's slot (pointer and masks are in place) */ \
+        "v_lshl_add_u32 %[hf], %[sc], 23, %[k_half]\n"                                                                             \
+        "v_fmac_f32_e32 %[crx], %[hf], %[tcx]\n"                 /* the centre planes' distances */                                \
+        "v_fmac_f32_e32 %[cry], %[hf], %[tcy]\n"                                                                                   \
+        "v_fmac_f32_e32 %[crz], %[hf], %[tcz]\n"                                                                                   \
+        "v_cmp_lt_f32_e32 vcc, %[tmin], %[crx]\n"                                                                                  \
+        "v_cndmask_b32_e32 %[t1], 0, %[hf], vcc\n"                                                                                 \
+        "v_add_f32_e32 %[px], %[px], %[t1]\n"                                                                                      \
+        "v_cmp_lt_f32_e32 vcc, %[tmin], %[cry]\n"                                                                                  \
+        "v_cndmask_b32_e32 %[t1], 0, %[hf], vcc\n"                                                                                 \
+        "v_add_f32_e32 %[py], %[py], %[t1]\n"                                                                                      \
+        "v_cmp_lt_f32_e32 vcc, %[tmin], %[crz]\n"                                                                                  \
+        "v_cndmask_b32_e32 %[t1], 0, %[hf], vcc\n"                                                                                 \
+        "v_add_f32_e32 %[pz], %[pz], %[t1]\n"                                                                                      \
+        "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
+        "v_add_u32_e32 %[sc], -1, %[sc]\n"                                                                                         \
+        "v_add_u32_e32 %[iter], 1, %[iter]\n"                                                                                      \
+        "s_branch 1b\n"                                                                                                            \
+        "9:\n"                                                                                                                     \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                                   \
+        "s_mov_b64 exec, %[s_entry]\n"
+#define VX_DESCEND_OPERANDS                                                                                                                        \
+        : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tmax] "+v"(tr.t_max), [sc] "+v"(scale), [iter] "+v"(tr.iter), [t0] "=&v"(t0), [t1] "=&v"(t1),  \
+          [t2] "=&v"(t2), [crx] "=&v"(crx), [cry] "=&v"(cry), [crz] "=&v"(crz), [tcm] "=&v"(tcm), [tvm] "=&v"(tvm), [hf] "=&v"(hf), [s_entry] "=&s"(s_entry) \
+        : [tmin] "v"(tr.t_min), [tcx] "v"(tr.tcx), [tcy] "v"(tr.tcy), [tcz] "v"(tr.tcz), [tbx] "v"(tr.tbx), [tby] "v"(tr.tby), [tbz] "v"(tr.tbz),       \
+          [ex] "v"(ex), [ey] "v"(ey), [ez] "v"(ez), [ps] "v"(parent_scale), [lds] "v"(lds_slot0), [k_half] "s"(k_half)                                  \
+        : "vcc", "scc", "memory"
+    if constexpr (LEVELS == 13) asm volatile(VX_DESCEND_ASM(3328) VX_DESCEND_OPERANDS);
+    else asm volatile(VX_DESCEND_ASM(4096) VX_DESCEND_OPERANDS);
+#undef VX_DESCEND_ASM
+#undef VX_DESCEND_OPERANDS
+    tr.px = __uint_as_float(px); tr.py = __uint_as_float(py); tr.pz = __uint_as_float(pz);
+    tr.scale = int(scale);
+    tr.scale_exp2 = pow2i(tr.scale - kMaxScale);
 }
 
 }  // namespace vxd

@@ -107,6 +107,7 @@ SYMBOLS = {
     "vx_render_counters": (_int, [_vp, C.POINTER(Uniforms), _u32, _u32, _u32, _u32, C.POINTER(Counters)]),
     "vx_excursion_counters": (_int, [_vp, C.POINTER(_u64 * 4), _int]),
     "vx_image_info": (_int, [_vp, C.POINTER(_u64 * 4)]),
+    "vx_debug_knobs": (_int, [_vp, C.POINTER(_u32 * 8)]),
     "vx_timeline_read": (_u32, [_vp, _vp, _u32]),
     "vx_gather_query": (_int, [_vp, _int]),
     "vx_comm_profile_read": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32)]),
@@ -391,6 +392,12 @@ class Svo:
         out = np.zeros((8192, 8), dtype=np.uint64)
         n = lib().vx_timeline_read(self._h, out.ctypes.data_as(_vp), 8192)
         return out[:n]
+
+    def knobs(self):
+        """vx_debug_knobs: the scheduling knobs the context runs with."""
+        out = (_u32 * 8)()
+        _check(lib().vx_debug_knobs(self._h, C.byref(out)))
+        return dict(zip(("refill_min", "service_min", "waves_per_cu", "queue_stripe", "tile_strip", "hot_first", "comm_headroom", "measurement_build"), [int(v) for v in out]))
 
     def image_info(self):
         out = (_u64 * 4)()
