@@ -6,6 +6,7 @@
 // kernels_aux.hip (kernels.h says what can be launched), the RCCL exchange in comm.cpp.
 // There is no CPU path: without a HIP device every entry point fails with VX_ERR_NO_DEVICE.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -925,6 +926,7 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
             image_ok = ctx->image.update(ctx->staging, used_bytes, nullptr, 0, threads);
         }
     }
+    const auto t_built = std::chrono::steady_clock::now();
     VX_LOCK(ctx);  // from here on: device memory, streams, events and the state renders read
     // The image is an accelerator: whatever goes wrong with it (a world that cannot be imaged, no device memory for it), the
     // context falls back to traversing the world's own bytes -- with nothing of a half-made image left behind.
@@ -1009,6 +1011,12 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         ctx->image_ok = false;
         g_last_error = why;
         return rc;
+    }
+    if (std::getenv("VX_COMMIT_TIMING")) {  // (measurement aid: where a commit's host time goes)
+        const double* t = ctx->image.last_timing();
+        const double upload_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_built).count();
+        std::fprintf(stderr, "[vx_commit] %llu bytes to upload; image: root walk %.3f s, chunk walk %.3f, place %.3f, encode %.3f, root + header %.3f; allocation + upload %.3f s\n",
+                     (unsigned long long)total, t[0], t[1], t[2], t[3], t[4], upload_s);
     }
     ctx->image_ok = image_ok;
     if (image_ok) {

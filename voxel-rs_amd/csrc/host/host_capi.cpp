@@ -286,6 +286,11 @@ void* vxh_stream_new(int svo_type, uint32_t scene_depth, uint32_t seed, uint32_t
     return new (std::nothrow) Streamer(svo_type, scene_depth, seed, radius, start_y, end_y);
 }
 void vxh_stream_free(void* s) { delete static_cast<Streamer*>(s); }
+// --no-lod of the reference's command line (src/main.rs:106, src/gamelogic/world.rs:141,151): before the first move
+void vxh_stream_set_no_lod(void* sp, int no_lod) {
+    Streamer* s = static_cast<Streamer*>(sp);
+    s->esvo.no_lod = s->csvo.no_lod = no_lod != 0;
+}
 
 uint64_t vxh_stream_move_to(void* sp, float x, float y, float z) {
     Streamer* s = static_cast<Streamer*>(sp);

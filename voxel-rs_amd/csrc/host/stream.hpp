@@ -117,6 +117,9 @@ public:
     WorldStreamer(const WorldStreamer&) = delete;
     WorldStreamer& operator=(const WorldStreamer&) = delete;
 
+    // --no-lod (src/gamelogic/world.rs:141,151): every chunk is loaded at full detail and LOD changes are ignored
+    bool no_lod = false;
+
     // pump(nullptr, ..) hands the dirty ranges here instead of to vx_commit (tests)
     std::function<void(WorldT&, const std::vector<vx_range>&)> on_dry_commit;
 
@@ -147,9 +150,11 @@ public:
             // a re-centre at radius 40 queues 25 K events, and an allocation per event was a millisecond of the frame loop's step)
             std::lock_guard<std::mutex> lock(m_);
             for (const ChunkEvent& e : events) {
+                if (no_lod && e.kind == ChunkEvent::LodChange) continue;  // (world.rs:151)
                 queue_.emplace_back();
                 Slot& slot = queue_.back();
                 slot.event = e;
+                if (no_lod && e.kind == ChunkEvent::Load) slot.event.lod = 5;  // (world.rs:141)
                 if (e.kind == ChunkEvent::Unload) slot.ready = true;  // nothing to build
                 else jobs_.push_back(&slot);
             }

@@ -49,6 +49,7 @@ def lib():
             "vxh_picker_deserialize": (None, [vp, u32, vp, u32, vp, vp, vp]),
             "vxh_stream_new": (vp, [C.c_int, u32, u32, u32, C.c_int32, C.c_int32]),
             "vxh_stream_free": (None, [vp]),
+            "vxh_stream_set_no_lod": (None, [vp, C.c_int]),
             "vxh_stream_move_to": (u64, [vp, C.c_float, C.c_float, C.c_float]),
             "vxh_stream_move_to_view": (u64, [vp, C.c_float, C.c_float, C.c_float, vp]),
             "vxh_stream_pump": (C.c_int, [vp, vp, u32, vp]),
@@ -225,10 +226,12 @@ class WorldStreamer:
 
     PUMP_FIELDS = ("events", "loads", "unloads", "lod_changes", "ranges", "bytes", "arena_bytes", "pending", "build_us", "apply_us", "commit_us")
 
-    def __init__(self, svo_type, scene_depth, radius, start_y, end_y, seed=0x5EED0001):
+    def __init__(self, svo_type, scene_depth, radius, start_y, end_y, seed=0x5EED0001, no_lod=False):
         self._h = lib().vxh_stream_new(svo_type, scene_depth, seed, radius, start_y, end_y)
         if not self._h:
             raise ValueError("bad streamer parameters")
+        if no_lod:  # (--no-lod of the reference: every chunk at full detail, world.rs:141,151)
+            lib().vxh_stream_set_no_lod(self._h, 1)
 
     def __del__(self):
         if getattr(self, "_h", None):
