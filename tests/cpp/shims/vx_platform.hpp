@@ -12,6 +12,7 @@ namespace vxd {
 
 struct buf_t { const uint8_t* p; uint32_t bytes; };
 inline buf_t make_buf(const void* p, uint32_t bytes) { return buf_t{static_cast<const uint8_t*>(p), bytes}; }
+inline buf_t make_buf_records8(const void* p, uint32_t bytes) { return make_buf(p, bytes); }  // (only the hand-scheduled loop reads through it: not in this build)
 // like the V#'s range check: a read that does not fit the buffer's range WHOLE returns 0. (The product keeps zero padding behind every buffer
 // it reads unaligned, inside the descriptor's range -- kWorldPad, kImagePad in runtime.cpp --, so that a straddling read returns the real bytes
 // plus zeros; the harness pads the arrays it hands over the same way. A buffer made without its padding shows up here as it would on the GPU.)

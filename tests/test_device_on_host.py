@@ -117,6 +117,7 @@ def image_cast(lib, fmt, world, mats, tex, mips, tasks, cast_translucent, layout
     head = 4 + (20 if fmt == "esvo" else 4)
     image, origin = hip.traversal_image(1 if fmt == "esvo" else 2, frame, frame.size * 4 - head, layout=layout, with_origin=True)
     image = np.concatenate([image, np.zeros(16, dtype=np.uint32)])  # the zero pad the context keeps behind the image
+    origin = image  # (a CSVO world's origins are units of the image itself)
     levels = orc.mip_chain(tex, mips)
     chain = np.concatenate([lv.ravel() for lv in levels])
     offsets = np.cumsum([0] + [lv.size for lv in levels[:-1]])
@@ -259,6 +260,7 @@ def shadow_pairs(lib, fmt, world, mats, tex, mips, tasks, to_light):
     head = 4 + (20 if fmt == "esvo" else 4)
     image, origin = hip.traversal_image(1 if fmt == "esvo" else 2, frame, frame.size * 4 - head, layout=1, with_origin=True)
     image = np.concatenate([image, np.zeros(16, dtype=np.uint32)])
+    origin = image
     levels = orc.mip_chain(tex, mips)
     chain = np.concatenate([lv.ravel() for lv in levels])
     offsets = np.cumsum([0] + [lv.size for lv in levels[:-1]])

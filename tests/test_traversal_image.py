@@ -128,61 +128,64 @@ def _walk_esvo_image(img):
 
 
 def _oct64_masks(m):
-    """child c: 'exists' at bit 31 - c, 'is a leaf' at bit 23 - c  ->  child_mask << 8 | leaf_mask"""
+    """child c: 'is a leaf' at bit 31 - c, 'exists' at bit 23 - c  ->  child_mask << 8 | leaf_mask"""
     assert m & 0xFFFF == 0
     rev = lambda b: int(f"{b:08b}"[::-1], 2)
-    return (rev(m >> 24) << 8) | rev((m >> 16) & 0xFF)
+    return (rev((m >> 16) & 0xFF) << 8) | rev(m >> 24)
 
 
-def _walk_oct64_image(img, wide=False):
-    """wide: pointers count 32-byte units (layout 2) instead of bytes (layout 1)"""
-    unit = 32 if wide else 1
+def _walk_oct64_image(img, with_origin=False):
+    """The layout the kernels walk (traversal_image.hpp): 8-byte units from the frame start; a node's octant = a {lo, hi} entry per EXISTING child, child 7
+    first, `lo` of an octant = the unit before its first entry; an octant of values only (all children leaves) = the existing children's u32 values in the
+    same order from unit lo + 1 on, padded to whole units, with (CSVO worlds) the origin in unit lo itself. Layouts 1 and 2 hold the same bytes."""
     out = []
-    stack = [((), int(img[2]) * unit, _oct64_masks(int(img[1])))]
+    stack = [((), int(img[2]), _oct64_masks(int(img[1])))]
     while stack:
-        path, octant, masks = stack.pop()
+        path, lo, masks = stack.pop()
         out.append((path, "node", masks))
         children, leaves = masks >> 8, masks & 0xFF
         assert leaves & ~children == 0
         if not children:
             continue  # an octant without children takes no room
-        assert octant % 32 == 0
-        if children == leaves:  # eight u32 values
-            for c in range(8):
-                v = int(img[octant // 4 + c])
-                if children & (1 << c):
-                    out.append((path + (c,), "leaf", v))
-                else:
-                    assert v == 0
+        first = (lo + 1) * 2  # frame word of the first entry / value
+        existing = [c for c in range(7, -1, -1) if children & (1 << c)]
+        if children == leaves:  # values only
+            for k, c in enumerate(existing):
+                out.append((path + (c,), "leaf", int(img[first + k])))
+            if len(existing) & 1:
+                assert int(img[first + len(existing)]) == 0  # padding
+            if with_origin:
+                assert int(img[lo * 2]) != 0  # where the leaf-mask byte lies in the world's bytes
             continue
-        for c in range(8):
-            lo, hi = int(img[octant // 4 + 2 * c]), int(img[octant // 4 + 2 * c + 1])
-            if not children & (1 << c):
-                assert lo == 0 and hi == 0
-            elif leaves & (1 << c):
-                out.append((path + (c,), "leaf", lo))
+        for k, c in enumerate(existing):
+            e_lo, e_hi = int(img[first + 2 * k]), int(img[first + 2 * k + 1])
+            if leaves & (1 << c):
+                assert e_hi == 0
+                out.append((path + (c,), "leaf", e_lo))
             else:
-                stack.append((path + (c,), lo * unit, _oct64_masks(hi)))
+                stack.append((path + (c,), e_lo, _oct64_masks(e_hi)))
     return sorted(out)
 
 
 @pytest.mark.parametrize("fmt", FMTS)
 def test_renderer_layout_holds_the_same_tree(fmt):
-    """Layout 1 (64-byte octants, what the kernel walks) against layout 0 (validated above with the oracle's traversal)."""
+    """Layout 1 (an entry per existing child, what the kernel walks) against layout 0 (validated above with the oracle's traversal)."""
     world = vra.World(FMTS[fmt])
     world.build_heightfield(7, threads=4)
     frame = world.frame()
     a = _walk_esvo_image(hip.traversal_image(FMTS[fmt], frame, world.size_in_bytes, 0))
     b_img = hip.traversal_image(FMTS[fmt], frame, world.size_in_bytes, 1)
-    assert b_img[0] == frame[0] and b_img.size % 8 == 0
-    b = _walk_oct64_image(b_img)
+    assert b_img[0] == frame[0] and b_img.size % 2 == 0
+    b = _walk_oct64_image(b_img, with_origin=fmt == "csvo")
     assert len(a) > 10000 and a == b
-    # ... and so does the layout for images beyond 4 GiB (octant indices for pointers)
-    assert _walk_oct64_image(hip.traversal_image(FMTS[fmt], frame, world.size_in_bytes, 2), wide=True) == a
+    # a surface shell takes about half of what eight entries per octant took: less than half the ESVO world's bytes, about twice the CSVO world's
+    assert b_img.size * 4 < (0.5 if fmt == "esvo" else 2.6) * world.size_in_bytes, (b_img.size * 4, world.size_in_bytes)
+    # ... and the layout for images beyond 4 GiB holds the same bytes (it is walked through a 64-bit pointer instead of a buffer resource)
+    assert np.array_equal(hip.traversal_image(FMTS[fmt], frame, world.size_in_bytes, 2), b_img)
     # the C++ comparison the incremental test relies on agrees, and notices a difference
     assert host.oct64_same_tree(b_img, b_img.copy())
     broken = b_img.copy()
-    leaf_words = [i for i in range(16, b_img.size, 2) if 0 < b_img[i] < 64 and b_img[i + 1] == 0]  # {value, 0} entries
+    leaf_words = [i for i in range(16, b_img.size) if 0 < b_img[i] < 64]  # values (block ids are small; pointers and masks are not)
     broken[leaf_words[len(leaf_words) // 2]] += 1
     assert not host.oct64_same_tree(b_img, broken)
 
@@ -235,7 +238,7 @@ def test_incremental_updates_keep_the_image_of_a_full_rebuild(fmt):
                 patched = s.image()
                 assert host.oct64_same_tree(patched, full)
                 if commits in (2, 5):  # (the comparison in Python too, where it is affordable)
-                    assert _walk_oct64_image(patched) == _walk_oct64_image(full)
+                    assert _walk_oct64_image(patched, fmt == "csvo") == _walk_oct64_image(full, fmt == "csvo")
             if st["pending"] == 0:
                 break
         sizes.append(s.image().size)  # with everything around this eye resident

@@ -56,7 +56,8 @@ SceneArgs scene_of(const vx_context* c) {
     for (int l = 0; l < 16; ++l) s.level_offset[l] = c->tex.level_offset[l];
     s.image = c->image_ok ? c->d_image : nullptr;
     s.image_bytes = c->image_ok ? c->pub.frame_bytes + kImagePad : 0u;
-    s.origin = c->image_ok ? c->d_origin : nullptr;
+    // (images of CSVO worlds: where a voxel-parent octant comes from in the world's bytes is in the image itself, the unit in front of its values)
+    s.origin = c->image_ok && c->svo_type == VX_SVO_CSVO ? c->d_image : nullptr;
     return s;
 }
 
@@ -914,10 +915,10 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         // (up to 32 workers for the chunk walk of a whole world, 16 for its encoding; WorldImage::update takes no more than a sixteenth of the chunks
         // it has to walk, so an incremental commit stays on a few)
         const unsigned threads = std::max(1u, std::min(32u, vximg::granted_cpus()));
-        // A world whose image will not fit 32-bit byte offsets starts in the wide layout instead of finding that out at the end of a whole
-        // build (an image is about 0.84 x the bytes of an ESVO world, 3.9 x those of a CSVO world; the wide layout serves any size)
+        // A world whose image will not fit a buffer resource's 32-bit offsets starts in the wide layout instead of finding that out at the end of a whole
+        // build (an image is about 0.37 x the bytes of an ESVO world, 2.3 x those of a CSVO world; the wide layout serves any size)
         if (ctx->image.chunk_count() == 0 && ctx->image.layout() == vximg::kOct64 &&
-            double(used_bytes) * (ctx->svo_type == VX_SVO_ESVO ? 0.95 : 4.4) >= 3.5 * double(1ull << 30))
+            double(used_bytes) * (ctx->svo_type == VX_SVO_ESVO ? 0.45 : 2.7) >= 3.5 * double(1ull << 30))
             ctx->image = vximg::WorldImage(ctx->svo_type, vximg::kOct64Wide);
         image_ok = ctx->image.update(ctx->staging, used_bytes, changed.data(), changed.size(), threads);
         if (!image_ok && ctx->image.too_big() && ctx->image.layout() == vximg::kOct64) {
@@ -943,7 +944,7 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
     bool whole_image = false;
     if (image_ok) {
         const size_t need = ctx->image.frame_bytes() + kImagePad;
-        const size_t need_origin = ctx->image.has_origin() ? ctx->image.origin_bytes() + kImagePad : 0;
+        const size_t need_origin = 0;  // (the origins of a CSVO world's voxel parents are units of the image itself since round 6: no table beside it)
         if (need > ctx->d_image_capacity || need_origin > ctx->d_origin_capacity) {
             // grow both (frames in flight still read the old ones: wait for them), then everything is uploaded again
             (void)drain_streams(ctx);
@@ -971,16 +972,10 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
     }
     if (image_ok) {
         const uint8_t* src = reinterpret_cast<const uint8_t*>(ctx->image.frame().data());
-        const uint8_t* osrc = reinterpret_cast<const uint8_t*>(ctx->image.origin().data());
         if (whole_image) {
             up.push_back(Upload{ctx->d_image, src, ctx->image.frame_bytes()});
-            if (ctx->image.has_origin()) up.push_back(Upload{ctx->d_origin, osrc, ctx->image.origin_bytes()});
         } else {
-            for (const vximg::Range& r : ctx->image.dirty_bytes()) {
-                up.push_back(Upload{ctx->d_image + r.start, src + r.start, r.length});
-                // two origin words per 32-byte unit of the frame
-                if (ctx->image.has_origin()) up.push_back(Upload{ctx->d_origin + r.start / 4, osrc + r.start / 4, (r.length + 3) / 4});
-            }
+            for (const vximg::Range& r : ctx->image.dirty_bytes()) up.push_back(Upload{ctx->d_image + r.start, src + r.start, r.length});
         }
     }
 

@@ -8,16 +8,20 @@
 // kForeign).
 //
 // Two encodings of the same octant tree:
-//   kOct64   what the renderer walks. Frame = 64-byte header [f32 2^-depth][u32 root masks][u32 byte offset of the root
-//            octant][0...] followed by 64-byte octants of eight {lo, hi} entries, one per child: lo = byte offset (from the
-//            frame start) of the child's own octant, or the leaf's value; hi = the child's masks (oct64_masks()).
-//            A descent is ONE aligned 8-byte load that yields the new pointer and the new masks; every pointer in the image
-//            is valid by construction, so the loads need no clamping. An octant ALL of whose children are leaves -- the
-//            majority: every voxel's parent -- is stored as eight u32 values only (32 bytes; its masks, which live in its
-//            parent's entry, say so: child bits == leaf bits), and an octant without children (the reference's root octree
-//            keeps such) takes no room at all, nothing ever reads it.
-//   kOct64Wide  kOct64 with frame byte offset / 32 for pointers: images from 4 GiB up to 128 GiB, walked through
-//            a 64-bit pointer at two more instructions per descent. A context switches to it when kOct64 no longer fits.
+//   kOct64   what the renderer walks (the name is round 2's, when an octant took 64 bytes; since round 6 it takes what its children take). Frame = 64-byte
+//            header [f32 2^-depth][u32 root masks][u32 `lo` of the root octant][0...] followed by octants. Everything is addressed in 8-byte UNITS from the
+//            frame start. A node's octant holds one {lo, hi} entry (one unit) per EXISTING child, the children in reverse order (child 7 first): lo = where
+//            the child's own octant lies -- the unit BEFORE its first entry --, or the leaf's value; hi = the child's masks (oct64_masks()). With m = the
+//            node's masks shifted left by the child's index (which the traversal forms anyway: "is a leaf" in the sign, "exists" in bit 23, below it the "exists" bits of the children above), the entry of that child is unit
+//            lo + popcount(m & 0xffffff): a descent is ONE aligned 8-byte load that yields the new pointer and the new masks, every pointer in the image is valid by
+//            construction. An octant ALL of whose children are leaves -- the majority: every voxel's parent -- holds 4-byte values only, again for the existing
+//            children in reverse order from unit lo + 1 on, padded to whole units (its masks, which live in its parent's entry, say so: child bits == leaf
+//            bits); in the image of a CSVO world unit `lo` itself holds where that leaf-mask byte lies in the world's own bytes (Octant::origin: what a ray
+//            that is led into a voxel needs, vx_device.hpp walk_voxel_on_bytes). An octant without children (the reference's root octree keeps such) takes
+//            no room. For a surface shell about half of what eight entries per octant took (rounds 2-5: 64 / 32 bytes an octant plus a separate origin table):
+//            0.4 x the bytes of an ESVO world, 2 x those of a CSVO world.
+//   kOct64Wide  the same bytes, walked through a 64-bit pointer instead of a buffer resource (whose offsets end at 4 GiB): images from 4 GiB up to 32 GiB,
+//            at two more instructions per descent. A context switches to it when kOct64 no longer fits.
 //   kEsvo48  the reference's ESVO format: [f32][5-word preamble][12-word octants], relative pointers. Kept because any ESVO
 //            traversal can walk it: tests/test_traversal_image.py checks the tree walk with the oracle.
 // The image never has more levels than the world's depth says (a world that breaks this is not imaged): the kernel relies on it.
@@ -174,8 +178,11 @@ struct NodeMasks {
     uint32_t packed() const { return (child_mask << 8) | leaf_mask; }
 };
 
-// kOct64's form of packed masks: child c's "exists" bit at 31 - c and its "is a leaf" bit at 23 - c (the traversal shifts the
-// word left by the child index and finds "exists" in the sign bit and "leaf" in bit 23, vx_device.hpp Trav::step_with)
+// kOct64's form of packed masks: child c's "is a leaf" bit at 31 - c and its "exists" bit at 23 - c, nothing in the lower half. The traversal shifts the
+// word left by the child's index: "leaf" of that child is then the sign, "exists" bit 23, and bits 22..0 hold the "exists" bits of the children ABOVE it and
+// nothing else (the leaf bits have moved up, the lower half was empty) -- so popcount(m & 0xffffff) counts this child and the existing ones above it, which is
+// where its entry lies in the octant (entries of the existing children only, child 7 first). (Rounds 2-5 had the two bytes the other way round; with "exists"
+// in the upper byte a shift brings leaf bits in below it and the count needs an instruction more.)
 // A leaf bit without its child bit means nothing to the traversal (svo.esvo.glsl:168-173) and is dropped: "all children are
 // leaves" must read the same on the device (child bits == leaf bits) as here (oct64_words()).
 inline uint32_t oct64_masks(uint32_t packed) {
@@ -185,7 +192,7 @@ inline uint32_t oct64_masks(uint32_t packed) {
         return ((b & 0xaau) >> 1) | ((b & 0x55u) << 1);
     };
     const uint32_t children = (packed >> 8) & 0xffu, leaves = packed & children;
-    return (reversed(children) << 24) | (reversed(leaves) << 16);
+    return (reversed(leaves) << 24) | (reversed(children) << 16);
 }
 
 // One node of the walked tree, layout independent. Per child: nothing, a leaf (value), a node (index of its octant in the
@@ -199,10 +206,17 @@ struct Octant {
     uint32_t origin[2] = {};
 };
 
-// frame words an octant takes in the kOct64 layouts: {pointer | value, masks} entries, values only, or nothing
-inline uint32_t oct64_words(const Octant& o) {
-    if (o.node_mask | o.chunk_mask) return 16;
-    return o.leaf_mask ? 8 : 0;
+// frame words an octant takes in the kOct64 layouts: a {pointer | value, masks} entry per existing child; or (all children leaves) their values, padded to
+// whole 8-byte units, behind the unit of the origin where the image keeps one; or nothing
+inline uint32_t oct64_words(const Octant& o, bool with_origin) {
+    if (o.node_mask | o.chunk_mask) return 2u * uint32_t(__builtin_popcount(uint32_t(o.node_mask | o.chunk_mask | o.leaf_mask)));
+    if (!o.leaf_mask) return 0;
+    return ((uint32_t(__builtin_popcount(uint32_t(o.leaf_mask))) + 1u) & ~1u) + (with_origin ? 2u : 0u);
+}
+// ... and its `lo` (what an entry that points to it holds) when it is placed at frame word `at`: the unit before its first entry / value
+inline uint32_t oct64_lo(const Octant& o, uint64_t at, bool with_origin) {
+    const bool values_only = !(o.node_mask | o.chunk_mask) && o.leaf_mask;
+    return uint32_t(at / 2) - ((values_only && with_origin) ? 0u : 1u);
 }
 
 struct Tree {
@@ -574,11 +588,11 @@ public:
         }
         return out;
     }
-    // CSVO worlds in the kOct64 layouts: the origin table, two words per 32-byte unit of the frame (a quarter of its size). For
-    // the unit a voxel-parent octant starts at: where that leaf-mask byte is in the world's own bytes (Octant::origin). The
-    // renderer reads it when a ray is led into a voxel (vx_device.hpp, enter_voxel_on_bytes). Its dirty ranges are the frame's / 4.
+    // CSVO worlds in the kOct64 layouts: every voxel-parent octant is preceded by a unit that says where that leaf-mask byte is in the world's own bytes
+    // (Octant::origin); the renderer reads it when a ray is led into a voxel (vx_device.hpp, walk_voxel_on_bytes). (Rounds 3-5 kept a table of its own beside
+    // the image, a quarter of its size; origin() is what is left of that interface: empty.)
     const ZeroedWords& origin() const { return origin_; }
-    uint64_t origin_bytes() const { return origin_.size() * 4; }
+    uint64_t origin_bytes() const { return 0; }
     bool has_origin() const { return !esvo_ && layout_ != kEsvo48; }
     size_t chunk_count() const { return chunks_.size(); }
     // levels of the imaged octree (the world's depth); no path of the image is longer
@@ -599,15 +613,16 @@ public:
         std::memcpy(&by, &y, 4);
         std::memcpy(&bz, &z, 4);
         uint32_t masks = frame_[1];
-        uint64_t at = layout_ == kOct64 ? frame_[2] / 4 : uint64_t(frame_[2]) * 8;  // frame word of the node's octant
+        uint64_t lo = frame_[2];  // the node's octant: the unit before its first entry
         for (int scale = 22; scale >= 0; --scale) {
             const uint32_t c = ((bx >> scale) & 1u) | (((by >> scale) & 1u) << 1) | (((bz >> scale) & 1u) << 2);
             const uint32_t m = masks << c;
-            if (!(m & 0x80000000u)) return false;
-            if (m & 0x00800000u) return true;
-            if (at + 2 * c + 1 >= frame_.size()) return false;
-            masks = frame_[at + 2 * c + 1];
-            at = layout_ == kOct64 ? frame_[at + 2 * c] / 4 : uint64_t(frame_[at + 2 * c]) * 8;
+            if (!(m & 0x00800000u)) return false;
+            if (m & 0x80000000u) return true;
+            const uint64_t entry = (lo + uint64_t(__builtin_popcount(m & 0x00ffffffu))) * 2;  // frame word of child c's entry
+            if (entry + 1 >= frame_.size()) return false;
+            masks = frame_[entry + 1];
+            lo = frame_[entry];
         }
         return false;
     }
@@ -734,6 +749,7 @@ private:
                 if (built[i].too_deep) return fail();
                 Placed& pl = placed[i];
                 pl.at = alloc_.alloc(pl.words);
+                pl.root_lo = (layout_ != kEsvo48 && !built[i].octants.empty()) ? oct64_lo(built[i].octants[0], pl.at, has_origin()) : 0u;
                 pl.masks = built[i].root.packed();
                 pl.levels = todo[base + i].levels;
                 pl.seen = epoch_;
@@ -744,7 +760,6 @@ private:
                 chunks_[todo[base + i].key] = pl;
             }
             if (frame_.size() < top) frame_.resize(top, 0u);
-            if (has_origin() && origin_.size() < frame_.size() / 4) origin_.resize(frame_.size() / 4, 0u);
             t_place += since(t_step);
             t_step = now();
             workers.run(n, encoders, [&](size_t i) { encode(built[i], placed[i].at); });
@@ -760,12 +775,11 @@ private:
         root_words_ = tree_words(root);
         root_at_ = alloc_.alloc(root_words_);
         if (frame_.size() < root_at_ + root_words_) frame_.resize(root_at_ + root_words_, 0u);
-        if (has_origin() && origin_.size() < (frame_.size() + 3) / 4) origin_.resize((frame_.size() + 3) / 4, 0u);
         for (Octant& o : root.octants)
             for (uint32_t c = 0; c < 8; ++c)
                 if ((o.chunk_mask >> c) & 1u) {
                     const Placed& pl = chunks_.at(o.lo[c]);
-                    o.lo[c] = uint32_t(layout_ == kEsvo48 ? pl.at : pl.at / 8);  // the chunk's root octant: frame word / 32-byte unit
+                    o.lo[c] = uint32_t(layout_ == kEsvo48 ? pl.at : pl.root_lo);  // the chunk's root octant: frame word / its `lo`
                     o.masks[c] = uint16_t(pl.masks);
                 }
         encode(root, root_at_);
@@ -775,7 +789,7 @@ private:
         frame_[0] = scale_bits;
         if (layout_ != kEsvo48) {
             frame_[1] = oct64_masks(root.root.packed());
-            frame_[2] = uint32_t(layout_ == kOct64 ? root_at_ * 4 : root_at_ / 8);
+            frame_[2] = root.octants.empty() ? 0u : oct64_lo(root.octants[0], root_at_, has_origin());
         } else {
             frame_[1] = root.root.packed();  // preamble: a fake octant whose child 0 is the root (esvo.rs:179-188)
             frame_[2] = frame_[3] = frame_[4] = 0;
@@ -785,7 +799,7 @@ private:
         // what the pointers can reach: 32-bit byte offsets (and the buffer resource's) / 32-bit octant indices / 31-bit word offsets
         const uint64_t end = alloc_.end();
         timing_[4] = since(t_step);
-        too_big_ = layout_ == kOct64 ? end * 4 + 4096 >= (uint64_t(1) << 32) : (layout_ == kOct64Wide ? end / 8 >= (uint64_t(1) << 32) : end >= (uint64_t(1) << 31));
+        too_big_ = layout_ == kOct64 ? end * 4 + 4096 >= (uint64_t(1) << 32) : (layout_ == kOct64Wide ? end / 2 + 16 >= (uint64_t(1) << 32) : end >= (uint64_t(1) << 31));
         return !too_big_;
     }
 
@@ -794,6 +808,7 @@ private:
         uint64_t at = 0, words = 0;             // in frame words
         uint64_t src_begin = 0, src_end = 0;    // arena bytes it was read from
         uint32_t masks = 0, levels = 0;
+        uint32_t root_lo = 0;  // kOct64*: what an entry that points to the chunk's root octant holds
         uint32_t seen = 0;  // the update() that last found it referenced
     };
 
@@ -812,50 +827,56 @@ private:
     uint64_t tree_words(const Tree& t) const {
         if (layout_ == kEsvo48) return t.octants.size() * 12;
         uint64_t n = 0;
-        for (const Octant& o : t.octants) n += oct64_words(o);
+        for (const Octant& o : t.octants) n += oct64_words(o, has_origin());
         return n;
     }
 
     // writes the tree's octants at frame word `at` (in walk order, each as large as its layout makes it); chunk children hold
-    // the frame word index (kEsvo48) / 32-byte unit (kOct64*) of the chunk's root octant by now
+    // the frame word index (kEsvo48) / the `lo` (kOct64*) of the chunk's root octant by now
     void encode(const Tree& t, uint64_t at) {
         uint32_t* dst = frame_.data() + at;
         std::vector<uint64_t> where;  // kOct64*: word offset of octant i inside the tree
+        const bool with_origin = has_origin();
         if (layout_ != kEsvo48) {
             where.resize(t.octants.size());
             uint64_t n = 0;
             for (size_t i = 0; i < t.octants.size(); ++i) {
                 where[i] = n;
-                n += oct64_words(t.octants[i]);
+                n += oct64_words(t.octants[i], with_origin);
             }
         }
         for (size_t i = 0; i < t.octants.size(); ++i) {
             const Octant& o = t.octants[i];
             if (layout_ != kEsvo48) {
                 uint32_t* w = dst + where[i];
-                const bool wide = layout_ == kOct64Wide;  // 32-byte units instead of byte offsets
-                const uint32_t words = oct64_words(o);
-                if (words == 8) {
-                    for (uint32_t c = 0; c < 8; ++c) w[c] = ((o.leaf_mask >> c) & 1u) ? o.lo[c] : 0u;
-                    if (has_origin()) {
-                        const uint64_t unit = (at + where[i]) / 8;
-                        origin_[unit * 2] = o.origin[0];
-                        origin_[unit * 2 + 1] = o.origin[1];
+                const uint32_t words = oct64_words(o, with_origin);
+                if (words == 0) continue;
+                if (!(o.node_mask | o.chunk_mask)) {  // values only: [origin][the existing children's values, child 7 first][padding]
+                    if (with_origin) {
+                        w[0] = o.origin[0];
+                        w[1] = o.origin[1];
+                        w += 2;
                     }
+                    uint32_t k = 0;
+                    for (int c = 7; c >= 0; --c)
+                        if ((o.leaf_mask >> c) & 1u) w[k++] = o.lo[c];
+                    if (k & 1u) w[k] = 0u;
                     continue;
                 }
-                if (words == 0) continue;
-                for (uint32_t c = 0; c < 8; ++c) {
+                uint32_t k = 0;
+                for (int c = 7; c >= 0; --c) {  // an entry per existing child, child 7 first
                     const uint32_t bit = 1u << c;
                     uint32_t lo = 0, hi = 0;
                     if (o.node_mask & bit) {
-                        const uint64_t child = at + where[o.lo[c]];  // (an empty child octant takes no room: wherever the next octant starts)
-                        lo = uint32_t(wide ? child / 8 : child * 4);
+                        // (an empty child octant takes no room: wherever the next octant starts -- nothing ever reads it)
+                        lo = oct64_lo(t.octants[o.lo[c]], at + where[o.lo[c]], with_origin);
                         hi = oct64_masks(o.masks[c]);
-                    } else if (o.chunk_mask & bit) { lo = wide ? o.lo[c] : o.lo[c] * 32u; hi = oct64_masks(o.masks[c]); }
+                    } else if (o.chunk_mask & bit) { lo = o.lo[c]; hi = oct64_masks(o.masks[c]); }
                     else if (o.leaf_mask & bit) { lo = o.lo[c]; }
-                    w[2 * c] = lo;
-                    w[2 * c + 1] = hi;
+                    else continue;
+                    w[2 * k] = lo;
+                    w[2 * k + 1] = hi;
+                    ++k;
                 }
             } else {
                 uint32_t* w = dst + i * 12;
@@ -895,29 +916,38 @@ private:
 
 // Do two kOct64 images ([64-byte header][octants]) hold the same tree -- same masks, same leaf values, same shape -- wherever their octants
 // were placed? 1 / 0; -1 = a pointer out of range. (Tests: an image kept up to date commit by commit against one built from scratch.)
-inline int oct64_same_tree(const uint32_t* a, uint64_t na, const uint32_t* b, uint64_t nb) {
+// with_origin: images of CSVO worlds (a unit in front of every octant of values).
+inline int oct64_same_tree(const uint32_t* a, uint64_t na, const uint32_t* b, uint64_t nb, bool with_origin = false) {
     if (na < 16 || nb < 16 || a[0] != b[0] || a[1] != b[1]) return 0;
-    struct Pair { uint32_t pa, pb, masks; };
+    struct Pair { uint32_t la, lb, masks; };
     std::vector<Pair> todo{{a[2], b[2], a[1]}};
     while (!todo.empty()) {
         const Pair p = todo.back();
         todo.pop_back();
-        const uint32_t children = p.masks >> 24, leaves = (p.masks >> 16) & 0xffu;
+        const uint32_t children = (p.masks >> 16) & 0xffu, leaves = p.masks >> 24;
         if (!children) continue;  // an octant without children takes no room
-        const uint32_t words = children == leaves ? 8u : 16u;  // values only / {pointer | value, masks} entries
-        if (p.pa % 32 || p.pb % 32 || uint64_t(p.pa) / 4 + words > na || uint64_t(p.pb) / 4 + words > nb) return -1;
-        const uint32_t *oa = a + p.pa / 4, *ob = b + p.pb / 4;
-        for (uint32_t c = 0; c < 8; ++c) {
-            const bool exists = (children >> (7 - c)) & 1u, leaf = (leaves >> (7 - c)) & 1u;
-            if (words == 8) {
-                if (oa[c] != ob[c] || (!exists && oa[c])) return 0;
-            } else if (!exists) {
-                if (oa[2 * c] | oa[2 * c + 1] | ob[2 * c] | ob[2 * c + 1]) return 0;
-            } else if (leaf) {
-                if (oa[2 * c] != ob[2 * c]) return 0;
+        const uint32_t n = uint32_t(__builtin_popcount(children));
+        const bool values_only = children == leaves;
+        const uint64_t wa = (uint64_t(p.la) + 1) * 2, wb = (uint64_t(p.lb) + 1) * 2;  // frame word of the first entry / value
+        const uint64_t words = values_only ? n : 2u * n;
+        if (wa + words > na || wb + words > nb) return -1;
+        if (values_only) {
+            if (with_origin && (wa < 2 || wb < 2)) return -1;
+            for (uint32_t k = 0; k < n; ++k)
+                if (a[wa + k] != b[wb + k]) return 0;
+            continue;  // (the origins say where the bytes lie in worlds that may be laid out differently: not compared)
+        }
+        uint32_t k = 0;
+        for (int c = 7; c >= 0; --c) {  // (bit 7 - c of `children` = child c: reversed masks)
+            if (!((children >> (7 - c)) & 1u)) continue;
+            const bool leaf = (leaves >> (7 - c)) & 1u;
+            const uint32_t *ea = a + wa + 2 * k, *eb = b + wb + 2 * k;
+            ++k;
+            if (leaf) {
+                if (ea[0] != eb[0]) return 0;
             } else {
-                if (oa[2 * c + 1] != ob[2 * c + 1]) return 0;
-                todo.push_back(Pair{oa[2 * c], ob[2 * c], oa[2 * c + 1]});
+                if (ea[1] != eb[1]) return 0;
+                todo.push_back(Pair{ea[0], eb[0], ea[1]});
             }
         }
     }

@@ -40,6 +40,7 @@ struct DevTextures {
 
 struct DevScene {
     buf_t world;              // device copy of the mapped world buffer, byte 0 = f32 octree_scale (the first 4 GiB of it)
+    buf_t records8;           // traversal images: the same memory as 8-byte records addressed by index (what the hand-scheduled loop loads entries through)
     buf_t materials;          // vx_material rows
     float octree_scale;       // = world[0]
     uint32_t root_ptr;        // CSVO: world[1]
@@ -49,8 +50,8 @@ struct DevScene {
     // (VX_SVO_IMAGE_WIDE), and an ESVO world of 4 GiB and more (VX_SVO_ESVO_BIG; descriptors[] indices stay 32 bits: 16 GiB)
     const uint8_t* wide;
     uint64_t wide_bytes;
-    // CSVO worlds only: where the image's voxel-parent octants come from in the world's own bytes (traversal_image.hpp, origin
-    // table), two dwords per 32-byte unit of the image -- read when a ray is led INTO a voxel (walk_voxel_on_bytes)
+    // CSVO worlds only: the image again, as a plain pointer -- where a voxel-parent octant comes from in the world's own bytes is the unit in front of its
+    // values (traversal_image.hpp), read when a ray is led INTO a voxel (walk_voxel_on_bytes)
     const uint8_t* origin;
 };
 
@@ -59,6 +60,7 @@ __device__ __forceinline__ uint32_t clamp_u32(uint64_t v) { return v < 0xfffffff
 __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
     DevScene sc;
     sc.world = make_buf(a.world, clamp_u32(a.world_bytes));
+    sc.records8 = sc.world;  // (unused on the world's own bytes)
     sc.materials = make_buf(a.materials, a.n_materials * uint32_t(sizeof(vx_material)));
     sc.tex.buf = make_buf(a.tex, a.tex_bytes);
     sc.tex.width = a.width; sc.tex.height = a.height; sc.tex.layers = a.layers; sc.tex.levels = a.levels;
@@ -77,6 +79,7 @@ __device__ __forceinline__ DevScene make_scene(const SceneArgs& a) {
 __device__ __forceinline__ DevScene make_image_scene(const SceneArgs& a) {
     DevScene sc;
     sc.world = make_buf(a.image, clamp_u32(a.image_bytes));  // (a wide image is not read through this)
+    sc.records8 = make_buf_records8(a.image, clamp_u32(a.image_bytes));
     sc.materials = make_buf(a.materials, a.n_materials * uint32_t(sizeof(vx_material)));
     sc.tex.buf = make_buf(a.tex, a.tex_bytes);
     sc.tex.width = a.width; sc.tex.height = a.height; sc.tex.layers = a.layers; sc.tex.levels = a.levels;
@@ -93,9 +96,20 @@ __device__ __forceinline__ DevScene make_image_scene(const SceneArgs& a) {
     return sc;
 }
 
-// wide images: pointers count 32-byte units from the start of the image (the header is unit 0)
-__device__ __forceinline__ uint2 wide_entry(const DevScene& sc, uint32_t octant, uint32_t child) { return mem_u64(sc.wide + (uint64_t(octant) << 5) + child * 8u); }
-__device__ __forceinline__ uint32_t wide_u32(const DevScene& sc, uint32_t octant, uint32_t byte) { return mem_u32(sc.wide + (uint64_t(octant) << 5) + byte); }
+// Traversal images (traversal_image.hpp): everything is addressed in 8-byte units from the start of the image. A node's octant holds an entry per EXISTING
+// child, child 7 first; `lo` = the unit before the first. With m = the node's masks shifted left by the child's index ("exists" of that child in bit 23, of
+// the children above it below, "is a leaf" in the sign), the child's entry is unit lo + popcount(m & 0xffffff). An octant of values only (all children leaves) holds 4-byte values in the
+// same order from unit lo + 1 on. Byte-offset layout: through the buffer resource (range-checked: any `lo` is harmless); wide layout (beyond 4 GiB): a
+// 64-bit pointer, so `lo` has to stay inside the image.
+template <bool WIDE>
+__device__ __forceinline__ uint2 image_entry(const DevScene& sc, uint32_t lo, uint32_t m) {
+    const uint32_t unit = lo + uint32_t(__popc(m & 0x00ffffffu));
+    return WIDE ? mem_u64(sc.wide + (uint64_t(unit) << 3)) : buf_u64(sc.world, unit << 3);
+}
+template <bool WIDE>
+__device__ __forceinline__ uint32_t image_u32(const DevScene& sc, uint32_t unit, uint32_t byte) {
+    return WIDE ? mem_u32(sc.wide + (uint64_t(unit) << 3) + byte) : buf_u32(sc.world, (unit << 3) + byte);
+}
 
 struct Result {
     float t;
@@ -166,18 +180,25 @@ struct Stack {
         const VX_AS_LDS uint32_t* e = at(kStackBytes + n * 64u + child * 8u);
         return make_uint2(e[0], e[1]);
     }
-    // HOT: fills the copy (one wave; `lane` 0..63). The root's entries first, then entry (lane & 7) of the root's child (lane >> 3)
-    // -- whatever that child is: only octants of inner nodes are ever read back.
+    // HOT: fills the copy (one wave; `lane` 0..63), every octant EXPANDED to eight entries (zeros where a child does not exist) so that hot_entry() needs no
+    // popcount. The root's entries first, then entry (lane & 7) of the root's child (lane >> 3) -- whatever that child is: only octants of inner nodes are
+    // ever read back.
     template <class SCENE>
     __device__ __forceinline__ void load_hot(const SCENE& sc, uint32_t lane) const {
-        const uint32_t root = buf_u32(sc.world, 8);
+        const uint32_t root_masks = sc.image_root_masks, root_lo = sc.image_root_octant;
+        auto entry_of = [&](uint32_t lo, uint32_t masks, uint32_t child) -> uint2 {
+            const uint32_t m = masks << child;
+            if (!(m & 0x00800000u)) return make_uint2(0u, 0u);
+            return buf_u64(sc.world, (lo + uint32_t(__popc(m & 0x00ffffffu))) << 3);
+        };
         if (lane < 8) {
-            const uint2 e = buf_u64(sc.world, root + lane * 8u);
+            const uint2 e = entry_of(root_lo, root_masks, lane);
             VX_AS_LDS uint32_t* d = at(kStackBytes + lane * 8u);
             d[0] = e.x; d[1] = e.y;
         }
-        const uint32_t child_octant = *at(kStackBytes + (lane >> 3) * 8u);
-        const uint2 e = buf_u64(sc.world, child_octant + (lane & 7u) * 8u);
+        const uint2 parent = entry_of(root_lo, root_masks, lane >> 3);  // (the root's child: its `lo` and masks; a leaf's value is no octant: nothing of it is read back)
+        const bool inner = ((root_masks << (lane >> 3)) & 0x80800000u) == 0x00800000u;
+        const uint2 e = inner ? entry_of(parent.x, parent.y, lane & 7u) : make_uint2(0u, 0u);
         VX_AS_LDS uint32_t* d = at(kStackBytes + 64u + lane * 8u);
         d[0] = e.x; d[1] = e.y;
     }
@@ -788,18 +809,18 @@ struct Trav {
         // read through a buffer resource with its range check; the wide layout's 64-bit addresses are kept valid: see `ptr` below).
         constexpr bool kAhead = IMG && !ST::kHot;
         uint2 ahead = make_uint2(0u, 0u);
-        if (kAhead) ahead = WIDE ? wide_entry(sc, ptr, octant_idx) : buf_u64(sc.world, ptr + octant_idx * 8u);
+        if (kAhead) ahead = image_entry<WIDE>(sc, ptr, node << octant_idx);
         bool pushed = false;
         const float cell_before = scale_exp2;
 
         bool is_child, is_leaf;
         uint32_t tag = 0;  // CSVO: the child's 2-bit pointer-width tag (01 for every present child of the 1-bit levels)
         if (IMG) {
-            // image masks (traversal_image.hpp, oct64_masks): child c's "exists" bit at 31 - c, its "is a leaf" bit at 23 - c, so
-            // that one shift brings both to fixed places and "exists" into the sign
+            // image masks (traversal_image.hpp, oct64_masks): child c's "is a leaf" bit at 31 - c, its "exists" bit at 23 - c, so
+            // that one shift brings both to fixed places ("leaf" into the sign) and leaves the existing children above c below bit 23
             const uint32_t m = node << octant_idx;
-            is_child = int32_t(m) < 0;
-            is_leaf = (m & 0x00800000u) != 0;
+            is_child = (m & 0x00800000u) != 0;
+            is_leaf = int32_t(m) < 0;
         } else if (!CSVO) {
             is_child = (node & (0x100u << octant_idx)) != 0;
             is_leaf = (node & (1u << octant_idx)) != 0;
@@ -867,7 +888,7 @@ struct Trav {
                     const uint32_t at_root = uint32_t(bit_at(__float_as_uint(px), 22) | (bit_at(__float_as_uint(py), 22) << 1) | (bit_at(__float_as_uint(pz), 22) << 2)) ^ uint32_t(octant_mask);
                     e = st.hot_entry(scale == kMaxScale - 1 ? 0u : 1u + at_root, octant_idx);
                 } else {
-                    e = WIDE ? wide_entry(sc, ptr, octant_idx) : buf_u64(sc.world, ptr + octant_idx * 8u);
+                    e = image_entry<WIDE>(sc, ptr, node << octant_idx);
                 }
                 if (!kAhead) w0 = e.x;
                 // A ray that starts inside a voxel is led INTO it (the leaf was not accepted above: t_min <= 0). In an ESVO world a voxel's
@@ -986,12 +1007,12 @@ struct Trav {
         ++iter;
         const uint32_t bx = __float_as_uint(px), by = __float_as_uint(py), bz = __float_as_uint(pz);
         const uint32_t octant_idx = (bit_at(bx, scale) | (bit_at(by, scale) << 1) | (bit_at(bz, scale) << 2)) ^ uint32_t(octant_mask);
+        const uint32_t m = node << octant_idx;
         // the entry a PUSH into this child reads, requested for every lane (see step_with): looked at last
-        const uint2 ahead = WIDE ? wide_entry(sc, ptr, octant_idx) : buf_u64(sc.world, ptr + octant_idx * 8u);
+        const uint2 ahead = image_entry<WIDE>(sc, ptr, m);
         const float tcrx = __builtin_fmaf(px, tcx, -tbx), tcry = __builtin_fmaf(py, tcy, -tby), tcrz = __builtin_fmaf(pz, tcz, -tbz);
         const float tc_max = gmin3(tcrx, tcry, tcrz);
-        const uint32_t m = node << octant_idx;
-        const bool is_child = int32_t(m) < 0, is_leaf = (m & 0x00800000u) != 0;
+        const bool is_child = (m & 0x00800000u) != 0, is_leaf = int32_t(m) < 0;
         const bool descend = is_child && t_min <= t_max;
         flags = descend ? flags : (flags & ~kHasAdjacentLeaf);
         if (descend && is_leaf) {
@@ -1094,9 +1115,13 @@ struct Trav {
         }
     }
 
-    // image octants: bytes between the children's values -- an octant all of whose children are leaves (child bits 31..24 == leaf
-    // bits 23..16 of its masks) holds eight u32 values, any other eight {value | pointer, masks} entries (traversal_image.hpp)
-    __device__ __forceinline__ uint32_t image_value_stride() const { return (((node >> 8) ^ node) & 0x00ff0000u) ? 8u : 4u; }
+    // image octants: an octant all of whose children are leaves (child bits 23..16 == leaf bits 31..24 of its masks) holds u32 values only -- for the
+    // existing children, child 7 first, from unit ptr + 1 on --, any other a {value | pointer, masks} entry per existing child (traversal_image.hpp)
+    __device__ __forceinline__ uint32_t image_leaf_value(const DevScene& sc, uint32_t octant_idx) const {
+        const uint32_t k = uint32_t(__popc((node << octant_idx) & 0x00ffffffu));  // this child and the existing ones above it
+        const bool values_only = (((node >> 8) ^ node) & 0x00ff0000u) == 0u;
+        return values_only ? image_u32<WIDE>(sc, ptr + 1u, (k - 1u) * 4u) : image_u32<WIDE>(sc, ptr + k, 0u);
+    }
 
     // child index from the corner's mantissa bits (scale >= 0)
     __device__ __forceinline__ int idx_from_position() const {
@@ -1107,9 +1132,8 @@ struct Trav {
     // The voxel's value (block id) for a ray whose step() returned kTravAtLeaf.
     __device__ __forceinline__ uint32_t leaf_value(const DevScene& sc) const {
         const uint32_t octant_idx = uint32_t(idx ^ octant_mask);
-        return CSVO  ? csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx)
-               : WIDE ? wide_u32(sc, ptr, octant_idx * image_value_stride())
-               : IMG  ? buf_u32(sc.world, ptr + octant_idx * image_value_stride())
+        return CSVO ? csvo_read_leaf(sc, material_section_ptr, pre_leaf_pointer, ptr, octant_idx)
+               : IMG ? image_leaf_value(sc, octant_idx)
                      : word(sc, ptr + 4 + octant_idx);
     }
 
@@ -1269,18 +1293,19 @@ __device__ __forceinline__ TravStatus walk_voxel_on_bytes(const DevScene& img, b
     auto u32_at = [&](uint32_t p) -> uint32_t { return buf_u32(world, 8u + csvo_clamp(p)); };
     const int parent_scale = tr.scale;
     const uint32_t img_ptr = tr.ptr, img_node = tr.node;
-    // origin table: [0] = byte pointer of L, [1] = k << 29 | (L - material section), k = L's place among its depth-2 parent's leaf-mask bytes
-    const uint64_t unit = T::WIDE ? uint64_t(tr.ptr) : uint64_t(tr.ptr >> 5);
+    // the origin of the voxel-parent's octant, the unit in front of its values (unit `ptr`: traversal_image.hpp): [0] = byte pointer of L, [1] = k << 29 |
+    // (L - material section), k = L's place among its depth-2 parent's leaf-mask bytes
+    const uint64_t unit = uint64_t(tr.ptr);
     const uint32_t o0 = mem_u32(img.origin + unit * 8u), o1 = mem_u32(img.origin + unit * 8u + 4u);
     uint32_t bp = o0;  // the byte node the cursor examines: L first
     // its header in the 2-bits-per-child form (tag 01 per present child of a 1-bit level, csvo_header()): L's is the image node's child mask
-    // (child c at bit 31 - c there)
+    // (child c at bit 23 - c there)
     auto spread8 = [](uint32_t x) -> uint32_t {
         x = (x | (x << 4)) & 0x0f0fu;
         x = (x | (x << 2)) & 0x3333u;
         return (x | (x << 1)) & 0x5555u;
     };
-    uint32_t hd = spread8(rev_bits32(img_node) & 0xffu);
+    uint32_t hd = spread8((rev_bits32(img_node) >> 8) & 0xffu);
     if (tr.iter >= uint32_t(kMaxSteps)) return kTravFinished;
     // One iteration is ONE stretch of code for every lane: the PUSH's and the ADVANCE / POP's values are both worked out and the cursor takes one set
     // or the other by selects; only the memory operations (table entry, child header, stack slot) sit under their lanes' predicate, and a lane whose

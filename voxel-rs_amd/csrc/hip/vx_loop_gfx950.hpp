@@ -51,19 +51,19 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 #define VX_FOREIGN_EXIT "s_cmp_ge_u32 %[waiting], %[fmin]\n s_cbranch_scc1 9f\n"
 // (an ESVO world's voxel is walked as an empty node whatever its place in the octant holds: vx_device.hpp, step_image)
 // (... and in the wide layout, where `ptr` is dereferenced unchecked, the image's first octant for its pointer)
-#define VX_TAKE_ENTRY_ESVO_BYTES "v_mov_b32_e32 %[ptr], v" VX_E0 "\n v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[node], 0, v" VX_E1 ", vcc\n"
-#define VX_TAKE_ENTRY_ESVO_UNITS "v_cmp_eq_u32_e32 vcc, 0, %[t2]\n v_cndmask_b32_e32 %[ptr], 0, v" VX_E0 ", vcc\n v_cndmask_b32_e32 %[node], 0, v" VX_E1 ", vcc\n"
+#define VX_TAKE_ENTRY_ESVO_BYTES "v_mov_b32_e32 %[ptr], v" VX_E0 "\n v_cmp_le_i32_e32 vcc, 0, %[m]\n v_cndmask_b32_e32 %[node], 0, v" VX_E1 ", vcc\n"
+#define VX_TAKE_ENTRY_ESVO_UNITS "v_cmp_le_i32_e32 vcc, 0, %[m]\n v_cndmask_b32_e32 %[ptr], 0, v" VX_E0 ", vcc\n v_cndmask_b32_e32 %[node], 0, v" VX_E1 ", vcc\n"
 #define VX_TAKE_ENTRY_CSVO "v_mov_b32_e32 %[ptr], v" VX_E0 "\n v_mov_b32_e32 %[node], v" VX_E1 "\n"
 #define VX_COUNT_TRIP "s_add_u32 %[trips], %[trips], 1\n"
 // (measurement build: which tail a trip took, in ten-bit fields of the same counter -- a loop call makes at most kMaxSteps = 1000 trips)
 #define VX_COUNT_TRIP_ADVANCE_ONLY "s_add_u32 %[trips], %[trips], 0x401\n"
 #define VX_COUNT_TRIP_PUSH_ONLY "s_add_u32 %[trips], %[trips], 0x100001\n"
-// the entry of child `oct` of the octant at `ptr`: a byte offset through a raw buffer resource (out of range reads 0: any `ptr` is
-// harmless) | (images beyond 4 GiB, which no buffer resource reaches -- a structured one wraps at 4 GiB too, measured) an octant index in
-// 32-byte units: entry 4 * ptr + oct (the image is smaller than 32 GiB) behind a 64-bit base, so `ptr` has to stay a valid octant
-#define VX_LOAD_ENTRY_BYTES "v_lshl_add_u32 %[t1], %[oct], 3, %[ptr]\n buffer_load_dwordx2 v[" VX_E0 ":" VX_E1 "], %[t1], %[rsrc], 0 offen\n"
+// the entry of the child the ray is in: unit ptr + popcount(%[t2]) of the image (8-byte units; %[t2] = "exists" of this child and of the existing ones above
+// it: traversal_image.hpp) -- through a buffer resource of 8-byte records (out of range reads 0: any `ptr` is harmless) | (images beyond 4 GiB, which no
+// buffer resource reaches -- its offsets are 32 bits, measured) behind a 64-bit base, so `ptr` has to stay inside the image (smaller than 32 GiB)
+#define VX_LOAD_ENTRY_BYTES "v_bcnt_u32_b32 %[t1], %[t2], %[ptr]\n buffer_load_dwordx2 v[" VX_E0 ":" VX_E1 "], %[t1], %[rsrc], 0 idxen\n"
 #define VX_LOAD_ENTRY_UNITS                                                                                                        \
-    "v_lshl_add_u32 v" VX_A0 ", %[ptr], 2, %[oct]\n v_mov_b32_e32 v" VX_A1 ", 0\n v_lshl_add_u64 v[" VX_A0 ":" VX_A1 "], v[" VX_A0 ":" VX_A1 "], 3, %[base]\n"         \
+    "v_bcnt_u32_b32 v" VX_A0 ", %[t2], %[ptr]\n v_mov_b32_e32 v" VX_A1 ", 0\n v_lshl_add_u64 v[" VX_A0 ":" VX_A1 "], v[" VX_A0 ":" VX_A1 "], 3, %[base]\n"         \
     "global_load_dwordx2 v[" VX_E0 ":" VX_E1 "], v[" VX_A0 ":" VX_A1 "], off\n"
 // the stack: 13 levels of three words (planes 13 x 256 bytes apart) | 16 levels with a 16-bit third plane (the masks' upper half: all a
 // cursor on an image needs), planes 16 x 256 bytes apart, the third at half the slot's offset behind them
@@ -110,22 +110,22 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_lshlrev_b32_e32 %[t1], 1, %[t1]\n"                                                                                      \
         "v_lshl_or_b32 %[t0], %[t2], 2, %[t0]\n"                                                                                   \
         "v_bitop3_b32 %[oct], %[t0], %[om], %[t1] bitop3:0x36\n" /* (t0 | t1) ^ octant_mask */                                     \
+        "v_lshlrev_b32_e32 %[m], %[oct], %[node]\n"              /* the child's "is a leaf" bit in the sign, its "exists" bit at 23 ... */ \
+        "v_and_b32_e32 %[t2], 0xffffff, %[m]\n"                  /* ... and below it "exists" of the children above: their count = where the entry lies */ \
         LOAD_ENTRY                                                                                                                 \
         "v_fma_f32 %[crx], %[px], %[tcx], -%[tbx]\n"                                                                               \
         "v_fma_f32 %[cry], %[py], %[tcy], -%[tby]\n"                                                                               \
         "v_fma_f32 %[crz], %[pz], %[tcz], -%[tbz]\n"                                                                               \
         "v_min3_f32 %[tcm], %[crx], %[cry], %[crz]\n"                                                                              \
-        "v_lshlrev_b32_e32 %[m], %[oct], %[node]\n"              /* the child's "exists" bit in the sign, its "is a leaf" bit at 23 */ \
         "v_min_f32_e32 %[tvm], %[tmax], %[tcm]\n"                                                                                  \
         "v_lshl_add_u32 %[sx], %[sc], 23, %[k_cell]\n"                                                                             \
         "v_lshl_add_u32 %[hf], %[sc], 23, %[k_half]\n"                                                                             \
         /* ---- a leaf the ray reaches (is a leaf, t_min <= t_max): the lane stops here ---- */                                    \
-        "v_and_b32_e32 %[t2], 0x800000, %[m]\n"                                                                                    \
-        "v_cmpx_ne_u32_e32 vcc, 0, %[t2]\n"                      /* exec: ... whose child is a leaf (a leaf is a child) */         \
+        "v_cmpx_gt_i32_e32 vcc, 0, %[m]\n"                       /* exec: ... whose child is a leaf (a leaf is a child) */         \
         "v_cmpx_le_f32_e32 vcc, %[tmin], %[tmax]\n"              /* ... and is reached */                                          \
         LEAF_EXITS                                                                                                                 \
         /* ---- PUSH or ADVANCE ---- */                                                                                            \
-        "v_cmp_gt_i32_e32 vcc, 0, %[m]\n"                                                                                          \
+        "v_cmp_le_u32_e32 vcc, 0x800000, %[t2]\n"                /* the child exists (bit 23 of what is left of m) */              \
         "v_cndmask_b32_e32 %[tq], %[inf], %[tmin], vcc\n"        /* t_min, or +inf where there is no child */                      \
         "v_cmp_le_f32_e64 %[s_push], %[tq], %[tvm]\n"            /* PUSH: a child, and t_min <= min(t_max, tc_max) */              \
         "s_cmp_eq_u64 %[s_push], 0\n"                                                                                              \

@@ -17,6 +17,11 @@ typedef __amdgpu_buffer_rsrc_t buf_t;
 __device__ __forceinline__ buf_t make_buf(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, int(bytes), 0x00020000);
 }
+// the same memory as records of 8 bytes addressed by their index (`idxen`): what the hand-scheduled loop reads a traversal image's entries through --
+// unit index in, no shift; an index beyond the records reads 0
+__device__ __forceinline__ buf_t make_buf_records8(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 8, int(bytes >> 3), 0x00020000);
+}
 __device__ __forceinline__ uint32_t buf_u32(buf_t b, uint32_t off) { return uint32_t(__builtin_amdgcn_raw_buffer_load_b32(b, int(off), 0, 0)); }
 __device__ __forceinline__ uint32_t buf_u8(buf_t b, uint32_t off) { return uint32_t(__builtin_amdgcn_raw_buffer_load_b8(b, int(off), 0, 0)); }
 __device__ __forceinline__ uint4 buf_u128(buf_t b, uint32_t off) {

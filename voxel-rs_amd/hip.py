@@ -184,17 +184,17 @@ def comm_unique_id():
 
 def traversal_image(svo_type, world_frame_words, used_bytes, layout=0, with_origin=False):
     """vx_traversal_image: world frame (uint32 words: scale, header, arena...) -> traversal image (uint32 words);
-    layout 0 = ESVO frame (walkable by any ESVO traversal), 1 = the 64-byte-octant layout the renderer walks, 2 = the same
-    with 32-byte units for pointers. with_origin: also the origin table (CSVO worlds, layouts 1 and 2; else all zeros)."""
+    layout 0 = ESVO frame (walkable by any ESVO traversal), 1 = what the renderer walks -- octants of one {pointer | value, masks} entry per existing
+    child, addressed in 8-byte units, through a buffer resource --, 2 = the same bytes walked through a 64-bit pointer (images beyond 4 GiB).
+    with_origin: (image, image) -- since round 6 the origin of a CSVO world's voxel-parent octant is a unit of the image itself, in front of the octant's
+    values; what used to be a table of its own IS the image (a walk reads unit `lo` of it)."""
     f = np.ascontiguousarray(world_frame_words, dtype=np.uint32)
     n = lib().vx_traversal_image(svo_type, f.ctypes.data_as(_vp), used_bytes, layout, None, 0)
     if n == 0:
         raise ValueError("this world frame cannot be imaged")
     out = np.zeros(n, dtype=np.uint32)
-    origin = np.zeros((n + 3) // 4, dtype=np.uint32)
-    lib().vx_traversal_image_with_origin(svo_type, f.ctypes.data_as(_vp), used_bytes, layout, out.ctypes.data_as(_vp), n,
-                                         origin.ctypes.data_as(_vp), origin.size)
-    return (out, origin) if with_origin else out
+    lib().vx_traversal_image(svo_type, f.ctypes.data_as(_vp), used_bytes, layout, out.ctypes.data_as(_vp), n)
+    return (out, out) if with_origin else out
 
 
 class Svo:
