@@ -204,9 +204,9 @@ size_t vx_arena_capacity(const vx_context* ctx);
  * (asynchronously; later renders/raycasts are ordered after it). used_bytes = WorldSvo::size_in_bytes() for
  * vx_get_stats (:183-187).
  * A context also keeps a traversal image of the world (vx_traversal_image): the chunks inside the given ranges and the root
- * octree are re-laid out as 64-byte octants on host worker threads and the changed parts uploaded; vx_render walks the image
- * (device memory on top of the world's own bytes: 0.84x them for ESVO, about 3.9x for CSVO; VX_TRAVERSAL_IMAGE=0 in the
- * environment turns it off). The staging mirror must hold the whole current world, i.e. every change has to go through
+ * octree are re-laid out as octants of one 8-byte entry per existing child on host worker threads and the changed parts uploaded;
+ * vx_render walks the image (device memory on top of the world's own bytes: 0.37x them for ESVO, about 2.3x for CSVO;
+ * VX_TRAVERSAL_IMAGE=0 in the environment turns it off). The staging mirror must hold the whole current world, i.e. every change has to go through
  * vx_staging_ptr (it does when write_changes_to is the only writer). */
 int vx_commit(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t count, uint64_t used_bytes);
 /* Same, treating [0, used_bytes) of the arena as dirty (what the first write_changes_to after write_to does). */
@@ -214,7 +214,7 @@ int vx_commit_all(vx_context* ctx, uint32_t depth, uint64_t used_bytes);
 /* Pipelined commits. VX_COMMIT_INLINE (default): vx_commit does the image update and queues the uploads before it returns, and
  * every later render sees the new world. VX_COMMIT_PIPELINED: vx_commit only posts the job to a worker thread of the context
  * (0.01 ms) and returns; the worker updates the image, packs and queues the uploads while the caller goes on -- renders issued
- * meanwhile show the world as of the commit before, WHOLLY (world bytes, image and origin table change together, ordered on the
+ * meanwhile show the world as of the commit before, WHOLLY (world bytes and image change together, ordered on the
  * device behind the frames in flight and before every later one), so a change becomes visible at most one frame late, like the
  * reference's own one-frame lag between Svo::update and the next fence (svo.rs:171-189, 196-229). One job at a time: the next
  * vx_commit, vx_staging_ptr (the worker reads the mirror: ask for the pointer before writing the next changes, as
@@ -335,17 +335,18 @@ int vx_assemble_tiles_on(vx_context* ctx, const float* tiles, uint64_t stride_fl
                          float* out_rgba32f, void* stream);
 /* The traversal image of a world: the octant tree a context traverses instead of the world's own bytes.
  * `world_frame` = the world as committed ([f32 scale][ESVO: 5-word preamble | CSVO: u32 root_ptr][arena]), `used_bytes` = arena
- * bytes in use. layout 1 = what the renderer walks ([64-byte header][octants: eight {pointer | value, masks} entries, or
- * just eight values when every child is a voxel], pointers = byte offsets); layout 2 = the same with 32-byte units for pointers, what the renderer switches to when
+ * bytes in use. layout 1 = what the renderer walks ([64-byte header][octants: a {pointer | value, masks} entry per EXISTING child, child 7
+ * first, or just the existing children's values when every child is a voxel -- behind a unit that says where the node lies in a CSVO world's bytes], everything
+ * addressed in 8-byte units); layout 2 = the same bytes, walked through a 64-bit pointer instead of a buffer resource: what the renderer switches to when
  * the image outgrows 4 GiB; layout 0 = the same tree as an ESVO frame ([f32 2^-depth][5-word preamble][12-word octants], esvo.rs:74-101),
  * which any ESVO traversal can walk (the tests do, with the oracle). Returns the image size in 32-bit words (0 = cannot be
  * imaged) and fills `out_words` when it is large enough. Pure host function (no device needed): vx_commit does this itself. */
 uint64_t vx_traversal_image(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words, uint64_t capacity_words);
-/* The same, also returning the image's ORIGIN TABLE (layouts 1 and 2 of a CSVO world; empty otherwise): two words per 32-byte unit
- * of the image -- image_words / 4 words in all -- which say, for the unit a voxel-parent octant starts at, where that node (a
- * leaf-mask byte, svo.csvo.glsl:114-115) lies in the world's own bytes: [0] = its byte pointer, [1] = k << 29 | (pointer - the
- * chunk's material section), k = its place among its depth-2 parent's leaf-mask bytes. The renderer consults it when a ray that
- * started inside a voxel is led into it (svo.csvo.glsl:293-295): that walk is format specific and is made on the world's bytes. */
+/* Rounds 3-5 kept an ORIGIN TABLE beside the image of a CSVO world and this call returned it. Since round 6 the origin of a voxel-parent octant -- where
+ * that node (a leaf-mask byte, svo.csvo.glsl:114-115) lies in the world's own bytes: [0] = its byte pointer, [1] = k << 29 | (pointer - the chunk's material
+ * section), k = its place among its depth-2 parent's leaf-mask bytes -- is the 8-byte unit of the image in front of the octant's values, and this call is
+ * vx_traversal_image (nothing is written to `out_origin_words`). The renderer consults the origin when a ray that started inside a voxel is led into it
+ * (svo.csvo.glsl:293-295): that walk is format specific and is made on the world's bytes. */
 uint64_t vx_traversal_image_with_origin(int svo_type, const uint8_t* world_frame, uint64_t used_bytes, int layout, uint32_t* out_words,
                                         uint64_t capacity_words, uint32_t* out_origin_words, uint64_t origin_capacity_words);
 /* 2x2 ordered-grid supersampling (BASELINE.json C5): box-filters a (2*width) x (2*height) RGBA32F render down to
@@ -380,8 +381,8 @@ int vx_comm_profile_read(vx_context* ctx, double* gather_ms_sum, uint32_t* gathe
  * in the walks. `out` holds capacity_waves x 8 words. Returns the number of waves copied. Waits for every frame in flight. */
 uint32_t vx_timeline_read(vx_context* ctx, uint64_t* out, uint32_t capacity_waves);
 /* What vx_render walks after the last commit: [0] 0 = the world's own bytes (no image: switched off, or the world cannot be
- * imaged), 1 = the traversal image with byte offsets, 2 = its layout for more than 4 GiB (32-byte units behind a 64-bit pointer);
- * [1] bytes of the image, [2] bytes of its origin table (CSVO worlds), [3] chunks it holds. */
+ * imaged), 1 = the traversal image walked through a buffer resource, 2 = walked through a 64-bit pointer (images beyond 4 GiB);
+ * [1] bytes of the image, [2] 0 (rounds 3-5: bytes of a CSVO world's origin table; the origins are units of the image now), [3] chunks it holds. */
 int vx_image_info(const vx_context* ctx, uint64_t out[4]);
 /* The scheduling knobs this context runs with (they reorder a frame's work and change no pixel): [0] refill threshold, [1] service threshold, [2] cap on
  * the persistent waves per CU (0 = none), [3] length of the sub-tile queue's stretches (0 = by the launch), [4] width of the tile numbering's strips, [5] cost-ordered

@@ -3,13 +3,14 @@
 C4  3840x2160 primary + shadow on the depth-14 terrain -- (a) streamed from the world generator by the chunk loader (radius 40
     of the 50 that src/gamelogic/world.rs:400 allows, at most 400 events per commit like src/systems/worldsvo.rs:139), frames
     compared while the stream is in flight, after the fill and after a flight; (b) the STATIC full-detail depth-14 terrain
-    (299 M voxels; CSVO 1.4 GB with a 5.5 GB traversal image in its layout for more than 4 GiB, ESVO 6.7 GB: a world buffer
+    (299 M voxels; CSVO 1.4 GB with a 3.3 GB traversal image -- here behind 5 GiB of nothing, in its layout for more than 4 GiB --, ESVO 6.7 GB: a world buffer
     beyond what 32-bit byte offsets reach).
 C5  4x-supersampled 3840x2160 on that static terrain: the 7680x4320 frame rendered as the tile shares of 8 ranks (what 8 GPUs
     would render), gathered (vx_assemble_tiles) and resolved (vx_resolve_2x2), against the oracle's 7680x4320 frame filtered the
     same way.
 Hit records exactly (t, position, uv, value, face, flags, shadow distance, step count), colours to 5e-6."""
 import gc
+import os
 import math
 
 import numpy as np
@@ -114,16 +115,32 @@ def depth14(request):
     st = world.build_heightfield(14)
     assert st["leaves"] > 270_000_000  # 270-320 M voxels
     tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
-    svo = hip.Svo(FMTS[fmt], world.size_in_bytes + (16 << 20))
+    # Since round 6 (an entry per existing child) the depth-14 terrain's image fits a buffer resource: 2.5 GB (ESVO) / 3.3 GB (CSVO world: its origins inline).
+    # The ESVO context runs as it comes (the byte-offset layout, beside a world buffer beyond 4 GiB); the CSVO context is made to use the layout for images
+    # beyond 4 GiB with its arena 5 GiB into the frame (VX_WIDE_IMAGE=2: read when the context is created), so that every pointer of a full-size frame
+    # needs more than 32 bits of byte offset -- for real.
+    wide = fmt == "csvo"
+    had = os.environ.get("VX_WIDE_IMAGE")
+    if wide:
+        os.environ["VX_WIDE_IMAGE"] = "2"
+    try:
+        svo = hip.Svo(FMTS[fmt], world.size_in_bytes + (16 << 20))
+    finally:
+        if wide:
+            if had is None:
+                del os.environ["VX_WIDE_IMAGE"]
+            else:
+                os.environ["VX_WIDE_IMAGE"] = had
     svo.set_materials(mats)
     svo.set_textures(tex, 6)
     svo.update(world)
     info = svo.image_info()
     if fmt == "csvo":
         assert 1.3e9 < world.size_in_bytes < 1.6e9
+        assert info["layout"] == 2 and info["image_bytes"] > (1 << 32) + (3 << 30), info
     else:
         assert world.size_in_bytes > (1 << 32)  # a world buffer beyond 32-bit byte offsets (esvo.rs:74-101: word indices)
-    assert info["layout"] == 2 and info["image_bytes"] > (1 << 32), info  # the image's layout for more than 4 GiB, for real
+        assert info["layout"] == 1 and 2.0e9 < info["image_bytes"] < (1 << 32), info
     scene = orc.OracleScene(FMTS[fmt], world.frame(), mats.view(orc.MATERIAL_DTYPE), tex, 6)
     yield fmt, world, st, svo, scene
     svo.close()

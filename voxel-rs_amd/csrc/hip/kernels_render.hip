@@ -181,8 +181,8 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long m) { return __bui
 __device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); }
 
-// IMAGE = the rays walk the traversal image of the world (traversal_image.hpp) instead of its own bytes: a build per image layout (byte
-// offsets / 32-byte units behind a 64-bit base). An image kernel is only launched for worlds whose depth its LDS-resident stack levels
+// IMAGE = the rays walk the traversal image of the world (traversal_image.hpp) instead of its own bytes: a build per way of addressing it (a buffer
+// resource / a 64-bit base). An image kernel is only launched for worlds whose depth its LDS-resident stack levels
 // cover (LV: 13 three-word levels, or 16 with a 16-bit third plane -- image cursors need no more of the third word), so its traversal loop
 // never hands a ray over to the spill-backed stack; deeper worlds are rendered on their own bytes.
 // FOREIGN (an image of a CSVO world): what happens to a ray that is about to be led into the voxel it started in -- VX_SVO_CSVO: it walks the

@@ -448,7 +448,7 @@ struct Upload {
 constexpr uint64_t kDeltaLimit = 64ull << 20;  // commits up to this size travel packed (one transfer, one scatter kernel)
 constexpr uint64_t kPiece = 32768;             // bytes one workgroup of the scatter kernel moves
 
-// A whole world (gigabytes): the staging mirror is pinned and travels as it is; the traversal image and its origin table live in pageable
+// A whole world (gigabytes): the staging mirror is pinned and travels as it is; the traversal image lives in pageable
 // memory, from which a copy command crawls (2.8 GB/s measured: 2.5 s for the depth-14 terrain's 7 GB) -- they go through a ring of pinned
 // bounce buffers instead, filled by a handful of threads while the previous ones are in flight. Returns when everything has been read.
 int upload_big(vx_context* ctx, const std::vector<Upload>& up) {
@@ -889,7 +889,7 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
 
     // What goes to the device: the writer's header, the dirty arena ranges (neighbours closer than 4 KiB travel as one: the
     // staging mirror holds the whole world, so the bytes between them are the device's own), and the parts of the traversal image
-    // and its origin table that the image update below rewrites.
+    // that the image update below rewrites.
     std::vector<Upload> up;
     up.push_back(Upload{ctx->d_world, ctx->staging, head});
     {
@@ -918,7 +918,7 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         // A world whose image will not fit a buffer resource's 32-bit offsets starts in the wide layout instead of finding that out at the end of a whole
         // build (an image is about 0.37 x the bytes of an ESVO world, 2.3 x those of a CSVO world; the wide layout serves any size)
         if (ctx->image.chunk_count() == 0 && ctx->image.layout() == vximg::kOct64 &&
-            double(used_bytes) * (ctx->svo_type == VX_SVO_ESVO ? 0.45 : 2.7) >= 3.5 * double(1ull << 30))
+            double(used_bytes) * (ctx->svo_type == VX_SVO_ESVO ? 0.42 : 2.45) >= 3.7 * double(1ull << 30))
             ctx->image = vximg::WorldImage(ctx->svo_type, vximg::kOct64Wide);
         image_ok = ctx->image.update(ctx->staging, used_bytes, changed.data(), changed.size(), threads);
         if (!image_ok && ctx->image.too_big() && ctx->image.layout() == vximg::kOct64) {

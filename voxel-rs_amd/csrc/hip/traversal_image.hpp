@@ -201,7 +201,7 @@ struct Octant {
     uint32_t lo[8] = {};
     uint16_t masks[8] = {};  // the child's own masks (nodes), filled in for chunks at placement
     uint8_t node_mask = 0, leaf_mask = 0, chunk_mask = 0;
-    // CSVO voxel parents (leaf-mask bytes, svo.csvo.glsl:114-115): where the byte is in the world, for the origin table --
+    // CSVO voxel parents (leaf-mask bytes, svo.csvo.glsl:114-115): where the byte is in the world, for the unit in front of the octant's values --
     // [0] = its byte pointer L, [1] = k << 29 | (L - the chunk's material section), k = its place among its depth-2 parent's bytes
     uint32_t origin[2] = {};
 };
@@ -261,7 +261,7 @@ private:
             const uint32_t material_offset = b_.u16(pre_leaf + 1);
             const uint64_t leaf_index = ptr - (pre_leaf + 3);
             if (leaf_index > 7 || ptr >= (uint64_t(1) << 31) || ptr - materials_ >= (uint64_t(1) << 29)) {
-                out_.too_deep = true;  // not a chunk the serializer wrote (csvo.rs:481-493): the origin table could not say where it is
+                out_.too_deep = true;  // not a chunk the serializer wrote (csvo.rs:481-493): the origin could not say where it is
                 return m;
             }
             out_.octants[at].origin[0] = uint32_t(ptr);
@@ -425,7 +425,7 @@ private:
         }
     }
 
-    static constexpr size_t kMaxOctants = size_t(1) << 26;  // 4 GiB of 64-byte octants
+    static constexpr size_t kMaxOctants = size_t(1) << 26;  // (a runaway walk: no world the serializer wrote has as many)
     Words w_;
     Tree& out_;
     std::vector<ChunkRef>* refs_;

@@ -14,7 +14,7 @@
 #define VX_HOST_DEVICE
 #endif
 
-// third node format, internal to the library: the 64-byte-octant traversal image of a world (traversal_image.hpp, kOct64)
+// third node format, internal to the library: the traversal image of a world (traversal_image.hpp, kOct64)
 #define VX_SVO_IMAGE 3
 // the same with octant INDICES for pointers and 64-bit addressing: images beyond 4 GiB (traversal_image.hpp, kOct64Wide)
 #define VX_SVO_IMAGE_WIDE 4
@@ -40,7 +40,7 @@ struct SceneArgs {
     uint32_t level_offset[16];
     const uint8_t* image;   // the traversal image of the world (traversal_image.hpp), or null
     uint64_t image_bytes;
-    const uint8_t* origin;  // its origin table (CSVO worlds), or null
+    const uint8_t* origin;  // CSVO worlds: the image again (the origin of a voxel-parent octant is the unit in front of its values), else null
 };
 
 struct RenderParams {

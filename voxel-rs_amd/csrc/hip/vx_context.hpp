@@ -114,7 +114,7 @@ struct vx_context {
     vximg::WorldImage image;
     uint8_t* d_image = nullptr;
     size_t d_image_capacity = 0;
-    uint8_t* d_origin = nullptr;  // CSVO worlds: the image's origin table (a quarter of the image's size)
+    uint8_t* d_origin = nullptr;  // (rounds 3-5: a CSVO world's origin table beside the image; the origins are units of the image now -- never allocated)
     size_t d_origin_capacity = 0;
     size_t image_cap_bytes = 0;   // VX_IMAGE_CAP_BYTES: never allocate more than this for the image (tests of the fall-back)
     // vx_commit's packed uploads: a small ring of pinned host buffers with their device twins, each guarded by an event

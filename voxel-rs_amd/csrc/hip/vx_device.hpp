@@ -805,7 +805,7 @@ struct Trav {
         // lane, whether the lane turns out to descend or not -- the address is known, and everything the iteration does (the tests
         // below, the stack access, the other lanes' ADVANCE and POP) runs while it is in flight; it is looked at once, at the very end.
         // Requested for nothing by the lanes that do not descend: the same one load instruction per trip of a wave, and any address
-        // is harmless (an octant of eight values is read beyond its 32 bytes, into the next one or the padding; a byte-offset image is
+        // is harmless (the unit in front of the octant for a child that does not exist, a unit among an octant's values; a byte-offset image is
         // read through a buffer resource with its range check; the wide layout's 64-bit addresses are kept valid: see `ptr` below).
         constexpr bool kAhead = IMG && !ST::kHot;
         uint2 ahead = make_uint2(0u, 0u);

@@ -17,7 +17,7 @@
 //     bits 28..30 = the TravStatus -- by one v_add under a narrowed execution mask; the caller decodes it once per service phase;
 //   * the cell size is derived from the scale (one shift-add) instead of being carried and selected;
 //   * PUSH's five register updates and POP's run under their lanes' execution masks as plain moves / loads into the state registers.
-// Variants: the image's pointers as byte offsets or (beyond 4 GiB) 32-byte units; a stack of 13 three-word levels or of 16 levels with
+// Variants: the image read through a buffer resource of 8-byte records or (beyond 4 GiB) a 64-bit base; a stack of 13 three-word levels or of 16 levels with
 // a 16-bit third plane; worlds in ESVO or CSVO (what happens to a ray that is led into a voxel); with or without a trip counter.
 // Hazards (no hazard recognizer looks inside an asm block): no DPP / SDWA / packed / transcendental / lane-access instructions, no SGPR
 // written by a VALU is read by a memory instruction, s_cbranch_execz only behind a SALU write of EXEC.
@@ -234,7 +234,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 
 // FOREIGN: the image of a CSVO world -- a ray about to be led into a voxel leaves the loop (kTravForeign, its iteration not counted);
 // otherwise (ESVO world) it walks the voxel as an empty node. COUNT: count the trips in `trips` (measurement).
-// SVO: VX_SVO_IMAGE (byte offsets; `image` = a raw resource over the image) or VX_SVO_IMAGE_WIDE (32-byte units behind `image_base`; the image
+// SVO: VX_SVO_IMAGE (`image` = a resource of 8-byte records over the image: make_buf_records8) or VX_SVO_IMAGE_WIDE (8-byte units behind `image_base`; the image
 // must be smaller than 32 GiB). LEVELS: 13 (three-word slots) or 16 (the
 // 16-bit third plane); lds_slot0 / lds_aux0 = the LDS addresses of this lane's slot for scale 0 in the first and in the third plane.
 // The caller guarantees that no traversing lane has kHasAdjacentLeaf set (the loop does not clear it; such rays -- they have just
