@@ -61,11 +61,11 @@ def image_model_bytes(c):
     return 8 * c["pushes"] + c["leaf_tests"] * (4 + 32) + nearest * 4 + c["leaf_tests_trilinear"] * 32 + 16 * c["pixels"] + c["lit_pixels"] * (32 + 4)
 
 
-def stored_counters(fmt):
+def stored_counters(fmt, config=None):
     """The committed rocprofv3 --pmc passes of this same command (profiles/roundN/profile*.sh -> profiles/roundN/traffic.json): PMC counters cannot
     be read from inside this run, so they are a STORED artifact -- and only quoted when they were measured on the library sources this run uses:
     traffic.json names the hash of voxel-rs_amd/csrc/hip (`csrc_sha16`, _pkg.csrc_hash), and any other hash makes `traffic` and `issue` null with a
-    note instead of stale numbers. Returns (row or None, source, note)."""
+    note instead of stale numbers. `config`: a key of the file other than the headline's ("C4": the depth-14 frames). Returns (row or None, source, note)."""
     from _pkg import csrc_hash
 
     here = csrc_hash()
@@ -77,8 +77,8 @@ def stored_counters(fmt):
         src = f"profiles/{rnd}/traffic.json" + (f" @ {t['commit']}" if "commit" in t else "")
         if t.get("csrc_sha16") != here:
             return None, src, (f"{src} was measured on other library sources (csrc_sha16 {t.get('csrc_sha16', 'not recorded')}, this run {here}): "
-                               "not quoted; re-run the profile passes (profiles/round5/profile_r5.sh)")
-        return t.get(fmt), src, None
+                               "not quoted; re-run the profile passes (profiles/round6/run_profiles.sh)")
+        return (t.get(config) or {}).get(fmt) if config else t.get(fmt), src, None
     return None, None, "no stored counter file"
 
 
@@ -462,7 +462,7 @@ def cpu_baseline(args, wl, orc):
 # ---- the other BASELINE configurations on this GPU -----------------------------------------------------------------------------------
 
 
-def other_configs(args, vra, hip, scenes, torch, formats):
+def other_configs(args, vra, hip, scenes, torch, formats, clock=None):
     """C2 (1080p primary rays, depth 10), C4 (4K primary + shadow on the full-detail depth-14 terrain: static, and streamed by the chunk loader),
     C5 (7680x4320 + 2x2 resolve on that terrain: one rank's share of eight, and the whole frame on this one GPU): the same moving camera, frames into
     device memory with the library's two frames in flight, the median of five blocks. Rays and iterations from the instrumented kernel (first view)."""
@@ -522,8 +522,39 @@ def other_configs(args, vra, hip, scenes, torch, formats):
                 imgs = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
                 torch.cuda.synchronize()
                 ms = timed(svo, lambda i: svo.render_device(path[i % 20], w, h, imgs[i % 2].data_ptr()), 40)
-                out.setdefault("C4_static", {})[fmt_name] = line(ms, svo.render_counters(path[0], w, h),
-                                                                 {"workload": "3840x2160 primary + shadow, static full-detail depth-14 terrain", **about, "image": svo.image_info()})
+                c4 = svo.render_counters(path[0], w, h)
+                # the depth-14 frame's own roofline block, as for the headline: the kernel alone (one frame at a time, HIP events around each launch), the
+                # algorithmic bytes of the first view, the stored counters of profiles/round6/c4_counters.sh (quoted for these library sources only)
+                svo.set_frames_in_flight(1)
+                for i in range(4):
+                    svo.render_device(path[i % 20], w, h, imgs[0].data_ptr())
+                svo.sync()
+                svo.profile_enable(True)
+                for i in range(12):
+                    svo.render_device(path[i % 20], w, h, imgs[0].data_ptr())
+                    svo.sync()
+                kms, launches = svo.profile_read()
+                svo.profile_enable(False)
+                svo.set_frames_in_flight(2)
+                excl = kms / max(launches, 1)
+                alg = algorithmic_bytes(fmt_name, c4)
+                stored, src, note = stored_counters(fmt_name, "C4")
+                roof = {"bound": "hbm", "achieved": round(alg / (excl * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (excl * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": stored.get("bytes_per_launch") if stored else None,
+                        "traffic_source": src, **({"traffic_note": note} if note else {}), "kernel": "render_persistent",
+                        "kernel_exclusive_ms": round(excl, 4), "algorithmic_bytes_per_launch": int(alg), "bytes_per_ray": round(alg / max(c4["rays"], 1), 2)}
+                if stored and clock:
+                    issue = issue_model(stored, src, clock["mhz_median"], "this run: " + clock["source"])
+                    if issue:
+                        issue["frac_of_bound_one_frame_at_a_time"] = round(issue["issue_bound_ms"] / excl, 4)
+                        issue["frac_of_bound_timed_mode"] = round(issue["issue_bound_ms"] / ms, 4)
+                        roof["issue"] = issue
+                        roof.update({"issue_bound_ms": issue["issue_bound_ms"], "issue_frac_timed_mode": issue["frac_of_bound_timed_mode"],
+                                     "wait_share_of_wave_cycles": issue["wait_share_of_wave_cycles"]})
+                    if stored.get("TCC_HIT") and stored.get("TCC_MISS"):
+                        roof["l2_hit_rate"] = round(stored["TCC_HIT"] / (stored["TCC_HIT"] + stored["TCC_MISS"]), 3)
+                out.setdefault("C4_static", {})[fmt_name] = line(ms, c4, {"workload": "3840x2160 primary + shadow, static full-detail depth-14 terrain", **about,
+                                                                       "image": svo.image_info(), "roofline": roof})
                 del imgs
                 # C5: 2x2 supersamples of the 4K frame. One rank's share of eight (its tile list; the resolve of the assembled frame is rank 0's), and
                 # the whole supersampled frame + the resolve on this one GPU
@@ -951,7 +982,7 @@ def main():
     if not sharded and not args.no_extras and rank == 0:
         if not args.no_configs:
             try:
-                configs = other_configs(args, vra, hip, scenes, torch, [f for f in args.config_formats.split(",") if f in ("csvo", "esvo")])
+                configs = other_configs(args, vra, hip, scenes, torch, [f for f in args.config_formats.split(",") if f in ("csvo", "esvo")], clock=clock)
             except Exception as e:  # (a box without the memory for the depth-14 terrain: the headline still stands)
                 configs = {"error": f"{type(e).__name__}: {e}"[:300]}
         forced = args.forced_sharded_result  # (measured before this process touched the GPU: see main())
@@ -1065,6 +1096,10 @@ def main():
         for name, short in (("C2", "c2"), ("C4_static", "c4_static"), ("C4_streamed", "c4_streamed"), ("C5_rank_share", "c5_rank_share"), ("C5_whole_on_one_gpu", "c5_whole")):
             for f, r in (configs.get(name) or {}).items():
                 flat_configs[f"{short}_{f}_ms"] = r.get("ms_per_step")
+                if name == "C4_static" and isinstance(r.get("roofline"), dict):
+                    flat_configs[f"c4_static_{f}_roofline_frac"] = r["roofline"].get("frac")
+                    flat_configs[f"c4_static_{f}_kernel_exclusive_ms"] = r["roofline"].get("kernel_exclusive_ms")
+                    flat_configs[f"c4_static_{f}_wait_share"] = r["roofline"].get("wait_share_of_wave_cycles")
     out = {
         "metric": "Mrays/sec (primary+shadow) at 1920x1080, depth-12 SVO; achieved HBM GB/s",
         "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,

@@ -30,7 +30,8 @@ if [ "$what" = pmc ] || [ "$what" = all ]; then
              "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
              "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_LEVEL_sum" \
              "TCC_TAG_STALL_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" \
-             "GRBM_UTCL2_BUSY TCP_GATE_EN1_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_LFIFO_FULL_sum TD_TC_STALL TD_TD_BUSY"; do
+             "GRBM_UTCL2_BUSY TCP_GATE_EN1_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_LFIFO_FULL_sum TD_TC_STALL TD_TD_BUSY" \
+             "FETCH_SIZE WRITE_SIZE"; do
     i=$((i+1))
     timeout -k 10 420 rocprofv3 --pmc $pmc --output-format csv -d "$out/pmc$i" -- $run > "$out/pmc$i.log" 2>&1
     [ -n "${SKIP_C3:-}" ] || timeout -k 10 240 rocprofv3 --pmc $pmc --output-format csv -d "$out/c3_pmc$i" -- $run3 > "$out/c3_pmc$i.log" 2>&1

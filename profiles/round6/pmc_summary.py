@@ -14,6 +14,7 @@ for log in sorted(glob.glob(out + "/*.log")):
     for line in open(log):
         if line.startswith("{"):
             print("== %s: %s" % (log.split("/")[-1], line.strip()[:260]))
+merged = collections.OrderedDict()  # kernel -> counter -> mean of the timed launches (every pass of the directory)
 for d in sorted(glob.glob(out + "/*pmc*/")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         per = collections.OrderedDict()  # (kernel, dispatch) -> counter -> sum
@@ -30,3 +31,8 @@ for d in sorted(glob.glob(out + "/*pmc*/")):
             print("== %s %s (%d launches; mean of the last %d)" % (d.rstrip("/").split("/")[-1], k, len(launches), len(last)))
             for c in last[0]:
                 print("   %-44s %.6g" % (c, sum(l[c] for l in last) / len(last)))
+                if not d.rstrip("/").split("/")[-1].startswith("c3_"):
+                    merged.setdefault(k, collections.OrderedDict())[c] = sum(l[c] for l in last) / len(last)
+import json
+
+json.dump(merged, open(out + "/pmc.json", "w"), indent=1)

@@ -27,11 +27,13 @@ def test_stored_counters_are_quoted_for_their_sources_only(tmp_path, monkeypatch
     import _pkg
 
     (tmp_path / "profiles" / "round5").mkdir(parents=True)
-    (tmp_path / "profiles" / "round5" / "traffic.json").write_text(json.dumps({"commit": "abc1234", "csrc_sha16": "0123456789abcdef", "csvo": {"bytes_per_launch": 42}}))
+    (tmp_path / "profiles" / "round5" / "traffic.json").write_text(json.dumps({"commit": "abc1234", "csrc_sha16": "0123456789abcdef", "csvo": {"bytes_per_launch": 42},
+                                                                                "C4": {"csvo": {"bytes_per_launch": 43}}}))
     monkeypatch.setattr(bench, "ROOT", tmp_path)
     monkeypatch.setattr(_pkg, "csrc_hash", lambda: "0123456789abcdef")
     row, source, note = bench.stored_counters("csvo")
     assert row == {"bytes_per_launch": 42} and "round5/traffic.json @ abc1234" in source and note is None
+    assert bench.stored_counters("csvo", "C4")[0] == {"bytes_per_launch": 43} and bench.stored_counters("esvo", "C4")[0] is None
     monkeypatch.setattr(_pkg, "csrc_hash", lambda: "fedcba9876543210")
     row, source, note = bench.stored_counters("csvo")
     assert row is None and "other library sources" in note and "fedcba9876543210" in note
@@ -41,14 +43,17 @@ def test_stored_counters_are_quoted_for_their_sources_only(tmp_path, monkeypatch
 
 
 def test_the_committed_counters_belong_to_the_committed_sources():
-    """profiles/round5/traffic.json was measured on the library sources in the tree: bench.py will quote it (a kernel change without a new profile
-    pass fails here instead of silently dropping `roofline.traffic` from the record)."""
+    """profiles/round6/traffic.json was measured on the library sources in the tree: bench.py will quote it (a kernel change without a new profile
+    pass fails here instead of silently dropping `roofline.traffic` from the record). It holds the headline's counters (C3) and the depth-14 frame's (C4)."""
     from _pkg import csrc_hash
 
-    t = json.loads((ROOT / "profiles" / "round5" / "traffic.json").read_text())
-    assert t["csrc_sha16"] == csrc_hash(), "re-run profiles/round5/run_profiles.sh on the GPU box and commit its traffic.json"
-    row, _, note = bench.stored_counters("csvo")
-    assert note is None and row["bytes_per_launch"] > 0 and row["SQ_INSTS_VALU"] > 0
+    t = json.loads((ROOT / "profiles" / "round6" / "traffic.json").read_text())
+    assert t["csrc_sha16"] == csrc_hash(), "re-run profiles/round6/run_profiles.sh on the GPU box and commit its traffic.json"
+    for fmt in ("csvo", "esvo"):
+        row, _, note = bench.stored_counters(fmt)
+        assert note is None and row["bytes_per_launch"] > 0 and row["SQ_INSTS_VALU"] > 0 and row["read_bytes"] > 0
+        row4, _, note4 = bench.stored_counters(fmt, "C4")
+        assert note4 is None and row4["bytes_per_launch"] > row["bytes_per_launch"] and row4["SQ_INSTS_VALU"] > row["SQ_INSTS_VALU"] and row4["TCC_MISS"] > 0
 
 
 def test_granted_cpus_and_defaults():
