@@ -24,14 +24,14 @@ if [ "$what" = pmc ] || [ "$what" = all ]; then
   for pmc in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
              "SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
              "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM GRBM_GUI_ACTIVE" \
-             "TA_BUSY_avr TA_BUFFER_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum TA_BUFFER_READ_WAVEFRONTS_sum" \
+             "TA_BUFFER_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum" \
              "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" \
              "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum" \
              "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
              "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_LEVEL_sum" \
              "TCC_TAG_STALL_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" \
              "GRBM_UTCL2_BUSY TCP_GATE_EN1_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_LFIFO_FULL_sum TD_TC_STALL TD_TD_BUSY" \
-             "FETCH_SIZE WRITE_SIZE"; do
+             "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE"; do
     i=$((i+1))
     timeout -k 10 420 rocprofv3 --pmc $pmc --output-format csv -d "$out/pmc$i" -- $run > "$out/pmc$i.log" 2>&1
     [ -n "${SKIP_C3:-}" ] || timeout -k 10 240 rocprofv3 --pmc $pmc --output-format csv -d "$out/c3_pmc$i" -- $run3 > "$out/c3_pmc$i.log" 2>&1
