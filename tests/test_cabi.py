@@ -104,3 +104,4 @@ def test_comm_entry_points_reject_bad_arguments():
     n, r = C.c_int(-1), C.c_int(-1)
     assert L.vx_comm_info(None, C.byref(n), C.byref(r)) == 1
     assert L.vx_present_wait(None, 0, None, None) == 1
+    assert L.vx_set_comm_headroom(None, 2) == 1 and L.vx_debug_knobs(None, None) == 1

@@ -572,6 +572,15 @@ def test_error_behaviour(hip):
     assert rc == 4 and b"not large enough" in hip.lib().vx_last_error()
     with pytest.raises(hip.VoxelHipError):
         hip.Svo(3, 1 << 16)
+    # the wave slots a context leaves to RCCL's kernels: 0 .. 8, read per launch (vx_set_comm_headroom), visible through vx_debug_knobs
+    assert svo.knobs()["comm_headroom"] == 4 and svo.knobs()["measurement_build"] == 0
+    svo.set_comm_headroom(0)
+    assert svo.knobs()["comm_headroom"] == 0
+    svo.set_comm_headroom(8)
+    assert svo.knobs()["comm_headroom"] == 8
+    with pytest.raises(hip.VoxelHipError, match="0..8"):
+        svo.set_comm_headroom(9)
+    svo.close()
 
 
 OCCUPANCY_COUNTERS = ("wave_steps", "services", "refills", "tail_wave_steps", "tail_iterations")

@@ -328,8 +328,10 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                 // in the same trip; the build that lists such rays instead never waits for anything)
                 const uint32_t f_waiting = FOREIGN == VX_SVO_CSVO ? uint32_t(__popcll(__ballot(state == kForeign))) : 0u;
                 const uint32_t f_min = FOREIGN == VX_SVO_CSVO ? 1u : 0xffffffffu;
-                if (a.timeline) traverse_loop_gfx950<SVO, FOREIGN != 0, true, LV>(tr, sc.records8, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips, &loop_tails);
-                else traverse_loop_gfx950<SVO, FOREIGN != 0, false, LV>(tr, sc.records8, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips);
+                constexpr int kForeignKind = FOREIGN == VX_SVO_CSVO ? 1 : (FOREIGN == kForeignRerun ? 2 : 0);  // (waits for its walk / is listed / ESVO world)
+                if (a.timeline) traverse_loop_gfx950<SVO, kForeignKind, true, LV>(tr, sc.records8, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips, &loop_tails);
+                else if (keep_going == 0u) traverse_loop_gfx950<SVO, kForeignKind, false, LV, true>(tr, sc.records8, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips);
+                else traverse_loop_gfx950<SVO, kForeignKind, false, LV>(tr, sc.records8, sc.wide, lds_slot0, lds_aux0, keep_going, f_waiting, f_min, loop_trips);
                 // a lane the loop parked says why in bits 28..30 of its iteration count
                 const uint32_t why = (tr.iter >> 28) & 7u;
                 if (why) {

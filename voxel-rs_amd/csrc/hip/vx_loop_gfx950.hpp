@@ -41,14 +41,21 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
     "v_add_u32_e32 %[iter], 0xdfffffff, %[iter]\n"               /* parked | kTravForeign << 28, and the iteration taken back */   \
     "v_cmpx_lt_f32_e32 vcc, 0, %[tmin]\n"                                                                                          \
     "v_add_u32_e32 %[iter], 0xc0000001, %[iter]\n"               /* t_min > 0 after all: parked | kTravAtLeaf << 28, the iteration counted (sum: + 0xa0000000) */ \
-    "s_andn2_b64 vcc, %[s_save], exec\n"                         /* the lanes that are led into a voxel: how many wait for that walk now */ \
-    "s_bcnt1_i32_b64 %[s_n], vcc\n"                                                                                                \
-    "s_add_u32 %[waiting], %[waiting], %[s_n]\n"                                                                                   \
+    "s_andn2_b64 vcc, %[s_save], exec\n"                         /* the lanes that are led into a voxel: they wait for that walk now */ \
+    "s_or_b64 %[waiting], %[waiting], vcc\n"                                                                                       \
     "s_andn2_b64 exec, %[s_trav], %[s_save]\n"
-// ... and when enough of them wait, the wave leaves the loop for the service phase that walks them together (the others' rays pause
+// (worlds of at most 12 levels, whose rays led into a voxel are LISTED and run on the world's bytes afterwards -- render_persistent's kForeignRerun build, C3's:
+// nothing waits for anything, so nothing is counted and the loop has no second exit: five instructions a trip less than the walk's build)
+#define VX_LEAF_EXITS_CSVO_LISTED                                                                                                  \
+    "s_mov_b64 %[s_save], exec\n"                                                                                                  \
+    "v_add_u32_e32 %[iter], 0xdfffffff, %[iter]\n"               /* parked | kTravForeign << 28, and the iteration taken back */   \
+    "v_cmpx_lt_f32_e32 vcc, 0, %[tmin]\n"                                                                                          \
+    "v_add_u32_e32 %[iter], 0xc0000001, %[iter]\n"               /* t_min > 0 after all: parked | kTravAtLeaf << 28, the iteration counted */ \
+    "s_andn2_b64 exec, %[s_trav], %[s_save]\n"
+// ... and as soon as one of them waits (`waiting`: a mask; at entry non-zero if lanes wait from earlier rounds), the wave leaves the loop for the service phase that walks them together (the others' rays pause
 // where they are): a shadow ray that starts inside its voxel gets there after `depth` trips, all such rays of a batch in the same trip --
 // waiting for the other rays to END first would run the batch's two halves one after the other
-#define VX_FOREIGN_EXIT "s_cmp_ge_u32 %[waiting], %[fmin]\n s_cbranch_scc1 9f\n"
+#define VX_FOREIGN_EXIT "s_cmp_lg_u64 %[waiting], 0\n s_cbranch_scc1 9f\n"
 // (an ESVO world's voxel is walked as an empty node whatever its place in the octant holds: vx_device.hpp, step_image)
 // (... and in the wide layout, where `ptr` is dereferenced unchecked, the image's first octant for its pointer)
 #define VX_TAKE_ENTRY_ESVO_BYTES "v_mov_b32_e32 %[ptr], v" VX_E0 "\n v_cmp_le_i32_e32 vcc, 0, %[m]\n v_cndmask_b32_e32 %[node], 0, v" VX_E1 ", vcc\n"
@@ -72,13 +79,19 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 #define VX_STACK_READ_13 "ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:3328\n ds_read_b32 %[node], %[oct] offset:6656\n"
 #define VX_STACK_READ_16 "v_lshl_add_u32 %[m], %[sc], 7, %[lds16]\n ds_read_b32 %[ptr], %[oct]\n ds_read_b32 %[tmax], %[oct] offset:4096\n ds_read_u16_d16_hi %[node], %[m]\n"
 // who still traverses, and whether the wave goes on
-#define VX_LOOP_CONTROL(COUNT)                                                                                                     \
+#define VX_LOOP_CONTROL_false(COUNT)                                                                                               \
         "s_mov_b64 exec, %[s_trav]\n"                                                                                              \
         COUNT    /* (also carries the FOREIGN builds' second exit) */                                                              \
         "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
         "s_bcnt1_i32_b64 %[s_n], vcc\n"                                                                                            \
         "s_cmp_gt_u32 %[s_n], %[keep]\n"                                                                                           \
         "s_cbranch_scc1 1b\n"
+// ... in lockstep (keep_going == 0, the product's setting: the wave goes on while ANY lane traverses): two instructions less
+#define VX_LOOP_CONTROL_true(COUNT)                                                                                                \
+        "s_mov_b64 exec, %[s_trav]\n"                                                                                              \
+        COUNT                                                                                                                      \
+        "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
+        "s_cbranch_vccnz 1b\n"
 // POP (the execution mask = the lanes whose ADVANCE left the parent; %[t0] = the bits in which their corner changed)
 #define VX_TRIP_POP(STACK_READ)                                                                                                    \
         "v_ffbh_u32_e32 %[t1], %[t0]\n"                                                                                            \
@@ -95,7 +108,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
 // one ADVANCEs (measured, C3 in lockstep: 11.4 % / 10.7 %, profiles/round5/pass_a/tails.txt). The trip therefore has three tails behind its common part (the child, the entry request, the plane distances, the leaf
 // exits, the PUSH mask): the merged one (both kinds of lane), and the two it degenerates to when the mask is all or none -- 31 and 22
 // instructions shorter, the ADVANCE-only one without the wait for the entry it requested for nothing.
-#define VX_LOOP_ASM(LEAF_EXITS, TAKE_MASKS, COUNT, COUNT_A, COUNT_P, LOAD_ENTRY, STACK_WRITE, STACK_READ)                          \
+#define VX_LOOP_ASM(LEAF_EXITS, TAKE_MASKS, COUNT, COUNT_A, COUNT_P, LOAD_ENTRY, STACK_WRITE, STACK_READ, LOCKSTEP)                          \
         "v_cmp_gt_u32_e32 vcc, 0x3e8, %[iter]\n"                                                                                   \
         "s_cmp_eq_u64 vcc, 0\n"                                                                                                    \
         "s_cbranch_scc1 9f\n"                                                                                                      \
@@ -176,7 +189,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
         TAKE_MASKS                                                                                                                 \
         "s_waitcnt lgkmcnt(0)\n"                                                                                                   \
-        VX_LOOP_CONTROL(COUNT)                                                                                                     \
+        VX_LOOP_CONTROL_##LOCKSTEP(COUNT)                                                                                                     \
         "s_branch 9f\n"                                                                                                            \
         /* ======== every lane ADVANCEs ======== */                                                                                \
         "4:\n"                                                                                                                     \
@@ -203,7 +216,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         VX_TRIP_POP(STACK_READ)                                                                                                    \
         "s_waitcnt lgkmcnt(0)\n"                                                                                                   \
         "6:\n"                                                                                                                     \
-        VX_LOOP_CONTROL(COUNT_A)                                                                                                   \
+        VX_LOOP_CONTROL_##LOCKSTEP(COUNT_A)                                                                                                   \
         "s_branch 9f\n"                                                                                                            \
         /* ======== every lane PUSHes ======== */                                                                                  \
         "5:\n"                                                                                                                     \
@@ -225,21 +238,25 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
         TAKE_MASKS                                                                                                                 \
-        VX_LOOP_CONTROL(COUNT_P)                                                                                                   \
+        VX_LOOP_CONTROL_##LOCKSTEP(COUNT_P)                                                                                                   \
         "9:\n"                                                                                                                     \
         /* (the ADVANCE-only tail leaves its entry request in flight: it must have landed before the compiler's code reuses the pair -- */ \
         /* where every register is in use it did not always: one pixel in a few frames differed) */                                    \
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
         "s_mov_b64 exec, %[entry_exec]\n"
 
-// FOREIGN: the image of a CSVO world -- a ray about to be led into a voxel leaves the loop (kTravForeign, its iteration not counted);
+// FOREIGN != 0: the image of a CSVO world -- a ray about to be led into a voxel leaves the loop (kTravForeign, its iteration not counted);
 // otherwise (ESVO world) it walks the voxel as an empty node. COUNT: count the trips in `trips` (measurement).
 // SVO: VX_SVO_IMAGE (`image` = a resource of 8-byte records over the image: make_buf_records8) or VX_SVO_IMAGE_WIDE (8-byte units behind `image_base`; the image
 // must be smaller than 32 GiB). LEVELS: 13 (three-word slots) or 16 (the
 // 16-bit third plane); lds_slot0 / lds_aux0 = the LDS addresses of this lane's slot for scale 0 in the first and in the third plane.
 // The caller guarantees that no traversing lane has kHasAdjacentLeaf set (the loop does not clear it; such rays -- they have just
 // passed a translucent voxel -- are rare and take the compiler's loop); kInsideVoxel is not maintained (nothing in a render reads it).
-template <int SVO, bool FOREIGN, bool COUNT, int LEVELS>
+// FOREIGN: 0 = the image of an ESVO world, 1 = of a CSVO world whose rays walk inside voxels in a service phase (the loop counts the lanes that wait for that
+// and leaves when `foreign_min` do), 2 = of a CSVO world whose such rays are listed (no waiting, no second exit).
+// LOCKSTEP: the caller has found keep_going == 0 (wave-uniform): the loop's control is then a branch on the traversing lanes' mask alone. (Product builds only:
+// the measurement build's loop, which counts its trips, keeps the general control.)
+template <int SVO, int FOREIGN, bool COUNT, int LEVELS, bool LOCKSTEP = false>
 __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image, const uint8_t* image_base, uint32_t lds_slot0, uint32_t lds_aux0, uint32_t keep_going,
                                                      uint32_t foreign_waiting, uint32_t foreign_min, uint32_t& trips, unsigned long long* tails = nullptr) {
     static_assert(SVO == VX_SVO_IMAGE || SVO == VX_SVO_IMAGE_WIDE, "cursors on a traversal image");
@@ -257,8 +274,10 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
     keep_going = uint32_t(__builtin_amdgcn_readfirstlane(int(keep_going)));
     uint32_t n_trips = 0;
     // FOREIGN: lanes that wait for their walk into a voxel (at entry: those of earlier rounds), and how many of them make the wave leave the loop
-    uint32_t waiting = uint32_t(__builtin_amdgcn_readfirstlane(int(foreign_waiting)));
-    foreign_min = uint32_t(__builtin_amdgcn_readfirstlane(int(foreign_min)));
+    // (a mask of the lanes that have come to wait in this call; at entry: whether any waits already. The caller's `foreign_min` is 1 wherever lanes wait at all:
+    // the loop leaves for the walk as soon as one lane does)
+    unsigned long long waiting = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(foreign_waiting)));  // (their number: non-zero is all that counts)
+    (void)foreign_min;
 #define VX_LOOP_OPERANDS                                                                                                                                   \
         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tmin] "+v"(tr.t_min), [tmax] "+v"(tr.t_max), [sc] "+v"(scale), [ptr] "+v"(tr.ptr),  \
           [node] "+v"(tr.node), [iter] "+v"(tr.iter), [trips] "+s"(n_trips), [waiting] "+s"(waiting), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [oct] "=&v"(oct), [m] "=&v"(m), \
@@ -267,14 +286,23 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
           [s_save] "=&s"(s_save), [s_n] "=&s"(s_n)                                                                                                         \
         : [tcx] "v"(tr.tcx), [tcy] "v"(tr.tcy), [tcz] "v"(tr.tcz), [tbx] "v"(tr.tbx), [tby] "v"(tr.tby), [tbz] "v"(tr.tbz), [om] "v"(uint32_t(tr.octant_mask)), \
           [lds] "v"(lds_slot0), [lds16] "v"(lds_aux0), [inf] "v"(0x7f800000u), [rsrc] "s"(image), [base] "s"(image_base), [keep] "s"(keep_going), [k_cell] "s"(k_cell),           \
-          [k_half] "s"(k_half), [entry_exec] "s"(entry_exec), [fmin] "s"(foreign_min)                                                                                               \
+          [k_half] "s"(k_half), [entry_exec] "s"(entry_exec)                                                                                               \
         : "v" VX_A0, "v" VX_A1, "v" VX_E0, "v" VX_E1, "vcc", "scc", "memory"
-#define VX_LOOP_VARIANT(F, C, U, L)                                                                                                                        \
-    if constexpr (FOREIGN == F && COUNT == C && UNITS == U && LEVELS == L)                                                                                  \
-        asm volatile(VX_LOOP_ASM(VX_LOOP_PICK_##F(VX_LEAF_EXITS_CSVO, VX_LEAF_EXITS_ESVO), VX_LOOP_PICK_##F(VX_TAKE_ENTRY_CSVO, VX_LOOP_PICK_##U(VX_TAKE_ENTRY_ESVO_UNITS, VX_TAKE_ENTRY_ESVO_BYTES)),          \
-                                 VX_LOOP_PICK_##C(VX_COUNT_TRIP, "") VX_LOOP_PICK_##F(VX_FOREIGN_EXIT, ""), VX_LOOP_PICK_##C(VX_COUNT_TRIP_ADVANCE_ONLY, "") VX_LOOP_PICK_##F(VX_FOREIGN_EXIT, ""),     \
-                                 VX_LOOP_PICK_##C(VX_COUNT_TRIP_PUSH_ONLY, "") VX_LOOP_PICK_##F(VX_FOREIGN_EXIT, ""), VX_LOOP_PICK_##U(VX_LOAD_ENTRY_UNITS, VX_LOAD_ENTRY_BYTES),                 \
-                                 VX_STACK_WRITE_##L, VX_STACK_READ_##L) VX_LOOP_OPERANDS)
+#define VX_LOOP_VARIANT(F, C, U, L, K)                                                                                                                     \
+    if constexpr (FOREIGN == F && COUNT == C && UNITS == U && LEVELS == L && (LOCKSTEP && !COUNT) == K)                                                     \
+        asm volatile(VX_LOOP_ASM(VX_F_LEAF_##F, VX_F_TAKE_##F(U),                                                                                         \
+                                 VX_LOOP_PICK_##C(VX_COUNT_TRIP, "") VX_F_EXIT_##F, VX_LOOP_PICK_##C(VX_COUNT_TRIP_ADVANCE_ONLY, "") VX_F_EXIT_##F,     \
+                                 VX_LOOP_PICK_##C(VX_COUNT_TRIP_PUSH_ONLY, "") VX_F_EXIT_##F, VX_LOOP_PICK_##U(VX_LOAD_ENTRY_UNITS, VX_LOAD_ENTRY_BYTES),                 \
+                                 VX_STACK_WRITE_##L, VX_STACK_READ_##L, K) VX_LOOP_OPERANDS)
+#define VX_F_LEAF_0 VX_LEAF_EXITS_ESVO
+#define VX_F_LEAF_1 VX_LEAF_EXITS_CSVO
+#define VX_F_LEAF_2 VX_LEAF_EXITS_CSVO_LISTED
+#define VX_F_TAKE_0(U) VX_LOOP_PICK_##U(VX_TAKE_ENTRY_ESVO_UNITS, VX_TAKE_ENTRY_ESVO_BYTES)
+#define VX_F_TAKE_1(U) VX_TAKE_ENTRY_CSVO
+#define VX_F_TAKE_2(U) VX_TAKE_ENTRY_CSVO
+#define VX_F_EXIT_0 ""
+#define VX_F_EXIT_1 VX_FOREIGN_EXIT
+#define VX_F_EXIT_2 ""
 #define VX_LOOP_PICK_true(a, b) a
 #define VX_LOOP_PICK_false(a, b) b
     // (two pairs of fixed registers -- the entry a trip requests, the 64-bit address of it in the wide layout: an asm operand cannot name the
@@ -283,15 +311,26 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
 #define VX_E1 "125"
 #define VX_A0 "122"
 #define VX_A1 "123"
-    VX_LOOP_VARIANT(false, false, false, 13); VX_LOOP_VARIANT(false, false, false, 16); VX_LOOP_VARIANT(false, false, true, 13); VX_LOOP_VARIANT(false, false, true, 16);
-    VX_LOOP_VARIANT(false, true, false, 13); VX_LOOP_VARIANT(false, true, false, 16); VX_LOOP_VARIANT(false, true, true, 13); VX_LOOP_VARIANT(false, true, true, 16);
-    VX_LOOP_VARIANT(true, false, false, 13); VX_LOOP_VARIANT(true, false, false, 16); VX_LOOP_VARIANT(true, false, true, 13); VX_LOOP_VARIANT(true, false, true, 16);
-    VX_LOOP_VARIANT(true, true, false, 13); VX_LOOP_VARIANT(true, true, false, 16); VX_LOOP_VARIANT(true, true, true, 13); VX_LOOP_VARIANT(true, true, true, 16);
+    VX_LOOP_VARIANT(0, false, false, 13, false); VX_LOOP_VARIANT(0, false, false, 13, true); VX_LOOP_VARIANT(0, false, false, 16, false); VX_LOOP_VARIANT(0, false, false, 16, true); VX_LOOP_VARIANT(0, false, true, 13, false); VX_LOOP_VARIANT(0, false, true, 13, true); VX_LOOP_VARIANT(0, false, true, 16, false); VX_LOOP_VARIANT(0, false, true, 16, true);
+    VX_LOOP_VARIANT(0, true, false, 13, false); VX_LOOP_VARIANT(0, true, false, 16, false); VX_LOOP_VARIANT(0, true, true, 13, false); VX_LOOP_VARIANT(0, true, true, 16, false);
+    VX_LOOP_VARIANT(1, false, false, 13, false); VX_LOOP_VARIANT(1, false, false, 13, true); VX_LOOP_VARIANT(1, false, false, 16, false); VX_LOOP_VARIANT(1, false, false, 16, true); VX_LOOP_VARIANT(1, false, true, 13, false); VX_LOOP_VARIANT(1, false, true, 13, true); VX_LOOP_VARIANT(1, false, true, 16, false); VX_LOOP_VARIANT(1, false, true, 16, true);
+    VX_LOOP_VARIANT(1, true, false, 13, false); VX_LOOP_VARIANT(1, true, false, 16, false); VX_LOOP_VARIANT(1, true, true, 13, false); VX_LOOP_VARIANT(1, true, true, 16, false);
+    VX_LOOP_VARIANT(2, false, false, 13, false); VX_LOOP_VARIANT(2, false, false, 13, true); VX_LOOP_VARIANT(2, false, false, 16, false); VX_LOOP_VARIANT(2, false, false, 16, true); VX_LOOP_VARIANT(2, false, true, 13, false); VX_LOOP_VARIANT(2, false, true, 13, true); VX_LOOP_VARIANT(2, false, true, 16, false); VX_LOOP_VARIANT(2, false, true, 16, true);
+    VX_LOOP_VARIANT(2, true, false, 13, false); VX_LOOP_VARIANT(2, true, false, 16, false); VX_LOOP_VARIANT(2, true, true, 13, false); VX_LOOP_VARIANT(2, true, true, 16, false);
 #undef VX_E0
 #undef VX_E1
 #undef VX_A0
 #undef VX_A1
 #undef VX_LOOP_VARIANT
+#undef VX_F_LEAF_0
+#undef VX_F_LEAF_1
+#undef VX_F_LEAF_2
+#undef VX_F_TAKE_0
+#undef VX_F_TAKE_1
+#undef VX_F_TAKE_2
+#undef VX_F_EXIT_0
+#undef VX_F_EXIT_1
+#undef VX_F_EXIT_2
 #undef VX_LOOP_PICK_true
 #undef VX_LOOP_PICK_false
 #undef VX_LOOP_OPERANDS
