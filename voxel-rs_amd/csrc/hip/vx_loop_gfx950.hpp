@@ -130,7 +130,8 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_fma_f32 %[cry], %[py], %[tcy], -%[tby]\n"                                                                               \
         "v_fma_f32 %[crz], %[pz], %[tcz], -%[tbz]\n"                                                                               \
         "v_min3_f32 %[tcm], %[crx], %[cry], %[crz]\n"                                                                              \
-        "v_min_f32_e32 %[tvm], %[tmax], %[tcm]\n"                                                                                  \
+        /* (min(t_max, tc_max), the t_max a PUSH hands on, IS tc_max: the child's cell lies in the node's, t_max is the node's own exit distance and the  */ \
+        /* plane distances are monotone in the corner -- fma rounds once --, so the child's exit is never later. vx_device.hpp keeps the reference's min.) */ \
         "v_lshl_add_u32 %[sx], %[sc], 23, %[k_cell]\n"                                                                             \
         "v_lshl_add_u32 %[hf], %[sc], 23, %[k_half]\n"                                                                             \
         /* ---- a leaf the ray reaches (is a leaf, t_min <= t_max): the lane stops here ---- */                                    \
@@ -140,7 +141,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         /* ---- PUSH or ADVANCE ---- */                                                                                            \
         "v_cmp_le_u32_e32 vcc, 0x800000, %[t2]\n"                /* the child exists (bit 23 of what is left of m) */              \
         "v_cndmask_b32_e32 %[tq], %[inf], %[tmin], vcc\n"        /* t_min, or +inf where there is no child */                      \
-        "v_cmp_le_f32_e64 %[s_push], %[tq], %[tvm]\n"            /* PUSH: a child, and t_min <= min(t_max, tc_max) */              \
+        "v_cmp_le_f32_e64 %[s_push], %[tq], %[tcm]\n"            /* PUSH: a child, and t_min <= min(t_max, tc_max) = tc_max */      \
         "s_cmp_eq_u64 %[s_push], 0\n"                                                                                              \
         "s_cbranch_scc1 4f\n"                                    /* nobody: the ADVANCE-only tail */                               \
         "s_cmp_eq_u64 %[s_push], exec\n"                                                                                           \
@@ -185,7 +186,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         /* PUSH: the child becomes the node */                                                                                     \
         "s_and_b64 exec, %[s_save], %[s_push]\n"                                                                                   \
         "v_add_u32_e32 %[sc], -1, %[sc]\n"                                                                                         \
-        "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
+        "v_mov_b32_e32 %[tmax], %[tcm]\n"                                                                                          \
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
         TAKE_MASKS                                                                                                                 \
         "s_waitcnt lgkmcnt(0)\n"                                                                                                   \
@@ -235,7 +236,7 @@ __device__ __forceinline__ constexpr uint32_t loop_exit_bits(TravStatus s) { ret
         "v_cndmask_b32_e32 %[t1], 0, %[hf], vcc\n"                                                                                 \
         "v_add_f32_e32 %[pz], %[pz], %[t1]\n"                                                                                      \
         "v_add_u32_e32 %[sc], -1, %[sc]\n"                                                                                         \
-        "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
+        "v_mov_b32_e32 %[tmax], %[tcm]\n"                                                                                          \
         "s_waitcnt vmcnt(0)\n"                                                                                                     \
         TAKE_MASKS                                                                                                                 \
         VX_LOOP_CONTROL_##LOCKSTEP(COUNT_P)                                                                                                   \
@@ -263,7 +264,7 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
     static_assert(LEVELS == 13 || LEVELS == 16, "stack layouts: Stack<64, true, true, 13>, Stack<64, true, true, 16, true>");
     constexpr bool UNITS = SVO == VX_SVO_IMAGE_WIDE;
     uint32_t t0, t1, t2, oct, m, nx, ny, nz;
-    float crx, cry, crz, tcm, tvm, tq, hf, hm, ot, sx;
+    float crx, cry, crz, tcm, tq, hf, hm, ot, sx;
     unsigned long long s_trav, s_push, s_save;
     uint32_t s_n;
     uint32_t px = __float_as_uint(tr.px), py = __float_as_uint(tr.py), pz = __float_as_uint(tr.pz);
@@ -281,7 +282,7 @@ __device__ __forceinline__ void traverse_loop_gfx950(Trav<SVO>& tr, buf_t image,
 #define VX_LOOP_OPERANDS                                                                                                                                   \
         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tmin] "+v"(tr.t_min), [tmax] "+v"(tr.t_max), [sc] "+v"(scale), [ptr] "+v"(tr.ptr),  \
           [node] "+v"(tr.node), [iter] "+v"(tr.iter), [trips] "+s"(n_trips), [waiting] "+s"(waiting), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [oct] "=&v"(oct), [m] "=&v"(m), \
-          [nx] "=&v"(nx), [ny] "=&v"(ny), [nz] "=&v"(nz), [crx] "=&v"(crx), [cry] "=&v"(cry), [crz] "=&v"(crz), [tcm] "=&v"(tcm), [tvm] "=&v"(tvm),         \
+          [nx] "=&v"(nx), [ny] "=&v"(ny), [nz] "=&v"(nz), [crx] "=&v"(crx), [cry] "=&v"(cry), [crz] "=&v"(crz), [tcm] "=&v"(tcm),         \
           [tq] "=&v"(tq), [hf] "=&v"(hf), [hm] "=&v"(hm), [ot] "=&v"(ot), [sx] "=&v"(sx), [s_trav] "=&s"(s_trav), [s_push] "=&s"(s_push),                  \
           [s_save] "=&s"(s_save), [s_n] "=&s"(s_n)                                                                                                         \
         : [tcx] "v"(tr.tcx), [tcy] "v"(tr.tcy), [tcz] "v"(tr.tcz), [tbx] "v"(tr.tbx), [tby] "v"(tr.tby), [tbz] "v"(tr.tbz), [om] "v"(uint32_t(tr.octant_mask)), \
@@ -362,7 +363,7 @@ __device__ __forceinline__ void descend_along_gfx950(TRAV& tr, uint32_t lds_slot
     uint32_t px = __float_as_uint(tr.px), py = __float_as_uint(tr.py), pz = __float_as_uint(tr.pz);
     uint32_t scale = uint32_t(tr.scale);
     uint32_t t0, t1, t2;
-    float crx, cry, crz, tcm, tvm, hf;
+    float crx, cry, crz, tcm, hf;
     unsigned long long s_entry;
     const uint32_t k_half = 0x33800000u;  // half a cell at `scale`: 2^(scale - 24) = (scale + 103) << 23
 #define VX_DESCEND_ASM(TMAX_OFFSET)                                                                                                 \
@@ -379,9 +380,8 @@ __device__ __forceinline__ void descend_along_gfx950(TRAV& tr, uint32_t lds_slot
         "v_fma_f32 %[cry], %[py], %[tcy], -%[tby]\n"                                                                               \
         "v_fma_f32 %[crz], %[pz], %[tcz], -%[tbz]\n"                                                                               \
         "v_min3_f32 %[tcm], %[crx], %[cry], %[crz]\n"                                                                              \
-        "v_min_f32_e32 %[tvm], %[tmax], %[tcm]\n"                                                                                  \
         "v_cmpx_le_f32_e32 vcc, %[tmin], %[tmax]\n"              /* the reference PUSHes: t_min <= t_max ... */                    \
-        "v_cmp_le_f32_e32 vcc, %[tmin], %[tvm]\n"                /* ... and t_min <= min(t_max, tc_max) */                         \
+        "v_cmp_le_f32_e32 vcc, %[tmin], %[tcm]\n"                /* ... and t_min <= min(t_max, tc_max), which is tc_max (see the loop) */ \
         "s_and_b64 exec, exec, vcc\n"                                                                                              \
         "s_cbranch_execz 9f\n"                                                                                                     \
         "v_lshl_add_u32 %[t0], %[sc], 8, %[lds]\n"                                                                                 \
@@ -399,7 +399,7 @@ __device__ __forceinline__ void descend_along_gfx950(TRAV& tr, uint32_t lds_slot
         "v_cmp_lt_f32_e32 vcc, %[tmin], %[crz]\n"                                                                                  \
         "v_cndmask_b32_e32 %[t1], 0, %[hf], vcc\n"                                                                                 \
         "v_add_f32_e32 %[pz], %[pz], %[t1]\n"                                                                                      \
-        "v_mov_b32_e32 %[tmax], %[tvm]\n"                                                                                          \
+        "v_mov_b32_e32 %[tmax], %[tcm]\n"                                                                                          \
         "v_add_u32_e32 %[sc], -1, %[sc]\n"                                                                                         \
         "v_add_u32_e32 %[iter], 1, %[iter]\n"                                                                                      \
         "s_branch 1b\n"                                                                                                            \
@@ -408,7 +408,7 @@ __device__ __forceinline__ void descend_along_gfx950(TRAV& tr, uint32_t lds_slot
         "s_mov_b64 exec, %[s_entry]\n"
 #define VX_DESCEND_OPERANDS                                                                                                                        \
         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [tmax] "+v"(tr.t_max), [sc] "+v"(scale), [iter] "+v"(tr.iter), [t0] "=&v"(t0), [t1] "=&v"(t1),  \
-          [t2] "=&v"(t2), [crx] "=&v"(crx), [cry] "=&v"(cry), [crz] "=&v"(crz), [tcm] "=&v"(tcm), [tvm] "=&v"(tvm), [hf] "=&v"(hf), [s_entry] "=&s"(s_entry) \
+          [t2] "=&v"(t2), [crx] "=&v"(crx), [cry] "=&v"(cry), [crz] "=&v"(crz), [tcm] "=&v"(tcm), [hf] "=&v"(hf), [s_entry] "=&s"(s_entry) \
         : [tmin] "v"(tr.t_min), [tcx] "v"(tr.tcx), [tcy] "v"(tr.tcy), [tcz] "v"(tr.tcz), [tbx] "v"(tr.tbx), [tby] "v"(tr.tby), [tbz] "v"(tr.tbz),       \
           [ex] "v"(ex), [ey] "v"(ey), [ez] "v"(ez), [ps] "v"(parent_scale), [lds] "v"(lds_slot0), [k_half] "s"(k_half)                                  \
         : "vcc", "scc", "memory"

@@ -228,7 +228,7 @@ public:
     size_t write_to(uint8_t* dst) const {
         if (!root_info) return 0;
         write_root_ptr(dst);
-        std::memcpy(dst + 4, buffer.bytes.data(), buffer.bytes.size());
+        copy_bytes(dst + 4, buffer.bytes.data(), buffer.bytes.size());
         return 4 + buffer.bytes.size();
     }
 
@@ -238,7 +238,7 @@ public:
         write_root_ptr(dst);
         for (const Range& r : buffer.updated_ranges) {
             if (!(r.start + r.length < dst_len)) return false;
-            std::memcpy(dst + 4 + r.start, buffer.bytes.data() + r.start, r.length);
+            copy_bytes(dst + 4 + r.start, buffer.bytes.data() + r.start, r.length);
         }
         if (reset) buffer.updated_ranges.clear();
         return true;

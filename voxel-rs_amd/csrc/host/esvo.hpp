@@ -203,7 +203,7 @@ public:
     size_t write_to(uint8_t* dst) const {
         if (!root_info) return 0;
         write_preamble(*root_info, dst);
-        std::memcpy(dst + kPreambleU32 * 4, buffer.bytes.data(), buffer.bytes.size());
+        copy_bytes(dst + kPreambleU32 * 4, buffer.bytes.data(), buffer.bytes.size());
         return kPreambleU32 * 4 + buffer.bytes.size();
     }
 
@@ -214,7 +214,7 @@ public:
         uint8_t* body = dst + kPreambleU32 * 4;
         for (const Range& r : buffer.updated_ranges) {
             if (!(r.start + r.length < dst_len)) return false;
-            std::memcpy(body + r.start, buffer.bytes.data() + r.start, r.length);
+            copy_bytes(body + r.start, buffer.bytes.data() + r.start, r.length);
         }
         if (reset) buffer.updated_ranges.clear();
         return true;

@@ -10,10 +10,29 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
 namespace vx {
+
+// memcpy for the writers' large ranges (write_to / write_changes_to into the mapped buffer: the reference's one memcpy, esvo.rs:291-339, csvo.rs:262-312): a whole
+// depth-14 ESVO world is 6.7 GB, 0.8 s of a first Svo::update on one thread -- from 32 MiB on the range is cut into pieces for up to eight threads.
+inline void copy_bytes(uint8_t* dst, const uint8_t* src, size_t n) {
+    constexpr size_t kPiece = size_t(32) << 20;
+    if (n < 2 * kPiece) {
+        std::memcpy(dst, src, n);
+        return;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t threads = std::min<size_t>(std::min<size_t>(8, hw ? hw : 1), n / kPiece);
+    const size_t share = (n / threads + 4095) & ~size_t(4095);
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < threads && t * share < n; ++t)
+        pool.emplace_back([=] { std::memcpy(dst + t * share, src + t * share, std::min(share, n - t * share)); });
+    std::memcpy(dst, src, std::min(share, n));
+    for (std::thread& t : pool) t.join();
+}
 
 struct Range {
     size_t start = 0;
