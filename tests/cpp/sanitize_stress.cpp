@@ -144,6 +144,32 @@ void image_builds(const char* name, int svo_type, const WorldT& world, size_t he
     std::printf("%s: whole-world image on 1 / 4 / 16 threads identical (%zu words); %zu rays agree on bytes and image\n", name, first.size(), tasks.size());
 }
 
+// Worlds the serializer did NOT write: a few bytes of a good world overwritten at random, 300 times over. The image build may refuse such a world (the
+// context then traverses its bytes) or image what it reads; what it may not do is read or write out of bounds or never end -- the emitters write a chunk's
+// words through bare pointers into room they asked for up front (traversal_image.hpp, Emitted::room), and the sanitizer watches them here.
+template <class WorldT>
+void damaged_worlds(const char* name, int svo_type, const WorldT& world, size_t header) {
+    const std::vector<uint8_t> good = frame_of(world, header);
+    const uint64_t used = world.size_in_bytes();
+    int imaged = 0, refused = 0;
+    for (int round = 0; round < 300; ++round) {
+        std::vector<uint8_t> f = good;
+        const int hits = 1 + int(rnd() % 24);
+        for (int k = 0; k < hits; ++k) {
+            // (half of them where the chunks' nodes lie: the last third of the arena holds the latest chunks, and the root octree behind them)
+            const size_t at = 4 + header + size_t((rnd() & 1u) ? rnd() % used : used - 1 - rnd() % (used / 3));
+            f[at] = (rnd() & 3u) ? uint8_t(rnd()) : uint8_t(0xff);
+        }
+        for (vximg::Layout layout : {vximg::kOct64, vximg::kEsvo48}) {
+            vximg::WorldImage img(svo_type, layout);
+            if (img.update(f.data(), used, nullptr, 0, 4)) ++imaged;
+            else ++refused;
+        }
+    }
+    CHECK(imaged + refused == 600, "%s: damaged worlds", name);
+    std::printf("%s: 300 damaged worlds, both layouts: %d imaged, %d refused, none out of bounds\n", name, imaged, refused);
+}
+
 // the streamer (its own worker threads build chunks) feeding an incrementally maintained image (Workers at 1 / 4 / 16 threads per commit) for `steps` moves of
 // a camera, until `steps` commits have been made; at the end the image must hold the tree a from-scratch build of the final world holds
 template <class WorldT, class SerializedT>
@@ -201,11 +227,13 @@ int main(int argc, char** argv) {
         Esvo<EsvoSerializedChunk> world;
         const SceneStats st = build_heightfield_scene(world, 8, 0x5EED0001u, 4);
         image_builds("esvo depth 8", 1, world, 20, st.h_max, look);
+        damaged_worlds("esvo depth 8", 1, world, 20);
     }
     {
         Csvo world;
         const SceneStats st = build_heightfield_scene(world, 8, 0x5EED0001u, 4);
         image_builds("csvo depth 8", 2, world, 4, st.h_max, look);
+        damaged_worlds("csvo depth 8", 2, world, 4);
     }
     for (uint32_t threads : {1u, 4u, 16u}) {
         stream_and_update<Esvo<EsvoSerializedChunk>, EsvoSerializedChunk>("esvo stream", 1, 20, threads, steps);

@@ -88,23 +88,28 @@ public:
         clear();
         resize(n, 0u);
     }
+    // address space for n words (untouched pages cost nothing): a whole world's image grows to its size without being moved on the way
+    void reserve(size_t n) {
+        if (n > cap_) grow_to(n);
+    }
     // grows only (the image never shrinks between clear()s); the value is always zero
     void resize(size_t n, uint32_t /*zero*/) {
         if (n <= n_) return;
-        if (n > cap_) {
-            size_t want = std::max(n, cap_ + cap_ / 2);
-            want = (want * 4 + 4095) / 4096 * 4096 / 4;  // whole pages
-            void* q = p_ ? ::mremap(p_, cap_ * 4, want * 4, MREMAP_MAYMOVE) : ::mmap(nullptr, want * 4, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-            if (q == MAP_FAILED) throw std::bad_alloc();
-            p_ = static_cast<uint32_t*>(q);
-            cap_ = want;
-            // (gigabytes that the encoding threads touch for the first time: as huge pages where the system gives them -- a hint, ignored otherwise)
-            (void)::madvise(p_, cap_ * 4, MADV_HUGEPAGE);
-        }
+        if (n > cap_) grow_to(std::max(n, cap_ + cap_ / 2));
         n_ = n;
     }
 
 private:
+    void grow_to(size_t want) {
+        want = (want * 4 + 4095) / 4096 * 4096 / 4;  // whole pages
+        void* q = p_ ? ::mremap(p_, cap_ * 4, want * 4, MREMAP_MAYMOVE) : ::mmap(nullptr, want * 4, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) throw std::bad_alloc();
+        p_ = static_cast<uint32_t*>(q);
+        cap_ = want;
+        // (gigabytes that the encoding threads touch for the first time: as huge pages where the system gives them -- a hint, ignored otherwise)
+        (void)::madvise(p_, cap_ * 4, MADV_HUGEPAGE);
+    }
+
     uint32_t* p_ = nullptr;
     size_t n_ = 0, cap_ = 0;  // words
 };
@@ -432,6 +437,250 @@ private:
     uint64_t lo_ = 0, hi_ = 0;
 };
 
+// ---- chunks straight into image words (the kOct64 layouts) ----------------------------------------------------------------------------
+//
+// A whole world's first commit walks 400,000 chunks; through Tree (60 bytes an octant, written by the walk, read again by encode()) that was a
+// second and the larger half of the commit. The emitters below make the same walk -- same order, same checks, same words: octants in depth-first
+// order, a node's octant in front of its children's -- and write each octant's words when they meet it, relative to the chunk's first word; `relocs`
+// lists the words that hold a `lo` pointing into the chunk, to which the copy into the frame adds where the chunk was placed. (The root octree and
+// the kEsvo48 layout still go through Tree: ChunkWalker / EsvoWalker + encode() say the same thing in the other form, and
+// tests/test_traversal_image.py holds the two against each other.)
+struct Emitted {
+    std::vector<uint32_t> words, relocs;  // (words: grown by room(), which leaves what it adds unwritten -- size() is only right after finish())
+    size_t n_words = 0, n_relocs = 0;
+    NodeMasks root;
+    bool root_values_only = false;  // (the root octant is one of values: what points to it holds the unit of its origin)
+    bool too_deep = false;
+    uint64_t src_begin = 0, src_end = 0;
+    void start() {
+        n_words = n_relocs = 0;
+        root = NodeMasks();
+        root_values_only = too_deep = false;
+        src_begin = src_end = 0;
+    }
+    // room for `extra` more words and `extra` more relocs (a node asks once for itself and what it writes for its children)
+    void room(size_t extra) {
+        if (n_words + extra > words.size()) words.resize(std::max(words.size() * 2, n_words + extra + 4096));
+        if (n_relocs + extra > relocs.size()) relocs.resize(std::max(relocs.size() * 2, n_relocs + extra + 1024));
+    }
+};
+
+inline uint32_t entries_above(uint32_t mask, uint32_t c) { return uint32_t(__builtin_popcount((mask & 0xffu) >> (c + 1u))); }  // entries lie child 7 first
+
+// oct64_masks() of a node whose children are all voxels, by its leaf-mask byte
+inline const uint32_t* oct64_voxel_parent_masks() {
+    static const struct Table {
+        uint32_t m[256];
+        Table() { for (uint32_t i = 0; i < 256; ++i) m[i] = oct64_masks((i << 8) | i); }
+    } table;
+    return table.m;
+}
+
+// One chunk frame [lod:u8][material_bytes:u32][materials][nodes] (csvo.rs:217-227): ChunkWalker's walk.
+class ChunkEmitter {
+public:
+    ChunkEmitter(Bytes b, Emitted& out) : b_(b), out_(out), voxel_parent_masks_(oct64_voxel_parent_masks()) {}
+
+    void run(uint64_t frame) {
+        out_.start();
+        const uint32_t lod = b_.u8(frame);
+        const uint32_t material_bytes = b_.u32(frame + 1);
+        materials_ = frame + 5;
+        end_ = materials_ + material_bytes;
+        out_.root = node(materials_ + material_bytes, lod);
+        out_.src_begin = frame;
+        out_.src_end = end_;
+    }
+
+private:
+    static constexpr size_t kMaxWords = size_t(1) << 26;  // (a runaway walk: no chunk the serializer wrote comes near)
+
+    NodeMasks node(uint64_t ptr, uint32_t depth) {
+        NodeMasks m;
+        if (depth == 0 || depth > 32 || out_.too_deep) return m;  // malformed: an octant without children
+        if (depth == 1) {
+            // a leaf-mask byte without a depth-2 parent (a chunk of one level): nothing the serializer writes (csvo.rs:481-493), and no origin could
+            // say where it is
+            out_.too_deep = true;
+            return m;
+        }
+        if (out_.n_words > kMaxWords) {
+            out_.too_deep = true;
+            return m;
+        }
+        out_.room(2 * 8 + 8 * (2 + 8) + 2);
+        const size_t at = out_.n_words;
+        if (depth == 2) {
+            // leaf node: u8 mask, u16 material offset, one leaf-mask byte per child (svo.csvo.glsl:114-115); each of those is a voxel parent (read_leaf,
+            // svo.csvo.glsl:119-133) whose octant is [origin][the existing children's values, child 7 first][padding] -- the values of all of them lie
+            // one after the other, in child order, in the material section
+            const uint32_t header = b_.u8(ptr), material_offset = b_.u16(ptr + 1);
+            const uint32_t n_children = uint32_t(__builtin_popcount(header));
+            end_ = std::max(end_, ptr + 3 + n_children);
+            if (ptr + 3 + n_children > (uint64_t(1) << 31) || ptr + 3 + n_children - materials_ > (uint64_t(1) << 29)) {
+                out_.too_deep = true;  // (the origin could not say where the bytes are)
+                return m;
+            }
+            uint32_t* w = out_.words.data();
+            uint32_t* relocs = out_.relocs.data();
+            size_t top = at + 2u * n_children;
+            uint64_t value = materials_ + uint64_t(material_offset) * 4;
+            uint32_t entry = uint32_t(at) + 2u * n_children;  // (child 7 first: the entries are written from the back)
+            uint32_t left = header;
+            for (uint32_t j = 0; j < n_children; ++j, left &= left - 1u) {
+                const uint64_t byte = ptr + 3 + j;
+                const uint32_t mask = b_.u8(byte);
+                entry -= 2u;
+                w[entry] = uint32_t(top / 2) - (mask ? 0u : 1u);  // (an octant of values is pointed to by the unit of its origin: oct64_lo)
+                w[entry + 1] = voxel_parent_masks_[mask];
+                relocs[out_.n_relocs++] = entry;
+                if (!mask) continue;
+                const uint32_t n = uint32_t(__builtin_popcount(mask));
+                w[top] = uint32_t(byte);
+                w[top + 1] = (j << 29) | uint32_t(byte - materials_);
+                uint32_t* values = w + top + 2;
+                values[n] = 0u;  // (the padding, where n is odd)
+                if (value + 32 <= b_.n) {
+                    uint32_t in[8];
+                    std::memcpy(in, b_.p + value, 32);
+                    for (uint32_t k = 0; k < n; ++k) values[n - 1 - k] = in[k];
+                } else {
+                    for (uint32_t k = 0; k < n; ++k) values[n - 1 - k] = b_.u32(value + uint64_t(k) * 4);
+                }
+                value += uint64_t(n) * 4;
+                top += 2u + ((n + 1u) & ~1u);
+            }
+            (void)left;
+            out_.n_words = top;
+            m.child_mask = header;
+            return m;
+        }
+        // which children there are, before any of them is walked: the octant's entries come first
+        uint32_t header, present = 0;
+        if (depth > 3) {  // internal node: u16 header, 2 bits per child, 1/2/4-byte forward offsets (svo.csvo.glsl:56-97)
+            header = b_.u16(ptr);
+            const uint32_t any = (header | (header >> 1)) & 0x5555u;
+            for (uint32_t c = 0; c < 8; ++c) present |= ((any >> (2 * c)) & 1u) << c;
+        } else {  // pre-leaf node: u8 mask, u8 offsets (svo.csvo.glsl:107-112)
+            header = b_.u8(ptr);
+            present = header;
+        }
+        out_.n_words = at + 2u * uint32_t(__builtin_popcount(present));
+        const uint32_t table = depth > 3 ? tag_bytes(header) : uint32_t(__builtin_popcount(header));
+        end_ = std::max(end_, ptr + (depth > 3 ? 2u : 1u) + (present ? table : 0u));
+        for (uint32_t c = 0; c < 8; ++c) {
+            if (!((present >> c) & 1u)) continue;
+            uint64_t child = 0;
+            if (depth > 3) {
+                const uint32_t tag = (header >> (2 * c)) & 3u;
+                const uint32_t offset = tag_bytes(header & ((1u << (2 * c)) - 1u));
+                const uint32_t width = tag == 3 ? 4u : tag;
+                uint32_t e = 0;
+                for (uint32_t k = 0; k < width; ++k) e |= b_.u8(ptr + 2 + offset + k) << (8 * k);
+                child = ptr + 2 + table + e;  // (an absolute pointer, bit 31, only exists in the root octree: walk_root)
+            } else {
+                child = ptr + 1 + table + b_.u8(ptr + 1 + uint32_t(__builtin_popcount(header & ((1u << c) - 1u))));
+            }
+            const size_t child_at = out_.n_words;
+            const NodeMasks cm = node(child, depth - 1);
+            m.child_mask |= 1u << c;
+            const size_t entry = at + 2u * entries_above(present, c);
+            out_.words[entry] = uint32_t(child_at / 2) - 1u;
+            out_.words[entry + 1] = oct64_masks(cm.packed());
+            out_.relocs[out_.n_relocs++] = uint32_t(entry);
+        }
+        return m;
+    }
+
+    Bytes b_;
+    Emitted& out_;
+    const uint32_t* voxel_parent_masks_;
+    uint64_t materials_ = 0, end_ = 0;
+};
+
+// The subtree of an ESVO octant (esvo.rs:74-101), absolute pointers followed: EsvoWalker's walk of a chunk.
+class EsvoEmitter {
+public:
+    EsvoEmitter(Words w, Emitted& out) : w_(w), out_(out) {}
+
+    void run(uint64_t octant, uint32_t masks, uint32_t levels) {
+        out_.start();
+        lo_ = ~uint64_t(0);
+        hi_ = 0;
+        octants_ = 0;
+        out_.root.child_mask = (masks >> 8) & 0xffu;
+        out_.root.leaf_mask = masks & 0xffu;
+        node(octant, masks, levels);
+        out_.src_begin = lo_ == ~uint64_t(0) ? 0 : (lo_ < 5 ? 0 : (lo_ - 5) * 4);
+        out_.src_end = hi_ < 5 ? 0 : (hi_ - 5) * 4;
+    }
+
+private:
+    void node(uint64_t octant, uint32_t masks, uint32_t levels) {
+        if (octants_++ > kMaxOctants) {  // shared or cyclic subtrees would never end: not a world the serializer wrote
+            out_.too_deep = true;
+            return;
+        }
+        lo_ = std::min(lo_, octant);
+        hi_ = std::max(hi_, octant + 12);
+        const uint32_t child_mask = (masks >> 8) & 0xffu, leaf_mask = masks & child_mask;
+        // the octant's twelve words (reads beyond the end return 0 like the traversal's)
+        uint32_t o[12];
+        if (octant + 12 <= w_.n) std::memcpy(o, w_.p + octant, 48);
+        else for (uint32_t k = 0; k < 12; ++k) o[k] = w_.at(octant + k);
+        out_.room(16);
+        const size_t at = out_.n_words;
+        const uint32_t n = uint32_t(__builtin_popcount(child_mask));
+        if (child_mask == leaf_mask) {
+            // voxels only: their values, child 7 first, padded to a unit
+            uint32_t* v = out_.words.data() + at;
+            uint32_t k = 0;
+            for (int c = 7; c >= 0; --c) {
+                if (!((child_mask >> c) & 1u)) continue;
+                // (a voxel with masks of its own: a world the image's traversal would walk differently -- EsvoWalker::node)
+                if ((o[c >> 1] >> ((c & 1) * 16)) & 0xffffu) out_.too_deep = true;
+                v[k++] = o[4 + c];
+            }
+            v[k] = 0u;
+            out_.n_words = at + ((n + 1u) & ~1u);
+            return;
+        }
+        out_.n_words = at + 2u * n;
+        for (uint32_t c = 0; c < 8 && !out_.too_deep; ++c) {
+            if (!((child_mask >> c) & 1u)) continue;
+            const uint32_t body = o[4 + c];
+            const size_t entry = at + 2u * entries_above(child_mask, c);
+            const uint32_t cm = (o[c >> 1] >> ((c & 1u) * 16)) & 0xffffu;
+            if ((leaf_mask >> c) & 1u) {
+                if (cm) {
+                    out_.too_deep = true;
+                    return;
+                }
+                out_.words[entry] = body;
+                out_.words[entry + 1] = 0u;
+                continue;
+            }
+            if (levels <= 1) {  // a node where only voxels fit
+                out_.too_deep = true;
+                return;
+            }
+            const bool relative = (body & 0x80000000u) != 0;
+            const uint64_t target = relative ? octant + 4 + c + (body & 0x7fffffffu) : body;  // svo.esvo.glsl:283-290
+            const size_t child_at = out_.n_words;
+            node(target, cm, levels - 1);
+            out_.words[entry] = uint32_t(child_at / 2) - 1u;
+            out_.words[entry + 1] = oct64_masks(cm);
+            out_.relocs[out_.n_relocs++] = uint32_t(entry);
+        }
+    }
+
+    static constexpr size_t kMaxOctants = size_t(1) << 26;
+    Words w_;
+    Emitted& out_;
+    uint64_t lo_ = 0, hi_ = 0;
+    size_t octants_ = 0;
+};
+
 // first-fit word allocator over the image arena (the reference's RangeBuffer idea, internal.rs:163-277)
 class WordAllocator {
 public:
@@ -729,42 +978,100 @@ private:
         // pages contends in the kernel, on sixteen at most: measured on the depth-14 terrain, profiles/round4/pass_p)
         Workers workers(std::max(1u, std::min<unsigned>(threads, unsigned(todo.size() / 16 + 1))));
         const unsigned encoders = std::min(16u, workers.size());
-        std::vector<Tree> built(std::min(todo.size(), batch));
-        std::vector<Placed> placed(built.size());
+        const bool direct = layout_ != kEsvo48;  // (the renderer's layouts: a chunk's words straight from the walk)
+        const size_t width = std::min(todo.size(), batch);
+        std::vector<Tree> built(direct ? 0 : width);
+        std::vector<Emitted> emitted(direct ? width : 0);
+        // (two sets: a batch's book-keeping -- its entries in chunks_, its dirty range -- is one more task of the NEXT batch's walk, done by whichever
+        // worker draws it while the others walk: 400,000 map insertions were a tenth of a second of everybody waiting for this thread)
+        std::vector<Placed> placed_sets[2] = {std::vector<Placed>(width), std::vector<Placed>(width)};
         chunks_.reserve(chunks_.size() + todo.size());
+        // a whole world: the frame's address space up front (about 2.3 x a CSVO world's bytes, 0.37 x an ESVO world's), so that it is not moved as it grows
+        if (direct && todo.size() >= batch) frame_.reserve(frame_.size() + size_t(double(used) * (esvo_ ? 0.45 : 2.6) / 4.0));
         uint64_t top = frame_.size();
         double t_walk = since(t_step), t_place = 0.0, t_encode = 0.0;
-        for (size_t base = 0; base < todo.size(); base += batch) {
+        size_t kept_base = 0, kept_n = 0;  // the batch whose book-keeping is still to be done
+        auto keep_books = [&](size_t from, size_t count, const std::vector<Placed>& of) {
+            for (size_t i = 0; i < count; ++i) {
+                const Placed& pl = of[i];
+                if (!dirty_.empty() && dirty_.back().start + dirty_.back().length == pl.at * 4) dirty_.back().length += pl.words * 4;
+                else dirty_.push_back(Range{pl.at * 4, pl.words * 4});
+                chunks_[todo[from + i].key] = pl;
+            }
+        };
+        for (size_t base = 0, round = 0; base < todo.size(); base += batch, ++round) {
             const size_t n = std::min(batch, todo.size() - base);
+            std::vector<Placed>& placed = placed_sets[round & 1];
+            const std::vector<Placed>& placed_before = placed_sets[(round & 1) ^ 1];
             t_step = now();
-            workers.run(n, workers.size(), [&](size_t i) {
+            workers.run(n + 1, workers.size(), [&](size_t task) {
+                if (task == 0) {
+                    keep_books(kept_base, kept_n, placed_before);
+                    return;
+                }
+                const size_t i = task - 1;
+                const ChunkRef& r = todo[base + i];
+                if (direct) {
+                    if (esvo_) EsvoEmitter(w, emitted[i]).run(r.key, r.masks, r.levels);
+                    else ChunkEmitter(b, emitted[i]).run(r.key);
+                    placed[i].words = emitted[i].n_words;
+                    return;
+                }
                 built[i].too_deep = false;
-                if (esvo_) EsvoWalker(w, built[i], nullptr).run(todo[base + i].key, todo[base + i].masks, todo[base + i].levels);
-                else ChunkWalker(b, built[i]).run(todo[base + i].key);
+                if (esvo_) EsvoWalker(w, built[i], nullptr).run(r.key, r.masks, r.levels);
+                else ChunkWalker(b, built[i]).run(r.key);
                 placed[i].words = tree_words(built[i]);  // (here, not in the placing loop: it looks at every octant)
             });
+            kept_n = 0;
             t_walk += since(t_step);
             t_step = now();
             for (size_t i = 0; i < n; ++i) {
-                if (built[i].too_deep) return fail();
+                if (direct ? emitted[i].too_deep : built[i].too_deep) return fail();
                 Placed& pl = placed[i];
                 pl.at = alloc_.alloc(pl.words);
-                pl.root_lo = (layout_ != kEsvo48 && !built[i].octants.empty()) ? oct64_lo(built[i].octants[0], pl.at, has_origin()) : 0u;
-                pl.masks = built[i].root.packed();
+                if (direct) {
+                    const Emitted& e = emitted[i];
+                    pl.root_lo = uint32_t(pl.at / 2) - (e.root_values_only ? 0u : 1u);
+                    pl.masks = e.root.packed();
+                    pl.src_begin = e.src_begin;
+                    pl.src_end = e.src_end;
+                } else {
+                    pl.root_lo = 0u;
+                    pl.masks = built[i].root.packed();
+                    pl.src_begin = built[i].src_begin;
+                    pl.src_end = built[i].src_end;
+                }
                 pl.levels = todo[base + i].levels;
                 pl.seen = epoch_;
-                pl.src_begin = built[i].src_begin;
-                pl.src_end = built[i].src_end;
                 top = std::max(top, pl.at + pl.words);
-                dirty_.push_back(Range{pl.at * 4, pl.words * 4});
-                chunks_[todo[base + i].key] = pl;
             }
+            kept_base = base;
+            kept_n = n;
             if (frame_.size() < top) frame_.resize(top, 0u);
             t_place += since(t_step);
             t_step = now();
-            workers.run(n, encoders, [&](size_t i) { encode(built[i], placed[i].at); });
+            // (tasks are drawn in order: numbered across `encoders` stretches of the batch, the workers start in as many different places of the frame --
+            // neighbours in one huge page wait for whoever touched it first to have it zeroed)
+            const size_t rows = (n + encoders - 1) / encoders;
+            workers.run(rows * encoders, encoders, [&](size_t task) {
+                const size_t i = (task % encoders) * rows + task / encoders;
+                if (i >= n) return;
+                if (!direct) {
+                    encode(built[i], placed[i].at);
+                    return;
+                }
+                // the chunk's words where it was placed; what points into the chunk, from there
+                const Emitted& e = emitted[i];
+                uint32_t* dst = frame_.data() + placed[i].at;
+                if (e.n_words) std::memcpy(dst, e.words.data(), e.n_words * 4);
+                const uint32_t unit = uint32_t(placed[i].at / 2);
+                for (size_t k = 0; k < e.n_relocs; ++k) dst[e.relocs[k]] += unit;
+            });
             t_encode += since(t_step);
         }
+        t_step = now();
+        keep_books(kept_base, kept_n, placed_sets[((todo.size() + batch - 1) / batch + 1) & 1]);
+        t_place += since(t_step);
         timing_[1] = t_walk;
         timing_[2] = t_place;
         timing_[3] = t_encode;

@@ -237,7 +237,16 @@ class Svo:
     def update_full(self, world):
         """First upload into a fresh buffer: WorldSvo::write_to (whole arena) instead of the dirty ranges, which a
         WorldSvo only tracks for ONE target buffer (they are cleared by the first write_changes_to)."""
-        self.upload_frame(world.frame(pad_words=0), world.depth)
+        if not hasattr(world, "write_frame_to"):
+            self.upload_frame(world.frame(pad_words=0), world.depth)
+            return
+        # straight into the staging buffer, as graphics::Svo::update writes into its mapped buffer (svo.rs:171-189): no copy on the way
+        try:
+            wrote = world.write_frame_to(lib().vx_staging_ptr(self._h), lib().vx_capacity(self._h))
+        except ValueError as e:
+            raise VoxelHipError(str(e)) from None
+        header = 20 if self.svo_type == 1 else 4
+        _check(lib().vx_commit_all(self._h, world.depth, max(wrote - 4 - header, 0)))
 
     def upload_frame(self, frame_words, depth):
         """Copies a complete mapped-buffer image ([f32 scale][header][arena]) into staging and commits all of it."""

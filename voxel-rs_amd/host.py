@@ -175,6 +175,13 @@ class World:
         lib().vxh_world_frame(self._h, buf.ctypes.data_as(C.c_void_p), words * 4)
         return buf
 
+    def write_frame_to(self, ptr, capacity):
+        """frame() written at `ptr` (room for `capacity` bytes: a context's staging buffer); returns the bytes written."""
+        need = lib().vxh_world_frame(self._h, None, 0)
+        if need > capacity:
+            raise ValueError("frame larger than the buffer: %d > %d" % (need, capacity))
+        return int(lib().vxh_world_frame(self._h, C.c_void_p(ptr), capacity))
+
     def build_heightfield(self, depth, seed=0x5EED0001, threads=0):
         """Seeded synthetic scene; returns dict(chunks, leaves, h_max)."""
         import os
