@@ -183,6 +183,13 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint64_t* __restrict
     if (t < tail) d[head + body * 16 + t] = s[head + body * 16 + t];
 }
 
+// ... and the packed payload's way from the pinned slot to its device twin, as a kernel: a copy command goes to the DMA engines, and on a shared host those
+// answer a small request tens of milliseconds late now and then -- the streamer's initial fill (2,000 commits of a few KB to a few MB) took 0.6 to 6 s
+// with them, 0.5-0.8 s without (profiles/round6/fill_sdma.sh). 16-byte words, both ends 16-byte aligned.
+__global__ __launch_bounds__(256) void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, uint64_t words) {
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < words; i += uint64_t(gridDim.x) * 256) dst[i] = src[i];
+}
+
 // Scatters gathered compact tile lists back into a row-major image: ONE WAVE per 32x32 tile -- a workgroup of 64 threads needs one free wave slot
 // on a compute unit, which a context that renders tile lists keeps free everywhere (runtime.cpp: fifteen persistent waves a CU instead of sixteen,
 // -0.8 %): the assembly starts when it is issued instead of when a frame has drained (a 256-thread workgroup needs four slots on ONE unit, and
@@ -264,6 +271,14 @@ hipError_t launch_trace(int svo, hipStream_t stream, const SceneArgs& sc, const 
 
 hipError_t launch_order(hipStream_t stream, const uint32_t* cost, uint32_t tag, uint32_t n, uint32_t* order) {
     hipLaunchKernelGGL(order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, cost, tag, n, order);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy16(hipStream_t stream, void* dst, const void* src, uint64_t bytes) {
+    const uint64_t words = (bytes + 15) / 16;
+    if (!words) return hipSuccess;
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((words + 255) / 256, 2048));
+    hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<uint4*>(dst), static_cast<const uint4*>(src), words);
     return hipGetLastError();
 }
 

@@ -529,7 +529,8 @@ int upload_packed(vx_context* ctx, const std::vector<Upload>& up, WAIT&& wait_fo
         if (slot.dev) (void)hipFree(slot.dev);
         slot.host = slot.dev = nullptr;
         slot.cap = 0;
-        const size_t cap = size_t(total + total / 2 + 4096);
+        // (twice what is asked for, 4 MB at least: a pinned allocation takes milliseconds, and a world that streams in asks for a little more every time)
+        const size_t cap = std::max(size_t(2 * total + 4096), size_t(4) << 20);
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&slot.host), cap, hipHostMallocDefault));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot.dev), cap));
         slot.cap = cap;
@@ -546,8 +547,9 @@ int upload_packed(vx_context* ctx, const std::vector<Upload>& up, WAIT&& wait_fo
             table[k * 3 + 2] = std::min(kPiece, up[i].bytes - off);
         }
     }
-    // the transfer needs no fence (the device twin is private to this commit): it runs while frames in flight finish
-    HIP_TRY(hipMemcpyAsync(slot.dev, slot.host, total, hipMemcpyHostToDevice, ctx->upload_stream));
+    // the transfer needs no fence (the device twin is private to this commit): it runs while frames in flight finish. (A kernel that reads the pinned
+    // slot, not a copy command: kernels_aux.hip, copy16_kernel.)
+    HIP_TRY(vxk::launch_copy16(ctx->upload_stream, slot.dev, slot.host, total));
     if (int rc = wait_for_frames()) return rc;
     HIP_TRY(vxk::launch_scatter(ctx->upload_stream, uint32_t(pieces), reinterpret_cast<const uint64_t*>(slot.dev), slot.dev));
     HIP_TRY(hipEventRecord(slot.done, ctx->upload_stream));
@@ -946,23 +948,40 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
         const size_t need = ctx->image.frame_bytes() + kImagePad;
         const size_t need_origin = 0;  // (the origins of a CSVO world's voxel parents are units of the image itself since round 6: no table beside it)
         if (need > ctx->d_image_capacity || need_origin > ctx->d_origin_capacity) {
-            // grow both (frames in flight still read the old ones: wait for them), then everything is uploaded again
-            (void)drain_streams(ctx);
+            // Grow: a buffer of twice what is needed (a streamed world's image grows commit by commit: at 1.5 x, and with everything sent again from
+            // the host each time, the initial fill of the depth-14 terrain's surroundings spent 1-2 of its 0.6-2.5 s re-allocating pinned transfer
+            // buffers for ever larger whole images, profiles/round6/fill_timing.sh). What the old buffer holds is the frame as the last commit left it:
+            // it travels on the device, and this commit's dirty ranges follow as in any other commit. Frames in flight go on reading the old buffer,
+            // which is freed when they and the copy are done.
+            // (a context's first image -- a whole world's, as a rule -- gets a quarter of headroom)
+            const size_t want = ctx->d_image ? 2 * need : need + need / 4;
+            const size_t cap = std::min(std::max(want, size_t(32) << 20), ctx->image_cap_bytes ? ctx->image_cap_bytes : ~size_t(0));
+            const size_t cap_origin = need_origin ? cap / 4 + kImagePad : 0;
+            uint8_t* fresh = nullptr;
+            bool ok = cap >= need && hipMalloc(reinterpret_cast<void**>(&fresh), cap) == hipSuccess;
+            const bool carry = ok && ctx->d_image && ctx->image_ok && ctx->d_image_capacity <= cap;
+            if (carry) {
+                ok = hipMemcpyAsync(fresh, ctx->d_image, ctx->d_image_capacity, hipMemcpyDeviceToDevice, ctx->upload_stream) == hipSuccess &&
+                     hipMemsetAsync(fresh + ctx->d_image_capacity, 0, cap - ctx->d_image_capacity, ctx->upload_stream) == hipSuccess;
+            } else if (ok) {
+                ok = hipMemsetAsync(fresh, 0, cap, ctx->upload_stream) == hipSuccess;
+            }
+            (void)drain_streams(ctx);  // (the frames that still walk the old buffer, and the copy out of it)
             if (ctx->d_image) (void)hipFree(ctx->d_image);
             if (ctx->d_origin) (void)hipFree(ctx->d_origin);
             ctx->d_image = ctx->d_origin = nullptr;
             ctx->d_image_capacity = ctx->d_origin_capacity = 0;
-            const size_t cap = std::min(need + need / 2 + (1 << 20), ctx->image_cap_bytes ? ctx->image_cap_bytes : ~size_t(0));
-            const size_t cap_origin = need_origin ? cap / 4 + kImagePad : 0;
-            bool ok = cap >= need && hipMalloc(reinterpret_cast<void**>(&ctx->d_image), cap) == hipSuccess;
-            if (ok && cap_origin) ok = hipMalloc(reinterpret_cast<void**>(&ctx->d_origin), cap_origin) == hipSuccess;
-            if (ok) ok = hipMemsetAsync(ctx->d_image, 0, cap, ctx->upload_stream) == hipSuccess;
-            if (ok && cap_origin) ok = hipMemsetAsync(ctx->d_origin, 0, cap_origin, ctx->upload_stream) == hipSuccess;
+            if (ok && cap_origin) {
+                ok = hipMalloc(reinterpret_cast<void**>(&ctx->d_origin), cap_origin) == hipSuccess &&
+                     hipMemsetAsync(ctx->d_origin, 0, cap_origin, ctx->upload_stream) == hipSuccess;
+            }
             if (ok) {
+                ctx->d_image = fresh;
                 ctx->d_image_capacity = cap;
                 ctx->d_origin_capacity = cap_origin;
-                whole_image = true;
+                whole_image = !carry;
             } else {
+                if (fresh) (void)hipFree(fresh);
                 (void)hipGetLastError();  // (an allocation failure is not the caller's error: the bytes path serves)
                 drop_image();
             }
@@ -1010,7 +1029,7 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
     if (std::getenv("VX_COMMIT_TIMING")) {  // (measurement aid: where a commit's host time goes)
         const double* t = ctx->image.last_timing();
         const double upload_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_built).count();
-        std::fprintf(stderr, "[vx_commit] %llu bytes to upload; image: root walk %.3f s, chunk walk %.3f, place %.3f, encode %.3f, root + header %.3f; allocation + upload %.3f s\n",
+        std::fprintf(stderr, "[vx_commit] %llu bytes to upload; image: root walk %.6f s, chunk walk %.6f, place %.6f, encode %.6f, root + header %.6f; allocation + upload %.6f s\n",
                      (unsigned long long)total, t[0], t[1], t[2], t[3], t[4], upload_s);
     }
     ctx->image_ok = image_ok;
