@@ -122,6 +122,9 @@ def run(args):
         "commit_mode": "pipelined" if args.pipelined else "inline",
         "host_ms_per_step_with_render_call_median": round(statistics.median(r["step_ms"] for r in streaming), 3) if streaming else None,
         "host_ms_per_step_max": round(max(r["host_ms"] for r in streaming), 3) if streaming else None,
+        # the three dearest steps of the flight: what the frame loop's thread spent where (pump's own clocks), and how many events the step applied
+        "host_ms_dearest_steps": [dict(frame=r["frame"], host_ms=round(r["host_ms"], 2), apply_ms=round(r["apply_us"] / 1e3, 2), commit_ms=round(r["commit_us"] / 1e3, 2),
+                                       events=r["events"], MB=round(r["bytes"] / 1e6, 2)) for r in sorted(streaming, key=lambda r: -r["host_ms"])[:3]],
         "build_ms_median": round(statistics.median(r["build_us"] for r in commits) / 1e3, 2) if commits else None,
         "apply_ms_median": round(statistics.median(r["apply_us"] for r in commits) / 1e3, 2) if commits else None,
         "commit_ms_median": round(statistics.median(r["commit_us"] for r in commits) / 1e3, 2) if commits else None,
