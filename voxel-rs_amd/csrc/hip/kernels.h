@@ -35,9 +35,6 @@ hipError_t launch_picker(int svo, hipStream_t stream, const vxd::SceneArgs& sc, 
 hipError_t launch_trace(int svo, hipStream_t stream, const vxd::SceneArgs& sc, const TraceArgs& a, vx_result* result, vx_frame* frames, uint32_t max_frames, uint32_t* n_frames);
 hipError_t launch_order(hipStream_t stream, const uint32_t* cost, uint32_t tag, uint32_t n, uint32_t* order);
 hipError_t launch_scatter(hipStream_t stream, uint32_t pieces, const uint64_t* table, const uint8_t* packed);
-// the eye's path, {octant, masks} per level (PersistentArgs::eye_table): 32 words from the launch's arguments to `dst`
-struct EyeTable { uint32_t w[32]; };
-hipError_t launch_eye_table(hipStream_t stream, uint32_t* dst, const EyeTable& table);
 // `bytes` (rounded up to 16) from pinned host memory or device memory to device memory, both 16-byte aligned, by a kernel instead of a copy command
 hipError_t launch_copy16(hipStream_t stream, void* dst, const void* src, uint64_t bytes);
 hipError_t launch_assemble(hipStream_t stream, int format, const void* tiles, uint64_t stride_px, uint32_t tile_count, uint32_t width, uint32_t height, uint32_t tiles_x,

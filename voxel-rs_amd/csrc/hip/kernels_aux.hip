@@ -190,12 +190,6 @@ __global__ __launch_bounds__(256) void copy16_kernel(uint4* __restrict__ dst, co
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < words; i += uint64_t(gridDim.x) * 256) dst[i] = src[i];
 }
 
-// The eye's path (PersistentArgs::eye_table) from the launch's arguments into device memory: one wave, in front of the render kernel on its stream, and only
-// when the path is not the one that stream's table already holds (runtime.cpp launch_render).
-__global__ __launch_bounds__(64) void eye_table_kernel(uint32_t* __restrict__ dst, EyeTable t) {
-    if (threadIdx.x < 32) dst[threadIdx.x] = t.w[threadIdx.x];
-}
-
 // Scatters gathered compact tile lists back into a row-major image: ONE WAVE per 32x32 tile -- a workgroup of 64 threads needs one free wave slot
 // on a compute unit, which a context that renders tile lists keeps free everywhere (runtime.cpp: fifteen persistent waves a CU instead of sixteen,
 // -0.8 %): the assembly starts when it is issued instead of when a frame has drained (a 256-thread workgroup needs four slots on ONE unit, and
@@ -277,11 +271,6 @@ hipError_t launch_trace(int svo, hipStream_t stream, const SceneArgs& sc, const 
 
 hipError_t launch_order(hipStream_t stream, const uint32_t* cost, uint32_t tag, uint32_t n, uint32_t* order) {
     hipLaunchKernelGGL(order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, cost, tag, n, order);
-    return hipGetLastError();
-}
-
-hipError_t launch_eye_table(hipStream_t stream, uint32_t* dst, const EyeTable& table) {
-    hipLaunchKernelGGL(eye_table_kernel, dim3(1), dim3(64), 0, stream, dst, table);
     return hipGetLastError();
 }
 

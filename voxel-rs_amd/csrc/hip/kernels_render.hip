@@ -658,16 +658,6 @@ __global__ __launch_bounds__(64, min_waves_of(SVO, HITS)) void render_persistent
                         new_ray = true;
                         shadow_ray = false;
                         steps = 0;
-                        if constexpr (kDescendAlong) {
-                            // every primary ray begins with the same PUSHes, through the nodes that hold the eye (PersistentArgs::eye_*): they go into the
-                            // ray's stack like a shadow ray's ancestors, and the set-up below runs through them
-                            if (a.eye_levels) {
-                                along = true;
-                                along_q[0] = a.eye_q[0]; along_q[1] = a.eye_q[1]; along_q[2] = a.eye_q[2];
-                                along_scale = kMaxScale - int(a.eye_levels);
-                                for (uint32_t l = 0; l < a.eye_levels; ++l) fast_st.push(kMaxScale - 1 - int(l), a.eye_table[2 * l], 0.0f, a.eye_table[2 * l + 1]);
-                            }
-                        }
                         if (STATS) { ctr.rays++; ++n_pixels; }
                     } else if (p.tile_count > 1) {
                         // padding pixel of an edge tile: keep the compact tile list fully defined

@@ -254,44 +254,6 @@ int launch_render(vx_context* ctx, const RenderParams& p, float* out, vx_hit* hi
         a.excursions = ctx->count_excursions ? ctx->d_excursions : nullptr;
         a.timeline = vxk::timeline_build() && imaged && !HITS && !build.hot ? ctx->d_timeline : nullptr;
         a.timeline_part = ctx->timeline_part;
-        a.eye_levels = 0;
-        a.eye_table = nullptr;
-        if (imaged && !build.hot && ctx->eye_path && ctx->d_eye_tables) {
-            // the nodes every primary ray begins with (PersistentArgs::eye_*), off the host's mirror of the image -- unless a commit is rewriting it
-            vxk::EyeTable path = {};
-            uint32_t n = 0;
-            float e[3];
-            for (int k = 0; k < 3; ++k) e[k] = p.ray_origin[k] * std::exp2(-float(depth)) + 1.0f;  // (Trav::init: octree space)
-            {
-                std::lock_guard<std::mutex> lk(ctx->image_mutex);
-                if (!ctx->mirror_ahead) {
-                    uint32_t lo[PersistentArgs::kEyeLevels], masks[PersistentArgs::kEyeLevels];
-                    n = ctx->image.path_to(e[0], e[1], e[2], lo, masks, PersistentArgs::kEyeLevels);
-                    for (uint32_t l = 0; l < n; ++l) { path.w[2 * l] = lo[l]; path.w[2 * l + 1] = masks[l]; }
-                }
-            }
-            // (the last node's scale must be one the kernel's stack holds: 13 or 16 levels from the top)
-            if (n > uint32_t(build.levels)) n = uint32_t(build.levels);
-            if (n > 1) {
-                const int at = slot + 1;
-                uint32_t* table = ctx->d_eye_tables + size_t(at) * 32;
-                if (!ctx->eye_cached_valid[at] || std::memcmp(ctx->eye_cached[at], path.w, sizeof path.w) != 0) {
-                    // (rare: the eye has left a cell of its path, or a commit has moved one of the path's nodes. In front of the render kernel, on its stream)
-                    HIP_TRY(vxk::launch_eye_table(stream, table, path));
-                    std::memcpy(ctx->eye_cached[at], path.w, sizeof path.w);
-                    ctx->eye_cached_valid[at] = true;
-                }
-                a.eye_levels = n;
-                a.eye_table = table;
-                const uint32_t keep = 0xffffffffu << (23u - n);  // the child cell of the last node that holds the eye: scale 23 - n
-                for (int k = 0; k < 3; ++k) {
-                    uint32_t b;
-                    std::memcpy(&b, &e[k], 4);
-                    b &= keep;
-                    std::memcpy(&a.eye_q[k], &b, 4);
-                }
-            }
-        }
         a.ticket_ahead = 1u + 2u;  // (the frame's last two quarter-grids of tickets are not drawn ahead)
         a.order = nullptr;
         a.cost_cur = nullptr;
@@ -677,12 +639,11 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), 2 * kQueues * kQueueStride * sizeof(uint32_t)));
     CREATE_TRY(hipMemset(c->d_work_counter, 0, 2 * kQueues * kQueueStride * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_eye_tables), size_t(vx_context::kFrameStreams + 1) * 32 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_excursions), 8 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(c->d_excursions, 0, 8 * sizeof(unsigned long long)));
     {
-        // The environment knobs of the product build (eleven; none of them changes a pixel): which kernel, how many frames in flight, the image on /
-        // off / wide / capped, where a CSVO world's inside-voxel rays go, the LDS copy of the top levels, primary rays on the eye's path, the wave slots left to a communicator,
+        // The environment knobs of the product build (ten; none of them changes a pixel): which kernel, how many frames in flight, the image on /
+        // off / wide / capped, where a CSVO world's inside-voxel rays go, the LDS copy of the top levels, the wave slots left to a communicator,
         // the lockstep threshold, how the tiles are numbered.
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("VX_FRAMES_IN_FLIGHT")) c->frames_in_flight = std::atoi(e);
@@ -691,7 +652,6 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_TRAVERSAL_IMAGE")) c->image_enabled = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_FOREIGN_RERUN")) c->foreign_rerun = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VX_HOT_LEVELS")) c->hot_levels = std::atoi(e) != 0;
-        if (const char* e = std::getenv("VX_EYE_PATH")) c->eye_path = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_IMAGE_CAP_BYTES")) c->image_cap_bytes = size_t(std::strtoull(e, nullptr, 10));
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)
@@ -741,7 +701,7 @@ void vx_destroy(vx_context* c) {
     if (c->h_pick_tasks) (void)hipHostFree(c->h_pick_tasks);
     if (c->h_pick_results) (void)hipHostFree(c->h_pick_results);
     void* dev[] = {c->d_world, c->d_materials, c->d_tex, c->d_frame, c->d_hits, c->d_tasks, c->d_results, c->d_trace_result, c->d_trace_frames,
-                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin, c->d_excursions, c->d_main_todo, c->d_timeline, c->d_eye_tables};
+                   c->d_trace_count, c->d_counters, c->d_work_counter, c->d_image, c->d_origin, c->d_excursions, c->d_main_todo, c->d_timeline};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     for (int i = 0; i < vx_context::kFrameStreams; ++i) {
@@ -950,10 +910,6 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
     }
 
     bool image_ok = false;
-    {
-        std::lock_guard<std::mutex> lk(ctx->image_mutex);
-        ctx->mirror_ahead = true;  // (until this commit's uploads are enqueued: launch_render)
-    }
     if (ctx->image_enabled && ctx->kernel_version != 1) {
         // re-lay the changed chunks (and the root octree, which every commit rewrites) out as octants
         std::vector<vximg::Range> changed(count);
@@ -1091,10 +1047,6 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
     ctx->stats.depth = depth;
     ctx->stats.used_bytes = used_bytes;
     ctx->committed = true;
-    {
-        std::lock_guard<std::mutex> lk(ctx->image_mutex);
-        ctx->mirror_ahead = false;  // what the mirror holds is what the streams' next frames will find
-    }
     return VX_OK;
 }
 

@@ -876,34 +876,6 @@ public:
         return false;
     }
 
-    // The nodes on the way from the root to the point (x, y, z) of the octree's [1, 2)^3: lo[i] / masks[i] = the octant and the masks (as an entry that points
-    // to the node holds them) of the node i levels below the root, for as long as the child that holds the point exists and is a node itself. Returns how
-    // many there are (at most `max`; 0: no image in a renderer's layout, or the point lies outside). Every primary ray of an eye at that point begins with
-    // PUSHes through exactly these nodes: the renderer hands them to its waves (runtime.cpp launch_render, PersistentArgs::eye_*).
-    uint32_t path_to(float x, float y, float z, uint32_t* lo, uint32_t* masks, uint32_t max) const {
-        if (layout_ == kEsvo48 || frame_.size() < 16 || max == 0 || !(x >= 1.0f && x < 2.0f && y >= 1.0f && y < 2.0f && z >= 1.0f && z < 2.0f)) return 0;
-        uint32_t bx, by, bz;
-        std::memcpy(&bx, &x, 4);
-        std::memcpy(&by, &y, 4);
-        std::memcpy(&bz, &z, 4);
-        uint32_t n = 0;
-        uint32_t node_masks = frame_[1];
-        uint64_t node_lo = frame_[2];
-        for (int scale = 22; scale >= 0; --scale) {
-            lo[n] = uint32_t(node_lo);
-            masks[n] = node_masks;
-            if (++n == max) break;
-            const uint32_t c = ((bx >> scale) & 1u) | (((by >> scale) & 1u) << 1) | (((bz >> scale) & 1u) << 2);
-            const uint32_t m = node_masks << c;
-            if (!(m & 0x00800000u) || (m & 0x80000000u)) break;  // no such child, or a voxel
-            const uint64_t entry = (node_lo + uint64_t(__builtin_popcount(m & 0x00ffffffu))) * 2;
-            if (entry + 1 >= frame_.size()) return 0;
-            node_masks = frame_[entry + 1];
-            node_lo = frame_[entry];
-        }
-        return n;
-    }
-
     // `world` = the frame as committed: [f32 scale][CSVO: u32 root_ptr | ESVO: 5-word preamble][arena]; `used` = bytes of the
     // arena in use; `changed` = byte ranges (relative to the arena, like vx_commit's) rewritten since the last call.
     // Returns false when the world cannot be imaged (malformed or image beyond 4 GiB): the caller then traverses the world's bytes.

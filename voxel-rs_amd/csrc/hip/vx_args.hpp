@@ -171,17 +171,6 @@ struct PersistentArgs {
                                     // except for the frame's last g quarter-grids of tickets
     uint32_t timeline_part;         // measurement: which part of the service phases the timeline's tick count covers (0 all, 1 leaf tests, 2 finished rays, 3 refill, 4 ray set-up, 5 walks inside voxels)
     unsigned long long* timeline;   // measurement (the timeline build of the library), else null: per wave {start, queue found empty, exit} in 10 ns ticks, pixels taken
-    // Where every primary ray begins: the eye lies inside the octree, so all of them PUSH through the same nodes -- the root, its child that holds the eye,
-    // ... -- before they part. The host reads those nodes off its mirror of the image (WorldImage::path_to; eye_levels of them, 0 = none: the eye is outside,
-    // or the mirror is ahead of the device) and a primary ray starts on that path like a shadow ray on its primary's (Trav::descend_along): the entries go
-    // into its stack, the levels are run through in the set-up phase instead of a trip of the loop each. eye_table (device memory, the launch's stream's own:
-    // runtime.cpp) = {octant, masks} of the node l levels below the root at words 2 l, 2 l + 1; eye_q = the un-mirrored corner of the last node's child
-    // cell that holds the eye (a cell of scale 23 - eye_levels). (A table in memory, not in these arguments: indexing an argument array by a variable makes the
-    // compiler copy the whole argument block to scratch -- measured: 40-60 vector registers spilled in every build.)
-    static constexpr uint32_t kEyeLevels = 16;
-    uint32_t eye_levels;
-    float eye_q[3];
-    const uint32_t* eye_table;
     unsigned long long* excursions;  // counted on request only (vx_excursion_counters), else null: [0] rays that walked inside a voxel on the world's bytes, [1] of which were given up and run on the bytes, [2] service phases that ran such walks, [3] loop iterations made on the bytes
 };
 

@@ -118,15 +118,6 @@ struct vx_context {
     size_t d_origin_capacity = 0;
     size_t image_cap_bytes = 0;   // VX_IMAGE_CAP_BYTES: never allocate more than this for the image (tests of the fall-back)
     // vx_commit's packed uploads: a small ring of pinned host buffers with their device twins, each guarded by an event
-    // The host's mirror of the image (`image`) is AHEAD of the device from the moment a commit starts to update it until that commit's uploads are enqueued:
-    // a render that is launched in between must not read it (launch_render: the eye's path). `image_mutex` guards the flag and a render's short read.
-    std::mutex image_mutex;
-    bool mirror_ahead = false;
-    bool eye_path = true;  // VX_EYE_PATH=0 (measurement): primary rays start at the root like the reference's
-    // ... the table each stream's launches read the path from (stream 0 = the context's own, 1 + i = frame stream i; 32 words each), and what it holds
-    uint32_t* d_eye_tables = nullptr;
-    uint32_t eye_cached[kFrameStreams + 1][32] = {};
-    bool eye_cached_valid[kFrameStreams + 1] = {};
     struct DeltaSlot { uint8_t* host = nullptr; uint8_t* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
     static constexpr int kDeltaSlots = 3;
     DeltaSlot delta[kDeltaSlots];
