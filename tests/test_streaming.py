@@ -51,12 +51,17 @@ def test_streamed_world_is_the_terrain(svo_type):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("first_image_bytes", [None, 8192], ids=["image-buffer-32MB", "image-buffer-8KB-doubling"])
 @pytest.mark.parametrize("svo_type", [host.SVO_ESVO, host.SVO_CSVO])
-def test_incremental_commits_render_like_a_full_upload(svo_type):
+def test_incremental_commits_render_like_a_full_upload(svo_type, first_image_bytes, monkeypatch):
+    """... and with a first image buffer of 8 KB the image outgrows its device buffer a dozen times on the way: what it holds is carried over on the
+    device into a buffer twice the size, only the commit's own ranges travel (runtime.cpp commit_now)."""
     from voxel_rs_amd import hip
 
     radius = 9  # LOD 5 within 6 chunks, LOD 4 beyond: both kinds resident, LOD changes while moving
     s = host.WorldStreamer(svo_type, SCENE_DEPTH, radius, 0, 8, SEED)
+    if first_image_bytes:
+        monkeypatch.setenv("VX_IMAGE_FIRST_BYTES", str(first_image_bytes))  # (read by vx_create)
     svo = hip.Svo(svo_type, 64 << 20)
     tex, mats = scenes.synthetic_textures(), scenes.synthetic_materials()
     svo.set_materials(mats)
@@ -87,3 +92,4 @@ def test_incremental_commits_render_like_a_full_upload(svo_type):
     assert (hits["flags"] & 1).mean() > 0.15
     # back at the start the same chunks are resident: the free list was reused instead of growing the arena without bound
     assert st["arena_bytes"] <= 1.5 * arena_after_first_visit
+    assert svo.image_info()["image_bytes"] > 1 << 20  # (the image did outgrow an 8 KB buffer many times over)

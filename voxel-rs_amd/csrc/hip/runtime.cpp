@@ -642,8 +642,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
     CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_excursions), 8 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(c->d_excursions, 0, 8 * sizeof(unsigned long long)));
     {
-        // The environment knobs of the product build (ten; none of them changes a pixel): which kernel, how many frames in flight, the image on /
-        // off / wide / capped, where a CSVO world's inside-voxel rays go, the LDS copy of the top levels, the wave slots left to a communicator,
+        // The environment knobs of the product build (eleven; none of them changes a pixel): which kernel, how many frames in flight, the image on /
+        // off / wide / capped / its first buffer, where a CSVO world's inside-voxel rays go, the LDS copy of the top levels, the wave slots left to a communicator,
         // the lockstep threshold, how the tiles are numbered.
         if (const char* e = std::getenv("VX_RENDER_KERNEL")) c->kernel_version = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("VX_FRAMES_IN_FLIGHT")) c->frames_in_flight = std::atoi(e);
@@ -653,6 +653,8 @@ int vx_create(int svo_type, size_t capacity_bytes, int device, vx_context** out)
         if (const char* e = std::getenv("VX_FOREIGN_RERUN")) c->foreign_rerun = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("VX_HOT_LEVELS")) c->hot_levels = std::atoi(e) != 0;
         if (const char* e = std::getenv("VX_IMAGE_CAP_BYTES")) c->image_cap_bytes = size_t(std::strtoull(e, nullptr, 10));
+        // (tests: a first buffer of a few KB makes a small streamed world's image outgrow it again and again -- the carry-over on the device, commit_now)
+        if (const char* e = std::getenv("VX_IMAGE_FIRST_BYTES")) c->image_first_bytes = std::max<size_t>(4096, size_t(std::strtoull(e, nullptr, 10)));
         // VX_WIDE_IMAGE=1: the layout for images beyond 4 GiB from the start; 2: and its arena starts 5 GiB into the frame, so that
         // every pointer needs more than 32 bits of byte offset (tests)
         int wide_image = 0;
@@ -955,7 +957,7 @@ int commit_now(vx_context* ctx, uint32_t depth, const vx_range* ranges, uint32_t
             // which is freed when they and the copy are done.
             // (a context's first image -- a whole world's, as a rule -- gets a quarter of headroom)
             const size_t want = ctx->d_image ? 2 * need : need + need / 4;
-            const size_t cap = std::min(std::max(want, size_t(32) << 20), ctx->image_cap_bytes ? ctx->image_cap_bytes : ~size_t(0));
+            const size_t cap = std::min(std::max(want, ctx->image_first_bytes), ctx->image_cap_bytes ? ctx->image_cap_bytes : ~size_t(0));
             const size_t cap_origin = need_origin ? cap / 4 + kImagePad : 0;
             uint8_t* fresh = nullptr;
             bool ok = cap >= need && hipMalloc(reinterpret_cast<void**>(&fresh), cap) == hipSuccess;

@@ -117,6 +117,7 @@ struct vx_context {
     uint8_t* d_origin = nullptr;  // (rounds 3-5: a CSVO world's origin table beside the image; the origins are units of the image now -- never allocated)
     size_t d_origin_capacity = 0;
     size_t image_cap_bytes = 0;   // VX_IMAGE_CAP_BYTES: never allocate more than this for the image (tests of the fall-back)
+    size_t image_first_bytes = size_t(32) << 20;  // VX_IMAGE_FIRST_BYTES: the least the image's device buffer is given (it doubles from there as a streamed world's image grows)
     // vx_commit's packed uploads: a small ring of pinned host buffers with their device twins, each guarded by an event
     struct DeltaSlot { uint8_t* host = nullptr; uint8_t* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
     static constexpr int kDeltaSlots = 3;
