@@ -90,7 +90,12 @@ public:
     }
     // address space for n words (untouched pages cost nothing): a whole world's image grows to its size without being moved on the way
     void reserve(size_t n) {
-        if (n > cap_) grow_to(n);
+        if (n <= cap_) return;
+        try {
+            grow_to(n);
+        } catch (const std::bad_alloc&) {
+            // (a hint: where the address space is not to be had up front the frame grows in steps as before)
+        }
     }
     // grows only (the image never shrinks between clear()s); the value is always zero
     void resize(size_t n, uint32_t /*zero*/) {
