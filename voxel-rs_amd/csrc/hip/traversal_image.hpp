@@ -451,16 +451,15 @@ private:
 // the kEsvo48 layout still go through Tree: ChunkWalker / EsvoWalker + encode() say the same thing in the other form, and
 // tests/test_traversal_image.py holds the two against each other.)
 struct Emitted {
-    std::vector<uint32_t> words, relocs;  // (words: grown by room(), which leaves what it adds unwritten -- size() is only right after finish())
+    std::vector<uint32_t> words, relocs;  // (room to write into, grown by room(): what counts is n_words / n_relocs, not their size())
     size_t n_words = 0, n_relocs = 0;
     NodeMasks root;
-    bool root_values_only = false;  // (the root octant is one of values: what points to it holds the unit of its origin)
     bool too_deep = false;
     uint64_t src_begin = 0, src_end = 0;
     void start() {
         n_words = n_relocs = 0;
         root = NodeMasks();
-        root_values_only = too_deep = false;
+        too_deep = false;
         src_begin = src_end = 0;
     }
     // room for `extra` more words and `extra` more relocs (a node asks once for itself and what it writes for its children)
@@ -531,8 +530,7 @@ private:
             size_t top = at + 2u * n_children;
             uint64_t value = materials_ + uint64_t(material_offset) * 4;
             uint32_t entry = uint32_t(at) + 2u * n_children;  // (child 7 first: the entries are written from the back)
-            uint32_t left = header;
-            for (uint32_t j = 0; j < n_children; ++j, left &= left - 1u) {
+            for (uint32_t j = 0; j < n_children; ++j) {
                 const uint64_t byte = ptr + 3 + j;
                 const uint32_t mask = b_.u8(byte);
                 entry -= 2u;
@@ -555,7 +553,6 @@ private:
                 value += uint64_t(n) * 4;
                 top += 2u + ((n + 1u) & ~1u);
             }
-            (void)left;
             out_.n_words = top;
             m.child_mask = header;
             return m;
@@ -1036,7 +1033,9 @@ private:
                 pl.at = alloc_.alloc(pl.words);
                 if (direct) {
                     const Emitted& e = emitted[i];
-                    pl.root_lo = uint32_t(pl.at / 2) - (e.root_values_only ? 0u : 1u);
+                    // (oct64_lo of the chunk's root octant: the unit before its first entry -- a root of values with an origin in front of them would be a CSVO
+                    // chunk of one level, which ChunkEmitter refuses)
+                    pl.root_lo = uint32_t(pl.at / 2) - 1u;
                     pl.masks = e.root.packed();
                     pl.src_begin = e.src_begin;
                     pl.src_end = e.src_end;
