@@ -138,7 +138,7 @@ struct vx_context {
     // profiles/round5/pass_a/refill.txt, tails_detail.txt). Smaller: the measurement build's VX_REFILL_MIN.
     uint32_t refill_min = 64, service_min = 64;
     int tile_strip = 8;  // VX_TILE_STRIP: tile numbering 1's strips are this many tiles wide
-    int tile_numbering = 1;  // VX_TILE_NUMBERING: how a whole-image render's tile numbers lie on the screen (RenderParams::tile_numbering)
+    int tile_numbering = 1;  // VX_TILE_NUMBERING: how a whole-image render's tile numbers lie on the screen (RenderParams::tile_numbering); vx_create: 2 for ESVO worlds
     int queue_stripe = 0;  // VX_QUEUE_STRIPE: the length of the stretches the sub-tile queue deals out to its dispensers (0: by the launch, launch_render)
     // Block ids 0..63 all of whose textures are opaque throughout (RenderParams::opaque_*): from host copies of what vx_set_materials and
     // vx_set_textures were given. opaque_layer[l] = every texel of layer l, on every mip level, has alpha > 0.
