@@ -935,8 +935,21 @@ static void sort_chunks_by_view_frustum() {  // world.rs:233-262 (the reference 
     CHECK(sorted.front().pos == (vx::ChunkPos{0, 0, 0}));  // the chunk the camera is in: its sphere reaches the near plane
 }
 
+// The writers' large ranges are copied on several threads (range_buffer.hpp, copy_bytes: a whole depth-14 ESVO world is 6.7 GB): every byte arrives,
+// whatever the length does to the last thread's share; nothing of the pieces' book-keeping in the reference (its write_to is one memcpy, esvo.rs:291-339).
+static void copy_bytes_in_pieces() {
+    for (size_t n : {size_t(0), size_t(5), (size_t(64) << 20) - 1, size_t(64) << 20, (size_t(70) << 20) + 4097, (size_t(96) << 20) + 1}) {
+        std::vector<uint8_t> src(n), dst(n + 8, 0xEE);
+        for (size_t i = 0; i < n; ++i) src[i] = uint8_t((i * 2654435761u) >> 13);
+        vx::copy_bytes(dst.data() + 4, src.data(), n);
+        CHECK(n == 0 || std::memcmp(dst.data() + 4, src.data(), n) == 0);
+        for (size_t k = 0; k < 4; ++k) CHECK(dst[k] == 0xEE && dst[n + 4 + k] == 0xEE);  // (nothing in front of it or behind it)
+    }
+}
+
 int main(int argc, char** argv) {
     const std::map<std::string, std::function<void()>> cases = {
+        {"copy_bytes_in_pieces", copy_bytes_in_pieces},
         {"camera_is_in_frustum", camera_is_in_frustum},
         {"sort_chunks_by_view_frustum", sort_chunks_by_view_frustum},
         {"octree_add_leaf_single", octree_add_leaf_single},

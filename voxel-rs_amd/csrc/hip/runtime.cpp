@@ -488,7 +488,7 @@ int upload_big(vx_context* ctx, const std::vector<Upload>& up) {
                 return fail(VX_ERR_HIP, "commit: upload failed");
             }
             const size_t n = size_t(std::min<uint64_t>(kSlot, u.bytes - off));
-            const size_t share = (n / workers + 4095) & ~size_t(4095);
+            const size_t share = ((n + workers - 1) / workers + 4095) & ~size_t(4095);  // (rounded up first: the shares must cover n)
             std::vector<std::thread> pool;
             for (unsigned t = 1; t < workers && t * share < n; ++t)
                 pool.emplace_back([&, t] { std::memcpy(b.host + t * share, u.src + off + t * share, std::min(share, n - t * share)); });

@@ -26,7 +26,7 @@ inline void copy_bytes(uint8_t* dst, const uint8_t* src, size_t n) {
     }
     const unsigned hw = std::thread::hardware_concurrency();
     const size_t threads = std::min<size_t>(std::min<size_t>(8, hw ? hw : 1), n / kPiece);
-    const size_t share = (n / threads + 4095) & ~size_t(4095);
+    const size_t share = ((n + threads - 1) / threads + 4095) & ~size_t(4095);  // (rounded UP first: the shares must cover n -- host_kats, copy_bytes_in_pieces)
     std::vector<std::thread> pool;
     for (size_t t = 1; t < threads && t * share < n; ++t)
         pool.emplace_back([=] { std::memcpy(dst + t * share, src + t * share, std::min(share, n - t * share)); });
