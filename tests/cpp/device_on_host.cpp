@@ -40,6 +40,8 @@ extern "C" int devhost_queue_covers(uint32_t total, uint32_t stripe) {
         uint32_t last = 0;
         for (uint32_t k = 0;; ++k) {
             const uint32_t t = vxk::queue_subtile(k, c, stripe);
+            // (a power-of-two stretch is handed to the kernel as its logarithm -- PersistentArgs::stripe_shift --: the same number without the division)
+            if ((stripe & (stripe - 1u)) == 0u && vxk::queue_subtile(k, c, stripe, uint32_t(__builtin_ctz(stripe))) != t) return 0;
             if (k && t <= last) return 0;  // (a dispenser's numbers grow: the first beyond the launch means it is dry)
             last = t;
             if (t >= total) break;
