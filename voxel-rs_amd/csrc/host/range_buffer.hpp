@@ -20,6 +20,7 @@ namespace vx {
 // depth-14 ESVO world is 6.7 GB, 0.8 s of a first Svo::update on one thread -- from 32 MiB on the range is cut into pieces for up to eight threads.
 inline void copy_bytes(uint8_t* dst, const uint8_t* src, size_t n) {
     constexpr size_t kPiece = size_t(32) << 20;
+    if (n == 0) return;  // (an empty range's pointers may be null: not memcpy's business)
     if (n < 2 * kPiece) {
         std::memcpy(dst, src, n);
         return;
